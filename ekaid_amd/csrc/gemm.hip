@@ -1,0 +1,374 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, k-ordered fma chain).
+//
+// C[M,N] = epilogue( alpha * op(A)[M,K] . op(B)[K,N] )     row-major everywhere
+//   transA = 0 : A stored [M][K] (k-contiguous)      transA = 1 : A stored [K][M] (m-contiguous)
+//   transB = 1 : B stored [N][K] (k-contiguous)      transB = 0 : B stored [K][N] (n-contiguous)
+// The three forms the path needs (reference fc.py / nn.Linear call sites):
+//   forward  y  = x . W^T      (transA=0, transB=1)
+//   dgrad    dx = dy . W       (transA=0, transB=0)
+//   wgrad    dW = dy^T . x     (transA=1, transB=0)
+//
+// Tiling: workgroup = 256 threads = 4 wave64 in a 2x2 grid; block tile (64*TM)x(64*TN), wave tile
+// (32*TM)x(32*TN) as TMxTN MFMA tiles of 32x32 (16 accumulator VGPRs each).  K-step 32.
+// Operand staging: global -> registers (16-B loads along the contiguous axis, issued before the
+// MFMA phase of the previous K-step) -> LDS.  k-contiguous operands sit in LDS as [row][32+4]
+// and are fetched with one ds_read_b128 per lane per 8-k group (lane half h supplies k = 4h..4h+3,
+// the contraction order inside the group is permuted identically for A and B, which is exact
+// reordering of an f32 sum); m/n-contiguous operands sit as [k][cols+4] and are fetched with
+// ds_read_b32 (consecutive lanes -> consecutive banks).
+// Small grids are split along K into `splitk` slabs reduced by a second kernel that also applies
+// the epilogue (deterministic; no float atomics).
+#include "common.h"
+#include "../../include/ekaid_hip.h"
+
+namespace ekaid {
+
+#define BK 32
+#define LDS_PAD 4
+
+struct Epi {
+    float alpha;
+    const float* alpha_dev;
+    int beta;
+    const float* bias;
+    const float* R;
+    int ldr;
+    int rdiv;
+    const float* rowmask;
+    int act;
+};
+
+__device__ __forceinline__ float epilogue(float acc, float cold, int m, int n, const Epi& e, float alpha) {
+    float v = acc * alpha;
+    if (e.beta) v += cold;
+    if (e.bias) v += e.bias[n];
+    if (e.R) {
+        float r = e.R[(long long)(m / e.rdiv) * e.ldr + n];
+        if (e.rowmask) r *= e.rowmask[m];
+        v += r;
+    }
+    return act_apply(v, e.act);
+}
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    int M, N, K, lda, ldb, ldc;
+    long long sA1, sA2, sB1, sB2, sC1, sC2;
+    int nb2;
+    int k_per_split;      // multiple of BK; == K rounded up when splitk == 1
+    int splitk;
+    float* ws;            // slabs [splitk][M][N] when splitk > 1
+    int tiles_m, tiles_n;
+    Epi e;
+};
+
+// 16-byte load with scalar fallback / zero fill.  `p` points at element 0 of the 4-vector, `nvalid`
+// = how many of the 4 elements are inside the matrix (<=0: none), `vec` = alignment allows b128.
+__device__ __forceinline__ f32x4 load4(const float* p, int nvalid, bool vec) {
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+    if (nvalid >= 4 && vec) {
+        r = *reinterpret_cast<const f32x4*>(p);
+    } else {
+        if (nvalid > 0) r[0] = p[0];
+        if (nvalid > 1) r[1] = p[1];
+        if (nvalid > 2) r[2] = p[2];
+        if (nvalid > 3) r[3] = p[3];
+    }
+    return r;
+}
+
+template <bool A_KC, bool B_KC, int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int A_ELEMS = A_KC ? BM * (BK + LDS_PAD) : BK * (BM + LDS_PAD);
+    constexpr int B_ELEMS = B_KC ? BN * (BK + LDS_PAD) : BK * (BN + LDS_PAD);
+    constexpr int A_V4 = BM * BK / 4 / 256;     // float4 per thread per tile
+    constexpr int B_V4 = BN * BK / 4 / 256;
+    __shared__ __attribute__((aligned(16))) float lds[A_ELEMS + B_ELEMS];
+    float* As = lds;
+    float* Bs = lds + A_ELEMS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = (wave >> 1) * (32 * TM), wn = (wave & 1) * (32 * TN);
+
+    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give every
+    // XCD a contiguous run of tiles -> neighbouring tiles (same A row panel) share one L2.
+    const int nwg = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    }
+    const int m0 = (bid / g.tiles_n) * BM, n0 = (bid % g.tiles_n) * BN;
+
+    const int z = blockIdx.z;
+    const float* A = g.A; const float* B = g.B;
+    int kbeg = 0, kend = g.K;
+    if (g.splitk > 1) {
+        kbeg = z * g.k_per_split;
+        kend = min(g.K, kbeg + g.k_per_split);
+    } else {
+        const long long z1 = z / g.nb2, z2 = z % g.nb2;
+        A += z1 * g.sA1 + z2 * g.sA2;
+        B += z1 * g.sB1 + z2 * g.sB2;
+    }
+    const bool vecA = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+    const bool vecB = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
+
+    f32x4 ra[A_V4], rb[B_V4];
+
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_V4; ++i) {
+            const int idx = tid + i * 256;
+            if (A_KC) {
+                const int row = idx >> 3, c4 = idx & 7;
+                const int gm = m0 + row, gk = k0 + 4 * c4;
+                const int nv = (gm < g.M) ? (kend - gk) : 0;
+                ra[i] = load4(A + (long long)gm * g.lda + gk, nv, vecA);
+            } else {
+                const int krow = idx / (BM / 4), c4 = idx % (BM / 4);
+                const int gk = k0 + krow, gm = m0 + 4 * c4;
+                const int nv = (gk < kend) ? (g.M - gm) : 0;
+                ra[i] = load4(A + (long long)gk * g.lda + gm, nv, vecA);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i) {
+            const int idx = tid + i * 256;
+            if (B_KC) {
+                const int row = idx >> 3, c4 = idx & 7;
+                const int gn = n0 + row, gk = k0 + 4 * c4;
+                const int nv = (gn < g.N) ? (kend - gk) : 0;
+                rb[i] = load4(B + (long long)gn * g.ldb + gk, nv, vecB);
+            } else {
+                const int krow = idx / (BN / 4), c4 = idx % (BN / 4);
+                const int gk = k0 + krow, gn = n0 + 4 * c4;
+                const int nv = (gk < kend) ? (g.N - gn) : 0;
+                rb[i] = load4(B + (long long)gk * g.ldb + gn, nv, vecB);
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_V4; ++i) {
+            const int idx = tid + i * 256;
+            if (A_KC) {
+                const int row = idx >> 3, c4 = idx & 7;
+                *reinterpret_cast<f32x4*>(&As[row * (BK + LDS_PAD) + 4 * c4]) = ra[i];
+            } else {
+                const int krow = idx / (BM / 4), c4 = idx % (BM / 4);
+                *reinterpret_cast<f32x4*>(&As[krow * (BM + LDS_PAD) + 4 * c4]) = ra[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i) {
+            const int idx = tid + i * 256;
+            if (B_KC) {
+                const int row = idx >> 3, c4 = idx & 7;
+                *reinterpret_cast<f32x4*>(&Bs[row * (BK + LDS_PAD) + 4 * c4]) = rb[i];
+            } else {
+                const int krow = idx / (BN / 4), c4 = idx % (BN / 4);
+                *reinterpret_cast<f32x4*>(&Bs[krow * (BN + LDS_PAD) + 4 * c4]) = rb[i];
+            }
+        }
+    };
+
+    if (kbeg < kend) {
+        gload(kbeg);
+        lstore();
+        __syncthreads();
+        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+            const bool more = (k0 + BK) < kend;
+            if (more) gload(k0 + BK);                 // next tile's HBM/L2 latency hides under the MFMAs
+#pragma unroll
+            for (int kb = 0; kb < BK; kb += 8) {
+                f32x4 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    if (A_KC) {
+                        a[i] = *reinterpret_cast<const f32x4*>(&As[(wm + 32 * i + r) * (BK + LDS_PAD) + kb + 4 * h]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[i][j] = As[(kb + 4 * h + j) * (BM + LDS_PAD) + wm + 32 * i + r];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    if (B_KC) {
+                        b[i] = *reinterpret_cast<const f32x4*>(&Bs[(wn + 32 * i + r) * (BK + LDS_PAD) + kb + 4 * h]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) b[i][j] = Bs[(kb + 4 * h + j) * (BN + LDS_PAD) + wn + 32 * i + r];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < TN; ++jj)
+                            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[jj][j], acc[i][jj], 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) {
+                lstore();
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (t&3) + 8*(t>>2) + 4*(lane>>5)
+    float* C;
+    int ldc;
+    const bool slab = g.splitk > 1;
+    if (slab) {
+        C = g.ws + (long long)z * g.M * g.N;
+        ldc = g.N;
+    } else {
+        const long long z1 = z / g.nb2, z2 = z % g.nb2;
+        C = g.C + z1 * g.sC1 + z2 * g.sC2;
+        ldc = g.ldc;
+    }
+    const float alpha = g.e.alpha_dev ? g.e.alpha * g.e.alpha_dev[0] : g.e.alpha;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj) {
+            const int n = n0 + wn + 32 * jj + r;
+            if (n >= g.N) continue;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int m = m0 + wm + 32 * i + (t & 3) + 8 * (t >> 2) + 4 * h;
+                if (m >= g.M) continue;
+                float* cp = C + (long long)m * ldc + n;
+                if (slab) {
+                    *cp = acc[i][jj][t];
+                } else {
+                    const float cold = g.e.beta ? *cp : 0.f;
+                    *cp = epilogue(acc[i][jj][t], cold, m, n, g.e, alpha);
+                }
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, float* C, int M, int N, int ldc,
+                                                            int splitk, Epi e) {
+    const long long total = (long long)M * N;
+    const float alpha = e.alpha_dev ? e.alpha * e.alpha_dev[0] : e.alpha;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        float s = 0.f;
+        for (int k = 0; k < splitk; ++k) s += ws[(long long)k * total + i];
+        float* cp = C + (long long)m * ldc + n;
+        const float cold = e.beta ? *cp : 0.f;
+        *cp = epilogue(s, cold, m, n, e, alpha);
+    }
+}
+
+template <bool A_KC, bool B_KC, int TM, int TN>
+static void launch(const GemmArgs& a, int batch, hipStream_t st) {
+    dim3 grid(a.tiles_m * a.tiles_n, 1, a.splitk > 1 ? a.splitk : batch);
+    hipLaunchKernelGGL((gemm_mfma_kernel<A_KC, B_KC, TM, TN>), grid, dim3(256), 0, st, a);
+}
+
+static int plan_splitk(int tiles, int K, int batch, long long MN) {
+    if (batch > 1) return 1;
+    const int target = 512;                       // ~2 workgroups per CU
+    if (tiles >= target / 2) return 1;
+    int s = target / tiles;
+    const int ksteps = cdiv(K, BK);
+    s = s > ksteps / 2 ? ksteps / 2 : s;          // at least two K-steps per split
+    while (s > 1 && (long long)s * MN * 4 > (1ll << 30)) --s;   // cap the slab workspace at 1 GiB
+    return s < 1 ? 1 : s;
+}
+
+static void plan(const ekaid_gemm_t* d, int& TMN, int& splitk, int& tiles_m, int& tiles_n) {
+    const int batch = d->batch1 * d->batch2;
+    // 128x128 tiles (split along K when the grid is small) for problems with many rows; 64x64 tiles
+    // for the small-M recurrent GEMMs and narrow outputs, where slab traffic would rival the math.
+    (void)batch;
+    TMN = (d->M >= 512 && d->N >= 128) ? 2 : 1;
+    const int bm = 64 * TMN;
+    tiles_m = cdiv(d->M, bm);
+    tiles_n = cdiv(d->N, bm);
+    splitk = plan_splitk(tiles_m * tiles_n, d->K, batch, (long long)d->M * d->N);
+}
+
+}  // namespace ekaid
+
+using namespace ekaid;
+
+extern "C" size_t ekaid_gemm_workspace_bytes(const ekaid_gemm_t* d) {
+    if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+    int TMN, splitk, tm, tn;
+    plan(d, TMN, splitk, tm, tn);
+    return splitk > 1 ? (size_t)splitk * d->M * d->N * sizeof(float) : 0;
+}
+
+extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!d || !d->A || !d->B || !d->C) { set_error("ekaid_gemm_f32: null pointer"); return EKAID_ERR_ARG; }
+    if (d->M < 0 || d->N < 0 || d->K < 0 || d->batch1 < 1 || d->batch2 < 1) {
+        set_error("ekaid_gemm_f32: bad dims M=%d N=%d K=%d batch=%dx%d", d->M, d->N, d->K, d->batch1, d->batch2);
+        return EKAID_ERR_ARG;
+    }
+    if (d->transA && d->transB) { set_error("ekaid_gemm_f32: transA && transB unsupported"); return EKAID_ERR_UNSUPPORTED; }
+    if (d->rdiv < 1 && d->R) { set_error("ekaid_gemm_f32: rdiv must be >= 1"); return EKAID_ERR_ARG; }
+    if (d->M == 0 || d->N == 0) return EKAID_OK;
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs a;
+    a.A = d->A; a.B = d->B; a.C = d->C;
+    a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
+    a.sA1 = d->strideA1; a.sA2 = d->strideA2; a.sB1 = d->strideB1; a.sB2 = d->strideB2;
+    a.sC1 = d->strideC1; a.sC2 = d->strideC2; a.nb2 = d->batch2;
+    a.e.alpha = d->alpha; a.e.alpha_dev = d->alpha_dev; a.e.beta = d->accumulate; a.e.bias = d->bias;
+    a.e.R = d->R; a.e.ldr = d->ldr; a.e.rdiv = d->rdiv < 1 ? 1 : d->rdiv; a.e.rowmask = d->rowmask; a.e.act = d->act;
+    int TMN;
+    plan(d, TMN, a.splitk, a.tiles_m, a.tiles_n);
+    if (d->K == 0) a.splitk = 1;
+    a.ws = nullptr;
+    a.k_per_split = cdiv(cdiv(d->K, BK), a.splitk) * BK;
+    if (a.splitk > 1) {
+        const size_t need = (size_t)a.splitk * d->M * d->N * sizeof(float);
+        if (!workspace || workspace_bytes < need) {
+            set_error("ekaid_gemm_f32: workspace too small (%zu < %zu)", workspace_bytes, need);
+            return EKAID_ERR_ARG;
+        }
+        a.ws = (float*)workspace;
+        a.splitk = cdiv(d->K, a.k_per_split);      // drop empty trailing splits
+        if (a.splitk <= 1) { a.splitk = 1; a.ws = nullptr; a.k_per_split = cdiv(d->K, BK) * BK; }
+    }
+    const int batch = d->batch1 * d->batch2;
+    const bool akc = !d->transA, bkc = d->transB != 0;
+#define EKAID_LAUNCH(AK, BKC)                                      \
+    do {                                                           \
+        if (TMN == 2) launch<AK, BKC, 2, 2>(a, batch, st);         \
+        else launch<AK, BKC, 1, 1>(a, batch, st);                  \
+    } while (0)
+    if (akc && bkc) EKAID_LAUNCH(true, true);
+    else if (akc && !bkc) EKAID_LAUNCH(true, false);
+    else EKAID_LAUNCH(false, false);
+#undef EKAID_LAUNCH
+    int rc = check_launch("gemm_mfma_kernel");
+    if (rc) return rc;
+    if (a.splitk > 1) {
+        const long long total = (long long)d->M * d->N;
+        int blocks = cdiv(total, 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.ws, d->C, d->M, d->N, d->ldc,
+                           a.splitk, a.e);
+        rc = check_launch("splitk_reduce_kernel");
+    }
+    return rc;
+}

@@ -1,0 +1,637 @@
+// HBM-bound point-wise / reduction kernels of the path.  Grid-stride, 256-thread workgroups, at most
+// 2048 workgroups (8 per CU); 16-byte accesses where the tensor allows it.
+#include "common.h"
+#include "../../include/ekaid_hip.h"
+
+namespace ekaid {
+
+static inline dim3 grid1d(long long n, int per_thread = 1) {
+    long long b = (n + 256ll * per_thread - 1) / (256ll * per_thread);
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return dim3((unsigned)b);
+}
+#define GS_LOOP(i, n) \
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+
+// ------------------------------------------------------------------ weight norm
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* v, long long n, double* acc) {
+    double s = 0.0;
+    GS_LOOP(i, n) { double x = v[i]; s += x * x; }
+    s = wave_sum_f64(s);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+}
+__global__ void wn_finish_kernel(const double* acc, const float* g, float* scale_out, float* norm_out) {
+    const float nrm = (float)sqrt(acc[0]);
+    norm_out[0] = nrm;
+    scale_out[0] = g[0] / nrm;
+}
+__global__ __launch_bounds__(256) void wn_bwd_kernel(const float* v, const float* g, const float* norm,
+                                                     const float* dscale, long long n, float* dv, int accumulate,
+                                                     float* dg) {
+    const float nrm = norm[0];
+    const float coef = -dscale[0] * g[0] / (nrm * nrm * nrm);
+    GS_LOOP(i, n) {
+        const float t = coef * v[i];
+        dv[i] = accumulate ? dv[i] + t : t;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) dg[0] = dscale[0] / nrm;
+}
+__global__ __launch_bounds__(256) void dot_kernel(const float* a, const float* b, long long n, double* acc) {
+    double s = 0.0;
+    GS_LOOP(i, n) s += (double)a[i] * (double)b[i];
+    s = wave_sum_f64(s);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+}
+__global__ __launch_bounds__(256) void scale_finish_kernel(float* G, const float* scale_dev, long long n,
+                                                           const double* acc, float* dot_out) {
+    const float s = scale_dev[0];
+    GS_LOOP(i, n) G[i] *= s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) dot_out[0] = (float)acc[0];
+}
+
+// ------------------------------------------------------------------ reductions
+// column sums of [M][N]: one thread per column, workgroups stride over row blocks, atomics at the end
+__global__ __launch_bounds__(256) void colsum_kernel(const float* x, int M, int N, int ldx, float* out, int rows_per_blk) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int r0 = blockIdx.y * rows_per_blk;
+    const int r1 = min(M, r0 + rows_per_blk);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += x[(long long)r * ldx + n];
+    atomicAdd(out + n, s);
+}
+__global__ __launch_bounds__(256) void rowsum_kernel(const float* x, long long rows, int cols, float* out, int as_mask) {
+    // one wave per row
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long r = wave0; r < rows; r += nwaves) {
+        const float* p = x + r * cols;
+        float s = 0.f;
+        for (int c = lane; c < cols; c += 64) s += p[c];
+        s = wave_sum(s);
+        if (lane == 0) out[r] = as_mask ? (s != 0.f ? 1.f : 0.f) : s;
+    }
+}
+
+// ------------------------------------------------------------------ element-wise
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* dy, const float* y, float* dz, long long n, int act) {
+    GS_LOOP(i, n) dz[i] = dy[i] * act_grad_from_out(y[i], act);
+}
+__global__ __launch_bounds__(256) void dropout_kernel(const float* x, float* y, long long n, float p, float inv_keep,
+                                                      uint64_t seed) {
+    GS_LOOP(i, n) y[i] = x[i] * dropout_scale(seed, (uint64_t)i, p, inv_keep);
+}
+__global__ __launch_bounds__(256) void axpby_kernel(const float* x, const float* y, float* out, long long n, float a, float b) {
+    GS_LOOP(i, n) out[i] = y ? a * x[i] + b * y[i] : a * x[i];
+}
+__global__ __launch_bounds__(256) void mul_kernel(const float* x, const float* y, float* out, long long n) {
+    GS_LOOP(i, n) out[i] = x[i] * y[i];
+}
+__global__ __launch_bounds__(256) void expand_rows_kernel(const float* q, const float* mask, long long rows, int group,
+                                                          int qrows, int cols, float* out) {
+    const long long n = rows * cols;
+    GS_LOOP(i, n) {
+        const long long r = i / cols;
+        const int c = (int)(i % cols);
+        out[i] = mask[r] * q[((r / group) % qrows) * cols + c];
+    }
+}
+__global__ __launch_bounds__(256) void expand_rows_bwd_kernel(const float* dout, const float* mask, long long rows,
+                                                              int group, int qrows, int cols, float* dq) {
+    const long long G = rows / group;            // row groups; group g reads q row (g % qrows)
+    const long long n = (long long)qrows * cols;
+    GS_LOOP(i, n) {
+        const long long qr = i / cols;
+        const int c = (int)(i % cols);
+        float s = 0.f;
+        for (long long g = qr; g < G; g += qrows)
+            for (int k = 0; k < group; ++k) {
+                const long long r = g * group + k;
+                s += mask[r] * dout[r * cols + c];
+            }
+        dq[i] = s;
+    }
+}
+__global__ __launch_bounds__(256) void residual_relu2_fwd_kernel(const float* v, const float* o, float* vnew, long long n,
+                                                                 float p, float inv_keep, uint64_t seed) {
+    GS_LOOP(i, n) {
+        const float t = (o[i] + o[i]) * dropout_scale(seed, (uint64_t)i, p, inv_keep);
+        vnew[i] = v[i] + (t > 0.f ? t : 0.f);
+    }
+}
+__global__ __launch_bounds__(256) void residual_relu2_bwd_kernel(const float* o, const float* dvnew, float* d_o, long long n,
+                                                                 float p, float inv_keep, uint64_t seed) {
+    GS_LOOP(i, n) {
+        const float k = dropout_scale(seed, (uint64_t)i, p, inv_keep);
+        const float t = (o[i] + o[i]) * k;
+        d_o[i] = t > 0.f ? dvnew[i] * 2.f * k : 0.f;
+    }
+}
+// out = drop(sigmoid(g2 + g1)) * drop(tanh(c2 + c1)); c1/g1 (n1 elements: the terms shared by both images) broadcast over
+// n = rep * n1 elements of c2/g2
+__global__ __launch_bounds__(256) void gate_fuse_fwd_kernel(const float* c2, const float* g2, const float* c1, const float* g1,
+                                                            float* out, long long n, long long n1, float p, float inv_keep,
+                                                            uint64_t seed_c, uint64_t seed_g) {
+    GS_LOOP(i, n) {
+        const long long j = i % n1;
+        const float c = tanhf(c2[i] + c1[j]) * dropout_scale(seed_c, (uint64_t)i, p, inv_keep);
+        const float g = (1.f / (1.f + expf(-(g2[i] + g1[j])))) * dropout_scale(seed_g, (uint64_t)i, p, inv_keep);
+        out[i] = g * c;
+    }
+}
+__global__ __launch_bounds__(256) void gate_fuse_bwd_kernel(const float* c2, const float* g2, const float* c1, const float* g1,
+                                                            const float* dout, float* dc2, float* dg2, float* dc1, float* dg1,
+                                                            long long n, long long n1, float p, float inv_keep, uint64_t seed_c,
+                                                            uint64_t seed_g) {
+    GS_LOOP(j, n1) {
+        float sc = 0.f, sg = 0.f;
+        for (long long i = j; i < n; i += n1) {
+            const float kc = dropout_scale(seed_c, (uint64_t)i, p, inv_keep);
+            const float kg = dropout_scale(seed_g, (uint64_t)i, p, inv_keep);
+            const float tc = tanhf(c2[i] + c1[j]);
+            const float sgm = 1.f / (1.f + expf(-(g2[i] + g1[j])));
+            const float d = dout[i];
+            const float dc = d * (sgm * kg) * kc * (1.f - tc * tc);
+            const float dg = d * (tc * kc) * kg * sgm * (1.f - sgm);
+            dc2[i] = dc; dg2[i] = dg;
+            sc += dc; sg += dg;
+        }
+        dc1[j] = sc; dg1[j] = sg;
+    }
+}
+
+// ------------------------------------------------------------------ weighted pooling  out[g][c] = sum_i w[g][i] x[g][i][c]
+__global__ __launch_bounds__(256) void weighted_pool_fwd_kernel(const float* w, const float* x, int G, int n, int C, float* out) {
+    const long long total = (long long)G * C;
+    GS_LOOP(i, total) {
+        const long long g = i / C;
+        const int c = (int)(i % C);
+        const float* xp = x + g * n * C + c;
+        const float* wp = w + g * n;
+        float s = 0.f;
+        for (int k = 0; k < n; ++k) s += wp[k] * xp[(long long)k * C];
+        out[i] = s;
+    }
+}
+// dx[g][i][c] = w[g][i] * dout[g][c];  dw[g][i] = sum_c x[g][i][c] * dout[g][c]   (one wave per (g,i))
+__global__ __launch_bounds__(256) void weighted_pool_bwd_kernel(const float* w, const float* x, const float* dout, int G, int n,
+                                                                int C, float* dw, float* dx) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const long long rows = (long long)G * n;
+    for (long long r = wave0; r < rows; r += nwaves) {
+        const long long g = r / n;
+        const float wv = w[r];
+        const float* xp = x + r * C;
+        const float* dp = dout + g * C;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float d = dp[c];
+            s += xp[c] * d;
+            dx[r * C + c] = wv * d;
+        }
+        s = wave_sum(s);
+        if (lane == 0) dw[r] = s;
+    }
+}
+
+// ------------------------------------------------------------------ question attention weights (quirk Q-C)
+// S[l][b] = softmax over b of atten[b][l];  weight[j] = S_flat[j]  (weight viewed (B,L), S viewed (L,B))
+__global__ __launch_bounds__(64) void qatt_weights_fwd_kernel(const float* atten, int B, int L, float* S, float* weight) {
+    const int l = blockIdx.x, lane = threadIdx.x;
+    float mx = -INFINITY;
+    for (int b = lane; b < B; b += 64) mx = fmaxf(mx, atten[(long long)b * L + l]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int b = lane; b < B; b += 64) s += expf(atten[(long long)b * L + l] - mx);
+    s = wave_sum(s);
+    for (int b = lane; b < B; b += 64) {
+        const float v = expf(atten[(long long)b * L + l] - mx) / s;
+        S[(long long)l * B + b] = v;
+        weight[(long long)l * B + b] = v;      // same flat memory order: the (B,L) view re-reads it
+    }
+}
+__global__ __launch_bounds__(64) void qatt_weights_bwd_kernel(const float* S, const float* dweight, int B, int L, float* datten) {
+    const int l = blockIdx.x, lane = threadIdx.x;
+    float dot = 0.f;
+    for (int b = lane; b < B; b += 64) dot += S[(long long)l * B + b] * dweight[(long long)l * B + b];
+    dot = wave_sum(dot);
+    for (int b = lane; b < B; b += 64) {
+        const float sv = S[(long long)l * B + b];
+        datten[(long long)b * L + l] = sv * (dweight[(long long)l * B + b] - dot);
+    }
+}
+
+// ------------------------------------------------------------------ embedding
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* tok, long long ntok, const float* table, int E,
+                                                            float* out, int ld_out, int col_off, int relu) {
+    const long long n = ntok * E;
+    GS_LOOP(i, n) {
+        const long long t = i / E;
+        const int e = (int)(i % E);
+        float v = table[tok[t] * E + e];
+        if (relu) v = v > 0.f ? v : 0.f;
+        out[t * ld_out + col_off + e] = v;
+    }
+}
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* tok, long long ntok, const float* table,
+                                                            const float* dout, int E, int ld_out, int col_off, int relu,
+                                                            long long padding_idx, float* dtable) {
+    const long long n = ntok * E;
+    GS_LOOP(i, n) {
+        const long long t = i / E;
+        const int e = (int)(i % E);
+        const int64_t id = tok[t];
+        if (id == padding_idx) continue;
+        float d = dout[t * ld_out + col_off + e];
+        if (relu && !(table[id * E + e] > 0.f)) d = 0.f;
+        atomicAdd(dtable + id * E + e, d);
+    }
+}
+
+// ------------------------------------------------------------------ row softmax / log-softmax (one wave per row)
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* x, float* y, long long rows, int cols, int log_mode) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long r = wave0; r < rows; r += nwaves) {
+        const float* xp = x + r * cols;
+        float mx = -INFINITY;
+        for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, xp[c]);
+        mx = wave_max(mx);
+        float s = 0.f;
+        for (int c = lane; c < cols; c += 64) s += expf(xp[c] - mx);
+        s = wave_sum(s);
+        const float ls = logf(s);
+        for (int c = lane; c < cols; c += 64) {
+            const float t = xp[c] - mx;
+            y[r * cols + c] = log_mode ? t - ls : expf(t) / s;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* y, const float* dy, float* dx, long long rows, int cols,
+                                                          int log_mode) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long r = wave0; r < rows; r += nwaves) {
+        const float* yp = y + r * cols;
+        const float* dp = dy + r * cols;
+        float s = 0.f;
+        for (int c = lane; c < cols; c += 64) s += log_mode ? dp[c] : dp[c] * yp[c];
+        s = wave_sum(s);
+        for (int c = lane; c < cols; c += 64)
+            dx[r * cols + c] = log_mode ? dp[c] - expf(yp[c]) * s : yp[c] * (dp[c] - s);
+    }
+}
+
+// ------------------------------------------------------------------ mix3
+__global__ __launch_bounds__(256) void mix3_fwd_kernel(const float* w, const float* a, const float* b, const float* c, int B,
+                                                       int C, float* out) {
+    const long long n = (long long)B * C;
+    GS_LOOP(i, n) {
+        const long long r = i / C;
+        out[i] = w[r * 3] * a[i] + w[r * 3 + 1] * b[i] + w[r * 3 + 2] * c[i];
+    }
+}
+__global__ __launch_bounds__(256) void mix3_bwd_kernel(const float* w, const float* a, const float* b, const float* c,
+                                                       const float* dout, int B, int C, float* dw, float* da, float* db,
+                                                       float* dc) {
+    // one wave per row
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long r = wave0; r < B; r += nwaves) {
+        const float w0 = w[r * 3], w1 = w[r * 3 + 1], w2 = w[r * 3 + 2];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int k = lane; k < C; k += 64) {
+            const long long i = r * C + k;
+            const float d = dout[i];
+            s0 += d * a[i]; s1 += d * b[i]; s2 += d * c[i];
+            da[i] = w0 * d; db[i] = w1 * d; dc[i] = w2 * d;
+        }
+        s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (lane == 0) { dw[r * 3] = s0; dw[r * 3 + 1] = s1; dw[r * 3 + 2] = s2; }
+    }
+}
+
+// ------------------------------------------------------------------ masked NLL
+__global__ __launch_bounds__(256) void nll_fwd_kernel(const float* logp, const int64_t* target, int ld_t, const float* mask,
+                                                      int ld_m, int B, int T, int V, float* sums) {
+    float s = 0.f, ms = 0.f;
+    const long long n = (long long)B * T;
+    GS_LOOP(i, n) {
+        const long long b = i / T;
+        const int t = (int)(i % T);
+        const float mk = mask[b * ld_m + t];
+        const int64_t tg = target[b * ld_t + t];
+        s -= logp[(b * T + t) * V + tg] * mk;
+        ms += mk;
+    }
+    s = wave_sum(s); ms = wave_sum(ms);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(sums, s); atomicAdd(sums + 1, ms); }
+}
+__global__ __launch_bounds__(256) void nll_bwd_kernel(const int64_t* target, int ld_t, const float* mask, int ld_m,
+                                                      const float* sums, const float* gscale, int B, int T, int V, float* dlogp) {
+    const long long n = (long long)B * T * V;
+    const float sc = -gscale[0] / sums[1];
+    GS_LOOP(i, n) {
+        const int v = (int)(i % V);
+        const long long bt = i / V;
+        const long long b = bt / T;
+        const int t = (int)(bt % T);
+        dlogp[i] = (target[b * ld_t + t] == v) ? sc * mask[b * ld_m + t] : 0.f;
+    }
+}
+
+__global__ void nll_finish_kernel(const float* sums, float* loss) { loss[0] = sums[0] / sums[1]; }
+__global__ __launch_bounds__(256) void total_loss_kernel(const float* sl, const float* a, const float* b, long long n, float coef,
+                                                         float* out) {
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 256) s += a[i] + b[i];
+    s = wave_sum(s);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = sl[0] + coef * (part[0] + part[1] + part[2] + part[3]);
+}
+__global__ __launch_bounds__(256) void fill_scaled_kernel(const float* scalar, float coef, float* out, long long n) {
+    const float v = scalar[0] * coef;
+    GS_LOOP(i, n) out[i] = v;
+}
+
+// ------------------------------------------------------------------ LayerNorm (one wave per row)
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, const float* gamma, const float* beta, long long rows,
+                                                            int cols, float eps, float* y, float* save) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long r = wave0; r < rows; r += nwaves) {
+        const float* xp = x + r * cols;
+        float s = 0.f;
+        for (int c = lane; c < cols; c += 64) s += xp[c];
+        const float mean = wave_sum(s) / cols;
+        float q = 0.f;
+        for (int c = lane; c < cols; c += 64) { const float d = xp[c] - mean; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) / cols + eps);
+        for (int c = lane; c < cols; c += 64) y[r * cols + c] = (xp[c] - mean) * rstd * gamma[c] + beta[c];
+        if (lane == 0) { save[r * 2] = mean; save[r * 2 + 1] = rstd; }
+    }
+}
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* x, const float* gamma, const float* save, const float* dy,
+                                                            long long rows, int cols, float* dx, float* dgamma, float* dbeta) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long r = wave0; r < rows; r += nwaves) {
+        const float mean = save[r * 2], rstd = save[r * 2 + 1];
+        const float* xp = x + r * cols;
+        const float* dp = dy + r * cols;
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = lane; c < cols; c += 64) {
+            const float xh = (xp[c] - mean) * rstd;
+            const float g = dp[c] * gamma[c];
+            s1 += g; s2 += g * xh;
+            atomicAdd(dgamma + c, dp[c] * xh);
+            atomicAdd(dbeta + c, dp[c]);
+        }
+        s1 = wave_sum(s1) / cols; s2 = wave_sum(s2) / cols;
+        for (int c = lane; c < cols; c += 64) {
+            const float xh = (xp[c] - mean) * rstd;
+            dx[r * cols + c] = rstd * (dp[c] * gamma[c] - s1 - xh * s2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ label matrix -> one-hot adjacency
+// ref: utils/mimic_utils.py:119-149.  adj: [B][S][S] (float64 as collated, or int64), cropped to NxN.
+template <typename T>
+__global__ __launch_bounds__(256) void process_matrix_kernel(const T* adj, int B, int S, int N, int L, float* out) {
+    const long long n = (long long)B * N * N * L;
+    GS_LOOP(i, n) {
+        const int l = (int)(i % L);
+        long long rest = i / L;
+        const int j = (int)(rest % N); rest /= N;
+        const int ii = (int)(rest % N);
+        const long long b = rest / N;
+        const T v = adj[(b * S + ii) * S + j];
+        out[i] = (v == (T)(l + 1)) ? 1.f : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------ Adam
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long long n, float lr_bc1,
+                                                   float beta1, float beta2, float eps, float inv_sqrt_bc2, float gscale) {
+    GS_LOOP(i, n) {
+        const float gr = g[i] * gscale;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gr;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gr * gr;
+        m[i] = mi; v[i] = vi;
+        p[i] -= lr_bc1 * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+}
+
+// scratch for the double-precision reductions (one slot per stream-ordered call; zeroed by memsetAsync)
+static double* reduction_scratch() {
+    static double* buf = nullptr;
+    if (!buf) {
+        if (hipMalloc(&buf, 64 * sizeof(double)) != hipSuccess) return nullptr;
+    }
+    return buf;
+}
+
+}  // namespace ekaid
+
+using namespace ekaid;
+#define ST ((hipStream_t)stream)
+#define INVK(p) ((p) > 0.f ? 1.f / (1.f - (p)) : 1.f)
+
+extern "C" int ekaid_wn_scale_fwd(const float* v, const float* g, long long n, float* scale_out, float* norm_out, void* stream) {
+    double* acc = reduction_scratch();
+    if (!acc) { set_error("wn_scale_fwd: scratch alloc failed"); return EKAID_ERR_LAUNCH; }
+    // NOTE: the scratch is allocated once at first use (outside any graph capture: ekaid_amd.hip warms it up)
+    (void)hipMemsetAsync(acc, 0, sizeof(double), ST);
+    hipLaunchKernelGGL(sumsq_kernel, grid1d(n, 4), dim3(256), 0, ST, v, n, acc);
+    hipLaunchKernelGGL(wn_finish_kernel, dim3(1), dim3(1), 0, ST, acc, g, scale_out, norm_out);
+    return check_launch("wn_scale_fwd");
+}
+extern "C" int ekaid_wn_scale_bwd(const float* v, const float* g, const float* norm, const float* dscale, long long n,
+                                  float* dv, int accumulate_dv, float* dg, void* stream) {
+    hipLaunchKernelGGL(wn_bwd_kernel, grid1d(n), dim3(256), 0, ST, v, g, norm, dscale, n, dv, accumulate_dv, dg);
+    return check_launch("wn_scale_bwd");
+}
+extern "C" int ekaid_scale_dot(float* G, const float* w, const float* scale_dev, long long n, float* dot_out, void* stream) {
+    double* acc = reduction_scratch();
+    if (!acc) { set_error("scale_dot: scratch alloc failed"); return EKAID_ERR_LAUNCH; }
+    (void)hipMemsetAsync(acc + 8, 0, sizeof(double), ST);
+    hipLaunchKernelGGL(dot_kernel, grid1d(n, 4), dim3(256), 0, ST, (const float*)G, w, n, acc + 8);
+    hipLaunchKernelGGL(scale_finish_kernel, grid1d(n), dim3(256), 0, ST, G, scale_dev, n, (const double*)(acc + 8), dot_out);
+    return check_launch("scale_dot");
+}
+extern "C" int ekaid_colsum(const float* x, int M, int N, int ldx, float* out, void* stream) {
+    (void)hipMemsetAsync(out, 0, sizeof(float) * N, ST);
+    if (M <= 0 || N <= 0) return EKAID_OK;
+    const int rows_per_blk = 128;
+    dim3 grid(cdiv(N, 256), cdiv(M, rows_per_blk));
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, ST, x, M, N, ldx, out, rows_per_blk);
+    return check_launch("colsum");
+}
+extern "C" int ekaid_act_bwd(const float* dy, const float* y, float* dz, long long n, int act, void* stream) {
+    hipLaunchKernelGGL(act_bwd_kernel, grid1d(n), dim3(256), 0, ST, dy, y, dz, n, act);
+    return check_launch("act_bwd");
+}
+extern "C" int ekaid_dropout(const float* x, float* y, long long n, float p, uint64_t seed, void* stream) {
+    if (p < 0.f || p >= 1.f) { set_error("dropout: p=%f out of range", p); return EKAID_ERR_ARG; }
+    hipLaunchKernelGGL(dropout_kernel, grid1d(n), dim3(256), 0, ST, x, y, n, p, INVK(p), seed);
+    return check_launch("dropout");
+}
+extern "C" int ekaid_axpby(const float* x, const float* y, float* out, long long n, float a, float b, void* stream) {
+    hipLaunchKernelGGL(axpby_kernel, grid1d(n), dim3(256), 0, ST, x, y, out, n, a, b);
+    return check_launch("axpby");
+}
+extern "C" int ekaid_mul(const float* x, const float* y, float* out, long long n, void* stream) {
+    hipLaunchKernelGGL(mul_kernel, grid1d(n), dim3(256), 0, ST, x, y, out, n);
+    return check_launch("mul");
+}
+extern "C" int ekaid_rowsum(const float* x, long long rows, int cols, float* out, int as_nonzero_mask, void* stream) {
+    hipLaunchKernelGGL(rowsum_kernel, grid1d(rows * 64), dim3(256), 0, ST, x, rows, cols, out, as_nonzero_mask);
+    return check_launch("rowsum");
+}
+extern "C" int ekaid_expand_rows_fwd(const float* q, const float* mask, long long rows, int group, int qrows, int cols, float* out,
+                                     void* stream) {
+    if (group < 1 || qrows < 1 || rows % group) { set_error("expand_rows: rows %% group != 0"); return EKAID_ERR_ARG; }
+    hipLaunchKernelGGL(expand_rows_kernel, grid1d(rows * cols), dim3(256), 0, ST, q, mask, rows, group, qrows, cols, out);
+    return check_launch("expand_rows_fwd");
+}
+extern "C" int ekaid_expand_rows_bwd(const float* dout, const float* mask, long long rows, int group, int qrows, int cols, float* dq,
+                                     void* stream) {
+    if (group < 1 || qrows < 1 || rows % group) { set_error("expand_rows: rows %% group != 0"); return EKAID_ERR_ARG; }
+    hipLaunchKernelGGL(expand_rows_bwd_kernel, grid1d((long long)qrows * cols), dim3(256), 0, ST, dout, mask, rows, group, qrows, cols, dq);
+    return check_launch("expand_rows_bwd");
+}
+extern "C" int ekaid_residual_relu2_fwd(const float* v, const float* o, float* vnew, long long n, float p, uint64_t seed, void* stream) {
+    hipLaunchKernelGGL(residual_relu2_fwd_kernel, grid1d(n), dim3(256), 0, ST, v, o, vnew, n, p, INVK(p), seed);
+    return check_launch("residual_relu2_fwd");
+}
+extern "C" int ekaid_residual_relu2_bwd(const float* o, const float* dvnew, float* d_o, long long n, float p, uint64_t seed, void* stream) {
+    hipLaunchKernelGGL(residual_relu2_bwd_kernel, grid1d(n), dim3(256), 0, ST, o, dvnew, d_o, n, p, INVK(p), seed);
+    return check_launch("residual_relu2_bwd");
+}
+extern "C" int ekaid_gate_fuse_fwd(const float* c2, const float* g2, const float* c1, const float* g1, float* out, long long n,
+                                   long long n1, float p, uint64_t seed_c, uint64_t seed_g, void* stream) {
+    if (n1 < 1 || n % n1) { set_error("gate_fuse: n %% n1 != 0"); return EKAID_ERR_ARG; }
+    hipLaunchKernelGGL(gate_fuse_fwd_kernel, grid1d(n), dim3(256), 0, ST, c2, g2, c1, g1, out, n, n1, p, INVK(p), seed_c, seed_g);
+    return check_launch("gate_fuse_fwd");
+}
+extern "C" int ekaid_gate_fuse_bwd(const float* c2, const float* g2, const float* c1, const float* g1, const float* dout, float* dc2,
+                                   float* dg2, float* dc1, float* dg1, long long n, long long n1, float p, uint64_t seed_c,
+                                   uint64_t seed_g, void* stream) {
+    if (n1 < 1 || n % n1) { set_error("gate_fuse: n %% n1 != 0"); return EKAID_ERR_ARG; }
+    hipLaunchKernelGGL(gate_fuse_bwd_kernel, grid1d(n1), dim3(256), 0, ST, c2, g2, c1, g1, dout, dc2, dg2, dc1, dg1, n, n1, p, INVK(p),
+                       seed_c, seed_g);
+    return check_launch("gate_fuse_bwd");
+}
+extern "C" int ekaid_weighted_pool_fwd(const float* w, const float* x, int G, int n, int C, float* out, void* stream) {
+    hipLaunchKernelGGL(weighted_pool_fwd_kernel, grid1d((long long)G * C), dim3(256), 0, ST, w, x, G, n, C, out);
+    return check_launch("weighted_pool_fwd");
+}
+extern "C" int ekaid_weighted_pool_bwd(const float* w, const float* x, const float* dout, int G, int n, int C, float* dw,
+                                       float* dx, void* stream) {
+    hipLaunchKernelGGL(weighted_pool_bwd_kernel, grid1d((long long)G * n * 64), dim3(256), 0, ST, w, x, dout, G, n, C, dw, dx);
+    return check_launch("weighted_pool_bwd");
+}
+extern "C" int ekaid_qatt_weights_fwd(const float* atten, int B, int L, float* S_out, float* weight, void* stream) {
+    hipLaunchKernelGGL(qatt_weights_fwd_kernel, dim3(L), dim3(64), 0, ST, atten, B, L, S_out, weight);
+    return check_launch("qatt_weights_fwd");
+}
+extern "C" int ekaid_qatt_weights_bwd(const float* S, const float* dweight, int B, int L, float* datten, void* stream) {
+    hipLaunchKernelGGL(qatt_weights_bwd_kernel, dim3(L), dim3(64), 0, ST, S, dweight, B, L, datten);
+    return check_launch("qatt_weights_bwd");
+}
+extern "C" int ekaid_embedding_fwd(const int64_t* tok, long long ntok, const float* table, int E, float* out, int ld_out,
+                                   int col_off, int relu, void* stream) {
+    hipLaunchKernelGGL(embedding_fwd_kernel, grid1d(ntok * E), dim3(256), 0, ST, tok, ntok, table, E, out, ld_out, col_off, relu);
+    return check_launch("embedding_fwd");
+}
+extern "C" int ekaid_embedding_bwd(const int64_t* tok, long long ntok, const float* table, const float* dout, int E, int ld_out,
+                                   int col_off, int relu, long long padding_idx, float* dtable, void* stream) {
+    hipLaunchKernelGGL(embedding_bwd_kernel, grid1d(ntok * E), dim3(256), 0, ST, tok, ntok, table, dout, E, ld_out, col_off, relu,
+                       padding_idx, dtable);
+    return check_launch("embedding_bwd");
+}
+extern "C" int ekaid_softmax_fwd(const float* x, float* y, long long rows, int cols, int log_mode, void* stream) {
+    hipLaunchKernelGGL(softmax_fwd_kernel, grid1d(rows * 64), dim3(256), 0, ST, x, y, rows, cols, log_mode);
+    return check_launch("softmax_fwd");
+}
+extern "C" int ekaid_softmax_bwd(const float* y, const float* dy, float* dx, long long rows, int cols, int log_mode, void* stream) {
+    hipLaunchKernelGGL(softmax_bwd_kernel, grid1d(rows * 64), dim3(256), 0, ST, y, dy, dx, rows, cols, log_mode);
+    return check_launch("softmax_bwd");
+}
+extern "C" int ekaid_mix3_fwd(const float* w, const float* a, const float* b, const float* c, int B, int C, float* out, void* stream) {
+    hipLaunchKernelGGL(mix3_fwd_kernel, grid1d((long long)B * C), dim3(256), 0, ST, w, a, b, c, B, C, out);
+    return check_launch("mix3_fwd");
+}
+extern "C" int ekaid_mix3_bwd(const float* w, const float* a, const float* b, const float* c, const float* dout, int B, int C,
+                              float* dw, float* da, float* db, float* dc, void* stream) {
+    hipLaunchKernelGGL(mix3_bwd_kernel, grid1d((long long)B * 64), dim3(256), 0, ST, w, a, b, c, dout, B, C, dw, da, db, dc);
+    return check_launch("mix3_bwd");
+}
+extern "C" int ekaid_nll_fwd(const float* logp, const int64_t* target, int ld_target, const float* mask, int ld_mask, int B, int T,
+                             int V, float* sums, float* loss_out, void* stream) {
+    hipLaunchKernelGGL(nll_fwd_kernel, grid1d((long long)B * T), dim3(256), 0, ST, logp, target, ld_target, mask, ld_mask, B, T, V, sums);
+    hipLaunchKernelGGL(nll_finish_kernel, dim3(1), dim3(1), 0, ST, (const float*)sums, loss_out);
+    return check_launch("nll_fwd");
+}
+extern "C" int ekaid_total_loss_fwd(const float* speaker_loss, const float* att_bef, const float* att_aft, long long n, float coef,
+                                    float* out, void* stream) {
+    hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(256), 0, ST, speaker_loss, att_bef, att_aft, n, coef, out);
+    return check_launch("total_loss_fwd");
+}
+extern "C" int ekaid_fill_scaled(const float* scalar_dev, float coef, float* out, long long n, void* stream) {
+    hipLaunchKernelGGL(fill_scaled_kernel, grid1d(n), dim3(256), 0, ST, scalar_dev, coef, out, n);
+    return check_launch("fill_scaled");
+}
+extern "C" int ekaid_nll_bwd(const int64_t* target, int ld_target, const float* mask, int ld_mask, const float* sums,
+                             const float* gscale_dev, int B, int T, int V, float* dlogp, void* stream) {
+    hipLaunchKernelGGL(nll_bwd_kernel, grid1d((long long)B * T * V), dim3(256), 0, ST, target, ld_target, mask, ld_mask, sums,
+                       gscale_dev, B, T, V, dlogp);
+    return check_launch("nll_bwd");
+}
+extern "C" int ekaid_layernorm_fwd(const float* x, const float* gamma, const float* beta, long long rows, int cols, float eps,
+                                   float* y, float* save, void* stream) {
+    hipLaunchKernelGGL(layernorm_fwd_kernel, grid1d(rows * 64), dim3(256), 0, ST, x, gamma, beta, rows, cols, eps, y, save);
+    return check_launch("layernorm_fwd");
+}
+extern "C" int ekaid_layernorm_bwd(const float* x, const float* gamma, const float* save, const float* dy, long long rows, int cols,
+                                   float* dx, float* dgamma, float* dbeta, void* stream) {
+    (void)hipMemsetAsync(dgamma, 0, sizeof(float) * cols, ST);
+    (void)hipMemsetAsync(dbeta, 0, sizeof(float) * cols, ST);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, grid1d(rows * 64), dim3(256), 0, ST, x, gamma, save, dy, rows, cols, dx, dgamma, dbeta);
+    return check_launch("layernorm_bwd");
+}
+extern "C" int ekaid_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                               float eps, int step, float grad_scale, void* stream) {
+    if (step < 1) { set_error("adam_step: step must be >= 1"); return EKAID_ERR_ARG; }
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, grid1d(n), dim3(256), 0, ST, p, g, m, v, n, (float)(lr / bc1), beta1, beta2, eps,
+                       (float)(1.0 / sqrt(bc2)), grad_scale);
+    return check_launch("adam_step");
+}
+extern "C" int ekaid_process_matrix(const void* adj, int is_int64, int B, int S, int N, int L, float* out, void* stream) {
+    if (N > S || N < 1 || L < 1) { set_error("process_matrix: bad dims N=%d S=%d L=%d", N, S, L); return EKAID_ERR_ARG; }
+    const long long n = (long long)B * N * N * L;
+    if (is_int64)
+        hipLaunchKernelGGL(process_matrix_kernel<long long>, grid1d(n), dim3(256), 0, ST, (const long long*)adj, B, S, N, L, out);
+    else
+        hipLaunchKernelGGL(process_matrix_kernel<double>, grid1d(n), dim3(256), 0, ST, (const double*)adj, B, S, N, L, out);
+    return check_launch("process_matrix");
+}

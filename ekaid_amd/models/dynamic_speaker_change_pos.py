@@ -1,0 +1,209 @@
+"""``DynamicCore`` / ``DynamicSpeaker`` -- mirror of reference
+``models/dynamic_speaker_change_pos.py:42-357`` (the answer decoder: module-attention LSTMCell, POS
+branch, gate MLP, language LSTMCell, ``logit`` + log-softmax per step).
+
+Same constructors, ``_forward`` / ``_sample`` / ``get_logprobs_state`` / ``get_module_weights`` signatures,
+``ss_prob`` attribute and ``state_dict`` keys.  Differences that do not change results:
+  * the loop-invariant ``core.embed`` Linear+ReLU is computed once per sequence (the reference recomputes
+    it every step, :98-99); its Dropout is still drawn per step;
+  * ``torch.cat`` inputs of the LSTM cells / gate MLP are fed as split-K GEMMs, never materialised;
+  * the teacher-forced loop length is found with ONE host synchronisation instead of one per step (:213).
+Not supported (outside the path): scheduled sampling (``ss_prob > 0``: inactive with the shipped
+config, config.py:137), beam search (``beam_size > 1``: broken in the reference, :273).
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..hip import ACT_NONE, ACT_RELU, ACT_SIGMOID
+from .CaptionModel import CaptionModel
+from .fc import Linear
+
+
+class TokenEmbedding(nn.Embedding):
+    """nn.Embedding parameters; lookup (+ fused ReLU) through the HIP kernel."""
+
+    def forward(self, it, relu=False):
+        return ops.embedding(it, [self.weight], relu=relu, padding_idx=-1)
+
+
+class DynamicCore(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        sp = cfg.model.speaker
+        self.rnn_num_layers = 2
+        self.drop_prob_lm = sp.drop_prob_lm
+        self.input_dim = sp.input_dim
+        self.embed_input_dim = sp.embed_input_dim
+        self.embed_dim = sp.embed_dim
+        self.rnn_size = sp.rnn_size
+
+        self.embed = nn.Sequential(Linear(self.embed_input_dim, self.embed_dim), nn.ReLU(), nn.Dropout(self.drop_prob_lm))
+        self.module_att_lstm = nn.LSTMCell(self.embed_dim + sp.rnn_size, sp.rnn_size)
+        self.weight_fc = nn.Sequential(Linear(sp.rnn_size, 3), nn.Softmax(dim=1))
+        self.pos1 = nn.Sequential(Linear(512, 512), nn.ReLU(), nn.Dropout(self.drop_prob_lm))
+        self.softmax = nn.Softmax(dim=1)
+        self.dropout = nn.Dropout(0.5)
+        self.weight_pos = Linear(sp.rnn_size, 16)
+        self.pos2 = Linear(16, sp.rnn_size)
+        self.gate1x = nn.Sequential(Linear(sp.rnn_size * 2 + sp.input_dim, sp.rnn_size * 2 + sp.input_dim), nn.ReLU(),
+                                    nn.Dropout(self.drop_prob_lm))
+        self.gate2x = Linear(sp.rnn_size * 2 + sp.input_dim, sp.input_dim)
+        self.lang_lstm = nn.LSTMCell(sp.word_embed_size + sp.input_dim, sp.rnn_size)
+        self.module_weights = None
+
+    def embed_pre(self, loc_feat_bef, loc_feat_aft, feat_diff):
+        """Linear + ReLU of ``self.embed`` on [bef | diff | aft] (loop invariant; dropout applied per step)."""
+        return self.embed[0]((loc_feat_bef, feat_diff, loc_feat_aft), ACT_RELU)
+
+    @staticmethod
+    def _lstm(cell, xs, h, c):
+        gx = ops.linear(xs, cell.weight_ih, cell.bias_ih)
+        gh = ops.linear(h, cell.weight_hh, cell.bias_hh)
+        return ops.LSTMCellFn.apply(gx, gh, c)
+
+    def forward(self, xt, loc_feat_bef, loc_feat_aft, feat_diff, state, embed_pre=None):
+        prev_h = state[0][-1]                                   # hidden state of the lang_lstm
+        if embed_pre is None:
+            embed_pre = self.embed_pre(loc_feat_bef, loc_feat_aft, feat_diff)
+        embed = ops.dropout(embed_pre, self.drop_prob_lm, self.training)
+        h_mod_att, c_mod_att = self._lstm(self.module_att_lstm, (embed, prev_h), state[0][0], state[1][0])
+        module_weights = ops.softmax(self.weight_fc[0](h_mod_att))
+        self.module_weights = module_weights
+
+        vpos = ops.dropout(self.pos1[0](prev_h, ACT_RELU), self.drop_prob_lm, self.training)
+        dpos = ops.dropout(self.weight_pos(vpos), self.dropout.p, self.training)
+        ppos = self.pos2(ops.softmax(dpos))
+
+        att_feat = ops.Mix3Fn.apply(module_weights, loc_feat_bef, feat_diff, loc_feat_aft)
+        g1 = ops.dropout(self.gate1x[0]((prev_h, ppos, att_feat), ACT_RELU), self.drop_prob_lm, self.training)
+        gate = self.gate2x(g1, ACT_SIGMOID)
+        gated_att_feat = ops.mul(gate, att_feat)
+
+        h_lang, c_lang = self._lstm(self.lang_lstm, (xt, gated_att_feat), state[0][1], state[1][1])
+        output = ops.dropout(h_lang, self.drop_prob_lm, self.training)
+        state = ((h_mod_att, h_lang), (c_mod_att, c_lang))
+        return output, state, dpos
+
+    def get_module_weights(self):
+        return self.module_weights
+
+
+class DynamicSpeaker(CaptionModel):
+    def __init__(self, cfg, vocab_size=0):
+        super().__init__()
+        sp = cfg.model.speaker
+        self.vocab_size = sp.vocab_size if vocab_size == 0 else vocab_size
+        self.word_embed_size = sp.word_embed_size
+        self.rnn_size = sp.rnn_size
+        self.drop_prob_lm = sp.drop_prob_lm
+        self.seq_length = sp.seq_length
+        self.ss_prob = 0.0  # Scheduled sampling probability
+
+        self.embed = nn.Sequential(TokenEmbedding(self.vocab_size, self.word_embed_size), nn.ReLU(),
+                                   nn.Dropout(self.drop_prob_lm))
+        self.core = DynamicCore(cfg)
+        self.rnn_num_layers = self.core.rnn_num_layers
+        self.logit_layers = getattr(sp, 'logit_layers', 1) if not isinstance(sp, dict) else sp.get('logit_layers', 1)
+        if self.logit_layers != 1:
+            raise NotImplementedError('logit_layers > 1 is not configured anywhere in the reference')
+        self.logit = Linear(self.rnn_size, self.vocab_size)
+        self.module_weights = []
+
+    def init_hidden(self, batch_size):
+        """((h_att, h_lang), (c_att, c_lang)); indexable like the reference's stacked (2, B, rnn) tensors."""
+        weight = self.logit.weight
+        z = weight.new_zeros(batch_size, self.rnn_size)
+        return ((z, z), (z, z))
+
+    def _word(self, it):
+        return ops.dropout(self.embed[0](it, relu=True), self.drop_prob_lm, self.training)
+
+    def _forward(self, feat_bef, feat_aft, feat_diff, seq):
+        self.module_weights = []
+        if self.training and self.ss_prob > 0.0:
+            raise NotImplementedError('scheduled sampling (ss_prob > 0) is outside the EKAID path')
+        batch_size = feat_bef.size(0)
+        state = self.init_hidden(batch_size)
+        # "break if all the sequences end" (:213) resolved with a single host read
+        nz = (seq[:, :self.seq_length] != 0).any(0).tolist()
+        steps = self.seq_length
+        for i in range(1, self.seq_length):
+            if not nz[i]:
+                steps = i
+                break
+        embed_pre = self.core.embed_pre(feat_bef, feat_aft, feat_diff)
+        outs, outs_pos = [], []
+        for i in range(steps):
+            output, state, output_pos = self.get_logprobs_state(seq[:, i].contiguous(), feat_bef, feat_aft, feat_diff,
+                                                                state, embed_pre)
+            outs.append(output)
+            outs_pos.append(output_pos)
+        outputs = torch.stack(outs, 1)
+        outputs_pos = torch.stack(outs_pos, 1)
+        if steps < self.seq_length:      # the reference returns zero rows after the break
+            pad = self.seq_length - steps
+            outputs = torch.cat([outputs, outputs.new_zeros(batch_size, pad, self.vocab_size)], 1)
+            outputs_pos = torch.cat([outputs_pos, outputs_pos.new_zeros(batch_size, pad, 16)], 1)
+        return outputs, outputs_pos
+
+    def get_logprobs_state(self, it, feat_bef, feat_aft, feat_diff, state, embed_pre=None):
+        xt = self._word(it)
+        output, state, output_pos = self.core(xt, feat_bef, feat_aft, feat_diff, state, embed_pre)
+        self.module_weights.append(self.core.get_module_weights())
+        log_probs = ops.log_softmax(self.logit(output))
+        log_pos_probs = ops.log_softmax(output_pos)
+        return log_probs, state, log_pos_probs
+
+    def get_module_weights(self):
+        if len(self.module_weights) == 0:
+            print('no module weights accumulated')
+            return None
+        return torch.stack(self.module_weights, dim=1)
+
+    def _sample_beam(self, *args, **kwargs):
+        raise NotImplementedError('beam search is outside the EKAID path (beam_size == 1; the reference '
+                                  'implementation is broken, dynamic_speaker_change_pos.py:273)')
+
+    def _sample(self, feat_bef, feat_aft, feat_diff, seq, cfg={}, sample_max=0):
+        self.module_weights = []
+        sp = cfg.model.speaker if hasattr(cfg, 'model') else {}
+        beam_size = sp.get('beam_size', 1)
+        temperature = sp.get('temperature', 1.0)
+        decoding_constraint = sp.get('decoding_contraint', 0)
+        if beam_size > 1:
+            return self._sample_beam(feat_bef, feat_aft, feat_diff, cfg)
+        batch_size = feat_bef.size(0)
+        state = self.init_hidden(batch_size)
+        seq = feat_bef.new_zeros((batch_size, self.seq_length), dtype=torch.long)
+        seq_logprobs = feat_bef.new_zeros(batch_size, self.seq_length)
+        embed_pre = self.core.embed_pre(feat_bef, feat_aft, feat_diff)
+        unfinished = None
+        it = feat_bef.new_zeros(batch_size, dtype=torch.long) + 2          # <bos> hard-coded as id 2 (:311)
+        for t in range(self.seq_length + 1):
+            logprobs, state, _ = self.get_logprobs_state(it, feat_bef, feat_aft, feat_diff, state, embed_pre)
+            logprobs = logprobs.detach()
+            if t == 0:
+                logprobs = logprobs.clone()
+                logprobs[:, 0] = float('-inf')                              # never sample NULL first (:319-322)
+            if decoding_constraint and t > 0:
+                tmp = logprobs.new_zeros(logprobs.size())
+                tmp.scatter_(1, seq[:, t - 1].unsqueeze(1), float('-inf'))
+                logprobs = logprobs + tmp
+            if t == self.seq_length:
+                break
+            if sample_max:
+                sample_logprobs, it = torch.max(logprobs, 1)
+                it = it.view(-1).long()
+            else:
+                prob_prev = torch.exp(logprobs) if temperature == 1.0 else torch.exp(logprobs / temperature)
+                it = torch.multinomial(prob_prev, 1)
+                sample_logprobs = logprobs.gather(1, it)
+                it = it.view(-1).long()
+            unfinished = (it > 0) if t == 0 else unfinished * (it > 0)
+            it = it * unfinished.type_as(it)
+            seq[:, t] = it
+            seq_logprobs[:, t] = sample_logprobs.view(-1)
+            if unfinished.sum() == 0:
+                break
+        return seq, seq_logprobs

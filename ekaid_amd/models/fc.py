@@ -1,0 +1,76 @@
+"""``FCNet`` and the parameter-holding leaf layers of the path.
+
+Mirror of reference ``models/fc.py:15-49``: a stack of ``[Dropout] -> weight_norm(Linear, dim=None)
+-> [activation]``; same constructor, same ``state_dict`` keys (``main.<i>.bias``, ``main.<i>.weight_g``
+(scalar), ``main.<i>.weight_v``), same default initialisation (the parameters are drawn by the very
+``nn.Linear`` constructor the reference uses, so an identical torch seed gives identical weights).
+The arithmetic is ``ekaid_amd.ops`` (HIP); the reference's two NaN-assert host synchronisations per
+call (fc.py:42,45) are not reproduced.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..hip import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
+
+_ACT_CODE = {None: ACT_NONE, '': ACT_NONE, 'ReLU': ACT_RELU, 'Tanh': ACT_TANH, 'Sigmoid': ACT_SIGMOID}
+
+
+class Linear(nn.Linear):
+    """``nn.Linear`` parameters, HIP arithmetic. ``xs`` may be a tuple of tensors whose feature axes are
+    concatenated (replaces ``torch.cat`` + Linear of the reference)."""
+
+    def forward(self, xs, act=ACT_NONE):
+        return ops.linear(xs, self.weight, self.bias, None, act)
+
+
+class WNLinear(nn.Module):
+    """weight_norm(nn.Linear(in, out, bias), dim=None) with the old-style parameter names."""
+
+    def __init__(self, in_dim, out_dim, bias=True):
+        super().__init__()
+        lin = nn.Linear(in_dim, out_dim, bias=bias)          # same init / RNG draw as the reference
+        if bias:
+            self.bias = nn.Parameter(lin.bias.detach().clone())
+        else:
+            self.register_parameter('bias', None)
+        self.weight_g = nn.Parameter(torch.linalg.vector_norm(lin.weight.detach()).clone())
+        self.weight_v = nn.Parameter(lin.weight.detach().clone())
+        self.in_features, self.out_features = in_dim, out_dim
+
+    def forward(self, xs, act=ACT_NONE):
+        return ops.wn_linear(xs, self.weight_v, self.weight_g, self.bias, act)
+
+    def extra_repr(self):
+        return 'in_features=%d, out_features=%d, bias=%s' % (self.in_features, self.out_features,
+                                                             self.bias is not None)
+
+
+class FCNet(nn.Module):
+    """Simple class for non-linear fully connect network (reference docstring)."""
+
+    def __init__(self, dims, act='ReLU', dropout=0, bias=True):
+        super(FCNet, self).__init__()
+        if act not in _ACT_CODE:
+            raise ValueError('FCNet: unsupported activation %r' % (act,))
+        layers = []
+        for i in range(len(dims) - 1):
+            if 0 < dropout:
+                layers.append(nn.Dropout(dropout))           # marker: applied through ops.dropout
+            layers.append(WNLinear(dims[i], dims[i + 1], bias=bias))
+            if '' != act and act is not None:
+                layers.append(getattr(nn, act)())            # marker: fused into the GEMM epilogue
+        self.main = nn.Sequential(*layers)
+        self.act = _ACT_CODE[act]
+
+    def forward(self, x):
+        """``x``: tensor or tuple of tensors (feature-axis concatenation)."""
+        for layer in self.main:
+            if isinstance(layer, nn.Dropout):
+                if isinstance(x, (tuple, list)):
+                    x = tuple(ops.dropout(t, layer.p, self.training) for t in x)
+                else:
+                    x = ops.dropout(x, layer.p, self.training)
+            elif isinstance(layer, WNLinear):
+                x = layer(x, self.act)
+        return x

@@ -1,0 +1,206 @@
+"""``ChangeDetector`` (+ ``SelfAttention``, ``AddSpatialInfo``) -- mirror of reference
+``models/modules.py:17-332``: same constructor (``cfg``, ``word_to_idx``), same ``forward`` signature and
+6-tuple return, same ``state_dict`` keys and shapes (dead parameters ``SSRE.*`` / ``fc1.*`` /
+``*.neighbor_net.0.*`` / ``*.linear_out_.*`` included, so reference checkpoints load unchanged).
+
+MI355X mapping: the main and the reference image are stacked into one batch of R = 2B graph slices
+so that every dense contraction runs once over 2*B*N rows; all arithmetic is libekaid_hip.so.
+Behavioural quirks reproduced on purpose: Q-A chained residual encoders,
+Q-B surviving direction only, Q-C batch-coupled question attention, Q-D coefficients read from
+``cfg.model.change_detector``.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..hip import ACT_RELU, ACT_SIGMOID
+from .fc import Linear
+from .language_model import QuestionEmbedding, QuestionSelfAttention, WordEmbedding
+from .relation_encoder import ExplicitRelationEncoder, ImplicitRelationEncoder, q_expand_v_cat
+
+
+class SelfAttention(nn.Module):
+    """SSRE block (modules.py:17-77): Q/K/V Linear(2A -> A), 4-head softmax attention, dropout .1 on the
+    probabilities, LayerNorm(A, eps=1e-6), no residual.  Only reached with ``setting='mode0'``."""
+
+    def __init__(self, cfg):
+        super(SelfAttention, self).__init__()
+        cd = cfg.model.change_detector
+        if cd.att_dim % cd.att_head != 0:
+            raise ValueError("The hidden size (%d) is not a multiple of the number of attention "
+                             "heads (%d)" % (cd.att_dim, cd.att_head))
+        self.num_attention_heads = cd.att_head
+        self.attention_head_size = int(cd.att_dim / cd.att_head)
+        self.all_head_size = self.num_attention_heads * self.attention_head_size
+        self.query = Linear(cd.att_dim * 2, self.all_head_size)
+        self.key = Linear(cd.att_dim * 2, self.all_head_size)
+        self.value = Linear(cd.att_dim * 2, self.all_head_size)
+        self.dropout = nn.Dropout(0.1)
+        self.layer_norm = nn.LayerNorm(cd.att_dim, eps=1e-6)
+
+    def _heads(self, x, B, L):
+        # (B, L, nh*dh) -> (B*nh, L, dh)
+        return x.view(B, L, self.num_attention_heads, self.attention_head_size).permute(0, 2, 1, 3) \
+                .reshape(B * self.num_attention_heads, L, self.attention_head_size)
+
+    def forward(self, query_states, key_states, value_states, bl=None):
+        """Each state: tensor (B, L, 2A), or tuple (v (B*L, A), q_exp (B*L, A)) standing for the concat
+        (then ``bl = (B, L)`` must be given)."""
+        if isinstance(query_states, (tuple, list)):
+            B, L = bl
+        else:
+            B, L = query_states.shape[0], query_states.shape[1]
+        nh, dh = self.num_attention_heads, self.attention_head_size
+        q = self._heads(self.query(query_states).view(B, L, -1), B, L)
+        k = self._heads(self.key(key_states).view(B, L, -1), B, L)
+        v = self._heads(self.value(value_states).view(B, L, -1), B, L)
+        scores = ops.bmm(q, k, transB=True, alpha=1.0 / math.sqrt(dh))          # (B*nh, L, L)
+        probs = ops.dropout(ops.softmax(scores), self.dropout.p, self.training)
+        ctx = ops.bmm(probs, v)                                                   # (B*nh, L, dh)
+        ctx = ctx.view(B, nh, L, dh).permute(0, 2, 1, 3).reshape(B, L, self.all_head_size)
+        return ops.layer_norm(ctx, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+
+
+class ChangeDetector(nn.Module):
+
+    def __init__(self, cfg, word_to_idx):
+        super().__init__()
+        cd = cfg.model.change_detector
+        self.input_dim = cd.input_dim
+        self.dim = cd.dim
+        self.feat_dim = cd.feat_dim - 2
+        self.att_head = cd.att_head
+        self.att_dim = cd.att_dim
+        self.nongt_dim = cd.nongt_dim
+        self.pos_emb_dim = cd.pos_emb_dim
+
+        self.img = Linear(self.feat_dim, self.att_dim)
+        self.SSRE = SelfAttention(cfg)
+        self.context1 = Linear(self.att_dim, self.att_dim, bias=False)
+        self.context2 = Linear(self.att_dim, self.att_dim)
+        self.gate1 = Linear(self.att_dim, self.att_dim, bias=False)
+        self.gate2 = Linear(self.att_dim, self.att_dim)
+        self.dropout = nn.Dropout(0.5)
+        self.embed = nn.Sequential(Linear(self.att_dim * 3, self.dim), nn.Dropout(0.5), nn.ReLU())
+        self.att = Linear(self.dim, 1)
+        self.fc1 = Linear(self.att_dim, 6)
+
+        self.coef_sem = cd.coef_sem        # Q-D: read from cfg.model.change_detector, not cfg.model
+        self.coef_spa = cd.coef_spa
+        assert self.coef_sem + self.coef_spa <= 1
+
+        q_dim = cfg.model.speaker.embed_dim
+        if cfg.train.setting == 'mode2':
+            g = cfg.train.graph
+            if g == 'all' or g == 'semantic':
+                self.semantic_relation = ExplicitRelationEncoder(
+                    cd.att_dim, q_dim, cd.att_dim, cd.dir_num, cd.sem_label_num, num_heads=cd.att_head,
+                    num_steps=1, nongt_dim=cd.nongt_dim, residual_connection=True, label_bias=False)
+            if g == 'all' or g == 'spatial' or g == 'i+s':
+                self.spatial_relation = ExplicitRelationEncoder(
+                    cd.att_dim, q_dim, cd.att_dim, cd.dir_num, cd.spa_label_num, num_heads=cd.att_head,
+                    num_steps=1, nongt_dim=cd.nongt_dim, residual_connection=True, label_bias=False)
+            if g == 'all' or g == 'implicit' or g == 'i+s':
+                self.imp_relation = ImplicitRelationEncoder(
+                    cd.att_dim, q_dim, cd.att_dim, cd.dir_num, 64, cd.nongt_dim, num_heads=cd.att_head,
+                    num_steps=1, residual_connection=True, label_bias=False)
+
+        self.w_emb = WordEmbedding(len(word_to_idx), 300, .0, 'c')
+        self.q_emb = QuestionEmbedding(600, q_dim, 1, False, .0)
+        self.q_att = QuestionSelfAttention(q_dim, .2)
+        self.cfg = cfg
+        if cfg.data.feature_mode == 'mode0':
+            raise NotImplementedError("feature_mode='mode0' (raw-image ResNet-101 extractor, modules.py:153-160) "
+                                      "is outside the ROI-feature hot path")
+        self._dim_mat = None
+
+    # ------------------------------------------------------------------ geometry
+    def position_emb(self, bb):
+        """(R, N, 4) float64 boxes (host or device) -> (R, N, M, pos_emb_dim) float32 on the device.
+        ref: modules.py:162-166 -> mimic_utils.py:152-208 (float64 math, cast at graph_att_layer.py:115)."""
+        dev = self.img.weight.device
+        if self._dim_mat is None or self._dim_mat.device != dev:
+            feat_range = torch.arange(0, self.pos_emb_dim / 8)
+            self._dim_mat = torch.pow(torch.ones((1,)) * 1000, (8. / self.pos_emb_dim) * feat_range).to(dev)
+        bb = bb.to(device=dev, dtype=torch.float64)
+        M = min(self.nongt_dim, bb.shape[1])
+        return ops.geom_embed(bb, M, self.pos_emb_dim, self._dim_mat)
+
+    def encode_question(self, question):
+        return self.q_att(self.q_emb.forward_all(self.w_emb(question)))
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input_1, input_2, d_adj_matrix, q_adj_matrix, d_sem_adj_matrix, q_sem_adj_matrix, d_bb, q_bb,
+                question, setting='mode2', graph='all'):
+        if self.cfg.data.train.empty_image == True:  # noqa: E712  (reference semantics, modules.py:170-178)
+            input_1, input_2 = torch.ones_like(input_1), torch.ones_like(input_2)
+            d_adj_matrix, q_adj_matrix = torch.ones_like(d_adj_matrix), torch.ones_like(q_adj_matrix)
+            d_sem_adj_matrix, q_sem_adj_matrix = torch.ones_like(d_sem_adj_matrix), torch.ones_like(q_sem_adj_matrix)
+            d_bb, q_bb = torch.ones_like(d_bb), torch.ones_like(q_bb)
+        B, N, C = input_1.size()
+        A = self.att_dim
+
+        # both images through the shared ROI projection, stacked: rows [0, B*N) = main, [B*N, 2*B*N) = reference
+        x = ops.linear_rowstack((input_1, input_2), self.img.weight, self.img.bias).view(2 * B, N, A)
+        q = self.encode_question(question)
+
+        if setting == 'mode2':
+            if graph == 'semantic' or graph == 'all':
+                x, _ = self.semantic_relation.forward(x, torch.cat((d_sem_adj_matrix, q_sem_adj_matrix), 0), q)
+            if graph == 'spatial' or graph == 'all' or graph == 'i+s':
+                x, _ = self.spatial_relation.forward(x, torch.cat((d_adj_matrix, q_adj_matrix), 0), q)
+            if graph == 'implicit' or graph == 'all' or graph == 'i+s':
+                pos = self.position_emb(torch.cat((d_bb, q_bb), 0))
+                x, _ = self.imp_relation.forward(x, pos, q)
+            if graph == 'all':
+                # Q-A: input_bef1/2/3 are one tensor -> cs*x + cp*x + (1-cs-cp)*x   (modules.py:234-235)
+                cs, cp = self.coef_sem, self.coef_spa
+                x = ops.AxpbyFn.apply(ops.AxpbyFn.apply(x, x, cs, cp), x, 1.0, 1 - cs - cp)
+            elif graph == 'i+s':
+                x = ops.scale(ops.add(x, x), 0.5)
+        elif setting == 'mode0':
+            xq = q_expand_v_cat(q, x)
+            x = self.SSRE(xq, xq, xq, bl=(2 * B, N))
+        else:
+            raise ValueError("setting %r references a non-existent graph_relation in the reference "
+                             "(modules.py:214,257,263) and is not supported" % (setting,))
+
+        x = x.reshape(2 * B, N, A)
+        bef, aft = x[:B], x[B:]
+        diff = ops.sub(aft, bef)                                            # (B, N, A)
+        c1d = self.context1(diff)                                           # shared by both images: computed once
+        g1d = self.gate1(diff)
+        c2 = self.context2(x)                                               # (2B, N, A), bias in the epilogue
+        g2 = self.gate2(x)
+        gated = ops.gate_fuse(c2, g2, c1d, g1d, self.dropout.p, self.training).view(2 * B, N, A)
+
+        emb_lin, emb_drop = self.embed[0], self.embed[1]
+
+        def region_attention(feat, gated_feat):
+            e = emb_lin((feat, diff, gated_feat), ACT_RELU)                 # relu(dropout(x)) == dropout(relu(x))
+            e = ops.dropout(e, emb_drop.p, self.training)
+            return self.att(e, ACT_SIGMOID).view(B, N)
+
+        att_b = region_attention(bef, gated[:B])
+        att_a = region_attention(aft, gated[B:])
+        attended_1 = ops.weighted_pool(att_b, bef)
+        attended_2 = ops.weighted_pool(att_a, aft)
+        input_attended = ops.sub(attended_2, attended_1)
+        pred = self.fc1(input_attended)
+        return pred, att_b.view(B, 1, N), att_a.view(B, 1, N), attended_1, attended_2, input_attended
+
+
+class AddSpatialInfo(nn.Module):
+    """Instantiated by the entry scripts, never applied on the ROI path (modules.py:316-332)."""
+
+    def _create_coord(self, img_feat):
+        batch_size, _, h, w = img_feat.size()
+        ys = (torch.arange(h, device=img_feat.device, dtype=img_feat.dtype) * 2.0 / h) - 1
+        xs = (torch.arange(w, device=img_feat.device, dtype=img_feat.dtype) * 2.0 / w) - 1
+        coord_map = torch.stack([xs.view(1, w).expand(h, w), ys.view(h, 1).expand(h, w)])
+        return coord_map.unsqueeze(0).expand(batch_size, -1, -1, -1)
+
+    def forward(self, img_feat):
+        return torch.cat([img_feat, self._create_coord(img_feat)], dim=1)

@@ -1,0 +1,934 @@
+"""Differentiable operators of the difference-VQA path, every one a pair of calls into the
+C ABI of libekaid_hip.so (forward kernels + hand-written backward kernels).
+
+PyTorch supplies device memory (``torch.empty``), the stream and the autograd tape only; no
+arithmetic on the path is done by ATen.  Every operator raises if its inputs are not on the
+HIP device -- there is no CPU fallback (the CPU restatement is ``oracle/``, test-only).
+"""
+import ctypes
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import hip
+from .hip import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, GemmDesc, check, ptr, require_cuda,
+                  stream)
+
+# --------------------------------------------------------------------------- #
+# dropout seeds: counter-based masks, forward and backward share the seed
+# --------------------------------------------------------------------------- #
+_seed_base = 1238
+_seed_counter = 0
+
+
+def manual_seed(seed):
+    global _seed_base, _seed_counter
+    _seed_base = int(seed)
+    _seed_counter = 0
+
+
+def next_seed():
+    global _seed_counter
+    _seed_counter += 1
+    return (_seed_base * 1000003 + _seed_counter * 7919) & 0xFFFFFFFFFFFFFFFF
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _rows2d(t):
+    """2-D view with unit inner stride; returns (tensor, leading dim)."""
+    if t.dim() != 2:
+        t = t.reshape(-1, t.shape[-1])
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+    return t, ld
+
+
+# --------------------------------------------------------------------------- #
+# raw GEMM
+# --------------------------------------------------------------------------- #
+def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=None,
+         accumulate=False, bias=None, R=None, ldr=0, rdiv=1, rowmask=None, act=ACT_NONE,
+         batch=(1, 1), strides=(0, 0, 0, 0, 0, 0), a_off=0, b_off=0, c_off=0):
+    """C = act(alpha * op(A) op(B) [+C] [+bias] [+R]) on raw device buffers (element offsets a_off..)."""
+    d = GemmDesc()
+    d.A = A.data_ptr() + 4 * a_off
+    d.B = B.data_ptr() + 4 * b_off
+    d.C = C.data_ptr() + 4 * c_off
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.transA, d.transB = int(transA), int(transB)
+    d.batch1, d.batch2 = batch
+    (d.strideA1, d.strideA2, d.strideB1, d.strideB2, d.strideC1, d.strideC2) = strides
+    d.alpha = alpha
+    d.alpha_dev = ptr(alpha_dev)
+    d.accumulate = int(accumulate)
+    d.bias = ptr(bias)
+    d.R = ptr(R)
+    d.ldr = ldr
+    d.rdiv = rdiv
+    d.rowmask = ptr(rowmask)
+    d.act = act
+    L = hip.lib()
+    need = L.ekaid_gemm_workspace_bytes(ctypes.byref(d))
+    ws = hip.workspace(need, C.device) if need else None
+    check(L.ekaid_gemm_f32(ctypes.byref(d), ptr(ws), need, stream()), 'ekaid_gemm_f32')
+
+
+# --------------------------------------------------------------------------- #
+# linear layers:  y = act( scale * sum_i x_i W[:, K_i]^T + b )
+# --------------------------------------------------------------------------- #
+class LinearFn(Function):
+    """nn.Linear / weight-normed FCNet layer over one or several inputs whose feature axes are
+    concatenated (so ``torch.cat`` of the reference never materialises).
+    ref: fc.py:15-49, modules.py:195,278-303, dynamic_speaker_change_pos.py:98-125."""
+
+    @staticmethod
+    def forward(ctx, W, b, scale, act, *xs):
+        require_cuda(W, *xs)
+        N, Ktot = W.shape
+        W = _c(W)
+        xs2, lds = zip(*[_rows2d(x) for x in xs])
+        M = xs2[0].shape[0]
+        assert sum(x.shape[1] for x in xs2) == Ktot, 'input widths do not add up to in_features'
+        y = torch.empty(M, N, device=W.device, dtype=torch.float32)
+        off = 0
+        for i, (x, ld) in enumerate(zip(xs2, lds)):
+            last = i == len(xs2) - 1
+            K = x.shape[1]
+            gemm(x, W, y, M, N, K, ld, Ktot, N, 0, 1, alpha_dev=scale, accumulate=i > 0,
+                 bias=b if last else None, act=act if last else ACT_NONE, b_off=off)
+            off += K
+        ctx.act = act
+        ctx.has_b = b is not None
+        ctx.has_scale = scale is not None
+        ctx.lead = [x.shape[:-1] for x in xs]
+        ctx.save_for_backward(W, scale, y if act != ACT_NONE else None, *xs2)
+        ctx.lds = lds
+        return y.view(*xs[0].shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        W, scale, y, *xs2 = ctx.saved_tensors
+        N, Ktot = W.shape
+        M = xs2[0].shape[0]
+        dy = _c(dy).view(M, N)
+        L = hip.lib()
+        if ctx.act != ACT_NONE:
+            dz = torch.empty_like(dy)
+            check(L.ekaid_act_bwd(ptr(dy), ptr(y), ptr(dz), dy.numel(), ctx.act, stream()), 'act_bwd')
+        else:
+            dz = dy
+        need = ctx.needs_input_grad
+        db = None
+        if ctx.has_b and need[1]:
+            db = torch.empty(N, device=W.device, dtype=torch.float32)
+            check(L.ekaid_colsum(ptr(dz), M, N, N, ptr(db), stream()), 'colsum')
+        dxs = []
+        off = 0
+        for i, x in enumerate(xs2):
+            K = x.shape[1]
+            if need[4 + i]:
+                dx = torch.empty(M, K, device=W.device, dtype=torch.float32)
+                gemm(dz, W, dx, M, K, N, N, Ktot, K, 0, 0, alpha_dev=scale, b_off=off)
+                dxs.append(dx.view(*ctx.lead[i], K))
+            else:
+                dxs.append(None)
+            off += K
+        dW = dscale = None
+        if need[0] or (ctx.has_scale and need[2]):
+            dW = torch.empty(N, Ktot, device=W.device, dtype=torch.float32)
+            off = 0
+            for x, ld in zip(xs2, ctx.lds):
+                K = x.shape[1]
+                gemm(dz, x, dW, N, K, M, N, ld, Ktot, 1, 0, c_off=off)
+                off += K
+            if ctx.has_scale:
+                dscale = torch.empty((), device=W.device, dtype=torch.float32)
+                check(L.ekaid_scale_dot(ptr(dW), ptr(W), ptr(scale), dW.numel(), ptr(dscale), stream()),
+                      'scale_dot')
+        return (dW, db, dscale, None) + tuple(dxs)
+
+
+def linear(xs, W, b=None, scale=None, act=ACT_NONE):
+    if isinstance(xs, torch.Tensor):
+        xs = (xs,)
+    return LinearFn.apply(W, b, scale, act, *xs)
+
+
+class LinearRowStackFn(Function):
+    """y = [x_1; x_2; ...] W^T + b with the inputs stacked along ROWS into one output buffer (the two
+    images of a pair share ``ChangeDetector.img``).  ref: modules.py:195-196."""
+
+    @staticmethod
+    def forward(ctx, W, b, *xs):
+        require_cuda(W, *xs)
+        W = _c(W)
+        N, K = W.shape
+        xs2, lds = zip(*[_rows2d(x) for x in xs])
+        Ms = [x.shape[0] for x in xs2]
+        y = torch.empty(sum(Ms), N, device=W.device, dtype=torch.float32)
+        r0 = 0
+        for x, ld, M in zip(xs2, lds, Ms):
+            gemm(x, W, y, M, N, K, ld, K, N, 0, 1, bias=b, c_off=r0 * N)
+            r0 += M
+        ctx.save_for_backward(W, *xs2)
+        ctx.lds, ctx.Ms, ctx.has_b = lds, Ms, b is not None
+        ctx.lead = [x.shape[:-1] for x in xs]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        W, *xs2 = ctx.saved_tensors
+        N, K = W.shape
+        dy = _c(dy)
+        Mtot = dy.shape[0]
+        need = ctx.needs_input_grad
+        db = None
+        if ctx.has_b and need[1]:
+            db = torch.empty(N, device=W.device, dtype=torch.float32)
+            check(hip.lib().ekaid_colsum(ptr(dy), Mtot, N, N, ptr(db), stream()), 'colsum')
+        dW = None
+        if need[0]:
+            dW = torch.empty(N, K, device=W.device, dtype=torch.float32)
+            r0 = 0
+            for i, (x, ld, M) in enumerate(zip(xs2, ctx.lds, ctx.Ms)):
+                gemm(dy, x, dW, N, K, M, N, ld, K, 1, 0, accumulate=i > 0, a_off=r0 * N)
+                r0 += M
+        dxs = []
+        r0 = 0
+        for i, (x, M) in enumerate(zip(xs2, ctx.Ms)):
+            if need[2 + i]:
+                dx = torch.empty(M, K, device=W.device, dtype=torch.float32)
+                gemm(dy, W, dx, M, K, N, N, K, K, 0, 0, a_off=r0 * N)
+                dxs.append(dx.view(*ctx.lead[i], K))
+            else:
+                dxs.append(None)
+            r0 += M
+        return (dW, db) + tuple(dxs)
+
+
+def linear_rowstack(xs, W, b=None):
+    return LinearRowStackFn.apply(W, b, *xs)
+
+
+class WNScaleFn(Function):
+    """scale = g / ||v||_F of weight_norm(..., dim=None).  ref: fc.py:26-33."""
+
+    @staticmethod
+    def forward(ctx, v, g):
+        require_cuda(v, g)
+        v = _c(v)
+        scale = torch.empty((), device=v.device, dtype=torch.float32)
+        norm = torch.empty((), device=v.device, dtype=torch.float32)
+        check(hip.lib().ekaid_wn_scale_fwd(ptr(v), ptr(g), v.numel(), ptr(scale), ptr(norm), stream()),
+              'wn_scale_fwd')
+        ctx.save_for_backward(v, g, norm)
+        return scale
+
+    @staticmethod
+    def backward(ctx, dscale):
+        v, g, norm = ctx.saved_tensors
+        dv = torch.empty_like(v)
+        dg = torch.empty((), device=v.device, dtype=torch.float32)
+        check(hip.lib().ekaid_wn_scale_bwd(ptr(v), ptr(g), ptr(norm), ptr(_c(dscale)), v.numel(), ptr(dv), 0,
+                                           ptr(dg), stream()), 'wn_scale_bwd')
+        return dv, dg.view(g.shape)
+
+
+def wn_linear(xs, v, g, b=None, act=ACT_NONE):
+    return linear(xs, v, b, WNScaleFn.apply(v, g), act)
+
+
+# --------------------------------------------------------------------------- #
+# element-wise
+# --------------------------------------------------------------------------- #
+class DropoutFn(Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        require_cuda(x)
+        x = _c(x)
+        y = torch.empty_like(x)
+        check(hip.lib().ekaid_dropout(ptr(x), ptr(y), x.numel(), p, seed, stream()), 'dropout')
+        ctx.p, ctx.seed = p, seed
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        check(hip.lib().ekaid_dropout(ptr(dy), ptr(dx), dy.numel(), ctx.p, ctx.seed, stream()), 'dropout')
+        return dx, None, None
+
+
+def dropout(x, p, training):
+    if not training or p <= 0.0:
+        return x
+    return DropoutFn.apply(x, float(p), next_seed())
+
+
+class AxpbyFn(Function):
+    """out = a*x + b*y."""
+
+    @staticmethod
+    def forward(ctx, x, y, a, b):
+        require_cuda(x, y)
+        x, y = _c(x), _c(y)
+        out = torch.empty_like(x)
+        check(hip.lib().ekaid_axpby(ptr(x), ptr(y), ptr(out), x.numel(), a, b, stream()), 'axpby')
+        ctx.a, ctx.b = a, b
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        d = _c(d)
+        L = hip.lib()
+        dx = dy = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(d)
+            check(L.ekaid_axpby(ptr(d), None, ptr(dx), d.numel(), ctx.a, 0.0, stream()), 'axpby')
+        if ctx.needs_input_grad[1]:
+            dy = torch.empty_like(d)
+            check(L.ekaid_axpby(ptr(d), None, ptr(dy), d.numel(), ctx.b, 0.0, stream()), 'axpby')
+        return dx, dy, None, None
+
+
+def sub(x, y):
+    return AxpbyFn.apply(x, y, 1.0, -1.0)
+
+
+def add(x, y):
+    return AxpbyFn.apply(x, y, 1.0, 1.0)
+
+
+class ScaleFn(Function):
+    @staticmethod
+    def forward(ctx, x, a):
+        require_cuda(x)
+        x = _c(x)
+        out = torch.empty_like(x)
+        check(hip.lib().ekaid_axpby(ptr(x), None, ptr(out), x.numel(), a, 0.0, stream()), 'axpby')
+        ctx.a = a
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        d = _c(d)
+        dx = torch.empty_like(d)
+        check(hip.lib().ekaid_axpby(ptr(d), None, ptr(dx), d.numel(), ctx.a, 0.0, stream()), 'axpby')
+        return dx, None
+
+
+def scale(x, a):
+    return ScaleFn.apply(x, float(a))
+
+
+class MulFn(Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        require_cuda(x, y)
+        x, y = _c(x), _c(y)
+        out = torch.empty_like(x)
+        check(hip.lib().ekaid_mul(ptr(x), ptr(y), ptr(out), x.numel(), stream()), 'mul')
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        x, y = ctx.saved_tensors
+        d = _c(d)
+        L = hip.lib()
+        dx = torch.empty_like(d)
+        dy = torch.empty_like(d)
+        check(L.ekaid_mul(ptr(d), ptr(y), ptr(dx), d.numel(), stream()), 'mul')
+        check(L.ekaid_mul(ptr(d), ptr(x), ptr(dy), d.numel(), stream()), 'mul')
+        return dx, dy
+
+
+def mul(x, y):
+    return MulFn.apply(x, y)
+
+
+def rowsum(x, as_mask=False):
+    """No-grad row reduction over the last axis (condensed adjacency / zero-row mask)."""
+    require_cuda(x)
+    x = _c(x.detach())
+    rows = x.numel() // x.shape[-1]
+    out = torch.empty(x.shape[:-1], device=x.device, dtype=torch.float32)
+    check(hip.lib().ekaid_rowsum(ptr(x), rows, x.shape[-1], ptr(out), int(as_mask), stream()), 'rowsum')
+    return out
+
+
+class ExpandRowsFn(Function):
+    """out[r] = mask[r] * q[(r // group) % qrows]  (the q half of q_expand_v_cat).
+    ref: relation_encoder.py:19-29."""
+
+    @staticmethod
+    def forward(ctx, q, mask, group):
+        require_cuda(q, mask)
+        q, mask = _c(q), _c(mask)
+        rows = mask.numel()
+        out = torch.empty(rows, q.shape[1], device=q.device, dtype=torch.float32)
+        check(hip.lib().ekaid_expand_rows_fwd(ptr(q), ptr(mask), rows, group, q.shape[0], q.shape[1], ptr(out),
+                                              stream()), 'expand_rows_fwd')
+        ctx.group = group
+        ctx.save_for_backward(mask)
+        ctx.qshape = q.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        (mask,) = ctx.saved_tensors
+        d = _c(d)
+        dq = torch.empty(ctx.qshape, device=d.device, dtype=torch.float32)
+        check(hip.lib().ekaid_expand_rows_bwd(ptr(d), ptr(mask), mask.numel(), ctx.group, ctx.qshape[0], ctx.qshape[1],
+                                              ptr(dq), stream()), 'expand_rows_bwd')
+        return dq, None, None
+
+
+def expand_rows(q, mask, group):
+    return ExpandRowsFn.apply(q, mask, group)
+
+
+class ResidualRelu2Fn(Function):
+    """v + relu(dropout(2*o)).  ref: graph_att.py:98-104 (Q-B), relation_encoder.py:80-81,128-129 (Q-A)."""
+
+    @staticmethod
+    def forward(ctx, v, o, p, seed):
+        require_cuda(v, o)
+        v, o = _c(v), _c(o)
+        out = torch.empty_like(v)
+        check(hip.lib().ekaid_residual_relu2_fwd(ptr(v), ptr(o), ptr(out), v.numel(), p, seed, stream()),
+              'residual_relu2_fwd')
+        ctx.p, ctx.seed = p, seed
+        ctx.save_for_backward(o)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        (o,) = ctx.saved_tensors
+        d = _c(d)
+        do = torch.empty_like(d)
+        check(hip.lib().ekaid_residual_relu2_bwd(ptr(o), ptr(d), ptr(do), d.numel(), ctx.p, ctx.seed, stream()),
+              'residual_relu2_bwd')
+        return d, do, None, None
+
+
+def residual_relu2(v, o, p, training):
+    p = float(p) if training else 0.0
+    return ResidualRelu2Fn.apply(v, o, p, next_seed() if p > 0 else 0)
+
+
+class GateFuseFn(Function):
+    """dropout(sigmoid(g2 + g1)) * dropout(tanh(c2 + c1)), c1/g1 broadcast over the two images.
+    ref: modules.py:278-288."""
+
+    @staticmethod
+    def forward(ctx, c2, g2, c1, g1, p, seed_c, seed_g):
+        require_cuda(c2, g2, c1, g1)
+        c2, g2, c1, g1 = _c(c2), _c(g2), _c(c1), _c(g1)
+        out = torch.empty_like(c2)
+        check(hip.lib().ekaid_gate_fuse_fwd(ptr(c2), ptr(g2), ptr(c1), ptr(g1), ptr(out), c2.numel(), c1.numel(), p,
+                                            seed_c, seed_g, stream()), 'gate_fuse_fwd')
+        ctx.args = (p, seed_c, seed_g)
+        ctx.save_for_backward(c2, g2, c1, g1)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        c2, g2, c1, g1 = ctx.saved_tensors
+        d = _c(d)
+        dc2, dg2 = torch.empty_like(c2), torch.empty_like(c2)
+        dc1, dg1 = torch.empty_like(c1), torch.empty_like(c1)
+        p, sc, sg = ctx.args
+        check(hip.lib().ekaid_gate_fuse_bwd(ptr(c2), ptr(g2), ptr(c1), ptr(g1), ptr(d), ptr(dc2), ptr(dg2), ptr(dc1),
+                                            ptr(dg1), c2.numel(), c1.numel(), p, sc, sg, stream()), 'gate_fuse_bwd')
+        return dc2, dg2, dc1, dg1, None, None, None
+
+
+def gate_fuse(c2, g2, c1, g1, p, training):
+    p = float(p) if training else 0.0
+    if p > 0:
+        return GateFuseFn.apply(c2, g2, c1, g1, p, next_seed(), next_seed())
+    return GateFuseFn.apply(c2, g2, c1, g1, 0.0, 0, 0)
+
+
+class WeightedPoolFn(Function):
+    """out[g] = sum_i w[g,i] * x[g,i,:].  ref: modules.py:305-308, language_model.py:151."""
+
+    @staticmethod
+    def forward(ctx, w, x):
+        require_cuda(w, x)
+        w, x = _c(w), _c(x)
+        G, n, C = x.shape
+        out = torch.empty(G, C, device=x.device, dtype=torch.float32)
+        check(hip.lib().ekaid_weighted_pool_fwd(ptr(w), ptr(x), G, n, C, ptr(out), stream()), 'weighted_pool_fwd')
+        ctx.save_for_backward(w, x)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        w, x = ctx.saved_tensors
+        G, n, C = x.shape
+        d = _c(d)
+        dw = torch.empty_like(w)
+        dx = torch.empty_like(x)
+        check(hip.lib().ekaid_weighted_pool_bwd(ptr(w), ptr(x), ptr(d), G, n, C, ptr(dw), ptr(dx), stream()),
+              'weighted_pool_bwd')
+        return dw, dx
+
+
+def weighted_pool(w, x):
+    return WeightedPoolFn.apply(w.reshape(x.shape[0], x.shape[1]), x)
+
+
+class QAttWeightsFn(Function):
+    """softmax over the batch axis of atten^T re-read as (B, L) (quirk Q-C).  ref: language_model.py:149."""
+
+    @staticmethod
+    def forward(ctx, atten):
+        require_cuda(atten)
+        atten = _c(atten)
+        B, L = atten.shape
+        S = torch.empty(L, B, device=atten.device, dtype=torch.float32)
+        w = torch.empty(B, L, device=atten.device, dtype=torch.float32)
+        check(hip.lib().ekaid_qatt_weights_fwd(ptr(atten), B, L, ptr(S), ptr(w), stream()), 'qatt_weights_fwd')
+        ctx.save_for_backward(S)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        (S,) = ctx.saved_tensors
+        L, B = S.shape
+        dw = _c(dw)
+        da = torch.empty(B, L, device=S.device, dtype=torch.float32)
+        check(hip.lib().ekaid_qatt_weights_bwd(ptr(S), ptr(dw), B, L, ptr(da), stream()), 'qatt_weights_bwd')
+        return da
+
+
+class EmbeddingFn(Function):
+    """One or two lookup tables written side by side (+ optional ReLU).
+    ref: language_model.py:48-53, dynamic_speaker_change_pos.py:153-156."""
+
+    @staticmethod
+    def forward(ctx, tok, relu, padding_idx, *tables):
+        require_cuda(tok, *tables)
+        tok = _c(tok)
+        ntok = tok.numel()
+        tables = [_c(t) for t in tables]
+        width = sum(t.shape[1] for t in tables)
+        out = torch.empty(*tok.shape, width, device=tok.device, dtype=torch.float32)
+        off = 0
+        for t in tables:
+            check(hip.lib().ekaid_embedding_fwd(ptr(tok), ntok, ptr(t), t.shape[1], ptr(out), width, off, int(relu),
+                                                stream()), 'embedding_fwd')
+            off += t.shape[1]
+        ctx.relu, ctx.pad, ctx.width = relu, padding_idx, width
+        ctx.save_for_backward(tok, *tables)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        tok, *tables = ctx.saved_tensors
+        d = _c(d)
+        grads = []
+        off = 0
+        for i, t in enumerate(tables):
+            if ctx.needs_input_grad[3 + i]:
+                dt = torch.zeros_like(t)
+                check(hip.lib().ekaid_embedding_bwd(ptr(tok), tok.numel(), ptr(t), ptr(d), t.shape[1], ctx.width, off,
+                                                    int(ctx.relu), ctx.pad, ptr(dt), stream()), 'embedding_bwd')
+                grads.append(dt)
+            else:
+                grads.append(None)
+            off += t.shape[1]
+        return (None, None, None) + tuple(grads)
+
+
+def embedding(tok, tables, relu=False, padding_idx=-1):
+    return EmbeddingFn.apply(tok, relu, padding_idx, *tables)
+
+
+class SoftmaxFn(Function):
+    @staticmethod
+    def forward(ctx, x, log_mode):
+        require_cuda(x)
+        x = _c(x)
+        y = torch.empty_like(x)
+        cols = x.shape[-1]
+        check(hip.lib().ekaid_softmax_fwd(ptr(x), ptr(y), x.numel() // cols, cols, int(log_mode), stream()),
+              'softmax_fwd')
+        ctx.log_mode = log_mode
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(y)
+        cols = y.shape[-1]
+        check(hip.lib().ekaid_softmax_bwd(ptr(y), ptr(dy), ptr(dx), y.numel() // cols, cols, int(ctx.log_mode),
+                                          stream()), 'softmax_bwd')
+        return dx, None
+
+
+def softmax(x):
+    return SoftmaxFn.apply(x, False)
+
+
+def log_softmax(x):
+    return SoftmaxFn.apply(x, True)
+
+
+class Mix3Fn(Function):
+    """w[:,0]*a + w[:,1]*b + w[:,2]*c.  ref: dynamic_speaker_change_pos.py:112-117."""
+
+    @staticmethod
+    def forward(ctx, w, a, b, c):
+        require_cuda(w, a, b, c)
+        w, a, b, c = _c(w), _c(a), _c(b), _c(c)
+        B, C = a.shape
+        out = torch.empty_like(a)
+        check(hip.lib().ekaid_mix3_fwd(ptr(w), ptr(a), ptr(b), ptr(c), B, C, ptr(out), stream()), 'mix3_fwd')
+        ctx.save_for_backward(w, a, b, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        w, a, b, c = ctx.saved_tensors
+        B, C = a.shape
+        d = _c(d)
+        dw = torch.empty_like(w)
+        da, db, dc = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+        check(hip.lib().ekaid_mix3_bwd(ptr(w), ptr(a), ptr(b), ptr(c), ptr(d), B, C, ptr(dw), ptr(da), ptr(db),
+                                       ptr(dc), stream()), 'mix3_bwd')
+        return dw, da, db, dc
+
+
+class GRUSeqFn(Function):
+    """Whole 1-layer unidirectional GRU (h0 = 0) with explicit BPTT: one input GEMM over all time
+    steps, then per step one recurrent GEMM + the fused gate kernel writing h_t straight into the
+    output sequence.  ref: language_model.py:66-70,106-115 (nn.GRU, gate order r,z,n)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        require_cuda(x, w_ih, w_hh, b_ih, b_hh)
+        x, w_ih, w_hh = _c(x), _c(w_ih), _c(w_hh)
+        B, T, E = x.shape
+        H = w_hh.shape[1]
+        dev = x.device
+        L = hip.lib()
+        gi = torch.empty(B, T, 3 * H, device=dev, dtype=torch.float32)
+        gemm(x, w_ih, gi, B * T, 3 * H, E, E, E, 3 * H, 0, 1, bias=b_ih)
+        out = torch.empty(B, T, H, device=dev, dtype=torch.float32)
+        h0 = torch.zeros(B, H, device=dev, dtype=torch.float32)
+        save = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
+        gh = torch.empty(B, 3 * H, device=dev, dtype=torch.float32)
+        for t in range(T):
+            hprev, off, ldh = (h0, 0, H) if t == 0 else (out, (t - 1) * H, T * H)
+            gemm(hprev, w_hh, gh, B, 3 * H, H, ldh, H, 3 * H, 0, 1, bias=b_hh, a_off=off)
+            check(L.ekaid_gru_cell_fwd(gi.data_ptr() + 4 * t * 3 * H, T * 3 * H, ptr(gh), 3 * H,
+                                       hprev.data_ptr() + 4 * off, ldh, B, H,
+                                       out.data_ptr() + 4 * t * H, T * H, save.data_ptr() + 4 * t * B * 4 * H,
+                                       stream()), 'gru_cell_fwd')
+        ctx.save_for_backward(x, w_ih, w_hh, out, h0, save)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w_ih, w_hh, out, h0, save = ctx.saved_tensors
+        B, T, E = x.shape
+        H = w_hh.shape[1]
+        dev = x.device
+        L = hip.lib()
+        dout = _c(dout)                                   # (B, T, H)
+        dgi = torch.empty(B, T, 3 * H, device=dev, dtype=torch.float32)
+        dgh = torch.empty(T, B, 3 * H, device=dev, dtype=torch.float32)
+        dh = torch.empty(B, H, device=dev, dtype=torch.float32)
+        dw_hh = torch.zeros_like(w_hh)
+        for t in range(T - 1, -1, -1):
+            carry = None if t == T - 1 else dh.data_ptr()
+            dgh_t = dgh.data_ptr() + 4 * t * B * 3 * H
+            hprev, off, ldh = (h0, 0, H) if t == 0 else (out, (t - 1) * H, T * H)
+            check(L.ekaid_gru_cell_bwd(dout.data_ptr() + 4 * t * H, T * H, carry, save.data_ptr() + 4 * t * B * 4 * H,
+                                       hprev.data_ptr() + 4 * off, ldh, B, H, dgi.data_ptr() + 4 * t * 3 * H, T * 3 * H,
+                                       dgh_t, ptr(dh), stream()), 'gru_cell_bwd')
+            if t > 0:
+                # dh_{t-1} = z*d (written by the kernel) + dgh_t . W_hh ;  dW_hh += dgh_t^T . h_{t-1}
+                gemm(dgh, w_hh, dh, B, H, 3 * H, 3 * H, H, H, 0, 0, accumulate=True, a_off=t * B * 3 * H)
+                gemm(dgh, out, dw_hh, 3 * H, H, B, 3 * H, ldh, H, 1, 0, accumulate=True, a_off=t * B * 3 * H,
+                     b_off=off)
+        db_hh = torch.empty(3 * H, device=dev, dtype=torch.float32)
+        check(L.ekaid_colsum(ptr(dgh), T * B, 3 * H, 3 * H, ptr(db_hh), stream()), 'colsum')
+        db_ih = torch.empty(3 * H, device=dev, dtype=torch.float32)
+        check(L.ekaid_colsum(ptr(dgi), B * T, 3 * H, 3 * H, ptr(db_ih), stream()), 'colsum')
+        dw_ih = torch.empty_like(w_ih)
+        gemm(dgi, x, dw_ih, 3 * H, E, B * T, 3 * H, E, E, 1, 0)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm(dgi, w_ih, dx, B * T, E, 3 * H, 3 * H, E, E, 0, 0)
+        return dx, dw_ih, dw_hh, db_ih, db_hh
+
+
+def gru_sequence(x, w_ih, w_hh, b_ih, b_hh):
+    return GRUSeqFn.apply(x, w_ih, w_hh, b_ih, b_hh)
+
+
+class LSTMCellFn(Function):
+    """Point-wise half of nn.LSTMCell: gates = gx + gh (i,f,g,o)."""
+
+    @staticmethod
+    def forward(ctx, gx, gh, c):
+        require_cuda(gx, gh, c)
+        gx, gh, c = _c(gx), _c(gh), _c(c)
+        B, H = c.shape
+        h2, c2 = torch.empty_like(c), torch.empty_like(c)
+        save = torch.empty(B, 4 * H, device=c.device, dtype=torch.float32)
+        check(hip.lib().ekaid_lstm_cell_fwd(ptr(gx), ptr(gh), ptr(c), B, H, ptr(h2), ptr(c2), ptr(save), stream()),
+              'lstm_cell_fwd')
+        ctx.save_for_backward(save, c, c2)
+        return h2, c2
+
+    @staticmethod
+    def backward(ctx, dh2, dc2):
+        save, c, c2 = ctx.saved_tensors
+        B, H = c.shape
+        dg = torch.empty(B, 4 * H, device=c.device, dtype=torch.float32)
+        dc = torch.empty_like(c)
+        check(hip.lib().ekaid_lstm_cell_bwd(ptr(_c(dh2)) if dh2 is not None else None,
+                                            ptr(_c(dc2)) if dc2 is not None else None, ptr(save), ptr(c), ptr(c2), B, H,
+                                            ptr(dg), ptr(dc), stream()), 'lstm_cell_bwd')
+        return dg, dg, dc
+
+
+class LMLossFn(Function):
+    """loss = -sum(logp[b,t,target[b,t]] * mask[b,t]) / sum(mask).  ref: utils/utils.py:208-216."""
+
+    @staticmethod
+    def forward(ctx, logp, target, mask):
+        require_cuda(logp, target, mask)
+        logp = _c(logp)
+        B, T, V = logp.shape
+        assert target.stride(1) == 1 and mask.stride(1) == 1 and target.dtype == torch.int64
+        assert target.shape[1] >= T and mask.shape[1] >= T and mask.dtype == torch.float32
+        sums = torch.zeros(2, device=logp.device, dtype=torch.float32)
+        loss = torch.empty((), device=logp.device, dtype=torch.float32)
+        check(hip.lib().ekaid_nll_fwd(ptr(logp), target.data_ptr(), target.stride(0), mask.data_ptr(), mask.stride(0),
+                                      B, T, V, ptr(sums), ptr(loss), stream()), 'nll_fwd')
+        ctx.save_for_backward(target, mask, sums)
+        ctx.shape = (B, T, V)
+        return loss
+
+    @staticmethod
+    def backward(ctx, d):
+        target, mask, sums = ctx.saved_tensors
+        B, T, V = ctx.shape
+        dlogp = torch.empty(B, T, V, device=sums.device, dtype=torch.float32)
+        check(hip.lib().ekaid_nll_bwd(target.data_ptr(), target.stride(0), mask.data_ptr(), mask.stride(0), ptr(sums),
+                                      ptr(_c(d)), B, T, V, ptr(dlogp), stream()), 'nll_bwd')
+        return dlogp, None, None
+
+
+def lm_loss(logp, target, mask):
+    return LMLossFn.apply(logp, target, mask)
+
+
+class TotalLossFn(Function):
+    """speaker_loss + coef * (sum(att_bef) + sum(att_aft)).  ref: train_mimic.py:246-247."""
+
+    @staticmethod
+    def forward(ctx, sl, att_b, att_a, coef):
+        require_cuda(sl, att_b, att_a)
+        att_b, att_a = _c(att_b), _c(att_a)
+        out = torch.empty((), device=sl.device, dtype=torch.float32)
+        check(hip.lib().ekaid_total_loss_fwd(ptr(sl), ptr(att_b), ptr(att_a), att_b.numel(), coef, ptr(out), stream()),
+              'total_loss_fwd')
+        ctx.coef = coef
+        ctx.shapes = (att_b.shape, att_a.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        d = _c(d)
+        L = hip.lib()
+        gb = torch.empty(ctx.shapes[0], device=d.device, dtype=torch.float32)
+        ga = torch.empty(ctx.shapes[1], device=d.device, dtype=torch.float32)
+        check(L.ekaid_fill_scaled(ptr(d), ctx.coef, ptr(gb), gb.numel(), stream()), 'fill_scaled')
+        check(L.ekaid_fill_scaled(ptr(d), ctx.coef, ptr(ga), ga.numel(), stream()), 'fill_scaled')
+        return d, gb, ga, None
+
+
+def total_loss(speaker_loss, att_bef, att_aft):
+    B = att_bef.shape[0]
+    return TotalLossFn.apply(speaker_loss, att_bef, att_aft, 2.5e-03 / (2 * B))
+
+
+class LayerNormFn(Function):
+    """ref: modules.py:33,76 (nn.LayerNorm(att_dim, eps=1e-6))."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        require_cuda(x, gamma, beta)
+        x = _c(x)
+        cols = x.shape[-1]
+        rows = x.numel() // cols
+        y = torch.empty_like(x)
+        save = torch.empty(rows, 2, device=x.device, dtype=torch.float32)
+        check(hip.lib().ekaid_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), rows, cols, eps, ptr(y), ptr(save), stream()),
+              'layernorm_fwd')
+        ctx.save_for_backward(x, gamma, save)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, save = ctx.saved_tensors
+        cols = x.shape[-1]
+        rows = x.numel() // cols
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+        check(hip.lib().ekaid_layernorm_bwd(ptr(x), ptr(gamma), ptr(save), ptr(dy), rows, cols, ptr(dx), ptr(dg), ptr(db),
+                                            stream()), 'layernorm_bwd')
+        return dx, dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps):
+    return LayerNormFn.apply(x, gamma, beta, float(eps))
+
+
+# --------------------------------------------------------------------------- #
+# graph attention core
+# --------------------------------------------------------------------------- #
+def geom_embed(bb_dev, M, feat_dim, dim_mat):
+    """float64 boxes (R,N,4) on the device -> float32 pair embedding (R,N,M,feat_dim); no gradient."""
+    require_cuda(bb_dev, dim_mat)
+    assert bb_dev.dtype == torch.float64
+    bb_dev = _c(bb_dev)
+    R, N, _ = bb_dev.shape
+    out = torch.empty(R, N, M, feat_dim, device=bb_dev.device, dtype=torch.float32)
+    check(hip.lib().ekaid_geom_embed(bb_dev.data_ptr(), ptr(dim_mat), R, N, M, feat_dim, ptr(out), stream()), 'geom_embed')
+    return out
+
+
+class GatAttentionFn(Function):
+    """Neighbour gather + edge softmax + weighted aggregation of GraphSelfAttentionLayer.
+    ref: graph_att_layer.py:105-172.  Forward = the fused kernel (impl='fused') or the same math
+    composed from batched GEMMs + the edge-softmax kernel (impl='gemm'); backward = batched GEMMs
+    around the edge-softmax backward kernel."""
+
+    @staticmethod
+    def forward(ctx, q, k, S, cond, lbias, geo, H, direction, impl):
+        require_cuda(q, k, S, cond, lbias)
+        q, k, S, cond, lbias = _c(q), _c(k), _c(S), _c(cond), _c(lbias)
+        geo = _c(geo) if geo is not None else None
+        R, N, A = q.shape
+        M = k.shape[1]
+        dh = A // H
+        L = hip.lib()
+        P = torch.empty(R, N, H, M, device=q.device, dtype=torch.float32)
+        outT = torch.empty(R, N, H * A, device=q.device, dtype=torch.float32)
+        done = False
+        if impl == 'fused':
+            rc = L.ekaid_gat_fused_fwd(ptr(q), ptr(k), ptr(S), ptr(cond), ptr(lbias), ptr(geo), R, N, M, A, H,
+                                       direction, ptr(P), ptr(outT), stream())
+            if rc == hip.ERR_UNSUPPORTED:
+                impl = 'gemm'              # shape outside the fused kernel's envelope: still HIP, composed
+            else:
+                check(rc, 'gat_fused_fwd')
+                done = True
+        if not done:
+            aff = torch.empty(R, N, H, M, device=q.device, dtype=torch.float32)
+            gemm(q, k, aff, N, M, dh, A, A, H * M, 0, 1, alpha=1.0 / math.sqrt(float(dh)), batch=(R, H),
+                 strides=(N * A, dh, M * A, dh, N * H * M, M))
+            check(L.ekaid_masked_softmax_fwd(ptr(aff), ptr(cond), ptr(lbias), ptr(geo), R, N, M, H, direction, ptr(P),
+                                             stream()), 'masked_softmax_fwd')
+            gemm(P, S, outT, N * H, A, M, M, A, A, 0, 0, batch=(R, 1), strides=(N * H * M, 0, N * A, 0, N * H * A, 0))
+        ctx.cfg = (H, direction)
+        ctx.save_for_backward(q, k, S, cond, geo, P)
+        ctx.has_geo = geo is not None
+        return outT, P
+
+    @staticmethod
+    def backward(ctx, doutT, dP_ext):
+        q, k, S, cond, geo, P = ctx.saved_tensors
+        H, direction = ctx.cfg
+        R, N, A = q.shape
+        M = k.shape[1]
+        dh = A // H
+        sc = 1.0 / math.sqrt(float(dh))
+        L = hip.lib()
+        dev = q.device
+        doutT = _c(doutT)
+        # dP = doutT . S[:M]^T   (R, N*H, M)
+        dP = torch.empty(R, N, H, M, device=dev, dtype=torch.float32)
+        gemm(doutT, S, dP, N * H, M, A, A, A, M, 0, 1, batch=(R, 1), strides=(N * H * A, 0, N * A, 0, N * H * M, 0))
+        if dP_ext is not None:
+            dP = AxpbyFn.apply(dP, _c(dP_ext), 1.0, 1.0)
+        # dS[:M] = P^T . doutT
+        dS = torch.zeros(R, N, A, device=dev, dtype=torch.float32) if M < N else \
+            torch.empty(R, N, A, device=dev, dtype=torch.float32)
+        gemm(P, doutT, dS, M, A, N * H, M, A, A, 1, 0, batch=(R, 1), strides=(N * H * M, 0, N * H * A, 0, N * A, 0))
+        daff = torch.empty(R, N, H, M, device=dev, dtype=torch.float32)
+        dlbias = torch.zeros(R, N, N, device=dev, dtype=torch.float32)
+        dgeo = torch.empty_like(geo) if ctx.has_geo else None
+        check(L.ekaid_masked_softmax_bwd(ptr(P), ptr(dP), ptr(cond), ptr(geo), R, N, M, H, direction, ptr(daff),
+                                         ptr(dlbias), ptr(dgeo), stream()), 'masked_softmax_bwd')
+        # dq[r,:,h] = sc * daff[r,:,h,:] . k[r,:,h]      dk[r,:,h] = sc * daff[r,:,h,:]^T . q[r,:,h]
+        dq = torch.empty(R, N, A, device=dev, dtype=torch.float32)
+        gemm(daff, k, dq, N, dh, M, H * M, A, A, 0, 0, alpha=sc, batch=(R, H),
+             strides=(N * H * M, M, M * A, dh, N * A, dh))
+        dk = torch.empty(R, M, A, device=dev, dtype=torch.float32)
+        gemm(daff, q, dk, M, dh, N, H * M, A, A, 1, 0, alpha=sc, batch=(R, H),
+             strides=(N * H * M, M, N * A, dh, M * A, dh))
+        return dq, dk, dS, None, dlbias, dgeo, None, None, None
+
+
+def gat_attention(q, k, S, cond, lbias, geo, H, direction, impl='fused'):
+    return GatAttentionFn.apply(q, k, S, cond, lbias, geo, H, direction, impl)
+
+
+def bmm(A, B, transA=False, transB=False, alpha=1.0):
+    return BmmFn.apply(A, B, transA, transB, alpha)
+
+
+class BmmFn(Function):
+    """Batched matmul C[b] = alpha * op(A[b]) op(B[b]) for 3-D contiguous tensors (transA and transB
+    are mutually exclusive).  Used by the SSRE attention (ref: modules.py:61,71)."""
+
+    @staticmethod
+    def forward(ctx, A, B, transA, transB, alpha):
+        require_cuda(A, B)
+        A, B = _c(A), _c(B)
+        nb = A.shape[0]
+        M = A.shape[2] if transA else A.shape[1]
+        K = A.shape[1] if transA else A.shape[2]
+        N = B.shape[1] if transB else B.shape[2]
+        C = torch.empty(nb, M, N, device=A.device, dtype=torch.float32)
+        gemm(A, B, C, M, N, K, A.shape[2], B.shape[2], N, transA, transB, alpha=alpha, batch=(nb, 1),
+             strides=(A.shape[1] * A.shape[2], 0, B.shape[1] * B.shape[2], 0, M * N, 0))
+        ctx.cfg = (transA, transB, alpha)
+        ctx.save_for_backward(A, B)
+        return C
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, B = ctx.saved_tensors
+        transA, transB, alpha = ctx.cfg
+        dC = _c(dC)
+        dA = dB = None
+        if not transA and not transB:          # C = A B
+            dA = BmmFn.apply(dC, B, False, True, alpha)      # dC B^T
+            dB = BmmFn.apply(A, dC, True, False, alpha)      # A^T dC
+        elif transB:                            # C = A B^T
+            dA = BmmFn.apply(dC, B, False, False, alpha)     # dC B
+            dB = BmmFn.apply(dC, A, True, False, alpha)      # dC^T A
+        else:                                   # C = A^T B
+            dA = BmmFn.apply(B, dC, False, True, alpha)      # B dC^T
+            dB = BmmFn.apply(A, dC, False, False, alpha)     # A dC
+        return dA, dB, None, None, None

@@ -1,0 +1,216 @@
+/* ekaid_hip.h -- C ABI of libekaid_hip.so: the MI355X (gfx950) kernels behind the EKAID
+ * difference-VQA forward/backward path.
+ *
+ * The reference (Holipori/EKAID) is pure Python/PyTorch and has NO FFI of its own: every entry
+ * point below replaces a run of ATen ops inside one reference function, cited as
+ * "ref: <file>:<lines>" relative to /root/reference/model.  The binding a maintainer of the
+ * reference would add is a ctypes stub; ekaid_amd/hip.py is that stub.
+ *
+ * Conventions
+ *   - plain C types only: device pointers + sizes, no torch/C++ types;
+ *   - every tensor is contiguous row-major float32 on the current device unless stated;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call only
+ *     enqueues work on that stream -- no allocation, no host synchronisation, so calls are
+ *     capturable into a hipGraph;
+ *   - outputs and workspaces are caller-allocated;
+ *   - return 0 on success, negative on error (ekaid_last_error() holds the message);
+ *   - dropout masks are a pure function of (seed, element index): forward and backward pass the
+ *     same seed, nothing is stored.  p == 0 disables dropout.
+ */
+#ifndef EKAID_HIP_H
+#define EKAID_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EKAID_ABI_VERSION 1
+
+int ekaid_version(void);
+const char* ekaid_last_error(void);
+
+/* activation codes for fused epilogues */
+#define EKAID_ACT_NONE 0
+#define EKAID_ACT_RELU 1
+#define EKAID_ACT_TANH 2
+#define EKAID_ACT_SIGMOID 3
+
+/* ------------------------------------------------------------------------------------------
+ * Dense contraction on the fp32 matrix cores.
+ *   C = act( alpha * alpha_dev[0] * op(A).op(B)  [+ C]  [+ bias[n]]  [+ rowmask[m] * R[m / rdiv][n]] )
+ * transA=0: A is [M][K]; transA=1: A is [K][M].  transB=1: B is [N][K]; transB=0: B is [K][N].
+ * Two batch dimensions (batch1 x batch2) with element strides; batch index z -> (z / batch2, z % batch2).
+ * ref: every nn.Linear / FCNet / matmul on the path -- modules.py:195-196,278-303,
+ *      graph_att.py:80,92, graph_att_layer.py:79,90,105,167,174, language_model.py:113,138-142,
+ *      dynamic_speaker_change_pos.py:99-125,238; their autograd backward (dgrad/wgrad).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ekaid_gemm {
+    const float* A;
+    const float* B;
+    float* C;
+    int M, N, K;
+    int lda, ldb, ldc;
+    int transA, transB;
+    int batch1, batch2;
+    long long strideA1, strideA2, strideB1, strideB2, strideC1, strideC2;
+    float alpha;
+    const float* alpha_dev; /* optional device scalar multiplied into alpha (weight-norm g/||v||) */
+    int accumulate;         /* 1: C += ... (before bias/residual/act) */
+    const float* bias;      /* [N] or NULL */
+    const float* R;         /* optional residual, row (m / rdiv), leading dim ldr */
+    int ldr;
+    int rdiv;
+    const float* rowmask;   /* optional [M] multiplier of the residual row */
+    int act;
+} ekaid_gemm_t;
+
+size_t ekaid_gemm_workspace_bytes(const ekaid_gemm_t* g);
+int ekaid_gemm_f32(const ekaid_gemm_t* g, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight normalisation, dim=None:  W = v * g / ||v||_F.   ref: fc.py:26-33 (weight_norm(Linear, dim=None))
+ * fwd: scale_out[0] = g / ||v||,  norm_out[0] = ||v||.
+ * bwd: given dscale (gradient of the loss w.r.t. scale): dg[0] = dscale / ||v||,
+ *      dv (+)= -dscale * g / ||v||^3 * v      (accumulate_dv: 1 adds into dv, 0 overwrites)
+ * scale_dot: dot_out[0] = <G, w>; then G *= scale_dev[0]   (G = unscaled wgrad; gives dW and dscale)
+ * ------------------------------------------------------------------------------------------ */
+int ekaid_wn_scale_fwd(const float* v, const float* g, long long n, float* scale_out, float* norm_out, void* stream);
+int ekaid_wn_scale_bwd(const float* v, const float* g, const float* norm, const float* dscale, long long n,
+                       float* dv, int accumulate_dv, float* dg, void* stream);
+int ekaid_scale_dot(float* G, const float* w, const float* scale_dev, long long n, float* dot_out, void* stream);
+
+/* column sum of an [M][N] matrix (bias gradient), out[N] */
+int ekaid_colsum(const float* x, int M, int N, int ldx, float* out, void* stream);
+/* dz = dy * act'(y) with the derivative written through the activation output y */
+int ekaid_act_bwd(const float* dy, const float* y, float* dz, long long n, int act, void* stream);
+/* y = x * keep(seed, i) / (1 - p)      (also its own backward)   ref: every nn.Dropout on the path */
+int ekaid_dropout(const float* x, float* y, long long n, float p, uint64_t seed, void* stream);
+/* out = a*x + b*y (y may be NULL) */
+int ekaid_axpby(const float* x, const float* y, float* out, long long n, float a, float b, void* stream);
+/* out = x * y */
+int ekaid_mul(const float* x, const float* y, float* out, long long n, void* stream);
+/* rowsum over the last dim: out[r] = sum_c x[r][c];  mask variant: out[r] = (sum != 0)
+ * ref: graph_att.py:89 (condensed adjacency), relation_encoder.py:24-27 (zero-row test) */
+int ekaid_rowsum(const float* x, long long rows, int cols, float* out, int as_nonzero_mask, void* stream);
+/* out[r][c] = mask[r] * q[(r / group) % qrows][c]     ref: relation_encoder.py:19-29 (q_expand_v_cat, q half;
+ * qrows = batch size lets the main and the reference image share one question matrix)
+ * bwd: dq[j][c] = sum over rows r with (r / group) % qrows == j of mask[r] * dout[r][c] */
+int ekaid_expand_rows_fwd(const float* q, const float* mask, long long rows, int group, int qrows, int cols, float* out,
+                          void* stream);
+int ekaid_expand_rows_bwd(const float* dout, const float* mask, long long rows, int group, int qrows, int cols, float* dq,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Graph attention core.   ref: graph_att_layer.py:105-172 (+ graph_att.py:76,88 for `dir`)
+ *   q,S : [R][N][A], k : [R][M][A], cond/lbias : [R][N][N] (condensed adjacency and
+ *   label bias in the ORIGINAL orientation; dir=1 reads them transposed), geo : [R][N][M][H] relu'd
+ *   pair_pos_fc1 output or NULL.  P : [R][N][H][M] softmax (returned by the layer),
+ *   outT : [R][N][H*A] = per-head P.S (input of linear_out_2).
+ * masked_softmax_{fwd,bwd}: the edge-softmax alone, on precomputed scaled affinities aff [R][N][H][M].
+ *   bwd writes daff, dgeo (may be NULL) and ACCUMULATES dlbias[R][N][N] (caller zero-fills).
+ * ------------------------------------------------------------------------------------------ */
+int ekaid_gat_fused_fwd(const float* q, const float* k, const float* S, const float* cond, const float* lbias,
+                        const float* geo, int R, int N, int M, int A, int H, int dir, float* P, float* outT,
+                        void* stream);
+int ekaid_masked_softmax_fwd(const float* aff, const float* cond, const float* lbias, const float* geo, int R,
+                             int N, int M, int H, int dir, float* P, void* stream);
+int ekaid_masked_softmax_bwd(const float* P, const float* dP, const float* cond, const float* geo, int R, int N,
+                             int M, int H, int dir, float* daff, float* dlbias, float* dgeo, void* stream);
+
+/* float64 box geometry -> float32 sinusoidal pair embedding [R][N][M][feat_dim]
+ * ref: utils/mimic_utils.py:152-208, modules.py:162-166.  bb is a DEVICE pointer to [R][N][4] doubles;
+ * dim_mat a device array of feat_dim/8 floats = 1000^(8t/feat_dim) (the reference's float32 table). */
+int ekaid_geom_embed(const double* bb, const float* dim_mat, int R, int N, int M, int feat_dim, float* out, void* stream);
+
+/* v_new = v + relu(dropout(2*o))       ref: graph_att.py:98-104 (quirk Q-B) + relation_encoder.py:80-81,128-129 (Q-A)
+ * bwd: do = dvnew * 2 * keep/(1-p) * [o*keep > 0]   (dv = dvnew) */
+int ekaid_residual_relu2_fwd(const float* v, const float* o, float* vnew, long long n, float p, uint64_t seed, void* stream);
+int ekaid_residual_relu2_bwd(const float* o, const float* dvnew, float* d_o, long long n, float p, uint64_t seed, void* stream);
+
+/* out = dropout(sigmoid(g2 + g1)) * dropout(tanh(c2 + c1))      ref: modules.py:278-288
+ * c2/g2: n elements (context2/gate2 of both images, bias included); c1/g1: n1 elements (context1/gate1 of the
+ * difference, shared by both images and computed once), broadcast: index i -> i % n1. */
+int ekaid_gate_fuse_fwd(const float* c2, const float* g2, const float* c1, const float* g1, float* out, long long n,
+                        long long n1, float p, uint64_t seed_c, uint64_t seed_g, void* stream);
+int ekaid_gate_fuse_bwd(const float* c2, const float* g2, const float* c1, const float* g1, const float* dout, float* dc2,
+                        float* dg2, float* dc1, float* dg1, long long n, long long n1, float p, uint64_t seed_c,
+                        uint64_t seed_g, void* stream);
+
+/* out[g][c] = sum_i w[g][i] * x[g][i][c]      ref: modules.py:305-308 (region pooling), language_model.py:151 (bmm) */
+int ekaid_weighted_pool_fwd(const float* w, const float* x, int G, int n, int C, float* out, void* stream);
+int ekaid_weighted_pool_bwd(const float* w, const float* x, const float* dout, int G, int n, int C, float* dw,
+                            float* dx, void* stream);
+
+/* Question self-attention weights with the reference's batch-coupled softmax (quirk Q-C):
+ * S = softmax over the batch axis of atten^T (L x B); weight = S's contiguous memory re-read as (B, L).
+ * ref: language_model.py:149.  S_out [L][B] is saved for the backward. */
+int ekaid_qatt_weights_fwd(const float* atten, int B, int L, float* S_out, float* weight, void* stream);
+int ekaid_qatt_weights_bwd(const float* S, const float* dweight, int B, int L, float* datten, void* stream);
+
+/* two-table embedding lookup / single table.  ref: language_model.py:48-53, dynamic_speaker_change_pos.py:153-156,229
+ * fwd: out[t][col_off + e] = act(table[tok[t]][e]); bwd: dtable[tok[t]][e] += dout[t][col_off+e] * act'
+ *      (rows equal to padding_idx receive no gradient) */
+int ekaid_embedding_fwd(const int64_t* tok, long long ntok, const float* table, int E, float* out, int ld_out,
+                        int col_off, int relu, void* stream);
+int ekaid_embedding_bwd(const int64_t* tok, long long ntok, const float* table, const float* dout, int E, int ld_out,
+                        int col_off, int relu, long long padding_idx, float* dtable, void* stream);
+
+/* GRU / LSTM cell point-wise parts (the gate GEMMs go through ekaid_gemm_f32).
+ * ref: language_model.py:66-70,113 (nn.GRU, gate order r,z,n), dynamic_speaker_change_pos.py:57,88,102,126 (nn.LSTMCell, i,f,g,o)
+ * gi/gh/gx may be strided views (leading dims ld*). save: GRU [B][4H] = r,z,n,gh_n ; LSTM [B][4H] = i,f,g,o.
+ * gru bwd: upstream gradient = dhnew (strided, may be NULL) + dh_carry (contiguous [B][H], may be NULL);
+ * dh receives only the direct (z * d) term -- the caller adds dgh . W_hh with an accumulating GEMM. */
+int ekaid_gru_cell_fwd(const float* gi, int ldgi, const float* gh, int ldgh, const float* h, int ldh, int B, int H,
+                       float* hnew, int ldhn, float* save, void* stream);
+int ekaid_gru_cell_bwd(const float* dhnew, int lddh, const float* dh_carry, const float* save, const float* h, int ldh,
+                       int B, int H, float* dgi, int lddgi, float* dgh, float* dh, void* stream);
+int ekaid_lstm_cell_fwd(const float* gx, const float* gh, const float* c, int B, int H, float* h2, float* c2,
+                        float* save, void* stream);
+int ekaid_lstm_cell_bwd(const float* dh2, const float* dc2, const float* save, const float* c, const float* c2, int B,
+                        int H, float* dgates, float* dc, void* stream);
+
+/* row softmax / log-softmax.  ref: dynamic_speaker_change_pos.py:61-63,71,238-239, modules.py:65 */
+int ekaid_softmax_fwd(const float* x, float* y, long long rows, int cols, int log_mode, void* stream);
+int ekaid_softmax_bwd(const float* y, const float* dy, float* dx, long long rows, int cols, int log_mode, void* stream);
+
+/* att_feat = w0*a + w1*b + w2*c per row.  ref: dynamic_speaker_change_pos.py:112-117 */
+int ekaid_mix3_fwd(const float* w, const float* a, const float* b, const float* c, int B, int C, float* out, void* stream);
+int ekaid_mix3_bwd(const float* w, const float* a, const float* b, const float* c, const float* dout, int B, int C,
+                   float* dw, float* da, float* db, float* dc, void* stream);
+
+/* masked NLL of teacher-forced log-probs.   ref: utils/utils.py:208-216
+ * sums[0] = -sum logp[b][t][target[b][t]] * mask[b][t], sums[1] = sum mask  (t < T); caller zero-fills sums;
+ * loss_out[0] = sums[0] / sums[1].
+ * bwd: dlogp[b][t][v] = -(v == target) * mask * gscale_dev[0] / sums[1]   (dlogp zero elsewhere, written in full) */
+int ekaid_nll_fwd(const float* logp, const int64_t* target, int ld_target, const float* mask, int ld_mask, int B, int T,
+                  int V, float* sums, float* loss_out, void* stream);
+int ekaid_nll_bwd(const int64_t* target, int ld_target, const float* mask, int ld_mask, const float* sums,
+                  const float* gscale_dev, int B, int T, int V, float* dlogp, void* stream);
+
+/* out[0] = speaker_loss[0] + coef * (sum(att_bef) + sum(att_aft)), both of n elements.  ref: train_mimic.py:246-247
+ * fill_scaled: out[i] = scalar_dev[0] * coef (its backward). */
+int ekaid_total_loss_fwd(const float* speaker_loss, const float* att_bef, const float* att_aft, long long n, float coef,
+                         float* out, void* stream);
+int ekaid_fill_scaled(const float* scalar_dev, float coef, float* out, long long n, void* stream);
+
+/* LayerNorm over the last dim (eps inside sqrt).  ref: modules.py:33,76 (eps = 1e-6). save: [rows][2] = mean, rstd */
+int ekaid_layernorm_fwd(const float* x, const float* gamma, const float* beta, long long rows, int cols, float eps,
+                        float* y, float* save, void* stream);
+int ekaid_layernorm_bwd(const float* x, const float* gamma, const float* save, const float* dy, long long rows, int cols,
+                        float* dx, float* dgamma, float* dbeta, void* stream);
+
+/* integer-valued label matrix [B][S][S] (float64 as the reference collates it, or int64) -> one-hot float32
+ * [B][N][N][L], channel l-1 = (label == l), cropped to the first N nodes.   ref: utils/mimic_utils.py:119-149 */
+int ekaid_process_matrix(const void* adj, int is_int64, int B, int S, int N, int L, float* out, void* stream);
+
+/* Adam, torch.optim.Adam semantics (no amsgrad, wd = 0), over one flat buffer.   ref: utils/utils.py:96-99
+ * g is multiplied by grad_scale first (1/world_size after an all-reduce sum). */
+int ekaid_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                    float eps, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,411 @@
+"""CPU ORACLE for the EKAID difference-VQA forward/backward path.
+
+>>> TEST INFRASTRUCTURE ONLY. <<<  Nothing in the product path (``ekaid_amd/``) may
+import this file; only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` use it, and only as the checker / the timed
+CPU baseline -- never as the thing shipped.
+
+What it is: a from-scratch, functional (no ``nn.Module``) float32 PyTorch-CPU
+restatement of the reference algorithm, working directly on ``state_dict``-keyed
+parameter dictionaries.  Every function cites the reference file:line it restates
+(paths relative to ``/root/reference/model``).  Dropout is the identity here
+(eval-mode / "eval-with-grad" semantics): dropout RNG streams of two different
+implementations cannot match, so parity is defined with dropout off.
+
+Parity pin: the reference ships no tests or golden vectors, so
+the oracle is pinned against outputs of the reference itself, imported in the build
+container by ``tests/golden/make_golden.py`` and stored under ``tests/golden/*.npz``;
+``tests/test_oracle_golden.py`` checks this file against those vectors (<= 1e-5).
+All arithmetic is ATen (torch) float32, except the box geometry which is float64
+exactly as in the reference.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+NEG_MASK = -9e15          # reference graph_att_layer.py:140 ("zero_vec")
+
+
+# --------------------------------------------------------------------------- #
+# a1  utils/mimic_utils.py:119-149
+# --------------------------------------------------------------------------- #
+def process_matrix(adj, num_objects, label_num):
+    """int-valued label matrix (B,100,100) -> one-hot float32 (B,N,N,L).
+    Channel l-1 is 1 where the label equals l (label 0 = no edge -> all zero)."""
+    adj = adj[:, :num_objects, :num_objects]
+    chans = [(adj == float(l)).to(torch.float32) for l in range(1, label_num + 1)]
+    return torch.stack(chans, dim=3)
+
+
+# --------------------------------------------------------------------------- #
+# a11  utils/mimic_utils.py:152-208, modules.py:162-166
+# --------------------------------------------------------------------------- #
+def position_matrix(bbox, nongt_dim):
+    """float64 (B,N,4) boxes -> float64 (B,N,min(nongt,N),4) log-geometry."""
+    xmin, ymin, xmax, ymax = bbox[..., 0:1], bbox[..., 1:2], bbox[..., 2:3], bbox[..., 3:4]
+    w = xmax - xmin + 1.0
+    h = ymax - ymin + 1.0
+    cx = 0.5 * (xmin + xmax)
+    cy = 0.5 * (ymin + ymax)
+    dx = torch.abs((cx - cx.transpose(1, 2)) / w).clamp_min(1e-3).log()
+    dy = torch.abs((cy - cy.transpose(1, 2)) / h).clamp_min(1e-3).log()
+    dw = (w / w.transpose(1, 2)).log()
+    dh = (h / h.transpose(1, 2)).log()
+    # NB the reference slices dim 1 (``sym[:, :nongt_dim]``, mimic_utils.py:186), i.e. rows
+    return torch.stack([t[:, :nongt_dim] for t in (dx, dy, dw, dh)], dim=3)
+
+
+def position_embedding(pos_mat, feat_dim=64, wave_length=1000.0):
+    """(B,N,M,4) f64 -> (B,N,M,feat_dim) f64: per component [sin x8, cos x8]."""
+    n = feat_dim // 8
+    feat_range = torch.arange(0, feat_dim / 8)                       # float32, as reference
+    dim_mat = torch.pow(torch.ones((1,)) * wave_length, (8.0 / feat_dim) * feat_range)
+    div = (100.0 * pos_mat).unsqueeze(4) / dim_mat.view(1, 1, 1, 1, n)
+    emb = torch.cat([torch.sin(div), torch.cos(div)], dim=-1)        # (B,N,M,4,2n)
+    return emb.reshape(emb.shape[0], emb.shape[1], emb.shape[2], feat_dim)
+
+
+# --------------------------------------------------------------------------- #
+# a10  models/fc.py:15-49   (weight_norm(Linear, dim=None): W = v * g/||v||_F)
+# --------------------------------------------------------------------------- #
+def wn_linear(P, prefix, x):
+    v = P[prefix + '.weight_v']
+    g = P[prefix + '.weight_g']
+    w = v * (g / torch.linalg.vector_norm(v))
+    return F.linear(x, w, P.get(prefix + '.bias'))
+
+
+def linear(P, prefix, x):
+    return F.linear(x, P[prefix + '.weight'], P.get(prefix + '.bias'))
+
+
+# --------------------------------------------------------------------------- #
+# a6  models/relation_encoder.py:19-29
+# --------------------------------------------------------------------------- #
+def q_expand_v_cat(q, v):
+    keep = (v.sum(-1) != 0).to(v.dtype).unsqueeze(-1)                # zero q on all-zero rows
+    q_exp = q.unsqueeze(1).expand(-1, v.shape[1], -1) * keep
+    return torch.cat([v, q_exp], dim=-1)
+
+
+# --------------------------------------------------------------------------- #
+# a9  models/graph_att_layer.py:60-178
+# --------------------------------------------------------------------------- #
+def graph_attention_layer(P, prefix, roi_feat, adj, pos_emb, label_bias, heads, nongt_dim,
+                          fc_idx=1):
+    """roi_feat (B,N,A), adj (B,N,M) condensed adjacency, pos_emb (B,N,M,64)|None,
+    label_bias (B,N,M).  Returns (out (B,N,A), softmax (B,N,H,M))."""
+    B, N, A = roi_feat.shape
+    M = min(nongt_dim, N)
+    dh = A // heads
+    key_feat = roi_feat[:, :M]
+    q = wn_linear(P, '%s.query.main.%d' % (prefix, fc_idx), roi_feat).view(B, N, heads, dh)
+    k = wn_linear(P, '%s.key.main.%d' % (prefix, fc_idx), key_feat).view(B, M, heads, dh)
+    aff = torch.matmul(q.transpose(1, 2), k.transpose(1, 2).transpose(2, 3))   # (B,H,N,M)
+    w_aff = ((1.0 / math.sqrt(float(dh))) * aff).transpose(1, 2)                 # (B,N,H,M)
+    if pos_emb is not None:
+        pe = pos_emb.float().reshape(B, -1, pos_emb.shape[-1])
+        gw = F.relu(wn_linear(P, '%s.pair_pos_fc1.main.%d' % (prefix, fc_idx), pe))
+        gw = gw.view(B, -1, M, heads).transpose(2, 3)                            # (B,N,H,M)
+        w_aff = w_aff + torch.log(torch.clamp_min(gw, 1e-6))
+    w_t = w_aff.transpose(2, 3)                                                  # (B,N,M,H)
+    masked = torch.where(adj.unsqueeze(3) > 0, w_t, torch.full_like(w_t, NEG_MASK))
+    masked = masked + label_bias.unsqueeze(3)          # bias added AFTER masking (:152)
+    soft = F.softmax(masked.transpose(2, 3), dim=3)                              # (B,N,H,M)
+    out_t = torch.matmul(soft.reshape(B, N * heads, M), key_feat)                # (B,N*H,A)
+    out = linear(P, prefix + '.linear_out_2', out_t.reshape(B * N, heads * A))
+    return out.view(B, N, A), soft
+
+
+# --------------------------------------------------------------------------- #
+# a8  models/graph_att.py:53-106   (quirk Q-B: only the last direction survives)
+# --------------------------------------------------------------------------- #
+def gat_net(P, prefix, v_cat_q, adj_onehot, pos_emb, dir_num, heads, nongt_dim,
+            faithful=False):
+    self_feat = wn_linear(P, prefix + '.self_weights.main.1', v_cat_q)
+    adj_list = [adj_onehot, adj_onehot.transpose(1, 2)]
+    dirs = range(dir_num) if faithful else [dir_num - 1]
+    output, affs = None, []
+    for d in dirs:
+        a = adj_list[d][:, :, :nongt_dim, :]
+        condensed = a.sum(-1)
+        bias = wn_linear(P, prefix + '.bias.main.0', a).squeeze(-1)
+        o, soft = graph_attention_layer(P, '%s.neighbor_net.%d' % (prefix, d), self_feat,
+                                        condensed, pos_emb, bias, heads, nongt_dim)
+        output = o + o                 # ``output = output + neighbor_emb[d]`` with both == o
+        affs.append(soft)
+    return F.relu(output), affs
+
+
+# --------------------------------------------------------------------------- #
+# a7  models/relation_encoder.py:57-84, 112-132   (in-place residual, quirk Q-A)
+# --------------------------------------------------------------------------- #
+def explicit_encoder(P, prefix, v, adj_onehot, q, cfg):
+    cd = cfg.model.change_detector
+    rel, aff = gat_net(P, prefix + '.explicit_relation', q_expand_v_cat(q, v), adj_onehot, None,
+                       cd.dir_num, cd.att_head, cd.nongt_dim)
+    return v + rel, aff
+
+
+def implicit_encoder(P, prefix, v, pos_emb, q, cfg):
+    cd = cfg.model.change_detector
+    ones = torch.ones(v.shape[0], v.shape[1], v.shape[1], 1, dtype=v.dtype)
+    rel, aff = gat_net(P, prefix + '.implicit_relation', q_expand_v_cat(q, v), ones, pos_emb,
+                       cd.dir_num, cd.att_head, cd.nongt_dim)
+    return v + rel, aff
+
+
+# --------------------------------------------------------------------------- #
+# a3-a5  models/language_model.py
+# --------------------------------------------------------------------------- #
+def word_embedding(P, tokens):                                       # :48-53
+    return torch.cat([F.embedding(tokens, P['w_emb.emb.weight']),
+                      F.embedding(tokens, P['w_emb.emb_.weight'])], dim=2)
+
+
+def gru_forward_all(P, x):                                           # :106-115 (nn.GRU, h0=0)
+    w_ih, w_hh = P['q_emb.rnn.weight_ih_l0'], P['q_emb.rnn.weight_hh_l0']
+    b_ih, b_hh = P['q_emb.rnn.bias_ih_l0'], P['q_emb.rnn.bias_hh_l0']
+    B, L, _ = x.shape
+    Hd = w_hh.shape[1]
+    gi_all = F.linear(x, w_ih, b_ih)                                 # (B,L,3H) gate order r,z,n
+    h = x.new_zeros(B, Hd)
+    outs = []
+    for t in range(L):
+        gi = gi_all[:, t]
+        gh = F.linear(h, w_hh, b_hh)
+        r = torch.sigmoid(gi[:, :Hd] + gh[:, :Hd])
+        z = torch.sigmoid(gi[:, Hd:2 * Hd] + gh[:, Hd:2 * Hd])
+        n = torch.tanh(gi[:, 2 * Hd:] + r * gh[:, 2 * Hd:])
+        h = (1.0 - z) * n + z * h
+        outs.append(h)
+    return torch.stack(outs, dim=1)
+
+
+def question_self_attention(P, ques_feat, gather_fn=None):           # :127-156 (quirk Q-C)
+    """softmax over the *batch* dimension of the (Lq,B) logits, whose contiguous
+    memory is then re-read as (B,1,Lq).  ``gather_fn`` (optional) maps the local (B,Lq)
+    logits to the global-batch logits for the data-parallel "global semantics" test."""
+    B, L, Hd = ques_feat.shape
+    a1 = torch.tanh(wn_linear(P, 'q_att.W1_self_att_q.main.1', ques_feat.reshape(-1, Hd)))
+    atten = wn_linear(P, 'q_att.W2_self_att_q.main.0', a1).view(B, L)
+    weight = F.softmax(atten.t(), dim=1).contiguous().view(-1, 1, L)
+    return torch.bmm(weight, ques_feat).view(-1, Hd)
+
+
+def question_encoder(P, question):
+    return question_self_attention(P, gru_forward_all(P, word_embedding(P, question)))
+
+
+# --------------------------------------------------------------------------- #
+# a13  models/modules.py:17-77   (SSRE, only for setting == 'mode0')
+# --------------------------------------------------------------------------- #
+def ssre(P, x, heads):
+    B, N, _ = x.shape
+    A = P['SSRE.query.weight'].shape[0]
+    dh = A // heads
+
+    def split(t):
+        return t.view(B, N, heads, dh).permute(0, 2, 1, 3)
+    q, k, v = (split(linear(P, 'SSRE.' + n, x)) for n in ('query', 'key', 'value'))
+    probs = F.softmax(torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh), dim=-1)
+    ctx = torch.matmul(probs, v).permute(0, 2, 1, 3).reshape(B, N, A)
+    return F.layer_norm(ctx, (A,), P['SSRE.layer_norm.weight'], P['SSRE.layer_norm.bias'], 1e-6)
+
+
+# --------------------------------------------------------------------------- #
+# a2 + a12  models/modules.py:169-313
+# --------------------------------------------------------------------------- #
+def change_detector_forward(P, cfg, input_1, input_2, d_adj, q_adj, d_sem, q_sem, d_bb, q_bb,
+                            question, setting='mode2', graph='all', q_vec=None):
+    cd = cfg.model.change_detector
+    B, N, _ = input_1.shape
+    bef = linear(P, 'img', input_1)
+    aft = linear(P, 'img', input_2)
+    q = question_encoder(P, question) if q_vec is None else q_vec
+    aux = {'q': q}
+    if setting == 'mode2':
+        if graph in ('semantic', 'all'):
+            bef, aux['aff_bef_sem'] = explicit_encoder(P, 'semantic_relation', bef, d_sem, q, cfg)
+            aft, aux['aff_aft_sem'] = explicit_encoder(P, 'semantic_relation', aft, q_sem, q, cfg)
+        if graph in ('spatial', 'all', 'i+s'):
+            bef, aux['aff_bef_spa'] = explicit_encoder(P, 'spatial_relation', bef, d_adj, q, cfg)
+            aft, aux['aff_aft_spa'] = explicit_encoder(P, 'spatial_relation', aft, q_adj, q, cfg)
+        if graph in ('implicit', 'all', 'i+s'):
+            pe_b = position_embedding(position_matrix(d_bb, cd.nongt_dim), cd.pos_emb_dim)
+            pe_a = position_embedding(position_matrix(q_bb, cd.nongt_dim), cd.pos_emb_dim)
+            bef, aux['aff_bef_imp'] = implicit_encoder(P, 'imp_relation', bef, pe_b, q, cfg)
+            aft, aux['aff_aft_imp'] = implicit_encoder(P, 'imp_relation', aft, pe_a, q, cfg)
+        if graph == 'all':
+            # Q-A: the three "branches" are one tensor; Q-D: coefficients from cfg (:234-235)
+            cs, cp = cd.coef_sem, cd.coef_spa
+            bef = cs * bef + cp * bef + (1 - cs - cp) * bef
+            aft = cs * aft + cp * aft + (1 - cs - cp) * aft
+        elif graph == 'i+s':
+            bef = (bef + bef) / 2
+            aft = (aft + aft) / 2
+    elif setting == 'mode0':
+        bef = ssre(P, q_expand_v_cat(q, bef), cd.att_head)
+        aft = ssre(P, q_expand_v_cat(q, aft), cd.att_head)
+    else:
+        raise ValueError('setting %r crashes in the reference (modules.py:214,257,263)' % setting)
+    diff = aft - bef
+    c1d = F.linear(diff, P['context1.weight'])
+    g1d = F.linear(diff, P['gate1.weight'])
+    befs = torch.sigmoid(g1d + linear(P, 'gate2', bef)) * torch.tanh(c1d + linear(P, 'context2', bef))
+    afts = torch.sigmoid(g1d + linear(P, 'gate2', aft)) * torch.tanh(c1d + linear(P, 'context2', aft))
+    emb_b = F.relu(linear(P, 'embed.0', torch.cat([bef, diff, befs], dim=2)))
+    emb_a = F.relu(linear(P, 'embed.0', torch.cat([aft, diff, afts], dim=2)))
+    att_b = torch.sigmoid(linear(P, 'att', emb_b)).transpose(1, 2)          # (B,1,N)
+    att_a = torch.sigmoid(linear(P, 'att', emb_a)).transpose(1, 2)
+    attended_1 = (bef.transpose(1, 2) * att_b).sum(2)
+    attended_2 = (aft.transpose(1, 2) * att_a).sum(2)
+    input_attended = attended_2 - attended_1
+    pred = linear(P, 'fc1', input_attended)
+    aux.update(bef=bef, aft=aft)
+    return (pred, att_b, att_a, attended_1, attended_2, input_attended), aux
+
+
+# --------------------------------------------------------------------------- #
+# a14-a16  models/dynamic_speaker_change_pos.py
+# --------------------------------------------------------------------------- #
+def lstm_cell(P, prefix, x, h, c):                                   # nn.LSTMCell, gates i,f,g,o
+    gates = F.linear(x, P[prefix + '.weight_ih'], P[prefix + '.bias_ih']) + \
+        F.linear(h, P[prefix + '.weight_hh'], P[prefix + '.bias_hh'])
+    Hd = h.shape[1]
+    i = torch.sigmoid(gates[:, :Hd])
+    f = torch.sigmoid(gates[:, Hd:2 * Hd])
+    g = torch.tanh(gates[:, 2 * Hd:3 * Hd])
+    o = torch.sigmoid(gates[:, 3 * Hd:])
+    c2 = f * c + i * g
+    return o * torch.tanh(c2), c2
+
+
+def speaker_step(P, it, feat_bef, feat_aft, feat_diff, state, embed_pre=None):   # :94-131, :225-240
+    (h_att, h_lang), (c_att, c_lang) = state
+    xt = F.relu(F.embedding(it, P['embed.0.weight']))
+    if embed_pre is None:
+        embed_pre = F.relu(linear(P, 'core.embed.0', torch.cat([feat_bef, feat_diff, feat_aft], 1)))
+    h_att, c_att = lstm_cell(P, 'core.module_att_lstm', torch.cat([embed_pre, h_lang], 1), h_att, c_att)
+    mod_w = F.softmax(linear(P, 'core.weight_fc.0', h_att), dim=1)               # (B,3)
+    vpos = F.relu(linear(P, 'core.pos1.0', h_lang))
+    dpos = linear(P, 'core.weight_pos', vpos)
+    ppos = linear(P, 'core.pos2', F.softmax(dpos, dim=1))
+    att_feat = mod_w[:, 0:1] * feat_bef + mod_w[:, 1:2] * feat_diff + mod_w[:, 2:3] * feat_aft
+    gate_in = torch.cat([h_lang, ppos, att_feat], -1)
+    gate = torch.sigmoid(linear(P, 'core.gate2x', F.relu(linear(P, 'core.gate1x.0', gate_in))))
+    h_lang, c_lang = lstm_cell(P, 'core.lang_lstm', torch.cat([xt, gate * att_feat], 1), h_lang, c_lang)
+    logp = F.log_softmax(linear(P, 'logit', h_lang), dim=1)
+    return logp, ((h_att, h_lang), (c_att, c_lang)), F.log_softmax(dpos, dim=1), mod_w
+
+
+def _zero_state(P, B):
+    Hd = P['core.lang_lstm.weight_hh'].shape[1]
+    z = P['logit.weight'].new_zeros(B, Hd)
+    return ((z, z), (z, z))
+
+
+def speaker_forward(P, cfg, feat_bef, feat_aft, feat_diff, seq):                 # :182-222
+    B = feat_bef.shape[0]
+    T = cfg.model.speaker.seq_length
+    V = P['logit.weight'].shape[0]
+    state = _zero_state(P, B)
+    embed_pre = F.relu(linear(P, 'core.embed.0', torch.cat([feat_bef, feat_diff, feat_aft], 1)))
+    outs, outs_pos = [], []
+    for i in range(T):
+        if i >= 1 and int(seq[:, i].sum()) == 0:
+            break
+        logp, state, logpos, _ = speaker_step(P, seq[:, i], feat_bef, feat_aft, feat_diff, state,
+                                              embed_pre)
+        outs.append(logp)
+        outs_pos.append(logpos)
+    pad = T - len(outs)
+    outputs = torch.stack(outs, 1)
+    outputs_pos = torch.stack(outs_pos, 1)
+    if pad:
+        outputs = torch.cat([outputs, outputs.new_zeros(B, pad, V)], 1)
+        outputs_pos = torch.cat([outputs_pos, outputs_pos.new_zeros(B, pad, 16)], 1)
+    return outputs, outputs_pos
+
+
+@torch.no_grad()
+def speaker_sample_greedy(P, cfg, feat_bef, feat_aft, feat_diff):               # :287-357
+    B = feat_bef.shape[0]
+    T = cfg.model.speaker.seq_length
+    state = _zero_state(P, B)
+    seq = torch.zeros(B, T, dtype=torch.long)
+    seq_logp = feat_bef.new_zeros(B, T)
+    it = torch.full((B,), 2, dtype=torch.long)                       # <bos> hard-coded as id 2 (:311)
+    unfinished = None
+    for t in range(T + 1):
+        logp, state, _, _ = speaker_step(P, it, feat_bef, feat_aft, feat_diff, state)
+        if t == 0:
+            logp = logp.clone()
+            logp[:, 0] = float('-inf')
+        if t == T:
+            break
+        sample_logp, it = torch.max(logp, 1)
+        unfinished = (it > 0) if t == 0 else unfinished & (it > 0)
+        it = it * unfinished.to(it.dtype)
+        seq[:, t] = it
+        seq_logp[:, t] = sample_logp
+        if int(unfinished.sum()) == 0:
+            break
+    return seq, seq_logp
+
+
+# --------------------------------------------------------------------------- #
+# a17  utils/utils.py:204-216 + train_mimic.py:242-247
+# --------------------------------------------------------------------------- #
+def lm_criterion(logprobs, target, mask):
+    target = target[:, :logprobs.shape[1]]
+    mask = mask[:, :logprobs.shape[1]]
+    picked = -logprobs.gather(2, target.unsqueeze(2)).squeeze(2) * mask
+    return picked.sum() / mask.sum()
+
+
+def total_loss(logprobs, labels, masks, att_bef, att_aft):
+    B = logprobs.shape[0]
+    speaker_loss = lm_criterion(logprobs, labels[:, 1:], masks[:, 1:])
+    att_sum = (att_bef.sum() + att_aft.sum()) / (2 * B)
+    return speaker_loss + 2.5e-03 * att_sum, speaker_loss
+
+
+# --------------------------------------------------------------------------- #
+# a18  torch.optim.Adam as configured by utils/utils.py:96-99 (wd = 0)
+# --------------------------------------------------------------------------- #
+@torch.no_grad()
+def adam_step(p, g, m, v, step, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8):
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+# --------------------------------------------------------------------------- #
+# whole training-loss graph (train_mimic.py:209-247) on a synthetic batch dict
+# --------------------------------------------------------------------------- #
+def prepare_inputs(cfg, batch):
+    cd = cfg.model.change_detector
+    N = batch['input_1'].shape[1]
+    return dict(
+        d_adj=process_matrix(batch['d_adj'], N, cd.spa_label_num),
+        q_adj=process_matrix(batch['q_adj'], N, cd.spa_label_num),
+        d_sem=process_matrix(batch['d_sem'], N, cd.sem_label_num),
+        q_sem=process_matrix(batch['q_sem'], N, cd.sem_label_num))
+
+
+def train_loss(Pcd, Psp, cfg, batch, setting=None, graph=None):
+    setting = setting or cfg.train.setting
+    graph = graph or cfg.train.graph
+    adj = prepare_inputs(cfg, batch)
+    outs, aux = change_detector_forward(
+        Pcd, cfg, batch['input_1'], batch['input_2'], adj['d_adj'], adj['q_adj'], adj['d_sem'],
+        adj['q_sem'], batch['d_bb'], batch['q_bb'], batch['question'], setting, graph)
+    pred, att_b, att_a, f_bef, f_aft, f_diff = outs
+    logp, logpos = speaker_forward(Psp, cfg, f_bef, f_aft, f_diff, batch['labels'])
+    loss, sp_loss = total_loss(logp, batch['labels'], batch['masks'], att_b, att_a)
+    return loss, dict(outs=outs, logp=logp, logpos=logpos, speaker_loss=sp_loss, aux=aux)

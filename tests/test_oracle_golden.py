@@ -1,0 +1,197 @@
+"""The CPU oracle (oracle/ekaid_oracle.py) against the golden vectors captured from the reference
+(tests/golden/*.npz, written by tests/golden/make_golden.py).  Pins the oracle: every later HIP
+parity test compares against it."""
+import numpy as np
+import pytest
+import torch
+
+from common import FULL, SMALL, build_models, oracle_params, small_models
+from ekaid_amd.config import bench_cfg
+from ekaid_amd.synthetic import make_batch
+from golden_util import assert_summary_close, load_golden, negligible_grad_names
+from oracle import ekaid_oracle as O
+
+TOL = 2e-5
+
+
+def close(a, b, tol=TOL, what=''):
+    a = a.detach().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, '%s: shape %s vs %s' % (what, a.shape, b.shape)
+    err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-6)
+    assert err <= tol, '%s: rel-to-max err %.3e > %.1e' % (what, err, tol)
+
+
+def run_oracle(cfg, cd, sp, batch, setting, graph, grads=True):
+    Pcd, Psp = oracle_params(cd, grads), oracle_params(sp, grads)
+    loss, res = O.train_loss(Pcd, Psp, cfg, batch, setting, graph)
+    named = []
+    if grads:
+        loss.backward()
+        named = [('cd.' + k, Pcd[k].grad) for k, _ in cd.named_parameters()] + \
+                [('sp.' + k, Psp[k].grad) for k, _ in sp.named_parameters()]
+    return loss, res, named
+
+
+@pytest.mark.parametrize('graph', ['semantic', 'spatial', 'implicit', 'all', 'i+s'])
+def test_f1_forward_backward(graph):
+    g = load_golden('f1_' + graph.replace('+', 'p'))
+    cfg, cd, sp = small_models(graph)
+    batch = make_batch(**SMALL)
+    loss, res, named = run_oracle(cfg, cd, sp, batch, 'mode2', graph)
+    close(loss, g['loss'], what='loss')
+    for i, k in enumerate(('pred', 'att_bef', 'att_aft', 'feat_bef', 'feat_aft', 'feat_diff')):
+        close(res['outs'][i], g[k], what=k)
+    close(res['logp'], g['logp'], what='logp')
+    close(res['logpos'], g['logpos'], what='logpos')
+    extra = assert_summary_close(g['grad_names'], g['grad_rows'], named, 2e-4, 'grads[%s]' % graph)
+    # parameters the reference never differentiates must get no (or zero) gradient from the oracle either
+    got = dict(named)
+    for k in extra:
+        if k == 'cd.w_emb.emb_.weight':      # frozen in the reference (language_model.py:29)
+            continue
+        assert float(got[k].abs().max()) == 0.0, 'oracle produced a gradient for dead parameter ' + k
+
+
+def test_f1_mode0_ssre_layernorm():
+    g = load_golden('f1_mode0')
+    cfg, cd, sp = small_models('all', 'mode0')
+    batch = make_batch(**SMALL)
+    loss, res, named = run_oracle(cfg, cd, sp, batch, 'mode0', 'all')
+    close(loss, g['loss'], what='loss')
+    close(res['logp'], g['logp'], what='logp')
+    close(res['outs'][3], g['feat_bef'], what='feat_bef')
+    assert_summary_close(g['grad_names'], g['grad_rows'], named, 2e-4, 'grads[mode0]')
+
+
+def test_f2_batch_coupled_question_attention():
+    g = load_golden('f2_qc')
+    cfg, cd, sp = small_models('semantic')
+    P = oracle_params(cd)
+    b4 = make_batch(**dict(SMALL, B=4))
+    qs = {}
+    for B in (2, 4):
+        seq = O.gru_forward_all(P, O.word_embedding(P, b4['question'][:B]))
+        close(seq, g['gru_%d' % B], what='gru B=%d' % B)
+        qs[B] = O.question_self_attention(P, seq)
+        close(qs[B], g['q_%d' % B], what='q B=%d' % B)
+    # quirk Q-C really couples the batch: same two samples, different answer
+    assert float((qs[2] - qs[4][:2]).abs().max()) > 1e-3
+
+
+def test_f3_blocks():
+    g = load_golden('f3_blocks')
+    cfg, cd, sp = small_models('all')
+    Pcd, Psp = oracle_params(cd), oracle_params(sp)
+    batch = make_batch(**SMALL)
+    N = SMALL['N']
+    spa = O.process_matrix(batch['d_adj'], N, 11)
+    sem = O.process_matrix(batch['d_sem'], N, 3)
+    close(spa, g['onehot_spa'], 0, 'onehot_spa')
+    close(sem, g['onehot_sem'], 0, 'onehot_sem')
+    pm = O.position_matrix(batch['d_bb'], 52)
+    close(pm, g['pos_mat'], 1e-12, 'pos_mat')
+    pe = O.position_embedding(pm, 64)
+    close(pe, g['pos_emb'], 1e-9, 'pos_emb')
+    x = torch.from_numpy(g['layer_x'])
+    pre = 'spatial_relation.explicit_relation.neighbor_net.1'
+    o, s = O.graph_attention_layer(Pcd, pre, x, torch.from_numpy(g['layer_cond']), None,
+                                   torch.from_numpy(g['layer_lb']), 4, 52)
+    close(o, g['layer_exp_out'], what='layer_exp_out')
+    close(s, g['layer_exp_soft'], what='layer_exp_soft')
+    assert np.allclose(s[0, 3].numpy(), 0.125)          # isolated node -> uniform row (the -9e15 mask)
+    pre = 'imp_relation.implicit_relation'
+    lbi = O.wn_linear(Pcd, pre + '.bias.main.0', torch.ones(2, N, N, 1)).squeeze(-1)
+    o, s = O.graph_attention_layer(Pcd, pre + '.neighbor_net.1', x, torch.ones(2, N, N), pe, lbi, 4, 52)
+    close(o, g['layer_imp_out'], what='layer_imp_out')
+    close(s, g['layer_imp_soft'], what='layer_imp_soft')
+    o, affs = O.gat_net(Pcd, 'spatial_relation.explicit_relation', torch.from_numpy(g['gat_in']), spa, None, 2, 4, 52,
+                        faithful=True)
+    close(o, g['gat_out'], what='gat_out')
+    close(affs[0], g['gat_aff0'], what='gat_aff0')
+    close(affs[1], g['gat_aff1'], what='gat_aff1')
+    o2, _ = O.gat_net(Pcd, 'spatial_relation.explicit_relation', torch.from_numpy(g['gat_in']), spa, None, 2, 4, 52)
+    assert torch.equal(o, o2)                            # Q-B: skipping the dead direction changes nothing
+    q = O.question_encoder(Pcd, batch['question'])
+    close(q, g['enc_q'], what='enc_q')
+    v0 = O.linear(Pcd, 'img', batch['input_1'])
+    close(v0, g['enc_v0'], what='enc_v0')
+    v1, _ = O.explicit_encoder(Pcd, 'semantic_relation', v0, sem, q, cfg)
+    close(v1, g['enc_v1'], what='enc_v1')
+    v2, _ = O.explicit_encoder(Pcd, 'spatial_relation', v1, spa, q, cfg)
+    close(v2, g['enc_v2'], what='enc_v2')
+    v3, _ = O.implicit_encoder(Pcd, 'imp_relation', v2, pe, q, cfg)
+    close(v3, g['enc_v3'], what='enc_v3')
+    h, c = torch.from_numpy(g['core_h']), torch.from_numpy(g['core_c'])
+    lp, st, lpp, mw = O.speaker_step(Psp, torch.from_numpy(g['core_it']), torch.from_numpy(g['core_fb']),
+                                     torch.from_numpy(g['core_fa']), torch.from_numpy(g['core_fd']),
+                                     ((h[0], h[1]), (c[0], c[1])))
+    close(lp, g['core_logp'], what='core_logp')
+    close(torch.stack(st[0]), g['core_h2'], what='core_h2')
+    close(torch.stack(st[1]), g['core_c2'], what='core_c2')
+    close(lpp, g['core_logpos'], what='core_logpos')
+    close(mw, g['core_modw'], what='core_modw')
+
+
+def test_f3_greedy_sample_ids():
+    g = load_golden('f3_sample')
+    cfg, cd, sp = small_models('all')
+    batch = make_batch(**SMALL)
+    Pcd, Psp = oracle_params(cd), oracle_params(sp)
+    with torch.no_grad():
+        _, res = O.train_loss(Pcd, Psp, cfg, batch, 'mode2', 'all')
+        seq, seq_lp = O.speaker_sample_greedy(Psp, cfg, res['outs'][3], res['outs'][4], res['outs'][5])
+    assert np.array_equal(seq.numpy(), g['seq'])
+    close(seq_lp, g['seq_logp'], what='seq_logp')
+
+
+def test_f5_adam_two_steps():
+    g = load_golden('f5_adam')
+    cfg, cd, sp = small_models('all')
+    batch = make_batch(**SMALL)
+    Pcd, Psp = oracle_params(cd, True), oracle_params(sp, True)
+    params = [(('cd.' + k), Pcd[k]) for k, _ in cd.named_parameters()] + \
+             [(('sp.' + k), Psp[k]) for k, _ in sp.named_parameters()]
+    frozen = {'cd.w_emb.emb_.weight'}
+    state = {k: (torch.zeros_like(p), torch.zeros_like(p)) for k, p in params}
+    loss = None
+    for step in (1, 2):
+        for _, p in params:
+            p.grad = None
+        loss, _ = O.train_loss(Pcd, Psp, cfg, batch, 'mode2', 'all')
+        loss.backward()
+        for k, p in params:
+            if p.grad is None or k in frozen:
+                continue
+            O.adam_step(p, p.grad, state[k][0], state[k][1], step)
+    close(loss, g['loss_step2'], 1e-5, 'loss at step 2')
+    # Adam turns noise-around-zero gradients into +-lr steps of arbitrary sign: those parameters are only
+    # required to stay within 2*lr*steps of the reference
+    g1 = load_golden('f1_all')
+    noisy = negligible_grad_names(g1['grad_names'], g1['grad_rows'])
+    assert_summary_close(g['param_names'], g['param_rows'], [(k, p.detach()) for k, p in params], 2e-5, 'adam params',
+                         skip=noisy)
+    import json
+    names = json.loads(str(g['param_names']))
+    cur = dict((k, p.detach()) for k, p in params)
+    from golden_util import tensor_summary
+    for k in noisy:
+        ref = g['param_rows'][names.index(k)]
+        assert np.abs(tensor_summary(cur[k])[2:] - ref[2:]).max() <= 4.1e-4, k
+
+
+def test_f4_full_width_spot_check():
+    g = load_golden('f4_full')
+    cfg = bench_cfg()
+    cd, sp = build_models(cfg, 147, 148)
+    batch = make_batch(B=2, **FULL)
+    loss, res, named = run_oracle(cfg, cd, sp, batch, 'mode2', 'all')
+    close(loss, g['loss'], what='loss')
+    close(res['logp'][:, :16], g['logp'], 5e-5, 'logp')
+    assert np.array_equal(res['logp'][:, :16].argmax(-1).numpy(), g['argmax'])
+    close(res['outs'][3], g['feat_bef'], 5e-5, 'feat_bef')
+    # weight_g gradients are <dW, v>/||v||: a 10^6-term sum with heavy cancellation, fp32-noisy at full width
+    assert_summary_close(g['grad_names'], g['grad_rows'], named, 5e-4, 'grads[full]',
+                         select=lambda k: not k.endswith('weight_g'))
+    assert_summary_close(g['grad_names'], g['grad_rows'], named, 1e-2, 'grads[full, weight_g]',
+                         select=lambda k: k.endswith('weight_g'))
