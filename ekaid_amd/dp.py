@@ -1,0 +1,194 @@
+"""Data-parallel training support: flat parameter/gradient storage, bucketed gradient all-reduce
+over RCCL (xGMI) overlapped with backward, and the fused Adam step.
+
+The reference is single-process (train_mimic.py:2 pins one GPU); this is new work.
+One process per GPU, weights replicated, the (image-pair, question) batch sharded by contiguous sample
+slices.  Only parameters that actually receive a gradient are communicated and updated: the reference
+model carries 31.5 M dead parameters (``SSRE.*``, ``fc1.*``, ``*.neighbor_net.0.*``, ``*.linear_out_.*``) and a
+frozen table; they are discovered on the first backward (their ``.grad`` stays ``None``), exactly the
+set ``torch.optim.Adam`` would skip.
+
+Layout: live gradients sit in ONE flat fp32 buffer ordered by the order in which autograd finished
+them during the first backward (speaker -> gating tail -> implicit -> spatial -> semantic encoder ->
+question encoder -> ROI projection).  The buffer is cut into buckets of ~``bucket_mb``; a
+post-accumulate hook counts finished parameters per bucket and launches an asynchronous
+``all_reduce(SUM)`` on the bucket's slice as soon as it is complete, so communication of early
+buckets overlaps the rest of backward.  xGMI is point-to-point (7 links x ~153 GB/s per GPU):
+223 MB of gradients need ~0.4-2.6 ms per step, far below the backward time, so a few large buckets
+(default 32 MB) are preferred over many small ones.  The 1/world_size averaging is folded into the
+Adam kernel (``grad_scale``).
+"""
+import torch
+import torch.distributed as dist
+
+from . import hip
+
+
+class GradBuckets:
+    """Device-agnostic flat-gradient bookkeeping + bucketed all-reduce (tested on CPU with gloo)."""
+
+    def __init__(self, params, process_group=None, bucket_mb=32.0, overlap=True):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.bucket_bytes = int(bucket_mb * (1 << 20))
+        self.overlap = overlap
+        self.built = False
+        self.order = []             # parameters in first-backward completion order
+        self._seen = set()
+        self.handles = []
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    # ------------------------------------------------------------------ discovery / build
+    def _on_grad(self, p):
+        if not self.built:
+            if id(p) not in self._seen:
+                self._seen.add(id(p))
+                self.order.append(p)
+            return
+        b = self._bucket_of.get(id(p))
+        if b is None:
+            raise RuntimeError('a parameter outside the live set discovered on the first backward received a '
+                               'gradient; rebuild GradBuckets (call reset())')
+        self._pending[b] -= 1
+        if self._pending[b] == 0 and self.overlap and self.world > 1:
+            self._launch(b)
+
+    def build(self):
+        """Freeze the live set (parameters whose .grad is set now) and move them into flat storage."""
+        live = [p for p in self.order if p.grad is not None]
+        if not live:
+            raise RuntimeError('GradBuckets.build(): no parameter has a gradient yet (run one backward first)')
+        dev, dt = live[0].device, live[0].dtype
+        sizes = [p.numel() for p in live]
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 3) // 4 * 4                    # keep every tensor 16-byte aligned
+        self.total = total
+        self.pflat = torch.zeros(total, device=dev, dtype=dt)
+        self.gflat = torch.zeros(total, device=dev, dtype=dt)
+        self.live, self.offsets = live, offs
+        with torch.no_grad():
+            for p, o in zip(live, offs):
+                n = p.numel()
+                self.pflat[o:o + n].copy_(p.detach().reshape(-1))
+                self.gflat[o:o + n].copy_(p.grad.reshape(-1))
+                p.data = self.pflat[o:o + n].view(p.shape)
+                p.grad = self.gflat[o:o + n].view(p.shape)
+        # buckets: contiguous ranges of the flat buffer in completion order
+        self.buckets, self._bucket_of = [], {}
+        start, cur_bytes, members = 0, 0, []
+        for i, (p, o) in enumerate(zip(live, offs)):
+            members.append(p)
+            cur_bytes += p.numel() * 4
+            last = i == len(live) - 1
+            if cur_bytes >= self.bucket_bytes or last:
+                end = total if last else offs[i + 1]
+                self.buckets.append((start, end, len(members)))
+                for m in members:
+                    self._bucket_of[id(m)] = len(self.buckets) - 1
+                start, cur_bytes, members = end, 0, []
+        self.built = True
+        self._reset_pending()
+
+    def _reset_pending(self):
+        self._pending = [n for (_, _, n) in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self.handles = []
+
+    def reset(self):
+        self.built = False
+        self.order, self._seen = [], set()
+
+    # ------------------------------------------------------------------ per-step API
+    def zero_grad(self):
+        if self.built:
+            self.gflat.zero_()
+            for p, o in zip(self.live, self.offsets):     # autograd then accumulates in place into the views
+                p.grad = self.gflat[o:o + p.numel()].view(p.shape)
+            self._reset_pending()
+        else:
+            for p in self.params:
+                p.grad = None
+
+    def _launch(self, b):
+        if self._launched[b]:
+            return
+        s, e, _ = self.buckets[b]
+        self._launched[b] = True
+        self.handles.append(dist.all_reduce(self.gflat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Make every bucket's reduced SUM visible to the current stream (call after backward)."""
+        if not self.built:
+            self.build()
+        if self.world > 1:
+            for b in range(len(self.buckets)):
+                self._launch(b)
+            for h in self.handles:
+                h.wait()
+        self.handles = []
+
+    def live_names(self, named_modules):
+        ids = {id(p): n for n, p in named_modules}
+        return [ids.get(id(p), '?') for p in self.live]
+
+
+class FlatAdam(GradBuckets):
+    """torch.optim.Adam semantics (utils/utils.py:96-99: lr, betas, eps, no weight decay / amsgrad) as one
+    fused HIP kernel over the flat live-parameter buffer, with the gradient all-reduce of GradBuckets."""
+
+    def __init__(self, modules, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, process_group=None, bucket_mb=32.0,
+                 overlap=True):
+        params = []
+        for m in modules:
+            params += list(m.parameters())
+        super().__init__(params, process_group, bucket_mb, overlap)
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.step_count = 0
+        self.m = self.v = None
+
+    def step(self):
+        self.finish()
+        hip.require_cuda(self.pflat)
+        if self.m is None:
+            self.m = torch.zeros_like(self.pflat)
+            self.v = torch.zeros_like(self.pflat)
+        self.step_count += 1
+        hip.check(hip.lib().ekaid_adam_step(hip.ptr(self.pflat), hip.ptr(self.gflat), hip.ptr(self.m), hip.ptr(self.v),
+                                            self.total, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count,
+                                            1.0 / self.world, hip.stream()), 'adam_step')
+
+    def state_dict(self):
+        return {'step': self.step_count, 'lr': self.lr, 'm': self.m, 'v': self.v}
+
+
+# --------------------------------------------------------------------------- Q-C under data parallelism
+class _AllGatherRows(torch.autograd.Function):
+    """(B_local, L) -> (B_global, L) with the matching backward (sum over ranks of the local slice)."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        world = dist.get_world_size(group)
+        out = x.new_empty(world * x.shape[0], *x.shape[1:])
+        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+        ctx.group, ctx.rows = group, x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        d = d.contiguous()
+        dist.all_reduce(d, op=dist.ReduceOp.SUM, group=ctx.group)
+        r = dist.get_rank(ctx.group)
+        return d[r * ctx.rows:(r + 1) * ctx.rows].clone(), None
+
+
+def enable_global_question_attention(change_detector, process_group=None):
+    """Opt-in "global-batch semantics" for quirk Q-C (contract ii): the batch-softmax of
+    ``QuestionSelfAttention`` runs over the GLOBAL batch, reproducing the single-GPU result at any world
+    size.  Default (contract i) is the reference run at the local batch."""
+    def gather(atten):
+        r = dist.get_rank(process_group)
+        return _AllGatherRows.apply(atten, process_group), r * atten.shape[0]
+    change_detector.q_att.gather_logits = gather

@@ -73,11 +73,12 @@ def wn_linear(P, prefix, x):
     v = P[prefix + '.weight_v']
     g = P[prefix + '.weight_g']
     w = v * (g / torch.linalg.vector_norm(v))
-    return F.linear(x, w, P.get(prefix + '.bias'))
+    return F.linear(x.to(w.dtype), w, P.get(prefix + '.bias'))
 
 
 def linear(P, prefix, x):
-    return F.linear(x, P[prefix + '.weight'], P.get(prefix + '.bias'))
+    w = P[prefix + '.weight']
+    return F.linear(x.to(w.dtype), w, P.get(prefix + '.bias'))
 
 
 # --------------------------------------------------------------------------- #

@@ -1,0 +1,268 @@
+"""Whole-path GPU parity: the product modules (ekaid_amd.models, HIP kernels through the C ABI)
+against (a) the golden vectors captured from the reference and (b) the CPU oracle on the same
+seeded inputs.  Tolerances: log-probs <= 1e-3 relative (BASELINE.json), greedy / argmax ids
+identical, gradients <= 1e-3 of the per-tensor scale."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from common import FULL, SMALL, build_models, oracle_params, small_models, to_device
+from ekaid_amd.config import bench_cfg
+from ekaid_amd.synthetic import make_batch
+from golden_util import assert_summary_close, load_golden, negligible_grad_names, tensor_summary
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+LOGIT_TOL = 1e-3
+
+
+def close(a, b, tol, what=''):
+    a = a.detach().double().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
+    b = b.detach().double().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, '%s: shape %s vs %s' % (what, a.shape, b.shape)
+    err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-6)
+    assert err <= tol, '%s: rel-to-max err %.3e > %.1e' % (what, err, tol)
+    return err
+
+
+def hip_step(cfg, cd, sp, batch, setting, graph):
+    """Replay of train_mimic.py:209-247 through the product modules."""
+    from ekaid_amd.utils.mimic_utils import process_matrix
+    from ekaid_amd.utils.utils import LanguageModelCriterion, total_loss
+    b = to_device(batch, DEV)
+    N = b['input_1'].shape[1]
+    adj = [process_matrix(b[k], cfg, N, DEV, type=t) for k, t in
+           (('d_adj', 'spatial'), ('q_adj', 'spatial'), ('d_sem', 'semantic'), ('q_sem', 'semantic'))]
+    outs = cd(b['input_1'], b['input_2'], adj[0], adj[1], adj[2], adj[3], b['d_bb'], b['q_bb'], b['question'],
+              setting=setting, graph=graph)
+    logp, logpos = sp._forward(outs[3], outs[4], outs[5], b['labels'])
+    sp_loss = LanguageModelCriterion()(logp, b['labels'][:, 1:], b['masks'][:, 1:])
+    loss = total_loss(sp_loss, outs[1], outs[2])
+    return loss, sp_loss, outs, logp, logpos
+
+
+def named_grads(cd, sp):
+    return [('cd.' + k, p.grad) for k, p in cd.named_parameters()] + \
+           [('sp.' + k, p.grad) for k, p in sp.named_parameters()]
+
+
+@pytest.mark.parametrize('graph', ['semantic', 'spatial', 'implicit', 'all', 'i+s'])
+def test_config1_matches_reference_golden(graph):
+    g = load_golden('f1_' + graph.replace('+', 'p'))
+    cfg, cd, sp = small_models(graph, device=DEV)
+    loss, sp_loss, outs, logp, logpos = hip_step(cfg, cd, sp, make_batch(**SMALL), 'mode2', graph)
+    close(loss, g['loss'], 1e-4, 'loss')
+    close(sp_loss, g['speaker_loss'], 1e-4, 'speaker_loss')
+    for i, k in enumerate(('pred', 'att_bef', 'att_aft', 'feat_bef', 'feat_aft', 'feat_diff')):
+        close(outs[i], g[k], 1e-4, k)
+    close(logp, g['logp'], LOGIT_TOL, 'logp')
+    close(logpos, g['logpos'], LOGIT_TOL, 'logpos')
+    assert np.array_equal(logp[:, :SMALL['T']].argmax(-1).cpu().numpy(), g['logp'][:, :SMALL['T']].argmax(-1))
+    loss.backward()
+    named = named_grads(cd, sp)
+    extra = assert_summary_close(g['grad_names'], g['grad_rows'], named, 1e-3, 'grads[%s]' % graph)
+    got = dict(named)
+    for k in extra:      # dead / frozen parameters must stay without gradient (DDP buckets rely on it)
+        assert got[k] is None or float(got[k].abs().max()) == 0.0, 'gradient on dead parameter ' + k
+
+
+def test_config1_mode0_ssre_layernorm():
+    g = load_golden('f1_mode0')
+    cfg, cd, sp = small_models('all', 'mode0', device=DEV)
+    loss, _, outs, logp, _ = hip_step(cfg, cd, sp, make_batch(**SMALL), 'mode0', 'all')
+    close(loss, g['loss'], 1e-4, 'loss')
+    close(logp, g['logp'], LOGIT_TOL, 'logp')
+    close(outs[3], g['feat_bef'], 1e-4, 'feat_bef')
+    loss.backward()
+    assert_summary_close(g['grad_names'], g['grad_rows'], named_grads(cd, sp), 1e-3, 'grads[mode0]')
+
+
+def test_question_attention_is_batch_coupled_like_the_reference():
+    g = load_golden('f2_qc')
+    cfg, cd, sp = small_models('semantic', device=DEV)
+    b4 = make_batch(**dict(SMALL, B=4))
+    for B in (2, 4):
+        q = b4['question'][:B].to(DEV)
+        seq = cd.q_emb.forward_all(cd.w_emb(q))
+        close(seq, g['gru_%d' % B], 1e-4, 'gru B=%d' % B)
+        close(cd.q_att(seq), g['q_%d' % B], 1e-4, 'q B=%d' % B)
+
+
+def test_encoder_chain_and_blocks():
+    g = load_golden('f3_blocks')
+    cfg, cd, sp = small_models('all', device=DEV)
+    batch = to_device(make_batch(**SMALL), DEV)
+    from ekaid_amd.utils.mimic_utils import process_matrix
+    N = SMALL['N']
+    spa = process_matrix(batch['d_adj'], cfg, N, DEV, 'spatial')
+    sem = process_matrix(batch['d_sem'], cfg, N, DEV, 'semantic')
+    assert np.array_equal(spa.cpu().numpy(), g['onehot_spa'])
+    assert np.array_equal(sem.cpu().numpy(), g['onehot_sem'])
+    pe = cd.position_emb(batch['d_bb'])
+    assert float(np.abs(pe.cpu().numpy() - g['pos_emb'].astype(np.float32)).max()) <= 2e-6
+    with torch.no_grad():
+        # layer-level: explicit (with an isolated node) and implicit
+        gat = cd.spatial_relation.explicit_relation
+        x = torch.from_numpy(g['layer_x']).to(DEV)
+        cond, lb = torch.from_numpy(g['layer_cond']).to(DEV), torch.from_numpy(g['layer_lb']).to(DEV)
+        # the golden cond/lb are already in neighbor_net[1]'s (transposed) frame: feed them with direction=0
+        o, s = gat.neighbor_net[1](x, cond, None, lb, direction=0)
+        close(o, g['layer_exp_out'], 1e-4, 'layer_exp_out')
+        close(s, g['layer_exp_soft'], 1e-4, 'layer_exp_soft')
+        assert np.allclose(s[0, 3].cpu().numpy(), 0.125)
+        gi = cd.imp_relation.implicit_relation
+        ones = torch.ones(2, N, N, device=DEV)
+        lbi = gi.bias(torch.ones(2 * N * N, 1, device=DEV)).view(2, N, N)
+        o, s = gi.neighbor_net[1](x, ones, pe, lbi, direction=0)
+        close(o, g['layer_imp_out'], 1e-4, 'layer_imp_out')
+        close(s, g['layer_imp_soft'], 1e-4, 'layer_imp_soft')
+        # GAttNet incl. the dead direction (attention maps only)
+        gat.compute_dead_directions = True
+        o, affs = gat.forward(torch.from_numpy(g['gat_in']).to(DEV), spa)
+        gat.compute_dead_directions = False
+        close(o, g['gat_out'], 1e-4, 'gat_out (quirk Q-B)')
+        close(affs[0], g['gat_aff0'], 1e-4, 'gat_aff0')
+        close(affs[1], g['gat_aff1'], 1e-4, 'gat_aff1')
+        # chained encoders (quirk Q-A)
+        q = cd.encode_question(batch['question'])
+        close(q, g['enc_q'], 1e-4, 'enc_q')
+        v0 = cd.img(batch['input_1'])
+        close(v0, g['enc_v0'], 1e-4, 'enc_v0')
+        v1, _ = cd.semantic_relation.forward(v0, sem, q)
+        close(v1, g['enc_v1'], 1e-4, 'enc_v1')
+        v2, _ = cd.spatial_relation.forward(v1, spa, q)
+        close(v2, g['enc_v2'], 1e-4, 'enc_v2')
+        v3, _ = cd.imp_relation.forward(v2, pe, q)
+        close(v3, g['enc_v3'], 1e-4, 'enc_v3')
+        # one speaker step from a non-zero state
+        h, c = torch.from_numpy(g['core_h']).to(DEV), torch.from_numpy(g['core_c']).to(DEV)
+        lp, st, lpp = sp.get_logprobs_state(torch.from_numpy(g['core_it']).to(DEV), torch.from_numpy(g['core_fb']).to(DEV),
+                                            torch.from_numpy(g['core_fa']).to(DEV), torch.from_numpy(g['core_fd']).to(DEV),
+                                            ((h[0], h[1]), (c[0], c[1])))
+        close(lp, g['core_logp'], 1e-4, 'core_logp')
+        close(torch.stack(st[0]), g['core_h2'], 1e-4, 'core_h2')
+        close(torch.stack(st[1]), g['core_c2'], 1e-4, 'core_c2')
+        close(lpp, g['core_logpos'], 1e-4, 'core_logpos')
+        close(sp.core.get_module_weights(), g['core_modw'], 1e-4, 'core_modw')
+
+
+def test_greedy_decode_ids_match_reference():
+    g = load_golden('f3_sample')
+    cfg, cd, sp = small_models('all', device=DEV)
+    with torch.no_grad():
+        _, _, outs, _, _ = hip_step(cfg, cd, sp, make_batch(**SMALL), 'mode2', 'all')
+        seq, seq_lp = sp._sample(outs[3], outs[4], outs[5], None, cfg, sample_max=1)
+    assert np.array_equal(seq.cpu().numpy(), g['seq'])
+    close(seq_lp, g['seq_logp'], LOGIT_TOL, 'seq_logp')
+
+
+def test_fused_adam_two_steps_match_reference():
+    from ekaid_amd.dp import FlatAdam
+    g = load_golden('f5_adam')
+    cfg, cd, sp = small_models('all', device=DEV)
+    batch = make_batch(**SMALL)
+    opt = FlatAdam([cd, sp], lr=1e-4, betas=(0.9, 0.999), eps=1e-8)
+    loss = None
+    for _ in range(2):
+        opt.zero_grad()
+        loss = hip_step(cfg, cd, sp, batch, 'mode2', 'all')[0]
+        loss.backward()
+        opt.step()
+    close(loss, g['loss_step2'], 1e-4, 'loss at step 2')
+    g1 = load_golden('f1_all')
+    noisy = negligible_grad_names(g1['grad_names'], g1['grad_rows'])
+    params = [('cd.' + k, p.detach()) for k, p in cd.named_parameters()] + \
+             [('sp.' + k, p.detach()) for k, p in sp.named_parameters()]
+    assert_summary_close(g['param_names'], g['param_rows'], params, 1e-4, 'adam params', skip=noisy)
+    names = json.loads(str(g['param_names']))
+    cur = dict(params)
+    for k in noisy:
+        ref = g['param_rows'][names.index(k)]
+        assert np.abs(tensor_summary(cur[k])[2:] - ref[2:]).max() <= 4.1e-4, k
+
+
+def test_full_width_matches_reference_golden():
+    """F4: the 87 M-parameter model at config-2 shapes (N=36, D=2048, Lq=20, T=16), B=2."""
+    g = load_golden('f4_full')
+    cfg = bench_cfg()
+    cd, sp = build_models(cfg, 147, 148, DEV)
+    loss, sp_loss, outs, logp, _ = hip_step(cfg, cd, sp, make_batch(B=2, **FULL), 'mode2', 'all')
+    close(loss, g['loss'], 1e-4, 'loss')
+    e = close(logp[:, :16], g['logp'], LOGIT_TOL, 'logp')
+    print('full-width logp max rel err vs reference: %.3e' % e)
+    assert np.array_equal(logp[:, :16].argmax(-1).cpu().numpy(), g['argmax'])
+    close(outs[3], g['feat_bef'], 1e-4, 'feat_bef')
+    close(outs[1], g['att_bef'], 1e-4, 'att_bef')
+    loss.backward()
+    # Gradients: at full width the reference's own float32 gradients sit ~1e-3 (median; up to 5e-2 for the
+    # cancellation-heavy weight_g scalars) from the float64 truth (tests/golden/make_f64_truth.py), so the bar is:
+    # the HIP path is at least as close to the truth as 1e-3 or 3x the reference's own float32 error.
+    t = load_golden('f4_full_f64')
+    names = json.loads(str(g['grad_names']))
+    got = dict(named_grads(cd, sp))
+    floor = 1e-6 * float(np.median(t['grad_rows'][:, 0]))
+    bad = []
+    for i, k in enumerate(names):
+        truth, ref = t['grad_rows'][i], g['grad_rows'][i]
+        if truth[0] <= floor:
+            continue
+        row = tensor_summary(got[k])
+        scale = max(float(np.abs(truth[2:]).max()), truth[0] / np.sqrt(got[k].numel()))
+        ref_err = max(abs(ref[0] - truth[0]) / truth[0], float(np.abs(ref[2:] - truth[2:]).max()) / scale)
+        hip_err = max(abs(row[0] - truth[0]) / truth[0], float(np.abs(row[2:] - truth[2:]).max()) / scale)
+        if hip_err > max(1e-3, 3 * ref_err):
+            bad.append((k, hip_err, ref_err))
+    assert not bad, 'gradients farther from the float64 truth than the reference float32 path: %s' % bad[:8]
+
+
+def test_config2_batch64_forward_against_cpu_oracle():
+    """BASELINE.json config 2: B=64 forward on the GPU, logits checked against the CPU oracle."""
+    from oracle import ekaid_oracle as O
+    cfg = bench_cfg()
+    cd, sp = build_models(cfg, 147, 148, DEV)
+    batch = make_batch(B=64, **FULL)
+    with torch.no_grad():
+        loss, _, outs, logp, _ = hip_step(cfg, cd, sp, batch, 'mode2', 'all')
+        Pcd, Psp = oracle_params(cd), oracle_params(sp)
+        loss_o, res = O.train_loss(Pcd, Psp, cfg, batch, 'mode2', 'all')
+    e = close(logp[:, :16], res['logp'][:, :16], LOGIT_TOL, 'logp B=64')
+    print('B=64 logp max rel err vs CPU oracle: %.3e' % e)
+    assert torch.equal(logp[:, :16].argmax(-1).cpu(), res['logp'][:, :16].argmax(-1)), 'argmax answers differ'
+    close(loss, loss_o, 1e-4, 'loss')
+
+
+def test_train_mode_dropout_path_runs_and_is_seed_reproducible():
+    from ekaid_amd import ops
+    cfg, cd, sp = small_models('all', device=DEV)
+    cd.train()
+    sp.train()
+    batch = make_batch(**SMALL)
+    losses = []
+    for seed in (5, 5, 6):
+        ops.manual_seed(seed)
+        cd.zero_grad()
+        sp.zero_grad()
+        loss = hip_step(cfg, cd, sp, batch, 'mode2', 'all')[0]
+        loss.backward()
+        losses.append(float(loss))
+        assert all(torch.isfinite(p.grad).all() for p in cd.parameters() if p.grad is not None)
+    assert losses[0] == losses[1], 'same dropout seed must reproduce the same loss'
+    assert losses[0] != losses[2], 'a different seed must change the masks'
+    # with every dropout probability forced to 0 the train-mode path equals the eval path
+    for m in list(cd.modules()) + list(sp.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    sp.drop_prob_lm = sp.core.drop_prob_lm = 0.0
+    l_train = float(hip_step(cfg, cd, sp, batch, 'mode2', 'all')[0])
+    cd.eval()
+    sp.eval()
+    l_eval = float(hip_step(cfg, cd, sp, batch, 'mode2', 'all')[0])
+    assert abs(l_train - l_eval) <= 1e-6 * abs(l_eval)
+
+
+def test_ops_refuse_cpu_tensors():
+    from ekaid_amd import hip, ops
+    with pytest.raises(hip.EkaidError):
+        ops.linear(torch.zeros(2, 4), torch.zeros(3, 4))

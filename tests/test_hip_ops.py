@@ -1,0 +1,429 @@
+"""GPU parity of every C-ABI kernel / autograd operator against plain float64/float32 PyTorch-CPU
+restatements of the same formula (op level).  Whole-model parity lives in test_hip_model.py."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def relerr(got, want):
+    got = got.detach().double().cpu()
+    want = want.detach().double().cpu()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    return float((got - want).abs().max() / want.abs().max().clamp_min(1e-12))
+
+
+def check(got, want, tol, what):
+    e = relerr(got, want)
+    assert e <= tol, '%s: rel-to-max err %.3e > %.1e' % (what, e, tol)
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _lib():
+    from ekaid_amd import hip
+    hip.load()
+    assert torch.cuda.is_available()
+    yield
+
+
+# --------------------------------------------------------------------------- GEMM
+GEMM_SHAPES = [
+    # M, N, K
+    (128, 128, 32), (256, 128, 64), (130, 70, 33), (1, 1, 1), (2, 148, 512), (576, 1024, 2048),
+    (64, 64, 1324), (37, 3, 512), (700, 4, 64), (16, 64, 128), (512, 256, 96), (9, 5, 11),
+]
+
+
+@pytest.mark.parametrize('M,N,K', GEMM_SHAPES)
+@pytest.mark.parametrize('mode', ['nt', 'nn', 'tn'])
+def test_gemm_variants(M, N, K, mode):
+    from ekaid_amd import ops
+    A = rnd(M, K, seed=1)
+    B = rnd(K, N, seed=2)
+    want = A.double() @ B.double()
+    if mode == 'nt':      # A [M][K], B stored [N][K]
+        a, b, ta, tb, lda, ldb = A, B.t().contiguous(), 0, 1, K, K
+    elif mode == 'nn':    # A [M][K], B stored [K][N]
+        a, b, ta, tb, lda, ldb = A, B, 0, 0, K, N
+    else:                 # A stored [K][M], B stored [K][N]
+        a, b, ta, tb, lda, ldb = A.t().contiguous(), B, 1, 0, M, N
+    C = torch.full((M, N), float('nan'), device=DEV)
+    ops.gemm(a.to(DEV), b.to(DEV), C, M, N, K, lda, ldb, N, ta, tb)
+    check(C, want, 2e-6 * max(1.0, math.sqrt(K) / 4), 'gemm %s %dx%dx%d' % (mode, M, N, K))
+
+
+def test_gemm_epilogue_and_strides():
+    from ekaid_amd import ops
+    from ekaid_amd.hip import ACT_RELU, ACT_SIGMOID, ACT_TANH
+    M, N, K = 200, 96, 72
+    A, W = rnd(M, K + 8, seed=3), rnd(N, K + 4, seed=4)     # padded leading dims
+    bias, R, rowmask = rnd(N, seed=5), rnd(M // 4, N, seed=6), (torch.rand(M) > 0.3).float()
+    alpha_dev = torch.tensor(0.37)
+    C0 = rnd(M, N + 5, seed=7)
+    for act, fn in ((ACT_RELU, torch.relu), (ACT_TANH, torch.tanh), (ACT_SIGMOID, torch.sigmoid)):
+        C = C0.clone().to(DEV)
+        ops.gemm(A.to(DEV), W.to(DEV), C, M, N, K, K + 8, K + 4, N + 5, 0, 1, alpha=2.0, alpha_dev=alpha_dev.to(DEV),
+                 accumulate=True, bias=bias.to(DEV), R=R.to(DEV), ldr=N, rdiv=4, rowmask=rowmask.to(DEV), act=act)
+        pre = 2.0 * 0.37 * (A[:, :K].double() @ W[:, :K].double().t()) + C0[:, :N].double() + bias.double() + \
+            rowmask.double()[:, None] * R.double().repeat_interleave(4, 0)
+        check(C[:, :N], fn(pre), 3e-6, 'epilogue act=%d' % act)
+        assert torch.equal(C[:, N:].cpu(), C0[:, N:]), 'gemm wrote outside its ldc window'
+
+
+def test_gemm_batched_two_level():
+    from ekaid_amd import ops
+    R, H, N, M, dh = 3, 4, 9, 7, 16
+    A = H * dh
+    q, k = rnd(R, N, A, seed=8), rnd(R, M, A, seed=9)
+    aff = torch.empty(R, N, H, M, device=DEV)
+    ops.gemm(q.to(DEV), k.to(DEV), aff, N, M, dh, A, A, H * M, 0, 1, alpha=0.25, batch=(R, H),
+             strides=(N * A, dh, M * A, dh, N * H * M, M))
+    want = 0.25 * torch.einsum('rnhd,rmhd->rnhm', q.view(R, N, H, dh).double(), k.view(R, M, H, dh).double())
+    check(aff, want, 2e-6, 'batched QK^T')
+
+
+def test_gemm_splitk_path_is_exercised():
+    from ekaid_amd import hip, ops
+    import ctypes
+    d = hip.GemmDesc()
+    d.M, d.N, d.K, d.batch1, d.batch2 = 16, 64, 4096, 1, 1
+    assert hip.lib().ekaid_gemm_workspace_bytes(ctypes.byref(d)) > 0
+    A, W = rnd(16, 4096, seed=10), rnd(64, 4096, seed=11)
+    C = torch.empty(16, 64, device=DEV)
+    ops.gemm(A.to(DEV), W.to(DEV), C, 16, 64, 4096, 4096, 4096, 64, 0, 1, bias=rnd(64, seed=12).to(DEV))
+    check(C, A.double() @ W.double().t() + rnd(64, seed=12).double(), 4e-6, 'split-K + bias')
+
+
+def test_gemm_rejects_bad_args():
+    from ekaid_amd import hip, ops
+    A = torch.zeros(4, 4, device=DEV)
+    with pytest.raises(hip.EkaidError):
+        ops.gemm(A, A, A, 4, 4, 4, 4, 4, 4, 1, 1)          # transA && transB unsupported
+
+
+# --------------------------------------------------------------------------- linear / weight norm
+def _grads(outs, ins):
+    loss = sum((o * rnd(*o.shape, seed=40 + i).to(o.device)).sum() for i, o in enumerate(outs))
+    return torch.autograd.grad(loss, ins, allow_unused=True)
+
+
+@pytest.mark.parametrize('act', ['none', 'relu', 'tanh', 'sigmoid'])
+def test_linear_multi_input_fwd_bwd(act):
+    from ekaid_amd import ops
+    from ekaid_amd.hip import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
+    code = dict(none=ACT_NONE, relu=ACT_RELU, tanh=ACT_TANH, sigmoid=ACT_SIGMOID)[act]
+    fn = dict(none=lambda t: t, relu=torch.relu, tanh=torch.tanh, sigmoid=torch.sigmoid)[act]
+    x1, x2, x3 = rnd(5, 7, 24, seed=13), rnd(5, 7, 12, seed=14), rnd(5, 7, 300, seed=15, scale=0.2)
+    W, b, v_g = rnd(40, 336, seed=16, scale=0.1), rnd(40, seed=17), torch.tensor(1.7)
+    cpu = [t.clone().double().requires_grad_(True) for t in (x1, x2, x3, W, b, v_g)]
+    w_eff = cpu[3] * (cpu[5] / cpu[3].norm())
+    y_ref = fn(F.linear(torch.cat(cpu[:3], -1), w_eff, cpu[4]))
+    gpu = [t.clone().to(DEV).requires_grad_(True) for t in (x1, x2, x3, W, b, v_g)]
+    y = ops.wn_linear(tuple(gpu[:3]), gpu[3], gpu[5], gpu[4], code)
+    check(y, y_ref, 3e-6, 'wn_linear fwd')
+    g_ref = _grads([y_ref], cpu)
+    g = _grads([y], gpu)
+    for name, a, r in zip(('x1', 'x2', 'x3', 'v', 'b', 'g'), g, g_ref):
+        check(a, r.float(), 2e-5, 'wn_linear grad ' + name)
+
+
+def test_linear_strided_rows_and_rowstack():
+    from ekaid_amd import ops
+    big = rnd(6, 5, 48, seed=18)
+    x = big[:, 2]                                   # (6, 48) with row stride 240
+    W, b = rnd(10, 48, seed=19), rnd(10, seed=20)
+    xg = big.to(DEV)[:, 2]
+    y = ops.linear(xg, W.to(DEV), b.to(DEV))
+    check(y, F.linear(x.double(), W.double(), b.double()), 3e-6, 'strided linear')
+    a1, a2 = rnd(3, 4, 48, seed=21), rnd(3, 4, 48, seed=22)
+    Wg = W.to(DEV).requires_grad_(True)
+    bg = b.to(DEV).requires_grad_(True)
+    y2 = ops.linear_rowstack((a1.to(DEV), a2.to(DEV)), Wg, bg)
+    ref_in = torch.cat([a1.reshape(-1, 48), a2.reshape(-1, 48)]).double()
+    Wc, bc = W.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.linear(ref_in, Wc, bc)
+    check(y2, yr, 3e-6, 'rowstack fwd')
+    gg = _grads([y2], [Wg, bg])
+    gr = _grads([yr], [Wc, bc])
+    check(gg[0], gr[0].float(), 2e-5, 'rowstack dW')
+    check(gg[1], gr[1].float(), 2e-5, 'rowstack db')
+
+
+# --------------------------------------------------------------------------- point-wise family
+def test_dropout_statistics_and_backward_mask():
+    from ekaid_amd import ops
+    x = torch.ones(1 << 20, device=DEV, requires_grad=True)
+    y = ops.DropoutFn.apply(x, 0.2, 1234)
+    kept = (y != 0).float().mean().item()
+    assert abs(kept - 0.8) < 5e-3, kept
+    assert torch.allclose(y[y != 0], torch.tensor(1.25, device=DEV))
+    (g,) = torch.autograd.grad(y.sum(), x)
+    assert torch.equal(g, y.detach()), 'backward must reuse the forward mask'
+    y2 = ops.DropoutFn.apply(x, 0.2, 1235)
+    assert (y2 != y).float().mean().item() > 0.2, 'different seeds must give different masks'
+    assert ops.dropout(x, 0.5, training=False) is x
+
+
+def test_residual_relu2_gate_fuse_mix3_pool():
+    from ekaid_amd import ops
+    v, o = rnd(6, 5, 32, seed=23), rnd(6, 5, 32, seed=24)
+    cv, co = v.double().requires_grad_(True), o.double().requires_grad_(True)
+    ref = cv + torch.relu(2 * co)
+    gv, go = v.to(DEV).requires_grad_(True), o.to(DEV).requires_grad_(True)
+    out = ops.residual_relu2(gv, go, 0.2, training=False)
+    check(out, ref, 1e-6, 'residual_relu2')
+    for a, r in zip(_grads([out], [gv, go]), _grads([ref], [cv, co])):
+        check(a, r.float(), 1e-6, 'residual_relu2 grad')
+    # with dropout: output = v + relu(2 o m/(1-p)); gradient consistent with the same mask
+    out_d = ops.ResidualRelu2Fn.apply(gv, go, 0.3, 77)
+    mask = ((out_d - gv).detach() != 0) | (go.detach() <= 0)
+    (gd,) = torch.autograd.grad(out_d.sum(), go)
+    assert torch.all((gd != 0) == ((out_d - gv).detach() != 0))
+    assert mask.float().mean() > 0.5
+    # gate fuse with the shared (difference) terms broadcast over two images
+    c2, g2, c1, g1 = rnd(4, 3, 16, seed=25), rnd(4, 3, 16, seed=26), rnd(2, 3, 16, seed=27), rnd(2, 3, 16, seed=28)
+    cc = [t.double().requires_grad_(True) for t in (c2, g2, c1, g1)]
+    ref = torch.sigmoid(cc[1] + cc[3].repeat(2, 1, 1)) * torch.tanh(cc[0] + cc[2].repeat(2, 1, 1))
+    gg = [t.to(DEV).requires_grad_(True) for t in (c2, g2, c1, g1)]
+    out = ops.gate_fuse(gg[0], gg[1], gg[2], gg[3], 0.5, training=False)
+    check(out, ref, 2e-6, 'gate_fuse')
+    for a, r in zip(_grads([out], gg), _grads([ref], cc)):
+        check(a, r.float(), 3e-6, 'gate_fuse grad')
+    # mix3
+    w, a, b, c = torch.softmax(rnd(7, 3, seed=29), 1), rnd(7, 20, seed=30), rnd(7, 20, seed=31), rnd(7, 20, seed=32)
+    cc = [t.double().requires_grad_(True) for t in (w, a, b, c)]
+    ref = cc[0][:, 0:1] * cc[1] + cc[0][:, 1:2] * cc[2] + cc[0][:, 2:3] * cc[3]
+    gg = [t.to(DEV).requires_grad_(True) for t in (w, a, b, c)]
+    out = ops.Mix3Fn.apply(*gg)
+    check(out, ref, 1e-6, 'mix3')
+    for x, r in zip(_grads([out], gg), _grads([ref], cc)):
+        check(x, r.float(), 2e-6, 'mix3 grad')
+    # weighted pool
+    w, x = torch.rand(5, 9), rnd(5, 9, 33, seed=33)
+    cw, cx = w.double().requires_grad_(True), x.double().requires_grad_(True)
+    ref = (cw.unsqueeze(-1) * cx).sum(1)
+    gw, gx = w.to(DEV).requires_grad_(True), x.to(DEV).requires_grad_(True)
+    out = ops.weighted_pool(gw, gx)
+    check(out, ref, 2e-6, 'weighted_pool')
+    for a, r in zip(_grads([out], [gw, gx]), _grads([ref], [cw, cx])):
+        check(a, r.float(), 2e-6, 'weighted_pool grad')
+
+
+def test_rowsum_expand_rows_axpby_mul():
+    from ekaid_amd import ops
+    x = rnd(4, 6, 10, seed=34)
+    x[1, 2] = 0
+    check(ops.rowsum(x.to(DEV)), x.sum(-1), 2e-6, 'rowsum')
+    m = ops.rowsum(x.to(DEV), as_mask=True)
+    assert torch.equal(m.cpu(), (x.sum(-1) != 0).float())
+    q = rnd(2, 12, seed=35)                                  # 2 question rows shared by 4 slices (2 images)
+    mask = (torch.rand(24) > 0.2).float()
+    cq = q.double().requires_grad_(True)
+    ref = mask.double()[:, None] * cq.repeat(2, 1).repeat_interleave(6, 0)
+    gq = q.to(DEV).requires_grad_(True)
+    out = ops.expand_rows(gq, mask.to(DEV), 6)
+    check(out, ref, 1e-7, 'expand_rows')
+    check(_grads([out], [gq])[0], _grads([ref], [cq])[0].float(), 2e-6, 'expand_rows grad')
+    a, b = rnd(33, seed=36), rnd(33, seed=37)
+    ga, gb = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    check(ops.sub(ga, gb), a - b, 1e-7, 'sub')
+    check(ops.mul(ga, gb), a * b, 1e-7, 'mul')
+    check(ops.scale(ga, 0.5), a * 0.5, 1e-7, 'scale')
+    gr = _grads([ops.mul(ops.sub(ga, gb), ga)], [ga, gb])
+    ca, cb = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    rr = _grads([(ca - cb) * ca], [ca, cb])
+    check(gr[0], rr[0].float(), 2e-6, 'mul/sub grad a')
+    check(gr[1], rr[1].float(), 2e-6, 'mul/sub grad b')
+
+
+def test_softmax_logsoftmax_embedding_qatt():
+    from ekaid_amd import ops
+    for cols in (3, 16, 148, 200):
+        x = rnd(11, cols, seed=38, scale=3)
+        for log_mode, fn in ((False, torch.softmax), (True, torch.log_softmax)):
+            cx = x.double().requires_grad_(True)
+            ref = fn(cx, -1)
+            gx = x.to(DEV).requires_grad_(True)
+            out = ops.SoftmaxFn.apply(gx, log_mode)
+            check(out, ref, 2e-6, 'softmax log=%s cols=%d' % (log_mode, cols))
+            check(_grads([out], [gx])[0], _grads([ref], [cx])[0].float(), 5e-6, 'softmax grad')
+    tok = torch.randint(0, 31, (4, 5))
+    t1, t2 = rnd(31, 8, seed=39), rnd(31, 6, seed=40)
+    ct1 = t1.double().requires_grad_(True)
+    ref = torch.cat([F.embedding(tok, ct1, padding_idx=30), F.embedding(tok, t2.double())], -1)
+    g1 = t1.to(DEV).requires_grad_(True)
+    out = ops.embedding(tok.to(DEV), [g1, t2.to(DEV)], relu=False, padding_idx=30)
+    check(out, ref, 0, 'embedding')
+    check(_grads([out], [g1])[0], _grads([ref], [ct1])[0].float(), 2e-6, 'embedding grad (padding row excluded)')
+    ref = torch.relu(F.embedding(tok, ct1))
+    out = ops.embedding(tok.to(DEV), [g1], relu=True)
+    check(out, ref, 0, 'embedding+relu')
+    check(_grads([out], [g1])[0], _grads([ref], [ct1])[0].float(), 2e-6, 'embedding+relu grad')
+    # quirk Q-C weights
+    atten = rnd(6, 5, seed=41)
+    ca = atten.double().requires_grad_(True)
+    ref = torch.softmax(ca.t(), dim=1).contiguous().view(-1, 5)
+    ga = atten.to(DEV).requires_grad_(True)
+    out = ops.QAttWeightsFn.apply(ga)
+    check(out, ref, 2e-6, 'qatt weights')
+    check(_grads([out], [ga])[0], _grads([ref], [ca])[0].float(), 5e-6, 'qatt weights grad')
+
+
+def test_losses_layernorm_adam_process_matrix_geometry():
+    from ekaid_amd import hip, ops
+    from ekaid_amd.hip import check as hcheck, ptr, stream
+    from ekaid_amd.utils.mimic_utils import process_matrix_labels
+    from oracle import ekaid_oracle as O
+    B, T, V = 3, 6, 31
+    logp = torch.log_softmax(rnd(B, T, V, seed=42), -1)
+    labels = torch.randint(1, V, (B, T + 1))
+    masks = torch.zeros(B, T + 1)
+    masks[:, :4] = 1
+    masks[0, :6] = 1
+    cl = logp.double().requires_grad_(True)
+    ref = O.lm_criterion(cl, labels[:, 1:], masks[:, 1:].double())
+    gl = logp.to(DEV).requires_grad_(True)
+    out = ops.lm_loss(gl, labels.to(DEV)[:, 1:], masks.to(DEV)[:, 1:])
+    check(out, ref, 2e-6, 'lm_loss (strided target/mask views)')
+    att_b, att_a = torch.rand(B, 1, 8), torch.rand(B, 1, 8)
+    cb, ca = att_b.double().requires_grad_(True), att_a.double().requires_grad_(True)
+    ref_t = ref + 2.5e-3 * (cb.sum() + ca.sum()) / (2 * B)
+    gb, ga = att_b.to(DEV).requires_grad_(True), att_a.to(DEV).requires_grad_(True)
+    tot = ops.total_loss(out, gb, ga)
+    check(tot, ref_t, 2e-6, 'total_loss')
+    gg = torch.autograd.grad(tot, [gl, gb, ga])
+    gr = torch.autograd.grad(ref_t, [cl, cb, ca])
+    for a, r, n in zip(gg, gr, ('dlogp', 'datt_b', 'datt_a')):
+        check(a, r.float(), 2e-6, 'loss grad ' + n)
+    # layernorm
+    x, gam, bet = rnd(7, 5, 64, seed=43), rnd(64, seed=44), rnd(64, seed=45)
+    cc = [t.double().requires_grad_(True) for t in (x, gam, bet)]
+    ref = F.layer_norm(cc[0], (64,), cc[1], cc[2], 1e-6)
+    gg = [t.to(DEV).requires_grad_(True) for t in (x, gam, bet)]
+    out = ops.layer_norm(gg[0], gg[1], gg[2], 1e-6)
+    check(out, ref, 3e-6, 'layernorm')
+    for a, r in zip(_grads([out], gg), _grads([ref], cc)):
+        check(a, r.float(), 2e-5, 'layernorm grad')
+    # adam vs torch.optim.Adam
+    p0, grads = rnd(1000, seed=46), [rnd(1000, seed=47), rnd(1000, seed=48)]
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], 1e-4, (0.9, 0.999), 1e-8)
+    pg, m, v = p0.clone().to(DEV), torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+    for step, g in enumerate(grads, 1):
+        pr.grad = g.clone()
+        opt.step()
+        hcheck(hip.lib().ekaid_adam_step(ptr(pg), ptr((2 * g).to(DEV)), ptr(m), ptr(v), 1000, 1e-4, 0.9, 0.999, 1e-8, step,
+                                         0.5, stream()), 'adam')
+    check(pg - p0.to(DEV), pr.detach() - p0, 1e-5, 'adam delta after 2 steps (grad_scale=0.5)')
+    # process_matrix (float64 and int64 inputs) and geometry embedding
+    lab = torch.randint(0, 12, (2, 100, 100))
+    want = O.process_matrix(lab.double(), 8, 11)
+    assert torch.equal(process_matrix_labels(lab.double().to(DEV), 8, 11).cpu(), want)
+    assert torch.equal(process_matrix_labels(lab.to(DEV), 8, 11).cpu(), want)
+    from ekaid_amd.synthetic import make_batch
+    bb = make_batch(B=3, N=9, D=8, Lq=5, T=3, seq_length=4, V=31)['d_bb']
+    want = O.position_embedding(O.position_matrix(bb, 52), 64).float()
+    feat_range = torch.arange(0, 64 / 8)
+    dim_mat = torch.pow(torch.ones((1,)) * 1000, (8. / 64) * feat_range)
+    got = ops.geom_embed(bb.to(DEV), 9, 64, dim_mat.to(DEV))
+    assert float((got.cpu() - want).abs().max()) <= 2e-6, 'geometry embedding'
+
+
+# --------------------------------------------------------------------------- recurrent cells
+def test_gru_sequence_and_lstm_cell():
+    from ekaid_amd import ops
+    from oracle import ekaid_oracle as O
+    B, L, E, H = 5, 6, 20, 24
+    x = rnd(B, L, E, seed=49)
+    names = ['q_emb.rnn.weight_ih_l0', 'q_emb.rnn.weight_hh_l0', 'q_emb.rnn.bias_ih_l0', 'q_emb.rnn.bias_hh_l0']
+    vals = [rnd(3 * H, E, seed=50, scale=0.3), rnd(3 * H, H, seed=51, scale=0.3), rnd(3 * H, seed=52), rnd(3 * H, seed=53)]
+    P = {n: v.double().requires_grad_(True) for n, v in zip(names, vals)}
+    cx = x.double().requires_grad_(True)
+    ref = O.gru_forward_all(P, cx)
+    # cross-check the oracle's GRU equations against nn.GRU once more, here, in float64
+    gru = torch.nn.GRU(E, H, 1, batch_first=True).double()
+    with torch.no_grad():
+        for n, v in zip(('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0'), vals):
+            getattr(gru, n).copy_(v.double())
+    assert float((gru(x.double())[0] - ref).abs().max()) < 1e-12
+    gp = [v.to(DEV).requires_grad_(True) for v in vals]
+    gx = x.to(DEV).requires_grad_(True)
+    out = ops.gru_sequence(gx, *gp)
+    check(out, ref, 3e-6, 'gru fwd')
+    gg = _grads([out], [gx] + gp)
+    gr = _grads([ref], [cx] + [P[n] for n in names])
+    for n, a, r in zip(['x'] + names, gg, gr):
+        check(a, r.float(), 3e-5, 'gru grad ' + n)
+    # LSTM cell
+    Hh = 16
+    gxs, ghs, c0 = rnd(B, 4 * Hh, seed=54), rnd(B, 4 * Hh, seed=55), rnd(B, Hh, seed=56)
+    cc = [t.double().requires_grad_(True) for t in (gxs, ghs, c0)]
+    gates = cc[0] + cc[1]
+    i, f, g, o = (torch.sigmoid(gates[:, :Hh]), torch.sigmoid(gates[:, Hh:2 * Hh]), torch.tanh(gates[:, 2 * Hh:3 * Hh]),
+                  torch.sigmoid(gates[:, 3 * Hh:]))
+    c2r = f * cc[2] + i * g
+    h2r = o * torch.tanh(c2r)
+    gg_in = [t.to(DEV).requires_grad_(True) for t in (gxs, ghs, c0)]
+    h2, c2 = ops.LSTMCellFn.apply(*gg_in)
+    check(h2, h2r, 2e-6, 'lstm h')
+    check(c2, c2r, 2e-6, 'lstm c')
+    for a, r in zip(_grads([h2, c2], gg_in), _grads([h2r, c2r], cc)):
+        check(a, r.float(), 5e-6, 'lstm grad')
+
+
+# --------------------------------------------------------------------------- graph attention core
+def _gat_reference(q, k, S, cond, lbias, geo, H, direction):
+    R, N, A = q.shape
+    M = k.shape[1]
+    dh = A // H
+    c = cond.transpose(1, 2) if direction else cond
+    lb = lbias.transpose(1, 2) if direction else lbias
+    aff = torch.einsum('rnhd,rmhd->rnhm', q.view(R, N, H, dh), k.view(R, M, H, dh)) / math.sqrt(dh)
+    if geo is not None:
+        aff = aff + torch.log(torch.clamp_min(geo, 1e-6)).permute(0, 1, 3, 2)
+    # the mask constant and the bias add are float32 operations in the reference: -9e15 + bias == -9e15
+    # there (uniform row for an isolated node), which a float64 add would not reproduce
+    aff32 = aff.float()
+    aff = (torch.where(c[:, :, None, :M] > 0, aff32, torch.full_like(aff32, -9e15)) + lb[:, :, None, :M].float()).double()
+    P = torch.softmax(aff, -1)
+    out = torch.einsum('rnhm,rma->rnha', P, S[:, :M]).reshape(R, N, H * A)
+    return out, P
+
+
+@pytest.mark.parametrize('N,M,A,H', [(8, 8, 64, 4), (36, 36, 128, 4), (52, 52, 64, 4), (9, 7, 32, 2), (36, 36, 1024, 4)])
+@pytest.mark.parametrize('direction', [0, 1])
+@pytest.mark.parametrize('with_geo', [False, True])
+def test_gat_attention_fused_and_composed(N, M, A, H, direction, with_geo):
+    from ekaid_amd import ops
+    R = 3
+    sc = 1.0 / math.sqrt(A / H) ** 0.5
+    q, k, S = rnd(R, N, A, seed=57, scale=sc), rnd(R, M, A, seed=58, scale=sc), rnd(R, N, A, seed=59)
+    cond = (torch.rand(R, N, N) > 0.4).float()
+    cond[0, 2, :] = 0
+    cond[0, :, 2] = 0                                  # an isolated node in both orientations -> uniform row
+    lbias = rnd(R, N, N, seed=60, scale=0.3)
+    geo = torch.relu(rnd(R, N, M, H, seed=61)) if with_geo else None
+    cpu = [t.double().requires_grad_(True) if t is not None else None for t in (q, k, S, lbias, geo)]
+    out_r, P_r = _gat_reference(cpu[0], cpu[1], cpu[2], cond.double(), cpu[3], cpu[4], H, direction)
+    assert torch.allclose(P_r[0, 2], torch.full_like(P_r[0, 2], 1.0 / M))
+    gr = _grads([out_r], [t for t in cpu if t is not None])
+    for impl in ('fused', 'gemm'):
+        gpu = [t.to(DEV).requires_grad_(True) if t is not None else None for t in (q, k, S, lbias, geo)]
+        out, P = ops.gat_attention(gpu[0], gpu[1], gpu[2], cond.to(DEV), gpu[3], gpu[4], H, direction, impl)
+        check(P, P_r, 5e-6, 'P ' + impl)
+        check(out, out_r, 5e-6, 'outT ' + impl)
+        ins_g = [t for t in gpu if t is not None]
+        gg = _grads([out], ins_g)
+        for n, a, r in zip(('dq', 'dk', 'dS', 'dlbias', 'dgeo'), gg, gr):
+            check(a, r.float(), 5e-5, '%s %s' % (n, impl))
