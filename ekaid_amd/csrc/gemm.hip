@@ -62,19 +62,85 @@ struct GemmArgs {
     Epi e;
 };
 
-// 16-byte load with scalar fallback / zero fill.  `p` points at element 0 of the 4-vector, `nvalid`
-// = how many of the 4 elements are inside the matrix (<=0: none), `vec` = alignment allows b128.
-__device__ __forceinline__ f32x4 load4(const float* p, int nvalid, bool vec) {
-    f32x4 r = {0.f, 0.f, 0.f, 0.f};
-    if (nvalid >= 4 && vec) {
-        r = *reinterpret_cast<const f32x4*>(p);
-    } else {
-        if (nvalid > 0) r[0] = p[0];
-        if (nvalid > 1) r[1] = p[1];
-        if (nvalid > 2) r[2] = p[2];
-        if (nvalid > 3) r[3] = p[3];
+// Operand staging is branch-free: every lane always issues its loads from a CLAMPED (in-bounds) address and
+// out-of-range elements are zeroed with selects afterwards, so the loads of a K-step go out back-to-back
+// and their latency hides under the MFMAs of the previous step (a per-element "load or zero" branch makes
+// hipcc wait vmcnt(0) per element).  `vec` (16-byte loads legal: leading dim, base pointer and the extent
+// along the contiguous axis all multiples of 4 elements) is kernel-uniform.
+struct TileLoader {
+    const float* base[4];   // per staged vector: pointer to its (clamped) row / k-row start + column offset
+    int lim[4];             // KC: row valid (0/1);  MC: number of valid elements along the contiguous axis (<=4, may be <=0)
+};
+
+template <bool KC, int BT, int NV>
+__device__ __forceinline__ void loader_init(TileLoader& L, const float* P, int ld, int t0, int T, int K, int tid, bool vec) {
+    // KC: tile rows t (extent T) are matrix rows, contiguous axis = k.   MC: contiguous axis = t, rows = k.
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * 256;
+        if (KC) {
+            const int row = idx >> 3, c4 = idx & 7;
+            const int gt = t0 + row;
+            L.base[i] = P + (long long)min(gt, T - 1) * ld + 4 * c4;
+            L.lim[i] = gt < T ? 1 : 0;
+        } else {
+            const int c4 = idx % (BT / 4);
+            const int gt = t0 + 4 * c4;
+            const int gtc = vec ? min(gt, T - 4) : min(gt, T - 1);
+            L.base[i] = P + max(gtc, 0);
+            L.lim[i] = T - gt;
+        }
     }
-    return r;
+}
+
+// issue the loads of one K-step (no consumer of the loaded values here: the zero-masking happens in
+// loader_mask(), called after the MFMA phase right before the LDS store, so nothing waits on vmcnt early)
+template <bool KC, int BT, int NV>
+__device__ __forceinline__ void loader_fetch(const TileLoader& L, f32x4* r, int ld, int k0, int K, int T, int t0, int tid,
+                                             bool vec) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * 256;
+        if (KC) {
+            const int c4 = idx & 7;
+            const int gk = k0 + 4 * c4;
+            if (vec) {
+                r[i] = *reinterpret_cast<const f32x4*>(L.base[i] + (min(gk, K - 4) - 4 * c4));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[i][e] = L.base[i][min(gk + e, K - 1) - 4 * c4];
+            }
+        } else {
+            const int krow = idx / (BT / 4);
+            const float* p = L.base[i] + (long long)min(k0 + krow, K - 1) * ld;
+            if (vec) {
+                r[i] = *reinterpret_cast<const f32x4*>(p);
+            } else {
+                const int c4 = idx % (BT / 4);
+                const int gt = t0 + 4 * c4;
+                const int gtc = max(min(gt, T - 1), 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[i][e] = p[min(gt + e, T - 1) - gtc];
+            }
+        }
+    }
+}
+
+template <bool KC, int BT, int NV>
+__device__ __forceinline__ void loader_mask(const TileLoader& L, f32x4* r, int k0, int kend, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * 256;
+        if (KC) {
+            const int gk = k0 + 4 * (idx & 7);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[i][e] = (L.lim[i] && gk + e < kend) ? r[i][e] : 0.f;
+        } else {
+            const bool kok = (k0 + idx / (BT / 4)) < kend;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[i][e] = (kok && e < L.lim[i]) ? r[i][e] : 0.f;
+        }
+    }
 }
 
 template <bool A_KC, bool B_KC, int TM, int TN>
@@ -114,8 +180,9 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
         A += z1 * g.sA1 + z2 * g.sA2;
         B += z1 * g.sB1 + z2 * g.sB2;
     }
-    const bool vecA = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
-    const bool vecB = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+    // contiguous-axis extent: k for k-contiguous operands, m (A) / n (B) otherwise
+    const bool vecA = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (((A_KC ? g.K : g.M) & 3) == 0);
+    const bool vecB = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (((B_KC ? g.K : g.N) & 3) == 0);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -126,40 +193,19 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
             for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
 
     f32x4 ra[A_V4], rb[B_V4];
+    TileLoader LA, LB;
+    loader_init<A_KC, BM, A_V4>(LA, A, g.lda, m0, g.M, g.K, tid, vecA);
+    loader_init<B_KC, BN, B_V4>(LB, B, g.ldb, n0, g.N, g.K, tid, vecB);
 
+    int kload = kbeg;       // K offset of the tile currently held in ra/rb
     auto gload = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < A_V4; ++i) {
-            const int idx = tid + i * 256;
-            if (A_KC) {
-                const int row = idx >> 3, c4 = idx & 7;
-                const int gm = m0 + row, gk = k0 + 4 * c4;
-                const int nv = (gm < g.M) ? (kend - gk) : 0;
-                ra[i] = load4(A + (long long)gm * g.lda + gk, nv, vecA);
-            } else {
-                const int krow = idx / (BM / 4), c4 = idx % (BM / 4);
-                const int gk = k0 + krow, gm = m0 + 4 * c4;
-                const int nv = (gk < kend) ? (g.M - gm) : 0;
-                ra[i] = load4(A + (long long)gk * g.lda + gm, nv, vecA);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_V4; ++i) {
-            const int idx = tid + i * 256;
-            if (B_KC) {
-                const int row = idx >> 3, c4 = idx & 7;
-                const int gn = n0 + row, gk = k0 + 4 * c4;
-                const int nv = (gn < g.N) ? (kend - gk) : 0;
-                rb[i] = load4(B + (long long)gn * g.ldb + gk, nv, vecB);
-            } else {
-                const int krow = idx / (BN / 4), c4 = idx % (BN / 4);
-                const int gk = k0 + krow, gn = n0 + 4 * c4;
-                const int nv = (gk < kend) ? (g.N - gn) : 0;
-                rb[i] = load4(B + (long long)gk * g.ldb + gn, nv, vecB);
-            }
-        }
+        kload = k0;
+        loader_fetch<A_KC, BM, A_V4>(LA, ra, g.lda, k0, g.K, g.M, m0, tid, vecA);
+        loader_fetch<B_KC, BN, B_V4>(LB, rb, g.ldb, k0, g.K, g.N, n0, tid, vecB);
     };
     auto lstore = [&]() {
+        loader_mask<A_KC, BM, A_V4>(LA, ra, kload, kend, tid);
+        loader_mask<B_KC, BN, B_V4>(LB, rb, kload, kend, tid);
 #pragma unroll
         for (int i = 0; i < A_V4; ++i) {
             const int idx = tid + i * 256;

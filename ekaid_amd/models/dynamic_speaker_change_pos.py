@@ -119,19 +119,26 @@ class DynamicSpeaker(CaptionModel):
     def _word(self, it):
         return ops.dropout(self.embed[0](it, relu=True), self.drop_prob_lm, self.training)
 
-    def _forward(self, feat_bef, feat_aft, feat_diff, seq):
+    @staticmethod
+    def count_steps(seq, seq_length):
+        """Number of decode steps the reference loop runs: up to the first column i >= 1 whose tokens are
+        all 0 (:213).  One host read of <= seq_length flags; call it on the HOST copy of the labels to
+        keep the training step free of device->host synchronisation."""
+        nz = (seq[:, :seq_length] != 0).any(0).tolist()
+        for i in range(1, seq_length):
+            if not nz[i]:
+                return i
+        return seq_length
+
+    def _forward(self, feat_bef, feat_aft, feat_diff, seq, num_steps=None):
         self.module_weights = []
         if self.training and self.ss_prob > 0.0:
             raise NotImplementedError('scheduled sampling (ss_prob > 0) is outside the EKAID path')
         batch_size = feat_bef.size(0)
         state = self.init_hidden(batch_size)
-        # "break if all the sequences end" (:213) resolved with a single host read
-        nz = (seq[:, :self.seq_length] != 0).any(0).tolist()
-        steps = self.seq_length
-        for i in range(1, self.seq_length):
-            if not nz[i]:
-                steps = i
-                break
+        # "break if all the sequences end" (:213): ``num_steps`` (optional, extension) lets the caller supply
+        # the count computed on the host copy of the labels; otherwise it costs one device->host read
+        steps = num_steps if num_steps is not None else self.count_steps(seq, self.seq_length)
         embed_pre = self.core.embed_pre(feat_bef, feat_aft, feat_diff)
         outs, outs_pos = [], []
         for i in range(steps):

@@ -76,7 +76,33 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=N
     L = hip.lib()
     need = L.ekaid_gemm_workspace_bytes(ctypes.byref(d))
     ws = hip.workspace(need, C.device) if need else None
+    prof = _gemm_profile
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(L.ekaid_gemm_f32(ctypes.byref(d), ptr(ws), need, stream()), 'ekaid_gemm_f32')
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        nb = batch[0] * batch[1]
+        prof.append((e0, e1, 2.0 * M * N * K * nb, (int(transA), int(transB), M, N, K, nb)))
+
+
+_gemm_profile = None
+
+
+def gemm_profile_begin():
+    """Start collecting (HIP event pair, FLOPs, shape) for every GEMM launch on the current stream."""
+    global _gemm_profile
+    _gemm_profile = []
+
+
+def gemm_profile_end():
+    """Stop collecting; returns [(milliseconds, flops, (transA, transB, M, N, K, batch))] (synchronises)."""
+    global _gemm_profile
+    rec, _gemm_profile = _gemm_profile, None
+    torch.cuda.synchronize()
+    return [(e0.elapsed_time(e1), fl, shape) for e0, e1, fl, shape in rec]
 
 
 # --------------------------------------------------------------------------- #
