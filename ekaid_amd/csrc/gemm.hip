@@ -20,10 +20,23 @@
 // the epilogue (deterministic; no float atomics).
 #include "common.h"
 #include "../../include/ekaid_hip.h"
+#include <type_traits>
+#include <cstdlib>
 
 namespace ekaid {
 
+#ifndef BK
 #define BK 32
+#endif
+#ifndef EKAID_GEMM_DBUF
+#define EKAID_GEMM_DBUF 0
+#endif
+#ifndef EKAID_GEMM_FRAGPF
+#define EKAID_GEMM_FRAGPF 0
+#endif
+#ifndef EKAID_GEMM_SETPRIO
+#define EKAID_GEMM_SETPRIO 0
+#endif
 #define LDS_PAD 4
 
 struct Epi {
@@ -79,7 +92,7 @@ __device__ __forceinline__ void loader_init(TileLoader& L, const float* P, int l
     for (int i = 0; i < NV; ++i) {
         const int idx = tid + i * 256;
         if (KC) {
-            const int row = idx >> 3, c4 = idx & 7;
+            const int row = idx / (BK / 4), c4 = idx % (BK / 4);
             const int gt = t0 + row;
             L.base[i] = P + (long long)min(gt, T - 1) * ld + 4 * c4;
             L.lim[i] = gt < T ? 1 : 0;
@@ -102,7 +115,7 @@ __device__ __forceinline__ void loader_fetch(const TileLoader& L, f32x4* r, int 
     for (int i = 0; i < NV; ++i) {
         const int idx = tid + i * 256;
         if (KC) {
-            const int c4 = idx & 7;
+            const int c4 = idx % (BK / 4);
             const int gk = k0 + 4 * c4;
             if (vec) {
                 r[i] = *reinterpret_cast<const f32x4*>(L.base[i] + (min(gk, K - 4) - 4 * c4));
@@ -132,7 +145,7 @@ __device__ __forceinline__ void loader_mask(const TileLoader& L, f32x4* r, int k
     for (int i = 0; i < NV; ++i) {
         const int idx = tid + i * 256;
         if (KC) {
-            const int gk = k0 + 4 * (idx & 7);
+            const int gk = k0 + 4 * (idx % (BK / 4));
 #pragma unroll
             for (int e = 0; e < 4; ++e) r[i][e] = (L.lim[i] && gk + e < kend) ? r[i][e] : 0.f;
         } else {
@@ -150,9 +163,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
     constexpr int B_ELEMS = B_KC ? BN * (BK + LDS_PAD) : BK * (BN + LDS_PAD);
     constexpr int A_V4 = BM * BK / 4 / 256;     // float4 per thread per tile
     constexpr int B_V4 = BN * BK / 4 / 256;
-    __shared__ __attribute__((aligned(16))) float lds[A_ELEMS + B_ELEMS];
-    float* As = lds;
-    float* Bs = lds + A_ELEMS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // 2 x (A tile | B tile), double buffered
+    constexpr int STAGE = A_ELEMS + B_ELEMS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -203,14 +215,21 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
         loader_fetch<A_KC, BM, A_V4>(LA, ra, g.lda, k0, g.K, g.M, m0, tid, vecA);
         loader_fetch<B_KC, BN, B_V4>(LB, rb, g.ldb, k0, g.K, g.N, n0, tid, vecB);
     };
-    auto lstore = [&]() {
-        loader_mask<A_KC, BM, A_V4>(LA, ra, kload, kend, tid);
-        loader_mask<B_KC, BN, B_V4>(LB, rb, kload, kend, tid);
+    // zero-masking is only needed for ragged K (rows/columns beyond M/N are computed on clamped data and never stored)
+    const bool ragged = ((kend - kbeg) % BK) != 0 || !vecA || !vecB ||
+                        (!A_KC && (m0 + BM > g.M)) || (!B_KC && (n0 + BN > g.N));
+    auto lstore = [&](int buf) {
+        float* As = lds + buf * STAGE;
+        float* Bs = As + A_ELEMS;
+        if (ragged) {
+            loader_mask<A_KC, BM, A_V4>(LA, ra, kload, kend, tid);
+            loader_mask<B_KC, BN, B_V4>(LB, rb, kload, kend, tid);
+        }
 #pragma unroll
         for (int i = 0; i < A_V4; ++i) {
             const int idx = tid + i * 256;
             if (A_KC) {
-                const int row = idx >> 3, c4 = idx & 7;
+                const int row = idx / (BK / 4), c4 = idx % (BK / 4);
                 *reinterpret_cast<f32x4*>(&As[row * (BK + LDS_PAD) + 4 * c4]) = ra[i];
             } else {
                 const int krow = idx / (BM / 4), c4 = idx % (BM / 4);
@@ -221,7 +240,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
         for (int i = 0; i < B_V4; ++i) {
             const int idx = tid + i * 256;
             if (B_KC) {
-                const int row = idx >> 3, c4 = idx & 7;
+                const int row = idx / (BK / 4), c4 = idx % (BK / 4);
                 *reinterpret_cast<f32x4*>(&Bs[row * (BK + LDS_PAD) + 4 * c4]) = rb[i];
             } else {
                 const int krow = idx / (BN / 4), c4 = idx % (BN / 4);
@@ -229,55 +248,86 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
             }
         }
     };
+    // MFMA operand fragments of one 8-k group: k-contiguous tiles give them as one ds_read_b128 per lane
+    // (lane half h holds k = 4h..4h+3), the others as four ds_read_b32 (consecutive lanes -> consecutive banks)
+    auto lfrag = [&](const float* As, const float* Bs, int kb, f32x4* a, f32x4* b) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (A_KC) {
+                a[i] = *reinterpret_cast<const f32x4*>(&As[(wm + 32 * i + r) * (BK + LDS_PAD) + kb + 4 * h]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[i][j] = As[(kb + 4 * h + j) * (BM + LDS_PAD) + wm + 32 * i + r];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            if (B_KC) {
+                b[i] = *reinterpret_cast<const f32x4*>(&Bs[(wn + 32 * i + r) * (BK + LDS_PAD) + kb + 4 * h]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[i][j] = Bs[(kb + 4 * h + j) * (BN + LDS_PAD) + wn + 32 * i + r];
+            }
+        }
+    };
 
     if (kbeg < kend) {
         gload(kbeg);
-        lstore();
+        lstore(0);
         __syncthreads();
+        int cur = 0;
         for (int k0 = kbeg; k0 < kend; k0 += BK) {
+#if defined(EKAID_GEMM_ABLATE)
+            const bool more = false;                  // timing-only ablation: no staging after the first tile
+#else
             const bool more = (k0 + BK) < kend;
-            if (more) gload(k0 + BK);                 // next tile's HBM/L2 latency hides under the MFMAs
+#endif
+            if (more) gload(k0 + BK);                 // next tile's HBM/L2 latency hides under this step's MFMAs
+            const float* As = lds + cur * STAGE;
+            const float* Bs = As + A_ELEMS;
+            f32x4 fa[2][TM], fb[2][TN];
+#if EKAID_GEMM_FRAGPF
+            lfrag(As, Bs, 0, fa[0], fb[0]);
+#endif
 #pragma unroll
-            for (int kb = 0; kb < BK; kb += 8) {
-                f32x4 a[TM], b[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    if (A_KC) {
-                        a[i] = *reinterpret_cast<const f32x4*>(&As[(wm + 32 * i + r) * (BK + LDS_PAD) + kb + 4 * h]);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) a[i][j] = As[(kb + 4 * h + j) * (BM + LDS_PAD) + wm + 32 * i + r];
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < TN; ++i) {
-                    if (B_KC) {
-                        b[i] = *reinterpret_cast<const f32x4*>(&Bs[(wn + 32 * i + r) * (BK + LDS_PAD) + kb + 4 * h]);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) b[i][j] = Bs[(kb + 4 * h + j) * (BN + LDS_PAD) + wn + 32 * i + r];
-                    }
-                }
+            for (int gidx = 0; gidx < BK / 8; ++gidx) {
+#if EKAID_GEMM_FRAGPF
+                if (gidx + 1 < BK / 8) lfrag(As, Bs, 8 * (gidx + 1), fa[(gidx + 1) & 1], fb[(gidx + 1) & 1]);   // prefetch
+#elif defined(EKAID_GEMM_ABLATE) && EKAID_GEMM_ABLATE >= 2
+                if (k0 == kbeg) lfrag(As, Bs, 8 * gidx, fa[0], fb[0]);   // ablation: fragments read once
+                fa[gidx & 1][0] = fa[0][0]; fb[gidx & 1][0] = fb[0][0];
+#else
+                lfrag(As, Bs, 8 * gidx, fa[gidx & 1], fb[gidx & 1]);
+#endif
+#if EKAID_GEMM_SETPRIO
+                __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int jj = 0; jj < TN; ++jj)
-                            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[jj][j], acc[i][jj], 0, 0, 0);
+                            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[gidx & 1][i][j], fb[gidx & 1][jj][j], acc[i][jj], 0, 0, 0);
+#if EKAID_GEMM_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
             }
+#if EKAID_GEMM_DBUF
+            if (more) lstore(cur ^ 1);                // other buffer: nobody reads it during this step
             __syncthreads();
-            if (more) {
-                lstore();
-                __syncthreads();
-            }
+            cur ^= 1;
+#else
+            __syncthreads();
+            if (more) { lstore(0); __syncthreads(); }
+#endif
         }
     }
 
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (t&3) + 8*(t>>2) + 4*(lane>>5)
+    const bool slab = g.splitk > 1;
     float* C;
     int ldc;
-    const bool slab = g.splitk > 1;
     if (slab) {
         C = g.ws + (long long)z * g.M * g.N;
         ldc = g.N;
@@ -287,25 +337,33 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
         ldc = g.ldc;
     }
     const float alpha = g.e.alpha_dev ? g.e.alpha * g.e.alpha_dev[0] : g.e.alpha;
+    const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+    auto store_tiles = [&](auto checked) {
+        constexpr bool CHECK = decltype(checked)::value;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int jj = 0; jj < TN; ++jj) {
-            const int n = n0 + wn + 32 * jj + r;
-            if (n >= g.N) continue;
+            for (int jj = 0; jj < TN; ++jj) {
+                const int n = n0 + wn + 32 * jj + r;
+                if (CHECK && n >= g.N) continue;
+                const int mb = m0 + wm + 32 * i + 4 * h;
+                float* cp0 = C + (long long)mb * ldc + n;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int m = m0 + wm + 32 * i + (t & 3) + 8 * (t >> 2) + 4 * h;
-                if (m >= g.M) continue;
-                float* cp = C + (long long)m * ldc + n;
-                if (slab) {
-                    *cp = acc[i][jj][t];
-                } else {
-                    const float cold = g.e.beta ? *cp : 0.f;
-                    *cp = epilogue(acc[i][jj][t], cold, m, n, g.e, alpha);
+                for (int t = 0; t < 16; ++t) {
+                    const int dm = (t & 3) + 8 * (t >> 2);
+                    if (CHECK && mb + dm >= g.M) continue;
+                    float* cp = cp0 + (long long)dm * ldc;
+                    if (slab) {
+                        *cp = acc[i][jj][t];
+                    } else {
+                        const float cold = g.e.beta ? *cp : 0.f;
+                        *cp = epilogue(acc[i][jj][t], cold, mb + dm, n, g.e, alpha);
+                    }
                 }
             }
-        }
+    };
+    if (full) store_tiles(std::false_type{});
+    else store_tiles(std::true_type{});
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, float* C, int M, int N, int ldc,
@@ -324,16 +382,34 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, flo
 }
 
 template <bool A_KC, bool B_KC, int TM, int TN>
-static void launch(const GemmArgs& a, int batch, hipStream_t st) {
+static int launch(const GemmArgs& a, int batch, hipStream_t st) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int A_ELEMS = A_KC ? BM * (BK + LDS_PAD) : BK * (BM + LDS_PAD);
+    constexpr int B_ELEMS = B_KC ? BN * (BK + LDS_PAD) : BK * (BN + LDS_PAD);
+    constexpr size_t lds = (EKAID_GEMM_DBUF ? 2 : 1) * (A_ELEMS + B_ELEMS) * sizeof(float);
+    auto kern = gemm_mfma_kernel<A_KC, B_KC, TM, TN>;
+    if (lds > 64 * 1024) {
+        static bool attr_set = false;            // once per instantiation (first call happens outside graph capture)
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                (void)hipGetLastError();
+                set_error("gemm: cannot raise the dynamic LDS limit to %zu bytes", lds);
+                return EKAID_ERR_LAUNCH;
+            }
+            attr_set = true;
+        }
+    }
     dim3 grid(a.tiles_m * a.tiles_n, 1, a.splitk > 1 ? a.splitk : batch);
-    hipLaunchKernelGGL((gemm_mfma_kernel<A_KC, B_KC, TM, TN>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+    return EKAID_OK;
 }
 
 static int plan_splitk(int tiles, int K, int batch, long long MN) {
     if (batch > 1) return 1;
-    const int target = 512;                       // ~2 workgroups per CU
-    if (tiles >= target / 2) return 1;
-    int s = target / tiles;
+    static const char* tgt = getenv("EKAID_GEMM_SPLIT_TARGET");   // tuning aid
+    const int target = tgt ? atoi(tgt) : 768;     // ~3 workgroups per CU (the register budget admits 3 per SIMD)
+    if (tiles * 4 >= target * 3) return 1;
+    int s = (target + tiles - 1) / tiles;
     const int ksteps = cdiv(K, BK);
     s = s > ksteps / 2 ? ksteps / 2 : s;          // at least two K-steps per split
     while (s > 1 && (long long)s * MN * 4 > (1ll << 30)) --s;   // cap the slab workspace at 1 GiB
@@ -346,6 +422,8 @@ static void plan(const ekaid_gemm_t* d, int& TMN, int& splitk, int& tiles_m, int
     // for the small-M recurrent GEMMs and narrow outputs, where slab traffic would rival the math.
     (void)batch;
     TMN = (d->M >= 512 && d->N >= 128) ? 2 : 1;
+    static const char* force = getenv("EKAID_GEMM_TILE");         // tuning aid: "1" / "2"
+    if (force && (force[0] == '1' || force[0] == '2')) TMN = force[0] - '0';
     const int bm = 64 * TMN;
     tiles_m = cdiv(d->M, bm);
     tiles_n = cdiv(d->N, bm);
@@ -397,16 +475,14 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     }
     const int batch = d->batch1 * d->batch2;
     const bool akc = !d->transA, bkc = d->transB != 0;
-#define EKAID_LAUNCH(AK, BKC)                                      \
-    do {                                                           \
-        if (TMN == 2) launch<AK, BKC, 2, 2>(a, batch, st);         \
-        else launch<AK, BKC, 1, 1>(a, batch, st);                  \
-    } while (0)
-    if (akc && bkc) EKAID_LAUNCH(true, true);
-    else if (akc && !bkc) EKAID_LAUNCH(true, false);
-    else EKAID_LAUNCH(false, false);
+    int rc;
+#define EKAID_LAUNCH(AK, BKC) (TMN == 2 ? launch<AK, BKC, 2, 2>(a, batch, st) : launch<AK, BKC, 1, 1>(a, batch, st))
+    if (akc && bkc) rc = EKAID_LAUNCH(true, true);
+    else if (akc && !bkc) rc = EKAID_LAUNCH(true, false);
+    else rc = EKAID_LAUNCH(false, false);
 #undef EKAID_LAUNCH
-    int rc = check_launch("gemm_mfma_kernel");
+    if (rc) return rc;
+    rc = check_launch("gemm_mfma_kernel");
     if (rc) return rc;
     if (a.splitk > 1) {
         const long long total = (long long)d->M * d->N;

@@ -1,0 +1,26 @@
+"""GEMM micro-benchmark over library variants (tuning aid, not part of the product)."""
+import glob, os, sys, ctypes, torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from ekaid_amd import hip, ops
+SHAPES = [('nt', 18432, 1024, 1024), ('nt', 18432, 1024, 4096), ('nn', 18432, 1024, 1024), ('nn', 18432, 4096, 1024),
+          ('tn', 1024, 1024, 18432), ('tn', 1024, 4096, 18432), ('nt', 256, 2048, 512), ('nt', 256, 2048, 2048), ('tn', 2048, 512, 256)]
+def run(lib):
+    res = []
+    for mode, M, N, K in SHAPES:
+        A = torch.randn(M * K, device='cuda'); B = torch.randn(K * N, device='cuda'); C = torch.empty(M * N, device='cuda')
+        ta, tb, lda, ldb = {'nt': (0, 1, K, K), 'nn': (0, 0, K, N), 'tn': (1, 0, M, N)}[mode]
+        f = lambda: ops.gemm(A, B, C, M, N, K, lda, ldb, N, ta, tb)
+        for _ in range(3): f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 20
+        e0.record()
+        for _ in range(n): f()
+        e1.record(); torch.cuda.synchronize()
+        res.append(2.0 * M * N * K * n / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    return res
+print('%-22s' % 'variant' + ''.join('%14s' % ('%s %dx%dx%d' % s)[:13] for s in SHAPES))
+for path in sorted(glob.glob(os.path.join(os.path.dirname(hip.LIB_PATH), 'libekaid_v*.so'))):
+    hip._lib = None
+    hip._lib = hip.load(path)
+    print('%-22s' % os.path.basename(path) + ''.join('%14.1f' % x for x in run(hip._lib)), flush=True)
