@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void mix3_fwd_kernel(const float* w, const flo
 }
 __global__ __launch_bounds__(256) void mix3_bwd_kernel(const float* w, const float* a, const float* b, const float* c,
                                                        const float* dout, int B, int C, float* dw, float* da, float* db,
-                                                       float* dc) {
+                                                       float* dc, int accumulate) {
     // one wave per row
     const int lane = threadIdx.x & 63;
     const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -317,7 +317,8 @@ __global__ __launch_bounds__(256) void mix3_bwd_kernel(const float* w, const flo
             const long long i = r * C + k;
             const float d = dout[i];
             s0 += d * a[i]; s1 += d * b[i]; s2 += d * c[i];
-            da[i] = w0 * d; db[i] = w1 * d; dc[i] = w2 * d;
+            if (accumulate) { da[i] += w0 * d; db[i] += w1 * d; dc[i] += w2 * d; }
+            else { da[i] = w0 * d; db[i] = w1 * d; dc[i] = w2 * d; }
         }
         s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
         if (lane == 0) { dw[r * 3] = s0; dw[r * 3 + 1] = s1; dw[r * 3 + 2] = s2; }
@@ -581,8 +582,8 @@ extern "C" int ekaid_mix3_fwd(const float* w, const float* a, const float* b, co
     return check_launch("mix3_fwd");
 }
 extern "C" int ekaid_mix3_bwd(const float* w, const float* a, const float* b, const float* c, const float* dout, int B, int C,
-                              float* dw, float* da, float* db, float* dc, void* stream) {
-    hipLaunchKernelGGL(mix3_bwd_kernel, grid1d((long long)B * 64), dim3(256), 0, ST, w, a, b, c, dout, B, C, dw, da, db, dc);
+                              float* dw, float* da, float* db, float* dc, int accumulate, void* stream) {
+    hipLaunchKernelGGL(mix3_bwd_kernel, grid1d((long long)B * 64), dim3(256), 0, ST, w, a, b, c, dout, B, C, dw, da, db, dc, accumulate);
     return check_launch("mix3_bwd");
 }
 extern "C" int ekaid_nll_fwd(const float* logp, const int64_t* target, int ld_target, const float* mask, int ld_mask, int B, int T,

@@ -79,7 +79,7 @@ SIGNATURES = {
     'ekaid_softmax_fwd': [P, P, L, I, I, P],
     'ekaid_softmax_bwd': [P, P, P, L, I, I, P],
     'ekaid_mix3_fwd': [P, P, P, P, I, I, P, P],
-    'ekaid_mix3_bwd': [P, P, P, P, P, I, I, P, P, P, P, P],
+    'ekaid_mix3_bwd': [P, P, P, P, P, I, I, P, P, P, P, I, P],
     'ekaid_nll_fwd': [P, P, I, P, I, I, I, I, P, P, P],
     'ekaid_total_loss_fwd': [P, P, P, L, F, P, P],
     'ekaid_fill_scaled': [P, F, P, L, P],

@@ -109,6 +109,7 @@ class DynamicSpeaker(CaptionModel):
             raise NotImplementedError('logit_layers > 1 is not configured anywhere in the reference')
         self.logit = Linear(self.rnn_size, self.vocab_size)
         self.module_weights = []
+        self.fused_sequence = True      # _forward as one BPTT node; False = step-by-step through autograd
 
     def init_hidden(self, batch_size):
         """((h_att, h_lang), (c_att, c_lang)); indexable like the reference's stacked (2, B, rnn) tensors."""
@@ -139,6 +140,18 @@ class DynamicSpeaker(CaptionModel):
         # "break if all the sequences end" (:213): ``num_steps`` (optional, extension) lets the caller supply
         # the count computed on the host copy of the labels; otherwise it costs one device->host read
         steps = num_steps if num_steps is not None else self.count_steps(seq, self.seq_length)
+        if self.fused_sequence:
+            # whole teacher-forced sequence as one autograd node with explicit BPTT (ekaid_amd/speaker_seq.py)
+            from ..speaker_seq import speaker_sequence
+            tok_tb = seq[:, :steps].t().contiguous()
+            logp_tb, logpos_tb, mw_tb = speaker_sequence(self, feat_bef, feat_aft, feat_diff, tok_tb)
+            self.module_weights = list(mw_tb.unbind(0))
+            outputs, outputs_pos = logp_tb.transpose(0, 1), logpos_tb.transpose(0, 1)
+            if steps < self.seq_length:
+                pad = self.seq_length - steps
+                outputs = torch.cat([outputs, outputs.new_zeros(batch_size, pad, self.vocab_size)], 1)
+                outputs_pos = torch.cat([outputs_pos, outputs_pos.new_zeros(batch_size, pad, 16)], 1)
+            return outputs, outputs_pos
         embed_pre = self.core.embed_pre(feat_bef, feat_aft, feat_diff)
         outs, outs_pos = [], []
         for i in range(steps):

@@ -632,7 +632,7 @@ class Mix3Fn(Function):
         dw = torch.empty_like(w)
         da, db, dc = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
         check(hip.lib().ekaid_mix3_bwd(ptr(w), ptr(a), ptr(b), ptr(c), ptr(d), B, C, ptr(dw), ptr(da), ptr(db),
-                                       ptr(dc), stream()), 'mix3_bwd')
+                                       ptr(dc), 0, stream()), 'mix3_bwd')
         return dw, da, db, dc
 
 

@@ -1,0 +1,361 @@
+"""Teacher-forced DynamicSpeaker sequence as ONE autograd node with explicit back-propagation through time.
+
+ref: dynamic_speaker_change_pos.py:94-131 (DynamicCore.forward), :182-240 (_forward / get_logprobs_state).
+
+Why: taken step by step through autograd the decoder is ~60 tiny launches per step and every weight
+receives T partial gradients (16 wgrad GEMMs with K = B, 16 bias reductions and 15 accumulation adds per
+weight).  Here everything that does not depend on the recurrence is batched over time
+  - input-side gate pre-activations  (dropout_t(embed) . W_ih_att[:, :E]^T,  relu(Emb[tok]) . W_ih_lang[:, :We]^T)
+  - the answer-logit GEMM + log-softmax over all T steps at once
+  - EVERY weight gradient: one contraction over K = T*B rows per weight, one bias reduction per bias
+and only the truly sequential part (two LSTM cells, the POS branch and the gate MLP: 12 small GEMMs per step)
+stays in the time loop.  All activations are stored time-major (T, B, .) so that "previous hidden state
+for every t" is a contiguous slice of the (T+1, B, R) state buffer.
+"""
+import torch
+from torch.autograd import Function
+
+from . import hip, ops
+from .hip import ACT_NONE, ACT_RELU, ACT_SIGMOID, check, ptr, stream
+from .ops import gemm
+
+PARAM_NAMES = ('embed.0.weight', 'core.embed.0.weight', 'core.embed.0.bias',
+               'core.module_att_lstm.weight_ih', 'core.module_att_lstm.weight_hh',
+               'core.module_att_lstm.bias_ih', 'core.module_att_lstm.bias_hh',
+               'core.weight_fc.0.weight', 'core.weight_fc.0.bias',
+               'core.pos1.0.weight', 'core.pos1.0.bias', 'core.weight_pos.weight', 'core.weight_pos.bias',
+               'core.pos2.weight', 'core.pos2.bias',
+               'core.gate1x.0.weight', 'core.gate1x.0.bias', 'core.gate2x.weight', 'core.gate2x.bias',
+               'core.lang_lstm.weight_ih', 'core.lang_lstm.weight_hh', 'core.lang_lstm.bias_ih', 'core.lang_lstm.bias_hh',
+               'logit.weight', 'logit.bias')
+
+
+def _nt(X, xoff, ldx, W, woff, ldw, Y, yoff, ldy, M, N, K, bias=None, acc=False, act=ACT_NONE):
+    """Y[M,N] (+)= X[M,K] . W[N,K]^T (+ bias) with element offsets / leading dims."""
+    gemm(X, W, Y, M, N, K, ldx, ldw, ldy, 0, 1, accumulate=acc, bias=bias, act=act, a_off=xoff, b_off=woff, c_off=yoff)
+
+
+def _nn(D, doff, ldd, W, woff, ldw, Y, yoff, ldy, M, N, K, acc=False):
+    """Y[M,N] (+)= D[M,K] . W[K,N]   (dgrad: W stored [out=K][in], column block at woff)."""
+    gemm(D, W, Y, M, N, K, ldd, ldw, ldy, 0, 0, accumulate=acc, a_off=doff, b_off=woff, c_off=yoff)
+
+
+def _tn(D, ldd, X, ldx, G, goff, ldg, Nout, Kin, rows, doff=0, xoff=0):
+    """G[Nout,Kin] = D[rows,Nout]^T . X[rows,Kin]   (wgrad over rows = T*B)."""
+    gemm(D, X, G, Nout, Kin, rows, ldd, ldx, ldg, 1, 0, a_off=doff, b_off=xoff, c_off=goff)
+
+
+def _colsum(x, rows, cols, out):
+    check(hip.lib().ekaid_colsum(ptr(x), rows, cols, cols, ptr(out), stream()), 'colsum')
+
+
+def _drop(x, y, n, p, seed, xoff=0, yoff=0):
+    check(hip.lib().ekaid_dropout(x.data_ptr() + 4 * xoff, y.data_ptr() + 4 * yoff, n, p, seed, stream()), 'dropout')
+
+
+class SpeakerSeqFn(Function):
+
+    @staticmethod
+    def forward(ctx, bef, aft, diff, tok_tb, p_lm, p_pos, training, *params):
+        hip.require_cuda(bef, aft, diff, tok_tb, *params)
+        (emb, w_e, b_e, wih_a, whh_a, bih_a, bhh_a, w_fc, b_fc, w_p1, b_p1, w_wp, b_wp, w_p2, b_p2,
+         w_g1, b_g1, w_g2, b_g2, wih_l, whh_l, bih_l, bhh_l, w_lo, b_lo) = [p.contiguous() for p in params]
+        bef, aft, diff = bef.contiguous(), aft.contiguous(), diff.contiguous()
+        T, B = tok_tb.shape
+        A = bef.shape[1]
+        E, R, We, V = w_e.shape[0], whh_a.shape[1], emb.shape[1], w_lo.shape[0]
+        G1 = w_g1.shape[0]                        # 2R + A
+        dev = bef.device
+        L = hip.lib()
+        f32 = dict(device=dev, dtype=torch.float32)
+        p = float(p_lm) if training else 0.0
+        p5 = float(p_pos) if training else 0.0      # core.dropout (nn.Dropout(0.5)) on the POS logits
+        seeds = {k: ops.next_seed() for k in ('ed', 'xt', 'out')}
+        seeds_t = [(ops.next_seed(), ops.next_seed(), ops.next_seed()) for _ in range(T)]     # vpos, dpos, g1
+        TB = T * B
+
+        # ---- time-batched, recurrence-independent part
+        embed_pre = torch.empty(B, E, **f32)
+        _nt(bef, 0, A, w_e, 0, 3 * A, embed_pre, 0, E, B, E, A)
+        _nt(diff, 0, A, w_e, A, 3 * A, embed_pre, 0, E, B, E, A, acc=True)
+        _nt(aft, 0, A, w_e, 2 * A, 3 * A, embed_pre, 0, E, B, E, A, bias=b_e, acc=True, act=ACT_RELU)
+        ED = torch.empty(T, B, E, **f32)
+        for t in range(T):                        # dropout mask differs per step (index offset folded into the seed)
+            _drop(embed_pre, ED, B * E, p, seeds['ed'] + t, 0, t * B * E)
+        Xr = torch.empty(T, B, We, **f32)
+        check(L.ekaid_embedding_fwd(tok_tb.data_ptr(), TB, ptr(emb), We, ptr(Xr), We, 0, 1, stream()), 'embedding_fwd')
+        Xd = torch.empty_like(Xr)
+        _drop(Xr, Xd, TB * We, p, seeds['xt'])
+        GXA = torch.empty(T, B, 4 * R, **f32)     # att-LSTM input-side gates: dropout(embed) part + b_ih
+        _nt(ED, 0, E, wih_a, 0, E + R, GXA, 0, 4 * R, TB, 4 * R, E, bias=bih_a)
+        GXL = torch.empty(T, B, 4 * R, **f32)     # lang-LSTM input-side gates: word part + b_ih
+        _nt(Xd, 0, We, wih_l, 0, We + A, GXL, 0, 4 * R, TB, 4 * R, We, bias=bih_l)
+
+        HA = torch.zeros(T + 1, B, R, **f32)      # h of the module-attention LSTM, HA[0] = 0
+        CA = torch.zeros(T + 1, B, R, **f32)
+        HL = torch.zeros(T + 1, B, R, **f32)      # h of the language LSTM
+        CL = torch.zeros(T + 1, B, R, **f32)
+        SA = torch.empty(T, B, 4 * R, **f32)      # gate activations (i,f,g,o)
+        SL = torch.empty(T, B, 4 * R, **f32)
+        MW = torch.empty(T, B, 3, **f32)
+        VP = torch.empty(T, B, R, **f32)          # dropout(relu(pos1(h_lang)))
+        DP = torch.empty(T, B, 16, **f32)         # dropout(weight_pos(vpos))   (= output_pos of the core)
+        PW = torch.empty(T, B, 16, **f32)
+        PP = torch.empty(T, B, R, **f32)
+        AT = torch.empty(T, B, A, **f32)
+        G1D = torch.empty(T, B, G1, **f32)
+        GT = torch.empty(T, B, A, **f32)          # gate (sigmoid)
+        GA = torch.empty(T, B, A, **f32)          # gated att feat
+        gh = torch.empty(B, 4 * R, **f32)
+        tmp3 = torch.empty(B, 3, **f32)
+        tmpR = torch.empty(B, R, **f32)
+        tmp16 = torch.empty(B, 16, **f32)
+        tmpG = torch.empty(B, G1, **f32)
+
+        for t in range(T):
+            o_prev, o_t = t * B * R, (t + 1) * B * R
+            # 1. module-attention LSTM: gates = GXA[t] + h_lang_{t-1} W_ih[:, E:]^T + h_att_{t-1} W_hh^T + b_hh
+            _nt(HL, o_prev, R, wih_a, E, E + R, gh, 0, 4 * R, B, 4 * R, R)
+            _nt(HA, o_prev, R, whh_a, 0, R, gh, 0, 4 * R, B, 4 * R, R, bias=bhh_a, acc=True)
+            check(L.ekaid_lstm_cell_fwd(GXA.data_ptr() + 4 * t * B * 4 * R, ptr(gh), CA.data_ptr() + 4 * o_prev, B, R,
+                                        HA.data_ptr() + 4 * o_t, CA.data_ptr() + 4 * o_t,
+                                        SA.data_ptr() + 4 * t * B * 4 * R, stream()), 'lstm_cell_fwd')
+            # 2. module weights
+            _nt(HA, o_t, R, w_fc, 0, R, tmp3, 0, 3, B, 3, R, bias=b_fc)
+            check(L.ekaid_softmax_fwd(ptr(tmp3), MW.data_ptr() + 4 * t * B * 3, B, 3, 0, stream()), 'softmax_fwd')
+            # 3. POS branch
+            sv, sd, sg = seeds_t[t]
+            _nt(HL, o_prev, R, w_p1, 0, R, tmpR, 0, R, B, R, R, bias=b_p1, act=ACT_RELU)
+            _drop(tmpR, VP, B * R, p, sv, 0, t * B * R)
+            _nt(VP, t * B * R, R, w_wp, 0, R, tmp16, 0, 16, B, 16, R, bias=b_wp)
+            _drop(tmp16, DP, B * 16, p5, sd, 0, t * B * 16)
+            check(L.ekaid_softmax_fwd(DP.data_ptr() + 4 * t * B * 16, PW.data_ptr() + 4 * t * B * 16, B, 16, 0, stream()),
+                  'softmax_fwd')
+            _nt(PW, t * B * 16, 16, w_p2, 0, 16, PP, t * B * R, R, B, R, 16, bias=b_p2)
+            # 4. attended feature
+            check(L.ekaid_mix3_fwd(MW.data_ptr() + 4 * t * B * 3, ptr(bef), ptr(diff), ptr(aft), B, A,
+                                   AT.data_ptr() + 4 * t * B * A, stream()), 'mix3_fwd')
+            # 5. gate MLP on [h_lang_{t-1} | ppos | att]
+            _nt(HL, o_prev, R, w_g1, 0, G1, tmpG, 0, G1, B, G1, R)
+            _nt(PP, t * B * R, R, w_g1, R, G1, tmpG, 0, G1, B, G1, R, acc=True)
+            _nt(AT, t * B * A, A, w_g1, 2 * R, G1, tmpG, 0, G1, B, G1, A, bias=b_g1, acc=True, act=ACT_RELU)
+            _drop(tmpG, G1D, B * G1, p, sg, 0, t * B * G1)
+            _nt(G1D, t * B * G1, G1, w_g2, 0, G1, GT, t * B * A, A, B, A, G1, bias=b_g2, act=ACT_SIGMOID)
+            check(L.ekaid_mul(GT.data_ptr() + 4 * t * B * A, AT.data_ptr() + 4 * t * B * A, GA.data_ptr() + 4 * t * B * A,
+                              B * A, stream()), 'mul')
+            # 6. language LSTM: gates = GXL[t] + gated W_ih[:, We:]^T + h_lang_{t-1} W_hh^T + b_hh
+            _nt(GA, t * B * A, A, wih_l, We, We + A, gh, 0, 4 * R, B, 4 * R, A)
+            _nt(HL, o_prev, R, whh_l, 0, R, gh, 0, 4 * R, B, 4 * R, R, bias=bhh_l, acc=True)
+            check(L.ekaid_lstm_cell_fwd(GXL.data_ptr() + 4 * t * B * 4 * R, ptr(gh), CL.data_ptr() + 4 * o_prev, B, R,
+                                        HL.data_ptr() + 4 * o_t, CL.data_ptr() + 4 * o_t,
+                                        SL.data_ptr() + 4 * t * B * 4 * R, stream()), 'lstm_cell_fwd')
+
+        # ---- time-batched head: dropout(h_lang) -> logit -> log-softmax;  log-softmax of the POS logits
+        HO = torch.empty(T, B, R, **f32)
+        _drop(HL, HO, TB * R, p, seeds['out'], B * R, 0)
+        logits = torch.empty(T, B, V, **f32)
+        _nt(HO, 0, R, w_lo, 0, R, logits, 0, V, TB, V, R, bias=b_lo)
+        logp = torch.empty(T, B, V, **f32)
+        check(L.ekaid_softmax_fwd(ptr(logits), ptr(logp), TB, V, 1, stream()), 'softmax_fwd')
+        logpos = torch.empty(T, B, 16, **f32)
+        check(L.ekaid_softmax_fwd(ptr(DP), ptr(logpos), TB, 16, 1, stream()), 'softmax_fwd')
+
+        ctx.dims = (T, B, A, E, R, We, V, G1)
+        ctx.pp = (p, p5, seeds, seeds_t)
+        ctx.save_for_backward(bef, aft, diff, tok_tb, embed_pre, ED, Xr, Xd, HA, CA, HL, CL, SA, SL, MW, VP, DP, PW, PP, AT,
+                              G1D, GT, GA, HO, logp, logpos, emb, w_e, wih_a, whh_a, w_fc, w_p1, w_wp, w_p2, w_g1, w_g2,
+                              wih_l, whh_l, w_lo)
+        ctx.mark_non_differentiable(MW)
+        return logp, logpos, MW
+
+    @staticmethod
+    def backward(ctx, dlogp, dlogpos, _dmw):
+        (bef, aft, diff, tok_tb, embed_pre, ED, Xr, Xd, HA, CA, HL, CL, SA, SL, MW, VP, DP, PW, PP, AT, G1D, GT, GA, HO,
+         logp, logpos, emb, w_e, wih_a, whh_a, w_fc, w_p1, w_wp, w_p2, w_g1, w_g2, wih_l, whh_l, w_lo) = ctx.saved_tensors
+        T, B, A, E, R, We, V, G1 = ctx.dims
+        p, p5, seeds, seeds_t = ctx.pp
+        dev = bef.device
+        L = hip.lib()
+        f32 = dict(device=dev, dtype=torch.float32)
+        TB = T * B
+        dlogp = dlogp.contiguous()
+        # ---- head (time-batched)
+        dlogits = torch.empty(T, B, V, **f32)
+        check(L.ekaid_softmax_bwd(ptr(logp), ptr(dlogp), ptr(dlogits), TB, V, 1, stream()), 'softmax_bwd')
+        d_w_lo = torch.empty_like(w_lo)
+        _tn(dlogits, V, HO, R, d_w_lo, 0, R, V, R, TB)
+        d_b_lo = torch.empty(V, **f32)
+        _colsum(dlogits, TB, V, d_b_lo)
+        dHO = torch.empty(T, B, R, **f32)
+        _nn(dlogits, 0, V, w_lo, 0, R, dHO, 0, R, TB, R, V)
+        dHLo = torch.empty(T, B, R, **f32)        # gradient reaching h_lang_t through the output dropout
+        _drop(dHO, dHLo, TB * R, p, seeds['out'])
+        dDPl = torch.zeros(T, B, 16, **f32)       # gradient reaching dpos through log_softmax(output_pos)
+        if dlogpos is not None:
+            check(L.ekaid_softmax_bwd(ptr(logpos), ptr(dlogpos.contiguous()), ptr(dDPl), TB, 16, 1, stream()), 'softmax_bwd')
+
+        DGA = torch.empty(T, B, 4 * R, **f32)     # pre-activation gate gradients, all steps (for the batched wgrads)
+        DGL = torch.empty(T, B, 4 * R, **f32)
+        DZFC = torch.empty(T, B, 3, **f32)
+        DZP1 = torch.empty(T, B, R, **f32)
+        DWP = torch.empty(T, B, 16, **f32)
+        DPP = torch.empty(T, B, R, **f32)
+        DZ1 = torch.empty(T, B, G1, **f32)
+        DZ2 = torch.empty(T, B, A, **f32)
+        d_bef = torch.zeros(B, A, **f32)
+        d_diff = torch.zeros(B, A, **f32)
+        d_aft = torch.zeros(B, A, **f32)
+        dh_l = torch.zeros(B, R, **f32)           # carries: gradient w.r.t. h_lang_t / c_lang_t / h_att_t / c_att_t
+        dc_l = torch.zeros(B, R, **f32)
+        dh_a = torch.zeros(B, R, **f32)
+        dc_a = torch.zeros(B, R, **f32)
+        dh_l_prev = torch.empty(B, R, **f32)
+        dh_a_prev = torch.empty(B, R, **f32)
+        dc_tmp = torch.empty(B, R, **f32)
+        t_BA = torch.empty(B, A, **f32)
+        t_BA2 = torch.empty(B, A, **f32)
+        t_BG = torch.empty(B, G1, **f32)
+        t_BG2 = torch.empty(B, G1, **f32)
+        t_BR = torch.empty(B, R, **f32)
+        t_BR2 = torch.empty(B, R, **f32)
+        t_B16 = torch.empty(B, 16, **f32)
+        t_B16b = torch.empty(B, 16, **f32)
+        t_B3 = torch.empty(B, 3, **f32)
+
+        def axpy_into(dst, src, n):               # dst += src
+            check(L.ekaid_axpby(ptr(dst), ptr(src), ptr(dst), n, 1.0, 1.0, stream()), 'axpby')
+
+        for t in range(T - 1, -1, -1):
+            o_prev, o_t = t * B * R, (t + 1) * B * R
+            sv, sd, sg = seeds_t[t]
+            # total gradient on h_lang_t: carry + output path
+            check(L.ekaid_axpby(ptr(dh_l), dHLo.data_ptr() + 4 * t * B * R, ptr(dh_l), B * R, 1.0, 1.0, stream()), 'axpby')
+            # 6'. language LSTM
+            check(L.ekaid_lstm_cell_bwd(ptr(dh_l), ptr(dc_l), SL.data_ptr() + 4 * t * B * 4 * R, CL.data_ptr() + 4 * o_prev,
+                                        CL.data_ptr() + 4 * o_t, B, R, DGL.data_ptr() + 4 * t * B * 4 * R, ptr(dc_tmp),
+                                        stream()), 'lstm_cell_bwd')
+            dc_l, dc_tmp = dc_tmp, dc_l
+            og = t * B * 4 * R
+            _nn(DGL, og, 4 * R, whh_l, 0, R, dh_l_prev, 0, R, B, R, 4 * R)                       # -> h_lang_{t-1}
+            _nn(DGL, og, 4 * R, wih_l, We, We + A, t_BA, 0, A, B, A, 4 * R)                      # d gated
+            # 5'. gated = gate * att ; gate = sigmoid(W_g2 g1d + b)
+            check(L.ekaid_mul(ptr(t_BA), AT.data_ptr() + 4 * t * B * A, ptr(t_BA2), B * A, stream()), 'mul')   # d gate
+            check(L.ekaid_act_bwd(ptr(t_BA2), GT.data_ptr() + 4 * t * B * A, DZ2.data_ptr() + 4 * t * B * A, B * A,
+                                  ACT_SIGMOID, stream()), 'act_bwd')
+            check(L.ekaid_mul(ptr(t_BA), GT.data_ptr() + 4 * t * B * A, ptr(t_BA2), B * A, stream()), 'mul')   # d att (part 1)
+            _nn(DZ2, t * B * A, A, w_g2, 0, G1, t_BG, 0, G1, B, G1, A)                            # d g1d
+            _drop(t_BG, t_BG2, B * G1, p, sg)
+            check(L.ekaid_act_bwd(ptr(t_BG2), G1D.data_ptr() + 4 * t * B * G1, DZ1.data_ptr() + 4 * t * B * G1, B * G1,
+                                  ACT_RELU, stream()), 'act_bwd')
+            oz1 = t * B * G1
+            _nn(DZ1, oz1, G1, w_g1, 0, G1, dh_l_prev, 0, R, B, R, G1, acc=True)                   # -> h_lang_{t-1}
+            _nn(DZ1, oz1, G1, w_g1, R, G1, DPP, t * B * R, R, B, R, G1)                           # d ppos
+            _nn(DZ1, oz1, G1, w_g1, 2 * R, G1, t_BA2, 0, A, B, A, G1, acc=True)                   # d att (total)
+            # 4'. att = mix3(mw, bef, diff, aft)
+            check(L.ekaid_mix3_bwd(MW.data_ptr() + 4 * t * B * 3, ptr(bef), ptr(diff), ptr(aft), ptr(t_BA2), B, A, ptr(t_B3),
+                                   ptr(d_bef), ptr(d_diff), ptr(d_aft), 1, stream()), 'mix3_bwd')
+            # 3'. POS branch
+            _nn(DPP, t * B * R, R, w_p2, 0, 16, t_B16, 0, 16, B, 16, R)                           # d pos_weights
+            check(L.ekaid_softmax_bwd(PW.data_ptr() + 4 * t * B * 16, ptr(t_B16), ptr(t_B16b), B, 16, 0, stream()),
+                  'softmax_bwd')
+            check(L.ekaid_axpby(ptr(t_B16b), dDPl.data_ptr() + 4 * t * B * 16, ptr(t_B16b), B * 16, 1.0, 1.0, stream()),
+                  'axpby')
+            _drop(t_B16b, DWP, B * 16, p5, sd, 0, t * B * 16)                                     # d weight_pos output
+            _nn(DWP, t * B * 16, 16, w_wp, 0, R, t_BR, 0, R, B, R, 16)                            # d vpos (post-dropout)
+            _drop(t_BR, t_BR2, B * R, p, sv)
+            check(L.ekaid_act_bwd(ptr(t_BR2), VP.data_ptr() + 4 * t * B * R, DZP1.data_ptr() + 4 * t * B * R, B * R,
+                                  ACT_RELU, stream()), 'act_bwd')
+            _nn(DZP1, t * B * R, R, w_p1, 0, R, dh_l_prev, 0, R, B, R, R, acc=True)               # -> h_lang_{t-1}
+            # 2'. module weights
+            check(L.ekaid_softmax_bwd(MW.data_ptr() + 4 * t * B * 3, ptr(t_B3), DZFC.data_ptr() + 4 * t * B * 3, B, 3, 0,
+                                      stream()), 'softmax_bwd')
+            _nn(DZFC, t * B * 3, 3, w_fc, 0, R, dh_a, 0, R, B, R, 3, acc=True)                    # += into h_att_t gradient
+            # 1'. module-attention LSTM
+            check(L.ekaid_lstm_cell_bwd(ptr(dh_a), ptr(dc_a), SA.data_ptr() + 4 * t * B * 4 * R, CA.data_ptr() + 4 * o_prev,
+                                        CA.data_ptr() + 4 * o_t, B, R, DGA.data_ptr() + 4 * t * B * 4 * R, ptr(dc_tmp),
+                                        stream()), 'lstm_cell_bwd')
+            dc_a, dc_tmp = dc_tmp, dc_a
+            _nn(DGA, og, 4 * R, whh_a, 0, R, dh_a_prev, 0, R, B, R, 4 * R)                        # -> h_att_{t-1}
+            _nn(DGA, og, 4 * R, wih_a, E, E + R, dh_l_prev, 0, R, B, R, 4 * R, acc=True)          # -> h_lang_{t-1}
+            dh_l, dh_l_prev = dh_l_prev, dh_l
+            dh_a, dh_a_prev = dh_a_prev, dh_a
+
+        # ---- time-batched weight gradients (K = T*B) and input gradients
+        g = {}
+        HLp, HAp, HAn = HL, HA, HA                 # HL[0:T] = previous h_lang; HA[1:T+1] = new h_att (offset B*R)
+        d_wih_a = torch.empty_like(wih_a)
+        _tn(DGA, 4 * R, ED, E, d_wih_a, 0, E + R, 4 * R, E, TB)
+        _tn(DGA, 4 * R, HLp, R, d_wih_a, E, E + R, 4 * R, R, TB)
+        d_whh_a = torch.empty_like(whh_a)
+        _tn(DGA, 4 * R, HAp, R, d_whh_a, 0, R, 4 * R, R, TB)
+        d_b_a = torch.empty(4 * R, **f32)
+        _colsum(DGA, TB, 4 * R, d_b_a)
+        d_w_fc = torch.empty_like(w_fc)
+        _tn(DZFC, 3, HAn, R, d_w_fc, 0, R, 3, R, TB, xoff=B * R)
+        d_b_fc = torch.empty(3, **f32)
+        _colsum(DZFC, TB, 3, d_b_fc)
+        d_w_p1 = torch.empty_like(w_p1)
+        _tn(DZP1, R, HLp, R, d_w_p1, 0, R, R, R, TB)
+        d_b_p1 = torch.empty(R, **f32)
+        _colsum(DZP1, TB, R, d_b_p1)
+        d_w_wp = torch.empty_like(w_wp)
+        _tn(DWP, 16, VP, R, d_w_wp, 0, R, 16, R, TB)
+        d_b_wp = torch.empty(16, **f32)
+        _colsum(DWP, TB, 16, d_b_wp)
+        d_w_p2 = torch.empty_like(w_p2)
+        _tn(DPP, R, PW, 16, d_w_p2, 0, 16, R, 16, TB)
+        d_b_p2 = torch.empty(R, **f32)
+        _colsum(DPP, TB, R, d_b_p2)
+        d_w_g1 = torch.empty_like(w_g1)
+        _tn(DZ1, G1, HLp, R, d_w_g1, 0, G1, G1, R, TB)
+        _tn(DZ1, G1, PP, R, d_w_g1, R, G1, G1, R, TB)
+        _tn(DZ1, G1, AT, A, d_w_g1, 2 * R, G1, G1, A, TB)
+        d_b_g1 = torch.empty(G1, **f32)
+        _colsum(DZ1, TB, G1, d_b_g1)
+        d_w_g2 = torch.empty_like(w_g2)
+        _tn(DZ2, A, G1D, G1, d_w_g2, 0, G1, A, G1, TB)
+        d_b_g2 = torch.empty(A, **f32)
+        _colsum(DZ2, TB, A, d_b_g2)
+        d_wih_l = torch.empty_like(wih_l)
+        _tn(DGL, 4 * R, Xd, We, d_wih_l, 0, We + A, 4 * R, We, TB)
+        _tn(DGL, 4 * R, GA, A, d_wih_l, We, We + A, 4 * R, A, TB)
+        d_whh_l = torch.empty_like(whh_l)
+        _tn(DGL, 4 * R, HLp, R, d_whh_l, 0, R, 4 * R, R, TB)
+        d_b_l = torch.empty(4 * R, **f32)
+        _colsum(DGL, TB, 4 * R, d_b_l)
+        # embed path: dED = DGA . W_ih_att[:, :E]; per-step dropout backward; sum over t; relu; Linear(3A -> E)
+        dED = torch.empty(T, B, E, **f32)
+        _nn(DGA, 0, 4 * R, wih_a, 0, E + R, dED, 0, E, TB, E, 4 * R)
+        for t in range(T):
+            _drop(dED, dED, B * E, p, seeds['ed'] + t, t * B * E, t * B * E)
+        d_epre = torch.empty(B, E, **f32)
+        check(L.ekaid_colsum(ptr(dED), T, B * E, B * E, ptr(d_epre), stream()), 'colsum')
+        d_ez = torch.empty(B, E, **f32)
+        check(L.ekaid_act_bwd(ptr(d_epre), ptr(embed_pre), ptr(d_ez), B * E, ACT_RELU, stream()), 'act_bwd')
+        d_w_e = torch.empty_like(w_e)
+        _tn(d_ez, E, bef, A, d_w_e, 0, 3 * A, E, A, B)
+        _tn(d_ez, E, diff, A, d_w_e, A, 3 * A, E, A, B)
+        _tn(d_ez, E, aft, A, d_w_e, 2 * A, 3 * A, E, A, B)
+        d_b_e = torch.empty(E, **f32)
+        _colsum(d_ez, B, E, d_b_e)
+        _nn(d_ez, 0, E, w_e, 0, 3 * A, d_bef, 0, A, B, A, E, acc=True)
+        _nn(d_ez, 0, E, w_e, A, 3 * A, d_diff, 0, A, B, A, E, acc=True)
+        _nn(d_ez, 0, E, w_e, 2 * A, 3 * A, d_aft, 0, A, B, A, E, acc=True)
+        # word path: dXd = DGL . W_ih_lang[:, :We]; dropout backward; relu + table scatter-add
+        dX = torch.empty(T, B, We, **f32)
+        _nn(DGL, 0, 4 * R, wih_l, 0, We + A, dX, 0, We, TB, We, 4 * R)
+        _drop(dX, dX, TB * We, p, seeds['xt'])
+        d_emb = torch.zeros_like(emb)
+        check(L.ekaid_embedding_bwd(tok_tb.data_ptr(), TB, ptr(emb), ptr(dX), We, We, 0, 1, -1, ptr(d_emb), stream()),
+              'embedding_bwd')
+        grads = (d_emb, d_w_e, d_b_e, d_wih_a, d_whh_a, d_b_a, d_b_a, d_w_fc, d_b_fc, d_w_p1, d_b_p1, d_w_wp, d_b_wp,
+                 d_w_p2, d_b_p2, d_w_g1, d_b_g1, d_w_g2, d_b_g2, d_wih_l, d_whh_l, d_b_l, d_b_l, d_w_lo, d_b_lo)
+        return (d_bef, d_aft, d_diff, None, None, None, None) + grads
+
+
+def speaker_sequence(speaker, feat_bef, feat_aft, feat_diff, tok_tb):
+    """tok_tb: (T, B) int64 teacher-forcing tokens, time-major.  Returns time-major (logp, logpos, module_weights)."""
+    sd = dict(speaker.named_parameters())
+    params = [sd[n] for n in PARAM_NAMES]
+    return SpeakerSeqFn.apply(feat_bef, feat_aft, feat_diff, tok_tb, speaker.drop_prob_lm, speaker.core.dropout.p,
+                              speaker.training, *params)

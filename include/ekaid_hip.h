@@ -178,7 +178,7 @@ int ekaid_softmax_bwd(const float* y, const float* dy, float* dx, long long rows
 /* att_feat = w0*a + w1*b + w2*c per row.  ref: dynamic_speaker_change_pos.py:112-117 */
 int ekaid_mix3_fwd(const float* w, const float* a, const float* b, const float* c, int B, int C, float* out, void* stream);
 int ekaid_mix3_bwd(const float* w, const float* a, const float* b, const float* c, const float* dout, int B, int C,
-                   float* dw, float* da, float* db, float* dc, void* stream);
+                   float* dw, float* da, float* db, float* dc, int accumulate /* 1: da/db/dc += */, void* stream);
 
 /* masked NLL of teacher-forced log-probs.   ref: utils/utils.py:208-216
  * sums[0] = -sum logp[b][t][target[b][t]] * mask[b][t], sums[1] = sum mask  (t < T); caller zero-fills sums;

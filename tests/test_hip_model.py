@@ -262,6 +262,26 @@ def test_train_mode_dropout_path_runs_and_is_seed_reproducible():
     assert abs(l_train - l_eval) <= 1e-6 * abs(l_eval)
 
 
+def test_speaker_fused_sequence_equals_stepwise_autograd():
+    """The BPTT node (speaker_seq.py) against the same decoder taken step by step through autograd."""
+    cfg, cd, sp = small_models('all', device=DEV)
+    batch = make_batch(**SMALL)
+    res = {}
+    for fused in (True, False):
+        sp.fused_sequence = fused
+        cd.zero_grad()
+        sp.zero_grad()
+        loss, _, outs, logp, logpos = hip_step(cfg, cd, sp, batch, 'mode2', 'all')
+        (loss + logpos.sum() * 1e-2).backward()          # also exercise the POS-logit gradient path
+        res[fused] = (logp.detach(), logpos.detach(), {k: p.grad.clone() for k, p in sp.named_parameters()},
+                      cd.img.weight.grad.clone())
+    close(res[True][0], res[False][0], 1e-5, 'logp')
+    close(res[True][1], res[False][1], 1e-5, 'logpos')
+    for k in res[True][2]:
+        close(res[True][2][k], res[False][2][k], 2e-4, 'grad ' + k)
+    close(res[True][3], res[False][3], 2e-4, 'grad img.weight (through the speaker inputs)')
+
+
 def test_ops_refuse_cpu_tensors():
     from ekaid_amd import hip, ops
     with pytest.raises(hip.EkaidError):
