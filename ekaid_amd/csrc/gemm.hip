@@ -25,8 +25,10 @@
 
 namespace ekaid {
 
-#ifndef BK
-#define BK 32
+#define BK_BIG 32      // K-step of the 128x128 kernel
+#ifndef BK_SMALL
+#define BK_SMALL 32    // K-step of the 64x64 / 32x32 kernels: their loop is load-latency bound (16 MFMAs per wave per
+                       // 32-deep step), so one iteration carries 4x the bytes in flight (measured: 50 -> 90 TF at M = 256)
 #endif
 #ifndef EKAID_GEMM_DBUF
 #define EKAID_GEMM_DBUF 0
@@ -80,19 +82,20 @@ struct GemmArgs {
 // and their latency hides under the MFMAs of the previous step (a per-element "load or zero" branch makes
 // hipcc wait vmcnt(0) per element).  `vec` (16-byte loads legal: leading dim, base pointer and the extent
 // along the contiguous axis all multiples of 4 elements) is kernel-uniform.
+template <int NV>
 struct TileLoader {
-    const float* base[4];   // per staged vector: pointer to its (clamped) row / k-row start + column offset
-    int lim[4];             // KC: row valid (0/1);  MC: number of valid elements along the contiguous axis (<=4, may be <=0)
+    const float* base[NV];   // per staged vector (up to 8: 64x64 tile with a 128-deep K-step): pointer to its (clamped) row / k-row start + column offset
+    int lim[NV];             // KC: row valid (0/1);  MC: number of valid elements along the contiguous axis (<=4, may be <=0)
 };
 
-template <bool KC, int BT, int NV>
-__device__ __forceinline__ void loader_init(TileLoader& L, const float* P, int ld, int t0, int T, int K, int tid, bool vec) {
+template <bool KC, int BT, int NV, int KB>
+__device__ __forceinline__ void loader_init(TileLoader<NV>& L, const float* P, int ld, int t0, int T, int K, int tid, bool vec) {
     // KC: tile rows t (extent T) are matrix rows, contiguous axis = k.   MC: contiguous axis = t, rows = k.
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = tid + i * 256;
         if (KC) {
-            const int row = idx / (BK / 4), c4 = idx % (BK / 4);
+            const int row = idx / (KB / 4), c4 = idx % (KB / 4);
             const int gt = t0 + row;
             L.base[i] = P + (long long)min(gt, T - 1) * ld + 4 * c4;
             L.lim[i] = gt < T ? 1 : 0;
@@ -108,14 +111,15 @@ __device__ __forceinline__ void loader_init(TileLoader& L, const float* P, int l
 
 // issue the loads of one K-step (no consumer of the loaded values here: the zero-masking happens in
 // loader_mask(), called after the MFMA phase right before the LDS store, so nothing waits on vmcnt early)
-template <bool KC, int BT, int NV>
-__device__ __forceinline__ void loader_fetch(const TileLoader& L, f32x4* r, int ld, int k0, int K, int T, int t0, int tid,
-                                             bool vec) {
+template <bool KC, int BT, int NV, int KB, bool FASTVEC>
+__device__ __forceinline__ void loader_fetch(const TileLoader<NV>& L, f32x4* r, int ld, int k0, int K, int T, int t0, int tid,
+                                             bool vec_rt) {
+    const bool vec = FASTVEC ? true : vec_rt;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = tid + i * 256;
         if (KC) {
-            const int c4 = idx % (BK / 4);
+            const int c4 = idx % (KB / 4);
             const int gk = k0 + 4 * c4;
             if (vec) {
                 r[i] = *reinterpret_cast<const f32x4*>(L.base[i] + (min(gk, K - 4) - 4 * c4));
@@ -139,13 +143,13 @@ __device__ __forceinline__ void loader_fetch(const TileLoader& L, f32x4* r, int 
     }
 }
 
-template <bool KC, int BT, int NV>
-__device__ __forceinline__ void loader_mask(const TileLoader& L, f32x4* r, int k0, int kend, int tid) {
+template <bool KC, int BT, int NV, int KB>
+__device__ __forceinline__ void loader_mask(const TileLoader<NV>& L, f32x4* r, int k0, int kend, int tid) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = tid + i * 256;
         if (KC) {
-            const int gk = k0 + 4 * (idx % (BK / 4));
+            const int gk = k0 + 4 * (idx % (KB / 4));
 #pragma unroll
             for (int e = 0; e < 4; ++e) r[i][e] = (L.lim[i] && gk + e < kend) ? r[i][e] : 0.f;
         } else {
@@ -156,13 +160,13 @@ __device__ __forceinline__ void loader_mask(const TileLoader& L, f32x4* r, int k
     }
 }
 
-template <bool A_KC, bool B_KC, int TM, int TN>
-__global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
+template <bool A_KC, bool B_KC, int TM, int TN, int KB>
+__global__ __launch_bounds__(256, 3) void gemm_mfma_kernel(GemmArgs g) {   // 3 workgroups per CU: <= 168 VGPR+AGPR
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int A_ELEMS = A_KC ? BM * (BK + LDS_PAD) : BK * (BM + LDS_PAD);
-    constexpr int B_ELEMS = B_KC ? BN * (BK + LDS_PAD) : BK * (BN + LDS_PAD);
-    constexpr int A_V4 = BM * BK / 4 / 256;     // float4 per thread per tile
-    constexpr int B_V4 = BN * BK / 4 / 256;
+    constexpr int A_ELEMS = A_KC ? BM * (KB + LDS_PAD) : KB * (BM + LDS_PAD);
+    constexpr int B_ELEMS = B_KC ? BN * (KB + LDS_PAD) : KB * (BN + LDS_PAD);
+    constexpr int A_V4 = BM * KB / 4 / 256;     // float4 per thread per tile
+    constexpr int B_V4 = BN * KB / 4 / 256;
     extern __shared__ __attribute__((aligned(16))) float lds[];      // 2 x (A tile | B tile), double buffered
     constexpr int STAGE = A_ELEMS + B_ELEMS;
 
@@ -205,32 +209,28 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
             for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
 
     f32x4 ra[A_V4], rb[B_V4];
-    TileLoader LA, LB;
-    loader_init<A_KC, BM, A_V4>(LA, A, g.lda, m0, g.M, g.K, tid, vecA);
-    loader_init<B_KC, BN, B_V4>(LB, B, g.ldb, n0, g.N, g.K, tid, vecB);
+    TileLoader<A_V4> LA;
+    TileLoader<B_V4> LB;
+    loader_init<A_KC, BM, A_V4, KB>(LA, A, g.lda, m0, g.M, g.K, tid, vecA);
+    loader_init<B_KC, BN, B_V4, KB>(LB, B, g.ldb, n0, g.N, g.K, tid, vecB);
 
     int kload = kbeg;       // K offset of the tile currently held in ra/rb
-    auto gload = [&](int k0) {
-        kload = k0;
-        loader_fetch<A_KC, BM, A_V4>(LA, ra, g.lda, k0, g.K, g.M, m0, tid, vecA);
-        loader_fetch<B_KC, BN, B_V4>(LB, rb, g.ldb, k0, g.K, g.N, n0, tid, vecB);
-    };
     // zero-masking is only needed for ragged K (rows/columns beyond M/N are computed on clamped data and never stored)
-    const bool ragged = ((kend - kbeg) % BK) != 0 || !vecA || !vecB ||
+    const bool ragged = ((kend - kbeg) % KB) != 0 || !vecA || !vecB ||
                         (!A_KC && (m0 + BM > g.M)) || (!B_KC && (n0 + BN > g.N));
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, bool need_mask) {
         float* As = lds + buf * STAGE;
         float* Bs = As + A_ELEMS;
-        if (ragged) {
-            loader_mask<A_KC, BM, A_V4>(LA, ra, kload, kend, tid);
-            loader_mask<B_KC, BN, B_V4>(LB, rb, kload, kend, tid);
+        if (need_mask) {
+            loader_mask<A_KC, BM, A_V4, KB>(LA, ra, kload, kend, tid);
+            loader_mask<B_KC, BN, B_V4, KB>(LB, rb, kload, kend, tid);
         }
 #pragma unroll
         for (int i = 0; i < A_V4; ++i) {
             const int idx = tid + i * 256;
             if (A_KC) {
-                const int row = idx / (BK / 4), c4 = idx % (BK / 4);
-                *reinterpret_cast<f32x4*>(&As[row * (BK + LDS_PAD) + 4 * c4]) = ra[i];
+                const int row = idx / (KB / 4), c4 = idx % (KB / 4);
+                *reinterpret_cast<f32x4*>(&As[row * (KB + LDS_PAD) + 4 * c4]) = ra[i];
             } else {
                 const int krow = idx / (BM / 4), c4 = idx % (BM / 4);
                 *reinterpret_cast<f32x4*>(&As[krow * (BM + LDS_PAD) + 4 * c4]) = ra[i];
@@ -240,8 +240,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
         for (int i = 0; i < B_V4; ++i) {
             const int idx = tid + i * 256;
             if (B_KC) {
-                const int row = idx / (BK / 4), c4 = idx % (BK / 4);
-                *reinterpret_cast<f32x4*>(&Bs[row * (BK + LDS_PAD) + 4 * c4]) = rb[i];
+                const int row = idx / (KB / 4), c4 = idx % (KB / 4);
+                *reinterpret_cast<f32x4*>(&Bs[row * (KB + LDS_PAD) + 4 * c4]) = rb[i];
             } else {
                 const int krow = idx / (BN / 4), c4 = idx % (BN / 4);
                 *reinterpret_cast<f32x4*>(&Bs[krow * (BN + LDS_PAD) + 4 * c4]) = rb[i];
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             if (A_KC) {
-                a[i] = *reinterpret_cast<const f32x4*>(&As[(wm + 32 * i + r) * (BK + LDS_PAD) + kb + 4 * h]);
+                a[i] = *reinterpret_cast<const f32x4*>(&As[(wm + 32 * i + r) * (KB + LDS_PAD) + kb + 4 * h]);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) a[i][j] = As[(kb + 4 * h + j) * (BM + LDS_PAD) + wm + 32 * i + r];
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
             if (B_KC) {
-                b[i] = *reinterpret_cast<const f32x4*>(&Bs[(wn + 32 * i + r) * (BK + LDS_PAD) + kb + 4 * h]);
+                b[i] = *reinterpret_cast<const f32x4*>(&Bs[(wn + 32 * i + r) * (KB + LDS_PAD) + kb + 4 * h]);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) b[i][j] = Bs[(kb + 4 * h + j) * (BN + LDS_PAD) + wn + 32 * i + r];
@@ -271,37 +271,32 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
         }
     };
 
-    if (kbeg < kend) {
+    // the K loop exists twice: FAST = every staged vector is a legal, fully in-range 16-byte load (no runtime
+    // alignment test, no masking: straight-line loads), otherwise the general clamped + masked form
+    auto mainloop = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        auto gload = [&](int k0) {
+            kload = k0;
+            loader_fetch<A_KC, BM, A_V4, KB, FAST>(LA, ra, g.lda, k0, g.K, g.M, m0, tid, vecA);
+            loader_fetch<B_KC, BN, B_V4, KB, FAST>(LB, rb, g.ldb, k0, g.K, g.N, n0, tid, vecB);
+        };
         gload(kbeg);
-        lstore(0);
+        lstore(0, !FAST);
         __syncthreads();
         int cur = 0;
-        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        for (int k0 = kbeg; k0 < kend; k0 += KB) {
 #if defined(EKAID_GEMM_ABLATE)
             const bool more = false;                  // timing-only ablation: no staging after the first tile
 #else
-            const bool more = (k0 + BK) < kend;
+            const bool more = (k0 + KB) < kend;
 #endif
-            if (more) gload(k0 + BK);                 // next tile's HBM/L2 latency hides under this step's MFMAs
+            if (more) gload(k0 + KB);                 // next tile's HBM/L2 latency hides under this step's MFMAs
             const float* As = lds + cur * STAGE;
             const float* Bs = As + A_ELEMS;
             f32x4 fa[2][TM], fb[2][TN];
-#if EKAID_GEMM_FRAGPF
-            lfrag(As, Bs, 0, fa[0], fb[0]);
-#endif
 #pragma unroll
-            for (int gidx = 0; gidx < BK / 8; ++gidx) {
-#if EKAID_GEMM_FRAGPF
-                if (gidx + 1 < BK / 8) lfrag(As, Bs, 8 * (gidx + 1), fa[(gidx + 1) & 1], fb[(gidx + 1) & 1]);   // prefetch
-#elif defined(EKAID_GEMM_ABLATE) && EKAID_GEMM_ABLATE >= 2
-                if (k0 == kbeg) lfrag(As, Bs, 8 * gidx, fa[0], fb[0]);   // ablation: fragments read once
-                fa[gidx & 1][0] = fa[0][0]; fb[gidx & 1][0] = fb[0][0];
-#else
+            for (int gidx = 0; gidx < KB / 8; ++gidx) {
                 lfrag(As, Bs, 8 * gidx, fa[gidx & 1], fb[gidx & 1]);
-#endif
-#if EKAID_GEMM_SETPRIO
-                __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -309,19 +304,14 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
 #pragma unroll
                         for (int jj = 0; jj < TN; ++jj)
                             acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[gidx & 1][i][j], fb[gidx & 1][jj][j], acc[i][jj], 0, 0, 0);
-#if EKAID_GEMM_SETPRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
             }
-#if EKAID_GEMM_DBUF
-            if (more) lstore(cur ^ 1);                // other buffer: nobody reads it during this step
             __syncthreads();
-            cur ^= 1;
-#else
-            __syncthreads();
-            if (more) { lstore(0); __syncthreads(); }
-#endif
+            if (more) { lstore(0, !FAST); __syncthreads(); }
         }
+    };
+    if (kbeg < kend) {
+        if (ragged) mainloop(std::false_type{});
+        else mainloop(std::true_type{});
     }
 
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (t&3) + 8*(t>>2) + 4*(lane>>5)
@@ -366,6 +356,125 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
     else store_tiles(std::true_type{});
 }
 
+// "Skinny" variant for the recurrent GEMMs (M = batch rows): 32x32 output tile per workgroup, the four waves
+// split every K-step (wave w contracts the k-groups 8w..8w+7 (+32, ...) of each KB-deep step for the whole tile)
+// and their partial accumulators are summed through LDS.  4x more workgroups than the 64x64 tiling for the same
+// problem and no slab round trip through HBM.
+template <bool A_KC, bool B_KC, int KB>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
+    constexpr int BT = 32;
+    constexpr int NVS = BT * KB / 4 / 256;
+    constexpr int A_ELEMS = A_KC ? BT * (KB + LDS_PAD) : KB * (BT + LDS_PAD);
+    constexpr int B_ELEMS = B_KC ? BT * (KB + LDS_PAD) : KB * (BT + LDS_PAD);
+    constexpr int STAGE = A_ELEMS + B_ELEMS;
+    __shared__ __attribute__((aligned(16))) float lds[(STAGE > 4 * 16 * 64 ? STAGE : 4 * 16 * 64)];
+    float* As = lds;
+    float* Bs = lds + A_ELEMS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int bid = blockIdx.x;
+    const int m0 = (bid / g.tiles_n) * BT, n0 = (bid % g.tiles_n) * BT;
+    const int z = blockIdx.z;
+    const float* A = g.A; const float* B = g.B;
+    int kbeg = 0, kend = g.K;
+    if (g.splitk > 1) {
+        kbeg = z * g.k_per_split;
+        kend = min(g.K, kbeg + g.k_per_split);
+    } else {
+        const long long z1 = z / g.nb2, z2 = z % g.nb2;
+        A += z1 * g.sA1 + z2 * g.sA2;
+        B += z1 * g.sB1 + z2 * g.sB2;
+    }
+    const bool vecA = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (((A_KC ? g.K : g.M) & 3) == 0);
+    const bool vecB = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (((B_KC ? g.K : g.N) & 3) == 0);
+    f32x16 acc;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+    f32x4 ra[NVS], rb[NVS];
+    TileLoader<NVS> LA, LB;
+    loader_init<A_KC, BT, NVS, KB>(LA, A, g.lda, m0, g.M, g.K, tid, vecA);
+    loader_init<B_KC, BT, NVS, KB>(LB, B, g.ldb, n0, g.N, g.K, tid, vecB);
+    int kload = kbeg;
+    auto gload = [&](int k0) {
+        kload = k0;
+        loader_fetch<A_KC, BT, NVS, KB, false>(LA, ra, g.lda, k0, g.K, g.M, m0, tid, vecA);
+        loader_fetch<B_KC, BT, NVS, KB, false>(LB, rb, g.ldb, k0, g.K, g.N, n0, tid, vecB);
+    };
+    auto lstore = [&]() {
+        loader_mask<A_KC, BT, NVS, KB>(LA, ra, kload, kend, tid);
+        loader_mask<B_KC, BT, NVS, KB>(LB, rb, kload, kend, tid);
+#pragma unroll
+        for (int i = 0; i < NVS; ++i) {
+            const int idx = tid + i * 256;
+            if (A_KC) *reinterpret_cast<f32x4*>(&As[(idx / (KB / 4)) * (KB + LDS_PAD) + 4 * (idx % (KB / 4))]) = ra[i];
+            else *reinterpret_cast<f32x4*>(&As[(idx / (BT / 4)) * (BT + LDS_PAD) + 4 * (idx % (BT / 4))]) = ra[i];
+            if (B_KC) *reinterpret_cast<f32x4*>(&Bs[(idx / (KB / 4)) * (KB + LDS_PAD) + 4 * (idx % (KB / 4))]) = rb[i];
+            else *reinterpret_cast<f32x4*>(&Bs[(idx / (BT / 4)) * (BT + LDS_PAD) + 4 * (idx % (BT / 4))]) = rb[i];
+        }
+    };
+    if (kbeg < kend) {
+        gload(kbeg);
+        lstore();
+        __syncthreads();
+        for (int k0 = kbeg; k0 < kend; k0 += KB) {
+            const bool more = (k0 + KB) < kend;
+            if (more) gload(k0 + KB);
+#pragma unroll
+            for (int kq = 0; kq < KB; kq += 32) {
+                const int kb = kq + 8 * wave;
+                f32x4 a, b;
+                if (A_KC) a = *reinterpret_cast<const f32x4*>(&As[r * (KB + LDS_PAD) + kb + 4 * h]);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] = As[(kb + 4 * h + j) * (BT + LDS_PAD) + r];
+                }
+                if (B_KC) b = *reinterpret_cast<const f32x4*>(&Bs[r * (KB + LDS_PAD) + kb + 4 * h]);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b[j] = Bs[(kb + 4 * h + j) * (BT + LDS_PAD) + r];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) { lstore(); __syncthreads(); }
+        }
+    }
+    // cross-wave reduction through LDS: red[wave][t][lane]
+    float* red = lds;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) red[(wave * 16 + t) * 64 + lane] = acc[t];
+    __syncthreads();
+    const bool slab = g.splitk > 1;
+    float* C;
+    int ldc;
+    if (slab) { C = g.ws + (long long)z * g.M * g.N; ldc = g.N; }
+    else {
+        const long long z1 = z / g.nb2, z2 = z % g.nb2;
+        C = g.C + z1 * g.sC1 + z2 * g.sC2;
+        ldc = g.ldc;
+    }
+    const float alpha = g.e.alpha_dev ? g.e.alpha * g.e.alpha_dev[0] : g.e.alpha;
+    // thread -> 4 consecutive lanes (= 4 consecutive columns) of one accumulator register t
+    const int e0 = tid * 4, t = e0 >> 6, l0 = e0 & 63;
+    const int m = m0 + (t & 3) + 8 * (t >> 2) + 4 * (l0 >> 5);
+    if (m < g.M) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int n = n0 + ((l0 + c) & 31);
+            if (n >= g.N) continue;
+            const float v = red[(0 * 16 + t) * 64 + l0 + c] + red[(1 * 16 + t) * 64 + l0 + c] +
+                            red[(2 * 16 + t) * 64 + l0 + c] + red[(3 * 16 + t) * 64 + l0 + c];
+            float* cp = C + (long long)m * ldc + n;
+            if (slab) *cp = v;
+            else {
+                const float cold = g.e.beta ? *cp : 0.f;
+                *cp = epilogue(v, cold, m, n, g.e, alpha);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, float* C, int M, int N, int ldc,
                                                             int splitk, Epi e) {
     const long long total = (long long)M * N;
@@ -381,13 +490,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, flo
     }
 }
 
-template <bool A_KC, bool B_KC, int TM, int TN>
+template <bool A_KC, bool B_KC, int TM, int TN, int KB>
 static int launch(const GemmArgs& a, int batch, hipStream_t st) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int A_ELEMS = A_KC ? BM * (BK + LDS_PAD) : BK * (BM + LDS_PAD);
-    constexpr int B_ELEMS = B_KC ? BN * (BK + LDS_PAD) : BK * (BN + LDS_PAD);
+    constexpr int A_ELEMS = A_KC ? BM * (KB + LDS_PAD) : KB * (BM + LDS_PAD);
+    constexpr int B_ELEMS = B_KC ? BN * (KB + LDS_PAD) : KB * (BN + LDS_PAD);
     constexpr size_t lds = (EKAID_GEMM_DBUF ? 2 : 1) * (A_ELEMS + B_ELEMS) * sizeof(float);
-    auto kern = gemm_mfma_kernel<A_KC, B_KC, TM, TN>;
+    auto kern = gemm_mfma_kernel<A_KC, B_KC, TM, TN, KB>;
     if (lds > 64 * 1024) {
         static bool attr_set = false;            // once per instantiation (first call happens outside graph capture)
         if (!attr_set) {
@@ -404,14 +513,23 @@ static int launch(const GemmArgs& a, int batch, hipStream_t st) {
     return EKAID_OK;
 }
 
-static int plan_splitk(int tiles, int K, int batch, long long MN) {
+template <bool A_KC, bool B_KC>
+static int launch_skinny(const GemmArgs& a, int batch, hipStream_t st) {
+    dim3 grid(a.tiles_m * a.tiles_n, 1, a.splitk > 1 ? a.splitk : batch);
+    hipLaunchKernelGGL((gemm_skinny_kernel<A_KC, B_KC, BK_SMALL>), grid, dim3(256), 0, st, a);
+    return EKAID_OK;
+}
+
+static int plan_splitk(int tiles, int K, int batch, long long MN, int BK) {
     if (batch > 1) return 1;
     static const char* tgt = getenv("EKAID_GEMM_SPLIT_TARGET");   // tuning aid
     const int target = tgt ? atoi(tgt) : 768;     // ~3 workgroups per CU (the register budget admits 3 per SIMD)
     if (tiles * 4 >= target * 3) return 1;
     int s = (target + tiles - 1) / tiles;
     const int ksteps = cdiv(K, BK);
-    s = s > ksteps / 2 ? ksteps / 2 : s;          // at least two K-steps per split
+    static const char* mk = getenv("EKAID_GEMM_MIN_KSTEPS");     // tuning aid
+    const int min_ksteps = mk ? atoi(mk) : (128 / BK);     // a split shorter than this is all prologue/epilogue + slab traffic
+    s = s > ksteps / min_ksteps ? ksteps / min_ksteps : s;
     while (s > 1 && (long long)s * MN * 4 > (1ll << 30)) --s;   // cap the slab workspace at 1 GiB
     return s < 1 ? 1 : s;
 }
@@ -422,12 +540,17 @@ static void plan(const ekaid_gemm_t* d, int& TMN, int& splitk, int& tiles_m, int
     // for the small-M recurrent GEMMs and narrow outputs, where slab traffic would rival the math.
     (void)batch;
     TMN = (d->M >= 512 && d->N >= 128) ? 2 : 1;
-    static const char* force = getenv("EKAID_GEMM_TILE");         // tuning aid: "1" / "2"
-    if (force && (force[0] == '1' || force[0] == '2')) TMN = force[0] - '0';
-    const int bm = 64 * TMN;
+    // skinny problems (recurrent GEMMs, M = batch rows): if 64x64 tiles cannot give every CU two workgroups,
+    // use 32x32 tiles with the K-step split across the four waves (TMN = 0)
+    // (measured: not faster than 64x64 tiles with the 128-deep K-step + split-K, so only on request)
+    static const char* skinny = getenv("EKAID_GEMM_SKINNY");
+    if (skinny && TMN == 1 && (long long)cdiv(d->M, 64) * cdiv(d->N, 64) * batch < 512 && d->K >= 64) TMN = 0;
+    static const char* force = getenv("EKAID_GEMM_TILE");         // tuning aid: "0" / "1" / "2"
+    if (force && force[0] >= '0' && force[0] <= '2') TMN = force[0] - '0';
+    const int bm = TMN == 0 ? 32 : 64 * TMN;
     tiles_m = cdiv(d->M, bm);
     tiles_n = cdiv(d->N, bm);
-    splitk = plan_splitk(tiles_m * tiles_n, d->K, batch, (long long)d->M * d->N);
+    splitk = plan_splitk(tiles_m * tiles_n, d->K, batch, (long long)d->M * d->N, TMN == 2 ? BK_BIG : BK_SMALL);
 }
 
 }  // namespace ekaid
@@ -462,6 +585,7 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     plan(d, TMN, a.splitk, a.tiles_m, a.tiles_n);
     if (d->K == 0) a.splitk = 1;
     a.ws = nullptr;
+    const int BK = TMN == 2 ? BK_BIG : BK_SMALL;
     a.k_per_split = cdiv(cdiv(d->K, BK), a.splitk) * BK;
     if (a.splitk > 1) {
         const size_t need = (size_t)a.splitk * d->M * d->N * sizeof(float);
@@ -476,7 +600,8 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     const int batch = d->batch1 * d->batch2;
     const bool akc = !d->transA, bkc = d->transB != 0;
     int rc;
-#define EKAID_LAUNCH(AK, BKC) (TMN == 2 ? launch<AK, BKC, 2, 2>(a, batch, st) : launch<AK, BKC, 1, 1>(a, batch, st))
+#define EKAID_LAUNCH(AK, BKC) (TMN == 2 ? launch<AK, BKC, 2, 2, BK_BIG>(a, batch, st) : TMN == 1 ? launch<AK, BKC, 1, 1, BK_SMALL>(a, batch, st) \
+                                        : launch_skinny<AK, BKC>(a, batch, st))
     if (akc && bkc) rc = EKAID_LAUNCH(true, true);
     else if (akc && !bkc) rc = EKAID_LAUNCH(true, false);
     else rc = EKAID_LAUNCH(false, false);

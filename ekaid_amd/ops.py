@@ -651,23 +651,21 @@ class GRUSeqFn(Function):
         L = hip.lib()
         gi = torch.empty(B, T, 3 * H, device=dev, dtype=torch.float32)
         gemm(x, w_ih, gi, B * T, 3 * H, E, E, E, 3 * H, 0, 1, bias=b_ih)
-        out = torch.empty(B, T, H, device=dev, dtype=torch.float32)
-        h0 = torch.zeros(B, H, device=dev, dtype=torch.float32)
+        hall = torch.zeros(T + 1, B, H, device=dev, dtype=torch.float32)     # time-major states, hall[0] = h0 = 0
         save = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
         gh = torch.empty(B, 3 * H, device=dev, dtype=torch.float32)
         for t in range(T):
-            hprev, off, ldh = (h0, 0, H) if t == 0 else (out, (t - 1) * H, T * H)
-            gemm(hprev, w_hh, gh, B, 3 * H, H, ldh, H, 3 * H, 0, 1, bias=b_hh, a_off=off)
+            gemm(hall, w_hh, gh, B, 3 * H, H, H, H, 3 * H, 0, 1, bias=b_hh, a_off=t * B * H)
             check(L.ekaid_gru_cell_fwd(gi.data_ptr() + 4 * t * 3 * H, T * 3 * H, ptr(gh), 3 * H,
-                                       hprev.data_ptr() + 4 * off, ldh, B, H,
-                                       out.data_ptr() + 4 * t * H, T * H, save.data_ptr() + 4 * t * B * 4 * H,
+                                       hall.data_ptr() + 4 * t * B * H, H, B, H,
+                                       hall.data_ptr() + 4 * (t + 1) * B * H, H, save.data_ptr() + 4 * t * B * 4 * H,
                                        stream()), 'gru_cell_fwd')
-        ctx.save_for_backward(x, w_ih, w_hh, out, h0, save)
-        return out
+        ctx.save_for_backward(x, w_ih, w_hh, hall, save)
+        return hall[1:].transpose(0, 1)          # (B, T, H) view of the time-major buffer
 
     @staticmethod
     def backward(ctx, dout):
-        x, w_ih, w_hh, out, h0, save = ctx.saved_tensors
+        x, w_ih, w_hh, hall, save = ctx.saved_tensors
         B, T, E = x.shape
         H = w_hh.shape[1]
         dev = x.device
@@ -676,19 +674,16 @@ class GRUSeqFn(Function):
         dgi = torch.empty(B, T, 3 * H, device=dev, dtype=torch.float32)
         dgh = torch.empty(T, B, 3 * H, device=dev, dtype=torch.float32)
         dh = torch.empty(B, H, device=dev, dtype=torch.float32)
-        dw_hh = torch.zeros_like(w_hh)
         for t in range(T - 1, -1, -1):
             carry = None if t == T - 1 else dh.data_ptr()
-            dgh_t = dgh.data_ptr() + 4 * t * B * 3 * H
-            hprev, off, ldh = (h0, 0, H) if t == 0 else (out, (t - 1) * H, T * H)
             check(L.ekaid_gru_cell_bwd(dout.data_ptr() + 4 * t * H, T * H, carry, save.data_ptr() + 4 * t * B * 4 * H,
-                                       hprev.data_ptr() + 4 * off, ldh, B, H, dgi.data_ptr() + 4 * t * 3 * H, T * 3 * H,
-                                       dgh_t, ptr(dh), stream()), 'gru_cell_bwd')
-            if t > 0:
-                # dh_{t-1} = z*d (written by the kernel) + dgh_t . W_hh ;  dW_hh += dgh_t^T . h_{t-1}
+                                       hall.data_ptr() + 4 * t * B * H, H, B, H, dgi.data_ptr() + 4 * t * 3 * H, T * 3 * H,
+                                       dgh.data_ptr() + 4 * t * B * 3 * H, ptr(dh), stream()), 'gru_cell_bwd')
+            if t > 0:       # dh_{t-1} = z*d (written by the kernel) + dgh_t . W_hh
                 gemm(dgh, w_hh, dh, B, H, 3 * H, 3 * H, H, H, 0, 0, accumulate=True, a_off=t * B * 3 * H)
-                gemm(dgh, out, dw_hh, 3 * H, H, B, 3 * H, ldh, H, 1, 0, accumulate=True, a_off=t * B * 3 * H,
-                     b_off=off)
+        # weight gradients batched over time: K = T*B rows (previous states are the contiguous slice hall[0:T])
+        dw_hh = torch.empty_like(w_hh)
+        gemm(dgh, hall, dw_hh, 3 * H, H, T * B, 3 * H, H, H, 1, 0)
         db_hh = torch.empty(3 * H, device=dev, dtype=torch.float32)
         check(L.ekaid_colsum(ptr(dgh), T * B, 3 * H, 3 * H, ptr(db_hh), stream()), 'colsum')
         db_ih = torch.empty(3 * H, device=dev, dtype=torch.float32)

@@ -2,7 +2,7 @@
 import glob, os, sys, ctypes, torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from ekaid_amd import hip, ops
-SHAPES = [('nt', 18432, 1024, 1024), ('nt', 18432, 1024, 4096), ('nn', 18432, 1024, 1024), ('nn', 18432, 4096, 1024),
+SHAPES = [('nt', 256, 2048, 1024), ('nn', 256, 512, 2048), ('nn', 256, 1024, 2048), ('nt', 256, 3072, 1024), ('nt', 18432, 1024, 1024), ('nt', 18432, 1024, 4096), ('nn', 18432, 1024, 1024), ('nn', 18432, 4096, 1024),
           ('tn', 1024, 1024, 18432), ('tn', 1024, 4096, 18432), ('nt', 256, 2048, 512), ('nt', 256, 2048, 2048), ('tn', 2048, 512, 256)]
 def run(lib):
     res = []
