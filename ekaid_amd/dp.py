@@ -171,10 +171,10 @@ class _AllGatherRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, group):
         world = dist.get_world_size(group)
-        out = x.new_empty(world * x.shape[0], *x.shape[1:])
-        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+        parts = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(parts, x.contiguous(), group=group)
         ctx.group, ctx.rows = group, x.shape[0]
-        return out
+        return torch.cat(parts, 0)
 
     @staticmethod
     def backward(ctx, d):

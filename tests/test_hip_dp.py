@@ -1,0 +1,76 @@
+"""Data-parallel step on the GPU box: two processes share cuda:0 and talk over gloo (the box has one GPU, so the
+RCCL transport itself is exercised only by the driver's multi-GPU runs; everything above the transport --
+live-set discovery, flat views, bucket hooks, fused Adam with grad_scale, the global-batch Q-C gather -- is the
+same code).  With global question-attention semantics, 2 ranks x B=2 must reproduce 1 process x B=4."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    from common import SMALL, small_models
+    from ekaid_amd.dp import FlatAdam, enable_global_question_attention
+    from ekaid_amd.synthetic import make_batch, slice_batch
+    from test_hip_model import hip_step
+    cfg, cd, sp = small_models('all', device='cuda')
+    if world > 1:
+        enable_global_question_attention(cd)
+    full = make_batch(**dict(SMALL, B=4))
+    per = 4 // world
+    batch = slice_batch(full, rank * per, (rank + 1) * per)
+    opt = FlatAdam([cd, sp], lr=1e-3, bucket_mb=0.5)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = hip_step(cfg, cd, sp, batch, 'mode2', 'all')[0]
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    if world > 1:
+        t = torch.tensor(losses, device='cuda')
+        dist.all_reduce(t)
+        losses = (t / world).tolist()
+    if rank == 0:
+        params = {('cd.' + k): p.detach().cpu().double().norm().item() for k, p in cd.named_parameters()}
+        params.update({('sp.' + k): p.detach().cpu().double().norm().item() for k, p in sp.named_parameters()})
+        json.dump({'losses': losses, 'norms': params, 'buckets': len(opt.buckets), 'live': len(opt.live)}, open(out_path, 'w'))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_match_one_process(tmp_path):
+    ctx = mp.get_context('spawn')
+    single = str(tmp_path / 'single.json')
+    p = ctx.Process(target=_run, args=(0, 1, 29731, single))
+    p.start(); p.join(300)
+    assert p.exitcode == 0
+    multi = str(tmp_path / 'multi.json')
+    procs = [ctx.Process(target=_run, args=(r, 2, 29733, multi)) for r in range(2)]
+    for q in procs:
+        q.start()
+    for q in procs:
+        q.join(300)
+        assert q.exitcode == 0
+    a, b = json.load(open(single)), json.load(open(multi))
+    assert b['buckets'] > 1 and a['live'] == b['live']
+    assert np.allclose(a['losses'], b['losses'], rtol=2e-5), (a['losses'], b['losses'])
+    from golden_util import load_golden, negligible_grad_names
+    g1 = load_golden('f1_all')
+    noisy = set(negligible_grad_names(g1['grad_names'], g1['grad_rows']))
+    worst = max(abs(a['norms'][k] - b['norms'][k]) / max(a['norms'][k], 1e-9) for k in a['norms'] if k not in noisy)
+    assert worst < 1e-5, worst
