@@ -46,6 +46,7 @@ def parse():
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--global-qc', action='store_true', help='global-batch semantics for quirk Q-C')
     ap.add_argument('--eval', action='store_true', help='dropout off (parity mode); default is train mode')
+    ap.add_argument('--backend', default='nccl', help='collective backend (nccl = RCCL; gloo only for single-GPU plumbing tests)')
     ap.add_argument('--gemm-shapes', action='store_true', help='print the per-shape GEMM time table to stderr')
     return ap.parse_args()
 
@@ -94,7 +95,30 @@ def cpu_baseline(cfg, cd, sp, batch_size, graph):
         one()
         iters += 1
     dt = (time.perf_counter() - t0) / iters
-    return {'value': round(batch_size / dt, 3), 'unit': 'QA-pairs/s', 'cores': threads, 'kind': 'port',
+    # parity of the very same weights/inputs through the HIP path (eval mode = dropout off): logit max|delta|
+    with torch.no_grad():
+        _, res = O.train_loss(Pcd, Psp, cfg, batch, 'mode2', graph)
+        was = (cd.training, sp.training)
+        cd.eval()
+        sp.eval()
+        dev = next(cd.parameters()).device
+        bb = {k: v.to(dev) for k, v in batch.items()}
+        from ekaid_amd.utils.mimic_utils import process_matrix
+        N = bb['input_1'].shape[1]
+        adj = [process_matrix(bb[k], cfg, N, dev, type=t) for k, t in
+               (('d_adj', 'spatial'), ('q_adj', 'spatial'), ('d_sem', 'semantic'), ('q_sem', 'semantic'))]
+        outs = cd(bb['input_1'], bb['input_2'], adj[0], adj[1], adj[2], adj[3], bb['d_bb'], bb['q_bb'], bb['question'],
+                  setting='mode2', graph=graph)
+        logp, _ = sp._forward(outs[3], outs[4], outs[5], bb['labels'])
+        cd.train(was[0])
+        sp.train(was[1])
+        T = SHAPE['T']
+        ref = res['logp'][:, :T]
+        got = logp[:, :T].cpu()
+        parity = {'logit_max_abs_delta': float((got - ref).abs().max()),
+                  'logit_max_rel_delta': float((got - ref).abs().max() / ref.abs().max()),
+                  'argmax_identical': bool(torch.equal(got.argmax(-1), ref.argmax(-1)))}
+    return {'value': round(batch_size / dt, 3), 'parity_vs_hip': parity, 'unit': 'QA-pairs/s', 'cores': threads, 'kind': 'port',
             'sample': 'CPU oracle (PyTorch %s, %d threads) train fwd+bwd, batch %d, %d timed iterations after 1 warm-up; '
                       'same shapes/weights as the GPU run, dropout off, no optimizer step' % (
                           torch.__version__, threads, batch_size, iters)}
@@ -109,11 +133,15 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)      # (several ranks may share a GPU in the gloo plumbing test)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from common import build_models
@@ -160,8 +188,10 @@ def main():
     roof = None
     if rank == 0:
         ops.gemm_profile_begin()
-        for _ in range(2):
-            train_step(cfg, cd, sp, opt, b, T, args.graph)
+    for _ in range(2):          # every rank runs them (they contain the gradient all-reduce); only rank 0 records events
+        train_step(cfg, cd, sp, opt, b, T, args.graph)
+    torch.cuda.synchronize()
+    if rank == 0:
         rec = ops.gemm_profile_end()
         ms = sum(r[0] for r in rec)
         fl = sum(r[1] for r in rec)

@@ -636,3 +636,27 @@ extern "C" int ekaid_process_matrix(const void* adj, int is_int64, int B, int S,
         hipLaunchKernelGGL(process_matrix_kernel<double>, grid1d(n), dim3(256), 0, ST, (const double*)adj, B, S, N, L, out);
     return check_launch("process_matrix");
 }
+
+// ------------------------------------------------------------------ tiled transpose (weights -> [in][out] for the forward GEMM)
+namespace ekaid {
+__global__ __launch_bounds__(256) void transpose_kernel(const float* src, int R, int C, int lds_, float* dst, int ldd) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? src[(long long)r * lds_ + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) dst[(long long)c * ldd + r] = tile[tx][i];
+    }
+}
+}  // namespace ekaid
+extern "C" int ekaid_transpose(const float* src, int R, int C, int ld_src, float* dst, int ld_dst, void* stream) {
+    if (R <= 0 || C <= 0) return EKAID_OK;
+    dim3 grid(ekaid::cdiv(C, 64), ekaid::cdiv(R, 64));
+    hipLaunchKernelGGL(ekaid::transpose_kernel, grid, dim3(256), 0, ST, src, R, C, ld_src, dst, ld_dst);
+    return ekaid::check_launch("transpose");
+}

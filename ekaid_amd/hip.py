@@ -87,6 +87,7 @@ SIGNATURES = {
     'ekaid_layernorm_fwd': [P, P, P, L, I, F, P, P, P],
     'ekaid_layernorm_bwd': [P, P, P, P, L, I, P, P, P, P],
     'ekaid_process_matrix': [P, I, I, I, I, I, P, P],
+    'ekaid_transpose': [P, I, I, I, P, I, P],
     'ekaid_adam_step': [P, P, P, P, L, F, F, F, F, I, F, P],
 }
 _RESTYPES = {'ekaid_last_error': c_char_p, 'ekaid_gemm_workspace_bytes': c_size_t}

@@ -108,6 +108,17 @@ def gemm_profile_end():
 # --------------------------------------------------------------------------- #
 # linear layers:  y = act( scale * sum_i x_i W[:, K_i]^T + b )
 # --------------------------------------------------------------------------- #
+TRANSPOSE_MIN_ROWS = 4096     # forward GEMMs with at least this many rows read a transposed copy of the weight
+
+
+def weight_transposed(W):
+    """W [N][K] -> fresh W^T [K][N] (one small kernel; weights change every step, so no caching)."""
+    N, K = W.shape
+    Wt = torch.empty(K, N, device=W.device, dtype=torch.float32)
+    check(hip.lib().ekaid_transpose(ptr(W), N, K, K, ptr(Wt), N, stream()), 'transpose')
+    return Wt
+
+
 class LinearFn(Function):
     """nn.Linear / weight-normed FCNet layer over one or several inputs whose feature axes are
     concatenated (so ``torch.cat`` of the reference never materialises).
@@ -122,12 +133,17 @@ class LinearFn(Function):
         M = xs2[0].shape[0]
         assert sum(x.shape[1] for x in xs2) == Ktot, 'input widths do not add up to in_features'
         y = torch.empty(M, N, device=W.device, dtype=torch.float32)
+        Wt = weight_transposed(W) if M >= TRANSPOSE_MIN_ROWS else None
         off = 0
         for i, (x, ld) in enumerate(zip(xs2, lds)):
             last = i == len(xs2) - 1
             K = x.shape[1]
-            gemm(x, W, y, M, N, K, ld, Ktot, N, 0, 1, alpha_dev=scale, accumulate=i > 0,
-                 bias=b if last else None, act=act if last else ACT_NONE, b_off=off)
+            if Wt is not None:      # B = W^T [K][N]: n-contiguous staging (512-byte row segments), the faster variant
+                gemm(x, Wt, y, M, N, K, ld, N, N, 0, 0, alpha_dev=scale, accumulate=i > 0,
+                     bias=b if last else None, act=act if last else ACT_NONE, b_off=off * N)
+            else:
+                gemm(x, W, y, M, N, K, ld, Ktot, N, 0, 1, alpha_dev=scale, accumulate=i > 0,
+                     bias=b if last else None, act=act if last else ACT_NONE, b_off=off)
             off += K
         ctx.act = act
         ctx.has_b = b is not None
@@ -199,8 +215,12 @@ class LinearRowStackFn(Function):
         Ms = [x.shape[0] for x in xs2]
         y = torch.empty(sum(Ms), N, device=W.device, dtype=torch.float32)
         r0 = 0
+        Wt = weight_transposed(W) if sum(Ms) >= TRANSPOSE_MIN_ROWS else None
         for x, ld, M in zip(xs2, lds, Ms):
-            gemm(x, W, y, M, N, K, ld, K, N, 0, 1, bias=b, c_off=r0 * N)
+            if Wt is not None:
+                gemm(x, Wt, y, M, N, K, ld, N, N, 0, 0, bias=b, c_off=r0 * N)
+            else:
+                gemm(x, W, y, M, N, K, ld, K, N, 0, 1, bias=b, c_off=r0 * N)
             r0 += M
         ctx.save_for_backward(W, *xs2)
         ctx.lds, ctx.Ms, ctx.has_b = lds, Ms, b is not None
