@@ -660,3 +660,44 @@ extern "C" int ekaid_transpose(const float* src, int R, int C, int ld_src, float
     hipLaunchKernelGGL(ekaid::transpose_kernel, grid, dim3(256), 0, ST, src, R, C, ld_src, dst, ld_dst);
     return ekaid::check_launch("transpose");
 }
+
+// ------------------------------------------------------------------ greedy decode bookkeeping (one step, whole batch)
+// ref: dynamic_speaker_change_pos.py:316-352 with sample_max=1: forbid token 0 at t == 0, argmax, stop flags,
+// it = it * unfinished, seq[:, t] = it, seq_logprobs[:, t] = max log-prob.  One wave per sample.
+namespace ekaid {
+__global__ __launch_bounds__(256) void greedy_step_kernel(const float* logp, int B, int V, int t, int* unfinished, int64_t* it,
+                                                          int64_t* seq, float* seq_logp, int seq_len, int* n_unfinished) {
+    const int lane = threadIdx.x & 63;
+    const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (b >= B) return;
+    const float* p = logp + (long long)b * V;
+    float best = -INFINITY;
+    int arg = V;
+    for (int v = lane; v < V; v += 64) {
+        float x = p[v];
+        if (t == 0 && v == 0) x = -INFINITY;
+        if (x > best) { best = x; arg = v; }            // strict '>' keeps the lowest index within a lane
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oa = __shfl_xor(arg, off, 64);
+        if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }     // ties -> lowest index (torch.max)
+    }
+    if (lane == 0) {
+        int un = (t == 0) ? (arg > 0) : (unfinished[b] && arg > 0);
+        unfinished[b] = un;
+        const int64_t tok = un ? arg : 0;
+        it[b] = tok;
+        seq[(long long)b * seq_len + t] = tok;
+        seq_logp[(long long)b * seq_len + t] = best;
+        if (un) atomicAdd(n_unfinished, 1);
+    }
+}
+}  // namespace ekaid
+extern "C" int ekaid_greedy_step(const float* logp, int B, int V, int t, int* unfinished, int64_t* it, int64_t* seq,
+                                 float* seq_logp, int seq_len, int* n_unfinished, void* stream) {
+    hipLaunchKernelGGL(ekaid::greedy_step_kernel, ekaid::grid1d((long long)B * 64), dim3(256), 0, ST, logp, B, V, t, unfinished, it,
+                       seq, seq_logp, seq_len, n_unfinished);
+    return ekaid::check_launch("greedy_step");
+}

@@ -87,6 +87,7 @@ SIGNATURES = {
     'ekaid_layernorm_fwd': [P, P, P, L, I, F, P, P, P],
     'ekaid_layernorm_bwd': [P, P, P, P, L, I, P, P, P, P],
     'ekaid_process_matrix': [P, I, I, I, I, I, P, P],
+    'ekaid_greedy_step': [P, I, I, I, P, P, P, P, I, P, P],
     'ekaid_transpose': [P, I, I, I, P, I, P],
     'ekaid_adam_step': [P, P, P, P, L, F, F, F, F, I, F, P],
 }

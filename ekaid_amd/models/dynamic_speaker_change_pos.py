@@ -110,6 +110,7 @@ class DynamicSpeaker(CaptionModel):
         self.logit = Linear(self.rnn_size, self.vocab_size)
         self.module_weights = []
         self.fused_sequence = True      # _forward as one BPTT node; False = step-by-step through autograd
+        self.greedy_poll = 8            # greedy _sample: host checks "all finished" every this many steps
 
     def init_hidden(self, batch_size):
         """((h_att, h_lang), (c_att, c_lang)); indexable like the reference's stacked (2, B, rnn) tensors."""
@@ -198,8 +199,28 @@ class DynamicSpeaker(CaptionModel):
         seq = feat_bef.new_zeros((batch_size, self.seq_length), dtype=torch.long)
         seq_logprobs = feat_bef.new_zeros(batch_size, self.seq_length)
         embed_pre = self.core.embed_pre(feat_bef, feat_aft, feat_diff)
-        unfinished = None
         it = feat_bef.new_zeros(batch_size, dtype=torch.long) + 2          # <bos> hard-coded as id 2 (:311)
+        if sample_max and not decoding_constraint:
+            # greedy path (test_mimic.py:119-122): argmax / stop-flag bookkeeping in one kernel per step; the
+            # "all finished" test (:354) is polled every ``self.greedy_poll`` steps instead of synchronising each step
+            from ..hip import check, lib, ptr, stream
+            unfinished = torch.zeros(batch_size, dtype=torch.int32, device=feat_bef.device)
+            counts = torch.zeros(self.seq_length, dtype=torch.int32, device=feat_bef.device)
+            for t in range(self.seq_length):
+                logprobs, state, _ = self.get_logprobs_state(it, feat_bef, feat_aft, feat_diff, state, embed_pre)
+                it = torch.empty_like(it)
+                check(lib().ekaid_greedy_step(ptr(logprobs.detach().contiguous()), batch_size, self.vocab_size, t, ptr(unfinished),
+                                              ptr(it), ptr(seq), ptr(seq_logprobs), self.seq_length,
+                                              counts.data_ptr() + 4 * t, stream()), 'greedy_step')
+                if (t + 1) % self.greedy_poll == 0 or t == self.seq_length - 1:
+                    done = (counts[:t + 1] == 0).nonzero()
+                    if done.numel():                                       # everything had finished at step `first`
+                        first = int(done[0])
+                        seq[:, first + 1:] = 0
+                        seq_logprobs[:, first + 1:] = 0
+                        break
+            return seq, seq_logprobs
+        unfinished = None
         for t in range(self.seq_length + 1):
             logprobs, state, _ = self.get_logprobs_state(it, feat_bef, feat_aft, feat_diff, state, embed_pre)
             logprobs = logprobs.detach()

@@ -205,6 +205,13 @@ int ekaid_layernorm_bwd(const float* x, const float* gamma, const float* save, c
  * [B][N][N][L], channel l-1 = (label == l), cropped to the first N nodes.   ref: utils/mimic_utils.py:119-149 */
 int ekaid_process_matrix(const void* adj, int is_int64, int B, int S, int N, int L, float* out, void* stream);
 
+/* One greedy decode step for the whole batch (sample_max = 1).   ref: dynamic_speaker_change_pos.py:316-352
+ * logp [B][V]; forbids token 0 at t == 0; it/seq[:, t]/seq_logp[:, t] written; unfinished[B] updated in place;
+ * n_unfinished[0] (caller zero-fills) += samples still running -> the host may poll it every few steps instead of
+ * synchronising every step. */
+int ekaid_greedy_step(const float* logp, int B, int V, int t, int* unfinished, int64_t* it, int64_t* seq, float* seq_logp,
+                      int seq_len, int* n_unfinished, void* stream);
+
 /* dst[c][r] = src[r][c] (R x C, leading dims in elements).  Used once per weight per step: the forward GEMM reads
  * W^T [in][out] with 512-byte row segments instead of W [out][in] with 128-byte segments (measured +15-20 %). */
 int ekaid_transpose(const float* src, int R, int C, int ld_src, float* dst, int ld_dst, void* stream);

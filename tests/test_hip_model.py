@@ -286,3 +286,51 @@ def test_ops_refuse_cpu_tensors():
     from ekaid_amd import hip, ops
     with pytest.raises(hip.EkaidError):
         ops.linear(torch.zeros(2, 4), torch.zeros(3, 4))
+
+
+def test_full_size_batch256_size_independent_properties():
+    """BASELINE.json configs[2]-[3] size (B=256, N=36, D=2048): properties that need no CPU oracle run.
+    (1) every kernel of the detector is row-independent: with the question vectors held fixed, samples computed
+    inside the 256-batch equal the same samples computed alone; (2) attention rows are probability vectors and the
+    region attention lies in (0,1); (3) decoder log-probs normalise; (4) loss/gradients finite, dead parameters
+    stay without gradient."""
+    cfg = bench_cfg()
+    cd, sp = build_models(cfg, 147, 148, DEV)
+    batch = make_batch(B=256, **FULL)
+    b = to_device(batch, DEV)
+    from ekaid_amd.utils.mimic_utils import process_matrix
+    N = FULL['N']
+    adj = [process_matrix(b[k], cfg, N, DEV, type=t) for k, t in
+           (('d_adj', 'spatial'), ('q_adj', 'spatial'), ('d_sem', 'semantic'), ('q_sem', 'semantic'))]
+    with torch.no_grad():
+        q_all = cd.encode_question(b['question'])
+        orig = cd.encode_question
+        try:
+            cd.encode_question = lambda question: q_all[:question.shape[0]]
+            big = cd(b['input_1'], b['input_2'], adj[0], adj[1], adj[2], adj[3], b['d_bb'], b['q_bb'], b['question'])
+            s = slice(0, 8)
+            small = cd(b['input_1'][s], b['input_2'][s], adj[0][s], adj[1][s], adj[2][s], adj[3][s], b['d_bb'][s], b['q_bb'][s],
+                       b['question'][s])
+        finally:
+            cd.encode_question = orig
+        for x, y, name in zip(big, small, ('pred', 'att_bef', 'att_aft', 'feat_bef', 'feat_aft', 'feat_diff')):
+            close(x[s], y, 2e-5, 'row independence of ' + name)
+        assert float(big[1].min()) > 0 and float(big[1].max()) < 1
+        v = cd.img(b['input_1'][:16]).view(16, N, -1)
+        _, aff = cd.spatial_relation.forward(v, adj[0][:16], q_all[:16])
+        P = aff[1]
+        assert P.shape == (16, N, 4, N)
+        close(P.sum(-1), torch.ones_like(P.sum(-1)), 1e-5, 'attention rows sum to 1')
+        masked = (adj[0][:16].sum(-1).transpose(1, 2) == 0)          # direction 1 reads the adjacency transposed
+        has_edge = ~masked.all(-1, keepdim=True)
+        assert float((P.permute(0, 1, 3, 2)[masked & has_edge]).abs().max()) == 0.0, 'masked neighbours must get zero weight'
+    loss, _, outs, logp, _ = hip_step(cfg, cd, sp, batch, 'mode2', 'all')
+    close(logp[:, :16].exp().sum(-1), torch.ones(256, 16), 1e-4, 'decoder log-probs normalise')
+    assert float(logp[:, 16:].abs().max()) == 0.0
+    loss.backward()
+    assert torch.isfinite(loss)
+    for k, p in list(cd.named_parameters()) + list(sp.named_parameters()):
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), k
+        dead = any(t in k for t in ('SSRE.', 'fc1.', 'neighbor_net.0.', 'linear_out_.', 'emb_.'))
+        assert (p.grad is None) == dead, 'gradient liveness of %s' % k
