@@ -540,17 +540,21 @@ static void plan(const ekaid_gemm_t* d, int& TMN, int& splitk, int& tiles_m, int
     // for the small-M recurrent GEMMs and narrow outputs, where slab traffic would rival the math.
     (void)batch;
     TMN = (d->M >= 512 && d->N >= 128) ? 2 : 1;
+    // tall outputs with few column tiles (forward/dgrad of the 1024-wide layers, M = 2*B*N rows): 128x64 tiles run
+    // 4-5 workgroups per CU and quantise better than 128x128 (measured 94 -> 104 TF NT, 114 -> 122 TF NN at N = 1024)
+    if (TMN == 2 && batch == 1 && d->M >= 4096 && d->N <= 2048) TMN = 3;
     // skinny problems (recurrent GEMMs, M = batch rows): if 64x64 tiles cannot give every CU two workgroups,
     // use 32x32 tiles with the K-step split across the four waves (TMN = 0)
     // (measured: not faster than 64x64 tiles with the 128-deep K-step + split-K, so only on request)
     static const char* skinny = getenv("EKAID_GEMM_SKINNY");
     if (skinny && TMN == 1 && (long long)cdiv(d->M, 64) * cdiv(d->N, 64) * batch < 512 && d->K >= 64) TMN = 0;
     static const char* force = getenv("EKAID_GEMM_TILE");         // tuning aid: "0" / "1" / "2"
-    if (force && force[0] >= '0' && force[0] <= '2') TMN = force[0] - '0';
-    const int bm = TMN == 0 ? 32 : 64 * TMN;
+    if (force && force[0] >= '0' && force[0] <= '4' && (force[0] < '3' || TMN == 2)) TMN = force[0] - '0';
+    const int bm = TMN == 0 ? 32 : (TMN == 4 ? 64 : (TMN == 3 ? 128 : 64 * TMN));
+    const int bn = TMN == 0 ? 32 : (TMN == 3 ? 64 : (TMN == 4 ? 128 : 64 * TMN));
     tiles_m = cdiv(d->M, bm);
-    tiles_n = cdiv(d->N, bm);
-    splitk = plan_splitk(tiles_m * tiles_n, d->K, batch, (long long)d->M * d->N, TMN == 2 ? BK_BIG : BK_SMALL);
+    tiles_n = cdiv(d->N, bn);
+    splitk = plan_splitk(tiles_m * tiles_n, d->K, batch, (long long)d->M * d->N, TMN >= 2 ? BK_BIG : BK_SMALL);
 }
 
 }  // namespace ekaid
@@ -585,7 +589,7 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     plan(d, TMN, a.splitk, a.tiles_m, a.tiles_n);
     if (d->K == 0) a.splitk = 1;
     a.ws = nullptr;
-    const int BK = TMN == 2 ? BK_BIG : BK_SMALL;
+    const int BK = TMN >= 2 ? BK_BIG : BK_SMALL;
     a.k_per_split = cdiv(cdiv(d->K, BK), a.splitk) * BK;
     if (a.splitk > 1) {
         const size_t need = (size_t)a.splitk * d->M * d->N * sizeof(float);
@@ -601,6 +605,7 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     const bool akc = !d->transA, bkc = d->transB != 0;
     int rc;
 #define EKAID_LAUNCH(AK, BKC) (TMN == 2 ? launch<AK, BKC, 2, 2, BK_BIG>(a, batch, st) : TMN == 1 ? launch<AK, BKC, 1, 1, BK_SMALL>(a, batch, st) \
+                               : TMN == 3 ? launch<AK, BKC, 2, 1, BK_BIG>(a, batch, st) : TMN == 4 ? launch<AK, BKC, 1, 2, BK_BIG>(a, batch, st) \
                                         : launch_skinny<AK, BKC>(a, batch, st))
     if (akc && bkc) rc = EKAID_LAUNCH(true, true);
     else if (akc && !bkc) rc = EKAID_LAUNCH(true, false);
