@@ -160,8 +160,12 @@ __device__ __forceinline__ void loader_mask(const TileLoader<NV>& L, f32x4* r, i
     }
 }
 
+#ifndef EKAID_LB_HALF
+#define EKAID_LB_HALF 4
+#endif
+// workgroups per CU the register allocator must admit: 3 for the 128x128 tile (<= 168 VGPR+AGPR), more for smaller tiles
 template <bool A_KC, bool B_KC, int TM, int TN, int KB>
-__global__ __launch_bounds__(256, 3) void gemm_mfma_kernel(GemmArgs g) {   // 3 workgroups per CU: <= 168 VGPR+AGPR
+__global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : (TM * TN == 2 ? EKAID_LB_HALF : 6))) void gemm_mfma_kernel(GemmArgs g) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int A_ELEMS = A_KC ? BM * (KB + LDS_PAD) : KB * (BM + LDS_PAD);
     constexpr int B_ELEMS = B_KC ? BN * (KB + LDS_PAD) : KB * (BN + LDS_PAD);

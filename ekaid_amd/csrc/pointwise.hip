@@ -57,15 +57,30 @@ __global__ __launch_bounds__(256) void scale_finish_kernel(float* G, const float
 }
 
 // ------------------------------------------------------------------ reductions
-// column sums of [M][N]: one thread per column, workgroups stride over row blocks, atomics at the end
+// column sums of [M][N]: one thread per column (coalesced rows), four independent accumulators so four row loads are
+// in flight per lane; the grid is cut along rows so that ~1024 workgroups stream concurrently; partial sums by atomics
 __global__ __launch_bounds__(256) void colsum_kernel(const float* x, int M, int N, int ldx, float* out, int rows_per_blk) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     const int r0 = blockIdx.y * rows_per_blk;
     const int r1 = min(M, r0 + rows_per_blk);
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += x[(long long)r * ldx + n];
-    atomicAdd(out + n, s);
+    const float* p = x + (long long)r0 * ldx + n;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {
+        s0 += p[0]; s1 += p[ldx]; s2 += p[2 * (long long)ldx]; s3 += p[3 * (long long)ldx];
+        p += 4 * (long long)ldx;
+    }
+    for (; r < r1; ++r) { s0 += p[0]; p += ldx; }
+    atomicAdd(out + n, (s0 + s1) + (s2 + s3));
+}
+__global__ __launch_bounds__(256) void rowsum_short_kernel(const float* x, long long rows, int cols, float* out, int as_mask) {
+    GS_LOOP(r, rows) {                          // short rows (one-hot label channels): one thread per row
+        const float* p = x + r * cols;
+        float s = 0.f;
+        for (int c = 0; c < cols; ++c) s += p[c];
+        out[r] = as_mask ? (s != 0.f ? 1.f : 0.f) : s;
+    }
 }
 __global__ __launch_bounds__(256) void rowsum_kernel(const float* x, long long rows, int cols, float* out, int as_mask) {
     // one wave per row
@@ -96,16 +111,17 @@ __global__ __launch_bounds__(256) void mul_kernel(const float* x, const float* y
     GS_LOOP(i, n) out[i] = x[i] * y[i];
 }
 __global__ __launch_bounds__(256) void expand_rows_kernel(const float* q, const float* mask, long long rows, int group,
-                                                          int qrows, int cols, float* out) {
+                                                          int qrows, int cols, float* out, float p, float inv_keep, uint64_t seed) {
     const long long n = rows * cols;
     GS_LOOP(i, n) {
         const long long r = i / cols;
         const int c = (int)(i % cols);
-        out[i] = mask[r] * q[((r / group) % qrows) * cols + c];
+        out[i] = mask[r] * q[((r / group) % qrows) * cols + c] * dropout_scale(seed, (uint64_t)i, p, inv_keep);
     }
 }
 __global__ __launch_bounds__(256) void expand_rows_bwd_kernel(const float* dout, const float* mask, long long rows,
-                                                              int group, int qrows, int cols, float* dq) {
+                                                              int group, int qrows, int cols, float* dq, float p, float inv_keep,
+                                                              uint64_t seed) {
     const long long G = rows / group;            // row groups; group g reads q row (g % qrows)
     const long long n = (long long)qrows * cols;
     GS_LOOP(i, n) {
@@ -115,7 +131,7 @@ __global__ __launch_bounds__(256) void expand_rows_bwd_kernel(const float* dout,
         for (long long g = qr; g < G; g += qrows)
             for (int k = 0; k < group; ++k) {
                 const long long r = g * group + k;
-                s += mask[r] * dout[r * cols + c];
+                s += mask[r] * dout[r * cols + c] * dropout_scale(seed, (uint64_t)(r * cols + c), p, inv_keep);
             }
         dq[i] = s;
     }
@@ -481,8 +497,10 @@ extern "C" int ekaid_scale_dot(float* G, const float* w, const float* scale_dev,
 extern "C" int ekaid_colsum(const float* x, int M, int N, int ldx, float* out, void* stream) {
     (void)hipMemsetAsync(out, 0, sizeof(float) * N, ST);
     if (M <= 0 || N <= 0) return EKAID_OK;
-    const int rows_per_blk = 128;
-    dim3 grid(cdiv(N, 256), cdiv(M, rows_per_blk));
+    const int colblks = cdiv(N, 256);
+    int rows_per_blk = (int)(((long long)M * colblks + 1023) / 1024);
+    rows_per_blk = rows_per_blk < 8 ? 8 : rows_per_blk;
+    dim3 grid(colblks, cdiv(M, rows_per_blk));
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, ST, x, M, N, ldx, out, rows_per_blk);
     return check_launch("colsum");
 }
@@ -504,19 +522,21 @@ extern "C" int ekaid_mul(const float* x, const float* y, float* out, long long n
     return check_launch("mul");
 }
 extern "C" int ekaid_rowsum(const float* x, long long rows, int cols, float* out, int as_nonzero_mask, void* stream) {
-    hipLaunchKernelGGL(rowsum_kernel, grid1d(rows * 64), dim3(256), 0, ST, x, rows, cols, out, as_nonzero_mask);
+    if (cols <= 32) hipLaunchKernelGGL(rowsum_short_kernel, grid1d(rows), dim3(256), 0, ST, x, rows, cols, out, as_nonzero_mask);
+    else hipLaunchKernelGGL(rowsum_kernel, grid1d(rows * 64), dim3(256), 0, ST, x, rows, cols, out, as_nonzero_mask);
     return check_launch("rowsum");
 }
 extern "C" int ekaid_expand_rows_fwd(const float* q, const float* mask, long long rows, int group, int qrows, int cols, float* out,
-                                     void* stream) {
+                                     float p, uint64_t seed, void* stream) {
     if (group < 1 || qrows < 1 || rows % group) { set_error("expand_rows: rows %% group != 0"); return EKAID_ERR_ARG; }
-    hipLaunchKernelGGL(expand_rows_kernel, grid1d(rows * cols), dim3(256), 0, ST, q, mask, rows, group, qrows, cols, out);
+    hipLaunchKernelGGL(expand_rows_kernel, grid1d(rows * cols), dim3(256), 0, ST, q, mask, rows, group, qrows, cols, out, p, INVK(p), seed);
     return check_launch("expand_rows_fwd");
 }
 extern "C" int ekaid_expand_rows_bwd(const float* dout, const float* mask, long long rows, int group, int qrows, int cols, float* dq,
-                                     void* stream) {
+                                     float p, uint64_t seed, void* stream) {
     if (group < 1 || qrows < 1 || rows % group) { set_error("expand_rows: rows %% group != 0"); return EKAID_ERR_ARG; }
-    hipLaunchKernelGGL(expand_rows_bwd_kernel, grid1d((long long)qrows * cols), dim3(256), 0, ST, dout, mask, rows, group, qrows, cols, dq);
+    hipLaunchKernelGGL(expand_rows_bwd_kernel, grid1d((long long)qrows * cols), dim3(256), 0, ST, dout, mask, rows, group, qrows, cols, dq,
+                       p, INVK(p), seed);
     return check_launch("expand_rows_bwd");
 }
 extern "C" int ekaid_residual_relu2_fwd(const float* v, const float* o, float* vnew, long long n, float p, uint64_t seed, void* stream) {

@@ -16,6 +16,14 @@ from ..hip import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
 _ACT_CODE = {None: ACT_NONE, '': ACT_NONE, 'ReLU': ACT_RELU, 'Tanh': ACT_TANH, 'Sigmoid': ACT_SIGMOID}
 
 
+class PreDropped:
+    """Marks a tensor whose dropout (that of the FCNet it is about to enter) was already applied by its producer
+    kernel (``ops.expand_rows`` fuses it), so ``FCNet.forward`` must not drop it again."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+
+
 class Linear(nn.Linear):
     """``nn.Linear`` parameters, HIP arithmetic. ``xs`` may be a tuple of tensors whose feature axes are
     concatenated (replaces ``torch.cat`` + Linear of the reference)."""
@@ -68,9 +76,16 @@ class FCNet(nn.Module):
         for layer in self.main:
             if isinstance(layer, nn.Dropout):
                 if isinstance(x, (tuple, list)):
-                    x = tuple(ops.dropout(t, layer.p, self.training) for t in x)
+                    x = tuple(t.tensor if isinstance(t, PreDropped) else ops.dropout(t, layer.p, self.training) for t in x)
                 else:
                     x = ops.dropout(x, layer.p, self.training)
             elif isinstance(layer, WNLinear):
+                if isinstance(x, (tuple, list)):
+                    x = tuple(t.tensor if isinstance(t, PreDropped) else t for t in x)
                 x = layer(x, self.act)
         return x
+
+    def input_dropout(self):
+        """Dropout probability applied to this FCNet's input (0 if none)."""
+        first = self.main[0]
+        return first.p if isinstance(first, nn.Dropout) else 0.0

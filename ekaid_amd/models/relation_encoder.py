@@ -9,11 +9,11 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .fc import FCNet
+from .fc import FCNet, PreDropped
 from .graph_att import GAttNet as GAT
 
 
-def q_expand_v_cat(q, v, mask=True):
+def q_expand_v_cat(q, v, mask=True, p=0.0, training=False):
     """Returns the PAIR (v [R*N, A], q_expanded [R*N, Q]) that stands for ``cat((v, q_expand), -1)``
     (relation_encoder.py:19-29): the question vector of each sample broadcast to its nodes and zeroed
     on nodes whose feature row sums to exactly 0.  ``q`` may hold fewer rows than R (R = 2B image
@@ -23,8 +23,9 @@ def q_expand_v_cat(q, v, mask=True):
         keep = ops.rowsum(v, as_mask=True).view(-1)
     else:
         keep = torch.ones(R * N, device=v.device, dtype=torch.float32)
-    q_exp = ops.expand_rows(q, keep, N)
-    return v.reshape(R * N, A), q_exp
+    if training and p > 0:      # the consumer FCNet's input dropout, fused into the expansion kernel
+        return v.reshape(R * N, A), PreDropped(ops.expand_rows(q, keep, N, p, True))
+    return v.reshape(R * N, A), ops.expand_rows(q, keep, N)
 
 
 class ImplicitRelationEncoder(nn.Module):
@@ -48,7 +49,8 @@ class ImplicitRelationEncoder(nn.Module):
         imp_v = self.v_transform(v) if self.v_transform else v
         affs = []
         for _ in range(self.num_steps):
-            v_cat_q = q_expand_v_cat(q, imp_v, mask=True)
+            fc = self.implicit_relation.self_weights
+            v_cat_q = q_expand_v_cat(q, imp_v, True, fc.input_dropout(), fc.training)
             imp_v, aff = self.implicit_relation.forward(
                 v_cat_q, imp_adj_mat, position_embedding,
                 residual=imp_v if self.residual_connection else None)
@@ -75,7 +77,8 @@ class ExplicitRelationEncoder(nn.Module):
         exp_v = self.v_transform(v) if self.v_transform else v
         aff = None
         for _ in range(self.num_steps):
-            v_cat_q = q_expand_v_cat(q, exp_v, mask=True)
+            fc = self.explicit_relation.self_weights
+            v_cat_q = q_expand_v_cat(q, exp_v, True, fc.input_dropout(), fc.training)
             exp_v, aff = self.explicit_relation.forward(
                 v_cat_q, exp_adj_matrix, residual=exp_v if self.residual_connection else None)
         return exp_v, aff

@@ -410,18 +410,18 @@ def rowsum(x, as_mask=False):
 
 
 class ExpandRowsFn(Function):
-    """out[r] = mask[r] * q[(r // group) % qrows]  (the q half of q_expand_v_cat).
-    ref: relation_encoder.py:19-29."""
+    """out[r] = dropout(mask[r] * q[(r // group) % qrows])  (the q half of q_expand_v_cat, with the dropout of the
+    following FCNet fused in).  ref: relation_encoder.py:19-29, fc.py:22-24."""
 
     @staticmethod
-    def forward(ctx, q, mask, group):
+    def forward(ctx, q, mask, group, p, seed):
         require_cuda(q, mask)
         q, mask = _c(q), _c(mask)
         rows = mask.numel()
         out = torch.empty(rows, q.shape[1], device=q.device, dtype=torch.float32)
-        check(hip.lib().ekaid_expand_rows_fwd(ptr(q), ptr(mask), rows, group, q.shape[0], q.shape[1], ptr(out),
+        check(hip.lib().ekaid_expand_rows_fwd(ptr(q), ptr(mask), rows, group, q.shape[0], q.shape[1], ptr(out), p, seed,
                                               stream()), 'expand_rows_fwd')
-        ctx.group = group
+        ctx.cfg = (group, p, seed)
         ctx.save_for_backward(mask)
         ctx.qshape = q.shape
         return out
@@ -429,15 +429,17 @@ class ExpandRowsFn(Function):
     @staticmethod
     def backward(ctx, d):
         (mask,) = ctx.saved_tensors
+        group, p, seed = ctx.cfg
         d = _c(d)
         dq = torch.empty(ctx.qshape, device=d.device, dtype=torch.float32)
-        check(hip.lib().ekaid_expand_rows_bwd(ptr(d), ptr(mask), mask.numel(), ctx.group, ctx.qshape[0], ctx.qshape[1],
-                                              ptr(dq), stream()), 'expand_rows_bwd')
-        return dq, None, None
+        check(hip.lib().ekaid_expand_rows_bwd(ptr(d), ptr(mask), mask.numel(), group, ctx.qshape[0], ctx.qshape[1],
+                                              ptr(dq), p, seed, stream()), 'expand_rows_bwd')
+        return dq, None, None, None, None
 
 
-def expand_rows(q, mask, group):
-    return ExpandRowsFn.apply(q, mask, group)
+def expand_rows(q, mask, group, p=0.0, training=False):
+    p = float(p) if training else 0.0
+    return ExpandRowsFn.apply(q, mask, group, p, next_seed() if p > 0 else 0)
 
 
 class ResidualRelu2Fn(Function):

@@ -98,9 +98,9 @@ int ekaid_rowsum(const float* x, long long rows, int cols, float* out, int as_no
  * qrows = batch size lets the main and the reference image share one question matrix)
  * bwd: dq[j][c] = sum over rows r with (r / group) % qrows == j of mask[r] * dout[r][c] */
 int ekaid_expand_rows_fwd(const float* q, const float* mask, long long rows, int group, int qrows, int cols, float* out,
-                          void* stream);
+                          float p /* fused dropout of the expanded rows, 0 = off */, uint64_t seed, void* stream);
 int ekaid_expand_rows_bwd(const float* dout, const float* mask, long long rows, int group, int qrows, int cols, float* dq,
-                          void* stream);
+                          float p, uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Graph attention core.   ref: graph_att_layer.py:105-172 (+ graph_att.py:76,88 for `dir`)
