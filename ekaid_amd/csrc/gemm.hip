@@ -360,6 +360,114 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : (TM * TN == 2 ? EKAID_LB_H
     else store_tiles(std::true_type{});
 }
 
+// "Direct" variant for the recurrent GEMMs (M = batch rows, a few hundred): the whole problem is ~128 MFMAs per
+// SIMD, i.e. ONE K-step of the tiled kernel, so LDS staging + barriers are pure overhead.  Here every wave owns one
+// 32x32 output tile and streams its A and B fragments straight from global memory (L2/MALL-resident activations and
+// weights) into MFMA operand registers -- no LDS, no barrier, loads of the next 64-deep chunk in flight under the
+// MFMAs of the current one.  Workgroup = 4 waves = a 64x64 block of tiles (the two waves of a row share A lines in
+// L1, the two of a column share B lines).  A must be k-contiguous (transA = 0).
+template <bool B_KC>
+__global__ __launch_bounds__(256) void gemm_direct_kernel(GemmArgs g) {
+    constexpr int U = 8;                          // 8-k groups per chunk (64 k)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int bid = blockIdx.x;
+    const int m0 = (bid / g.tiles_n) * 64 + (wave >> 1) * 32, n0 = (bid % g.tiles_n) * 64 + (wave & 1) * 32;
+    const int z = blockIdx.z;
+    const float* A = g.A; const float* B = g.B;
+    int kbeg = 0, kend = g.K;
+    if (g.splitk > 1) {
+        kbeg = z * g.k_per_split;
+        kend = min(g.K, kbeg + g.k_per_split);
+    } else {
+        const long long z1 = z / g.nb2, z2 = z % g.nb2;
+        A += z1 * g.sA1 + z2 * g.sA2;
+        B += z1 * g.sB1 + z2 * g.sB2;
+    }
+    const bool vecA = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((g.K & 3) == 0);
+    const bool vecB = B_KC && ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((g.K & 3) == 0);
+    const float* arow = A + (long long)min(m0 + r, g.M - 1) * g.lda;
+    const float* brow = B_KC ? B + (long long)min(n0 + r, g.N - 1) * g.ldb : B + min(n0 + r, g.N - 1);
+    f32x16 acc;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+    f32x4 a[2][U], b[2][U];
+    // fragment of 8-k group at k: lane half h supplies k + 4h .. k + 4h + 3 (same permutation for A and B)
+    auto fetch = [&](int kc, f32x4* fa, f32x4* fb) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = kc + 8 * u + 4 * h;
+            if (vecA) fa[u] = *reinterpret_cast<const f32x4*>(arow + min(k, g.K - 4));
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fa[u][e] = arow[min(k + e, g.K - 1)];
+            }
+            if (B_KC) {
+                if (vecB) fb[u] = *reinterpret_cast<const f32x4*>(brow + min(k, g.K - 4));
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fb[u][e] = brow[min(k + e, g.K - 1)];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fb[u][e] = brow[(long long)min(k + e, g.K - 1) * g.ldb];
+            }
+        }
+    };
+    auto mask = [&](int kc, f32x4* fa) {          // zero the A side beyond kend: kills the product for every ragged k
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = kc + 8 * u + 4 * h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fa[u][e] = (k + e < kend) ? fa[u][e] : 0.f;
+        }
+    };
+    if (kbeg < kend) {
+        fetch(kbeg, a[0], b[0]);
+        for (int kc = kbeg; kc < kend; kc += 16 * U) {
+            // two chunks per trip so that the register sets are indexed statically
+            if (kc + 8 * U < kend) fetch(kc + 8 * U, a[1], b[1]);
+            if (kc + 8 * U > kend) mask(kc, a[0]);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][u][j], b[0][u][j], acc, 0, 0, 0);
+            if (kc + 8 * U < kend) {
+                if (kc + 16 * U < kend) fetch(kc + 16 * U, a[0], b[0]);
+                if (kc + 16 * U > kend) mask(kc + 8 * U, a[1]);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][u][j], b[1][u][j], acc, 0, 0, 0);
+            }
+        }
+    }
+    const bool slab = g.splitk > 1;
+    float* C;
+    int ldc;
+    if (slab) { C = g.ws + (long long)z * g.M * g.N; ldc = g.N; }
+    else {
+        const long long z1 = z / g.nb2, z2 = z % g.nb2;
+        C = g.C + z1 * g.sC1 + z2 * g.sC2;
+        ldc = g.ldc;
+    }
+    const float alpha = g.e.alpha_dev ? g.e.alpha * g.e.alpha_dev[0] : g.e.alpha;
+    const int n = n0 + r;
+    if (n < g.N) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int m = m0 + (t & 3) + 8 * (t >> 2) + 4 * h;
+            if (m >= g.M) continue;
+            float* cp = C + (long long)m * ldc + n;
+            if (slab) *cp = acc[t];
+            else {
+                const float cold = g.e.beta ? *cp : 0.f;
+                *cp = epilogue(acc[t], cold, m, n, g.e, alpha);
+            }
+        }
+    }
+}
+
 // "Skinny" variant for the recurrent GEMMs (M = batch rows): 32x32 output tile per workgroup, the four waves
 // split every K-step (wave w contracts the k-groups 8w..8w+7 (+32, ...) of each KB-deep step for the whole tile)
 // and their partial accumulators are summed through LDS.  4x more workgroups than the 64x64 tiling for the same
@@ -524,6 +632,13 @@ static int launch_skinny(const GemmArgs& a, int batch, hipStream_t st) {
     return EKAID_OK;
 }
 
+template <bool B_KC>
+static int launch_direct(const GemmArgs& a, int batch, hipStream_t st) {
+    dim3 grid(a.tiles_m * a.tiles_n, 1, a.splitk > 1 ? a.splitk : batch);
+    hipLaunchKernelGGL((gemm_direct_kernel<B_KC>), grid, dim3(256), 0, st, a);
+    return EKAID_OK;
+}
+
 static int plan_splitk(int tiles, int K, int batch, long long MN, int BK) {
     if (batch > 1) return 1;
     static const char* tgt = getenv("EKAID_GEMM_SPLIT_TARGET");   // tuning aid
@@ -552,12 +667,29 @@ static void plan(const ekaid_gemm_t* d, int& TMN, int& splitk, int& tiles_m, int
     // (measured: not faster than 64x64 tiles with the 128-deep K-step + split-K, so only on request)
     static const char* skinny = getenv("EKAID_GEMM_SKINNY");
     if (skinny && TMN == 1 && (long long)cdiv(d->M, 64) * cdiv(d->N, 64) * batch < 512 && d->K >= 64) TMN = 0;
+    // recurrent GEMMs (a few hundred rows, k-contiguous A): LDS-free direct-fragment kernel (TMN = 5)
+    // (measured 28 TF vs 49 TF for the LDS-staged 64x64 kernel at 256x2048x1024: fragment-shaped global loads are
+    //  TA-bound -- kept for experiments only)
+    static const char* direct = getenv("EKAID_GEMM_DIRECT");
+    if (direct && TMN == 1 && !d->transA && d->M <= 1024 && d->K >= 64 && (long long)cdiv(d->M, 64) * cdiv(d->N, 64) * batch <= 1024) TMN = 5;
     static const char* force = getenv("EKAID_GEMM_TILE");         // tuning aid: "0" / "1" / "2"
-    if (force && force[0] >= '0' && force[0] <= '4' && (force[0] < '3' || TMN == 2)) TMN = force[0] - '0';
-    const int bm = TMN == 0 ? 32 : (TMN == 4 ? 64 : (TMN == 3 ? 128 : 64 * TMN));
-    const int bn = TMN == 0 ? 32 : (TMN == 3 ? 64 : (TMN == 4 ? 128 : 64 * TMN));
+    if (force && force[0] >= '0' && force[0] <= '5' && (force[0] < '3' || (force[0] < '5' && TMN == 2) || (force[0] == '5' && !d->transA && TMN <= 1)))
+        TMN = force[0] - '0';
+    const int bm = TMN == 0 ? 32 : (TMN == 4 || TMN == 5 ? 64 : (TMN == 3 ? 128 : 64 * TMN));
+    const int bn = TMN == 0 ? 32 : (TMN == 3 || TMN == 5 ? 64 : (TMN == 4 ? 128 : 64 * TMN));
     tiles_m = cdiv(d->M, bm);
     tiles_n = cdiv(d->N, bn);
+    if (TMN == 5) {
+        // 4 waves per tile-block: aim at ~4 waves per SIMD chip-wide (1024 workgroups), at least 128 k per split
+        splitk = 1;
+        if (batch == 1) {
+            const int blocks = tiles_m * tiles_n;
+            int sk = 1024 / (blocks > 0 ? blocks : 1);
+            const int kmax = d->K / 128;
+            sk = sk > kmax ? kmax : sk;
+            splitk = sk < 1 ? 1 : sk;
+        }
+    } else
     splitk = plan_splitk(tiles_m * tiles_n, d->K, batch, (long long)d->M * d->N, TMN >= 2 ? BK_BIG : BK_SMALL);
 }
 
@@ -593,7 +725,7 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     plan(d, TMN, a.splitk, a.tiles_m, a.tiles_n);
     if (d->K == 0) a.splitk = 1;
     a.ws = nullptr;
-    const int BK = TMN >= 2 ? BK_BIG : BK_SMALL;
+    const int BK = TMN == 5 ? 64 : (TMN >= 2 ? BK_BIG : BK_SMALL);
     a.k_per_split = cdiv(cdiv(d->K, BK), a.splitk) * BK;
     if (a.splitk > 1) {
         const size_t need = (size_t)a.splitk * d->M * d->N * sizeof(float);
@@ -610,6 +742,7 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     int rc;
 #define EKAID_LAUNCH(AK, BKC) (TMN == 2 ? launch<AK, BKC, 2, 2, BK_BIG>(a, batch, st) : TMN == 1 ? launch<AK, BKC, 1, 1, BK_SMALL>(a, batch, st) \
                                : TMN == 3 ? launch<AK, BKC, 2, 1, BK_BIG>(a, batch, st) : TMN == 4 ? launch<AK, BKC, 1, 2, BK_BIG>(a, batch, st) \
+                               : TMN == 5 ? launch_direct<BKC>(a, batch, st) \
                                         : launch_skinny<AK, BKC>(a, batch, st))
     if (akc && bkc) rc = EKAID_LAUNCH(true, true);
     else if (akc && !bkc) rc = EKAID_LAUNCH(true, false);
