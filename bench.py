@@ -51,23 +51,35 @@ def parse():
     return ap.parse_args()
 
 
-def train_step(cfg, cd, sp, opt, b, T, graph):
+def train_step(cfg, cd, sp, opt, b, T, graph, marks=None):
     from ekaid_amd.utils.mimic_utils import process_matrix
     from ekaid_amd.utils.utils import LanguageModelCriterion, total_loss
     N = b['input_1'].shape[1]
     dev = b['input_1'].device
+
+    def mark(name):
+        if marks is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append((name, e))
+    mark('start')
     opt.zero_grad()
     d_adj = process_matrix(b['d_adj'], cfg, N, dev, type='spatial')
     q_adj = process_matrix(b['q_adj'], cfg, N, dev, type='spatial')
     d_sem = process_matrix(b['d_sem'], cfg, N, dev, type='semantic')
     q_sem = process_matrix(b['q_sem'], cfg, N, dev, type='semantic')
+    mark('adjacency')
     outs = cd(b['input_1'], b['input_2'], d_adj, q_adj, d_sem, q_sem, b['d_bb'], b['q_bb'], b['question'],
               setting='mode2', graph=graph)
+    mark('detector_fwd')
     logp, _ = sp._forward(outs[3], outs[4], outs[5], b['labels'], num_steps=T)
     sp_loss = LanguageModelCriterion()(logp, b['labels'][:, 1:], b['masks'][:, 1:])
     loss = total_loss(sp_loss, outs[1], outs[2])
+    mark('speaker_fwd_loss')
     loss.backward()
+    mark('backward')
     opt.step()
+    mark('allreduce_wait_adam')
     return loss
 
 
@@ -188,8 +200,9 @@ def main():
     roof = None
     if rank == 0:
         ops.gemm_profile_begin()
+    marks = []
     for _ in range(2):          # every rank runs them (they contain the gradient all-reduce); only rank 0 records events
-        train_step(cfg, cd, sp, opt, b, T, args.graph)
+        train_step(cfg, cd, sp, opt, b, T, args.graph, marks if rank == 0 else None)
     torch.cuda.synchronize()
     if rank == 0:
         rec = ops.gemm_profile_end()
@@ -206,6 +219,10 @@ def main():
             print('%-44s %6s %9s %8s' % ('(tA,tB,M,N,K,batch)', 'calls', 'ms/step', 'TFLOP/s'), file=sys.stderr)
             for shape, (t_ms, f, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
                 print('%-44s %6d %9.3f %8.2f' % (shape, n // 2, t_ms / 2, f / (t_ms * 1e-3) / 1e12), file=sys.stderr)
+        phases = {}
+        for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+            if n1 != 'start':
+                phases[n1] = round(phases.get(n1, 0.0) + e0.elapsed_time(e1) / 2, 3)
         roof = {'bound': 'mfma', 'kernel': 'ekaid::gemm_mfma_kernel (v_mfma_f32_32x32x2_f32)',
                 'achieved': round(fl / (ms * 1e-3) / 1e12, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
@@ -233,6 +250,7 @@ def main():
                        'parallelism': 'dp%d' % world, 'question_attention': 'global-batch' if args.global_qc else 'local-batch',
                        'params_total': 87290418, 'loss': round(loss_val, 5)},
             'roofline': roof,
+            'phases_ms': phases if rank == 0 else None,
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, cd, sp, args.cpu_batch, args.graph)
