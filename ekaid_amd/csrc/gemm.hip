@@ -602,6 +602,36 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, flo
     }
 }
 
+// 16-byte variant (N and ldc multiples of 4, 16-byte aligned C): one float4 of the output per thread, the S slab
+// loads of a thread are independent (all in flight together), 32-bit index math only
+template <int S_UNROLL>
+__global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N4,
+                                                                int ldc, int splitk, Epi e) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * N4) return;
+    const int m = idx / N4, n = (idx - m * N4) * 4;
+    const long long total4 = (long long)M * N4;
+    const f32x4* w = reinterpret_cast<const f32x4*>(ws) + idx;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + S_UNROLL <= splitk; k += S_UNROLL) {
+        f32x4 v[S_UNROLL];
+#pragma unroll
+        for (int u = 0; u < S_UNROLL; ++u) v[u] = w[(long long)(k + u) * total4];
+#pragma unroll
+        for (int u = 0; u < S_UNROLL; ++u) s += v[u];
+    }
+    for (; k < splitk; ++k) s += w[(long long)k * total4];
+    const float alpha = e.alpha_dev ? e.alpha * e.alpha_dev[0] : e.alpha;
+    f32x4* cp = reinterpret_cast<f32x4*>(C + (long long)m * ldc + n);
+    f32x4 cold = {0.f, 0.f, 0.f, 0.f};
+    if (e.beta) cold = *cp;
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = epilogue(s[c], cold[c], m, n + c, e, alpha);
+    *cp = o;
+}
+
 template <bool A_KC, bool B_KC, int TM, int TN, int KB>
 static int launch(const GemmArgs& a, int batch, hipStream_t st) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -753,10 +783,18 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     if (rc) return rc;
     if (a.splitk > 1) {
         const long long total = (long long)d->M * d->N;
-        int blocks = cdiv(total, 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.ws, d->C, d->M, d->N, d->ldc,
-                           a.splitk, a.e);
+        const bool vec_ok = (d->N % 4 == 0) && (d->ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->C) & 15) == 0) &&
+                            total / 4 < (1ll << 30);
+        if (vec_ok) {
+            const int n4 = d->N / 4;
+            hipLaunchKernelGGL(splitk_reduce_vec_kernel<4>, dim3(cdiv((long long)d->M * n4, 256)), dim3(256), 0, st, a.ws, d->C,
+                               d->M, n4, d->ldc, a.splitk, a.e);
+        } else {
+            int blocks = cdiv(total, 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.ws, d->C, d->M, d->N, d->ldc,
+                               a.splitk, a.e);
+        }
         rc = check_launch("splitk_reduce_kernel");
     }
     return rc;
