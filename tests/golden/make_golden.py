@@ -139,6 +139,19 @@ def gen_f1():
             save('f5_adam', loss_step2=loss2, param_names=np.array(pn), param_rows=pr)
 
 
+def gen_f6():
+    """F6: explicit relation with nongt_dim (5) < regions (8): keys/values restricted to the first nodes."""
+    cfg = small_cfg(graph='spatial')
+    cfg.model.change_detector.nongt_dim = 5
+    cd, sp = build(cfg, 30, 31)
+    batch = make_batch(**SMALL)
+    loss, sp_loss, outs, logp, logpos, _ = ref_step(cfg, cd, sp, batch, 'mode2', 'spatial')
+    loss.backward()
+    names, rows = summarize(named_grads(cd, sp))
+    save('f6_spatial_nongt5', loss=loss, feat_bef=outs[3], feat_diff=outs[5], att_bef=outs[1], logp=logp,
+         grad_names=np.array(names), grad_rows=rows)
+
+
 def gen_f2():
     """F2: batch-coupled question attention (quirk Q-C): B=2 vs B=4 sharing 2 samples."""
     cfg = small_cfg(graph='semantic')
@@ -255,6 +268,7 @@ def gen_keys():
 if __name__ == '__main__':
     gen_keys()
     gen_f1()
+    gen_f6()
     gen_f2()
     gen_f3()
     gen_mode0()

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from common import FULL, SMALL, build_models, oracle_params, small_models, to_device
-from ekaid_amd.config import bench_cfg
+from ekaid_amd.config import bench_cfg, small_cfg
 from ekaid_amd.synthetic import make_batch
 from golden_util import assert_summary_close, load_golden, negligible_grad_names, tensor_summary
 
@@ -335,3 +335,86 @@ def test_full_size_batch256_size_independent_properties():
         dead = k.startswith('SSRE.') or k.startswith('fc1.') or '.neighbor_net.0.' in k or '.linear_out_.' in k or \
             k == 'w_emb.emb_.weight'
         assert (p.grad is None) == dead, 'gradient liveness of %s' % k
+
+
+def _oracle_vs_hip(cfg, cd, sp, batch, graph='all', tol_grad=1e-3, check=('img.weight', 'context1.weight', 'q_emb.rnn.weight_hh_l0')):
+    from oracle import ekaid_oracle as O
+    loss, sp_loss, outs, logp, logpos = hip_step(cfg, cd, sp, batch, 'mode2', graph)
+    loss.backward()
+    Pcd, Psp = oracle_params(cd, True), oracle_params(sp, True)
+    loss_o, res = O.train_loss(Pcd, Psp, cfg, batch, 'mode2', graph)
+    loss_o.backward()
+    close(loss, loss_o, 1e-4, 'loss')
+    T = int((batch['labels'][:, 1:] != 0).any(0).sum()) + 1
+    close(logp, res['logp'], LOGIT_TOL, 'logp')
+    assert torch.equal(logp[:, :T].argmax(-1).cpu(), res['logp'][:, :T].argmax(-1))
+    for i, k in enumerate(('pred', 'att_bef', 'att_aft', 'feat_bef', 'feat_aft', 'feat_diff')):
+        close(outs[i], res['outs'][i], 1e-4, k)
+    for k in check:
+        close(dict(cd.named_parameters())[k].grad, Pcd[k].grad, tol_grad, 'grad ' + k)
+    for k in ('logit.weight', 'core.lang_lstm.weight_hh', 'embed.0.weight'):
+        close(dict(sp.named_parameters())[k].grad, Psp[k].grad, tol_grad, 'grad sp.' + k)
+
+
+def test_real_data_shapes_ragged_answers_and_zero_rows():
+    """Medical-Diff-VQA shapes (52 regions x 1024-d, config.yaml widths shrunk only in att_dim to keep the CPU oracle
+    fast), ragged answer lengths (per-sample masks), an undetected region (all-zero ROI row -> question masked out
+    only if the projected row sums to zero, relation_encoder.py:23-27) and a fully isolated node."""
+    cfg = small_cfg(graph='all', D=1024, att_dim=128, heads=4, qdim=64, seq_length=12)
+    cd, sp = build_models(cfg, 30, 31, DEV)
+    batch = make_batch(B=3, N=52, D=1024, Lq=9, T=7, seq_length=12, V=31, seed=5)
+    batch['input_1'][0, 5] = 0                               # undetected region
+    batch['labels'][1, 4:] = 0                               # shorter answers
+    batch['labels'][2, 6:] = 0
+    batch['masks'] = torch.zeros_like(batch['masks'])
+    for b in range(3):
+        n = int((batch['labels'][b] != 0).sum()) + 1
+        batch['masks'][b, :n] = 1
+    batch['d_adj'][0, 7, :] = 0
+    batch['d_adj'][0, :, 7] = 0                              # isolated node in the spatial graph
+    _oracle_vs_hip(cfg, cd, sp, batch)
+
+
+def test_explicit_relation_nongt5_matches_reference_golden():
+    g = load_golden('f6_spatial_nongt5')
+    cfg = small_cfg(graph='spatial')
+    cfg.model.change_detector.nongt_dim = 5
+    cd, sp = build_models(cfg, 30, 31, DEV)
+    loss, _, outs, logp, _ = hip_step(cfg, cd, sp, make_batch(**SMALL), 'mode2', 'spatial')
+    close(loss, g['loss'], 1e-4, 'loss')
+    close(logp, g['logp'], LOGIT_TOL, 'logp')
+    close(outs[3], g['feat_bef'], 1e-4, 'feat_bef')
+    loss.backward()
+    assert_summary_close(g['grad_names'], g['grad_rows'], named_grads(cd, sp), 1e-3, 'grads[nongt5]')
+
+
+def test_explicit_encoders_with_fewer_neighbours_than_nodes():
+    """nongt_dim < N on the explicit graphs (keys/values restricted to the first M nodes, graph_att_layer.py:74-101)."""
+    for graph in ('semantic', 'spatial'):
+        cfg = small_cfg(graph=graph)
+        cfg.model.change_detector.nongt_dim = 5
+        cd, sp = build_models(cfg, 30, 31, DEV)
+        _oracle_vs_hip(cfg, cd, sp, make_batch(**SMALL), graph, check=('img.weight', 'context1.weight'))
+    cfg = small_cfg(graph='implicit')
+    cfg.model.change_detector.nongt_dim = 5
+    cd, sp = build_models(cfg, 30, 31, DEV)
+    with pytest.raises(NotImplementedError):
+        hip_step(cfg, cd, sp, make_batch(**SMALL), 'mode2', 'implicit')
+
+
+def test_batch_of_one_and_empty_image_flag():
+    cfg, cd, sp = small_models('all', device=DEV)
+    _oracle_vs_hip(cfg, cd, sp, make_batch(**dict(SMALL, B=1)))
+    cfg.data.train.empty_image = True                         # modules.py:170-178: every input replaced by ones
+    from oracle import ekaid_oracle as O
+    batch = make_batch(**SMALL)
+    with torch.no_grad():
+        outs = hip_step(cfg, cd, sp, batch, 'mode2', 'all')[2]
+        ones = {k: torch.ones_like(v) if k in ('input_1', 'input_2', 'd_bb', 'q_bb') else v for k, v in batch.items()}
+        N = SMALL['N']
+        adj1 = [torch.ones(2, N, N, L) for L in (11, 11, 3, 3)]
+        cfg.data.train.empty_image = False
+        ref, _ = O.change_detector_forward(oracle_params(cd), cfg, ones['input_1'], ones['input_2'], adj1[0], adj1[1], adj1[2],
+                                           adj1[3], ones['d_bb'], ones['q_bb'], batch['question'])
+    for a, r, n in zip(outs, ref, ('pred', 'att_bef', 'att_aft', 'feat_bef', 'feat_aft', 'feat_diff')):
+        close(a, r, 1e-4, 'empty_image ' + n)

@@ -53,6 +53,17 @@ def test_f1_forward_backward(graph):
         assert float(got[k].abs().max()) == 0.0, 'oracle produced a gradient for dead parameter ' + k
 
 
+def test_f6_explicit_relation_with_fewer_neighbours_than_nodes():
+    g = load_golden('f6_spatial_nongt5')
+    cfg, cd, sp = small_models('spatial')
+    cfg.model.change_detector.nongt_dim = 5
+    loss, res, named = run_oracle(cfg, cd, sp, make_batch(**SMALL), 'mode2', 'spatial')
+    close(loss, g['loss'], what='loss')
+    close(res['logp'], g['logp'], what='logp')
+    close(res['outs'][3], g['feat_bef'], what='feat_bef')
+    assert_summary_close(g['grad_names'], g['grad_rows'], named, 2e-4, 'grads[nongt5]')
+
+
 def test_f1_mode0_ssre_layernorm():
     g = load_golden('f1_mode0')
     cfg, cd, sp = small_models('all', 'mode0')
