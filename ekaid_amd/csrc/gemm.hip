@@ -26,6 +26,9 @@
 namespace ekaid {
 
 #define BK_BIG 32      // K-step of the 128x128 kernel
+#ifndef BK_HALF
+#define BK_HALF 32     // K-step of the 128x64 / 64x128 kernels
+#endif
 #ifndef BK_SMALL
 #define BK_SMALL 32    // K-step of the 64x64 / 32x32 kernels: their loop is load-latency bound (16 MFMAs per wave per
                        // 32-deep step), so one iteration carries 4x the bytes in flight (measured: 50 -> 90 TF at M = 256)
@@ -51,6 +54,9 @@ struct Epi {
     int rdiv;
     const float* rowmask;
     int act;
+    float drop_p, drop_inv;     // fused dropout of the activated output: mask index = m * N + n
+    unsigned long long drop_seed;
+    int n_cols;
 };
 
 __device__ __forceinline__ float epilogue(float acc, float cold, int m, int n, const Epi& e, float alpha) {
@@ -62,7 +68,9 @@ __device__ __forceinline__ float epilogue(float acc, float cold, int m, int n, c
         if (e.rowmask) r *= e.rowmask[m];
         v += r;
     }
-    return act_apply(v, e.act);
+    v = act_apply(v, e.act);
+    if (e.drop_p > 0.f) v *= dropout_scale(e.drop_seed, (uint64_t)m * e.n_cols + n, e.drop_p, e.drop_inv);
+    return v;
 }
 
 struct GemmArgs {
@@ -751,11 +759,12 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     a.sC1 = d->strideC1; a.sC2 = d->strideC2; a.nb2 = d->batch2;
     a.e.alpha = d->alpha; a.e.alpha_dev = d->alpha_dev; a.e.beta = d->accumulate; a.e.bias = d->bias;
     a.e.R = d->R; a.e.ldr = d->ldr; a.e.rdiv = d->rdiv < 1 ? 1 : d->rdiv; a.e.rowmask = d->rowmask; a.e.act = d->act;
+    a.e.drop_p = d->drop_p; a.e.drop_inv = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f; a.e.drop_seed = d->drop_seed; a.e.n_cols = d->N;
     int TMN;
     plan(d, TMN, a.splitk, a.tiles_m, a.tiles_n);
     if (d->K == 0) a.splitk = 1;
     a.ws = nullptr;
-    const int BK = TMN == 5 ? 64 : (TMN >= 2 ? BK_BIG : BK_SMALL);
+    const int BK = TMN == 5 ? 64 : (TMN == 3 || TMN == 4 ? BK_HALF : (TMN >= 2 ? BK_BIG : BK_SMALL));
     a.k_per_split = cdiv(cdiv(d->K, BK), a.splitk) * BK;
     if (a.splitk > 1) {
         const size_t need = (size_t)a.splitk * d->M * d->N * sizeof(float);
@@ -771,7 +780,7 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     const bool akc = !d->transA, bkc = d->transB != 0;
     int rc;
 #define EKAID_LAUNCH(AK, BKC) (TMN == 2 ? launch<AK, BKC, 2, 2, BK_BIG>(a, batch, st) : TMN == 1 ? launch<AK, BKC, 1, 1, BK_SMALL>(a, batch, st) \
-                               : TMN == 3 ? launch<AK, BKC, 2, 1, BK_BIG>(a, batch, st) : TMN == 4 ? launch<AK, BKC, 1, 2, BK_BIG>(a, batch, st) \
+                               : TMN == 3 ? launch<AK, BKC, 2, 1, BK_HALF>(a, batch, st) : TMN == 4 ? launch<AK, BKC, 1, 2, BK_HALF>(a, batch, st) \
                                : TMN == 5 ? launch_direct<BKC>(a, batch, st) \
                                         : launch_skinny<AK, BKC>(a, batch, st))
     if (akc && bkc) rc = EKAID_LAUNCH(true, true);

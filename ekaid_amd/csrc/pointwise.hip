@@ -721,3 +721,37 @@ extern "C" int ekaid_greedy_step(const float* logp, int B, int V, int t, int* un
                        seq, seq_logp, seq_len, n_unfinished);
     return ekaid::check_launch("greedy_step");
 }
+
+// ------------------------------------------------------------------ strided bias + activation + dropout, and its backward
+namespace ekaid {
+__global__ __launch_bounds__(256) void bias_act_drop_kernel(const float* x, int ldx, const float* bias, int rows, int cols, int act,
+                                                            float p, float inv_keep, uint64_t seed, float* out) {
+    const int n = rows * cols;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int r = i / cols, c = i - r * cols;
+        float v = x[(long long)r * ldx + c] + (bias ? bias[c] : 0.f);
+        out[i] = act_apply(v, act) * dropout_scale(seed, (uint64_t)i, p, inv_keep);
+    }
+}
+__global__ __launch_bounds__(256) void drop_act_bwd_kernel(const float* dy, const float* y, int ldy, int rows, int cols, int act, float p,
+                                                           float inv_keep, uint64_t seed, float* out, int ldo) {
+    const int n = rows * cols;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int r = i / cols, c = i - r * cols;
+        const float k = dropout_scale(seed, (uint64_t)i, p, inv_keep);
+        out[(long long)r * ldo + c] = dy[i] * k * act_grad_from_out(y[(long long)r * ldy + c], act);
+    }
+}
+}  // namespace ekaid
+extern "C" int ekaid_bias_act_drop(const float* x, int ldx, const float* bias, int rows, int cols, int act, float p, uint64_t seed,
+                                   float* out, void* stream) {
+    hipLaunchKernelGGL(ekaid::bias_act_drop_kernel, ekaid::grid1d((long long)rows * cols), dim3(256), 0, ST, x, ldx, bias, rows, cols, act, p,
+                       INVK(p), seed, out);
+    return ekaid::check_launch("bias_act_drop");
+}
+extern "C" int ekaid_drop_act_bwd(const float* dy, const float* y, int ldy, int rows, int cols, int act, float p, uint64_t seed,
+                                  float* out, int ldo, void* stream) {
+    hipLaunchKernelGGL(ekaid::drop_act_bwd_kernel, ekaid::grid1d((long long)rows * cols), dim3(256), 0, ST, dy, y, ldy, rows, cols, act, p,
+                       INVK(p), seed, out, ldo);
+    return ekaid::check_launch("drop_act_bwd");
+}

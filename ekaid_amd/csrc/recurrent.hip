@@ -47,14 +47,14 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(const float* dhnew, i
         dh[b * H + j] = d * z;
     }
 }
-__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(const float* gx, const float* gh, const float* c, int B, int H, float* h2,
-                                                            float* c2, float* save) {
+__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(const float* gx, const float* gh, int ldgh, const float* c, int B, int H,
+                                                            float* h2, float* c2, float* save) {
     const long long n = (long long)B * H;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const long long b = i / H;
         const int j = (int)(i % H);
         const float* x = gx + b * 4 * H;
-        const float* y = gh + b * 4 * H;
+        const float* y = gh + b * ldgh;
         const float ig = sigm(x[j] + y[j]);
         const float fg = sigm(x[H + j] + y[H + j]);
         const float gg = tanhf(x[2 * H + j] + y[2 * H + j]);
@@ -66,8 +66,9 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(const float* gx, con
         sp[j] = ig; sp[H + j] = fg; sp[2 * H + j] = gg; sp[3 * H + j] = og;
     }
 }
-__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* dh2, const float* dc2, const float* save, const float* c,
-                                                            const float* c2, int B, int H, float* dgates, float* dc) {
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* dh2, const float* dh2b, const float* dc2, const float* save,
+                                                            const float* c, const float* c2, int B, int H, float* dgates, int lddg,
+                                                            float* dc) {
     const long long n = (long long)B * H;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const long long b = i / H;
@@ -75,9 +76,9 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* dh2, co
         const float* sp = save + b * 4 * H;
         const float ig = sp[j], fg = sp[H + j], gg = sp[2 * H + j], og = sp[3 * H + j];
         const float tc = tanhf(c2[i]);
-        const float dh = dh2 ? dh2[i] : 0.f;
+        const float dh = (dh2 ? dh2[i] : 0.f) + (dh2b ? dh2b[i] : 0.f);
         const float dct = (dc2 ? dc2[i] : 0.f) + dh * og * (1.f - tc * tc);
-        float* o = dgates + b * 4 * H;
+        float* o = dgates + b * lddg;
         o[j] = dct * gg * ig * (1.f - ig);
         o[H + j] = dct * c[i] * fg * (1.f - fg);
         o[2 * H + j] = dct * ig * (1.f - gg * gg);
@@ -108,13 +109,14 @@ extern "C" int ekaid_gru_cell_bwd(const float* dhnew, int lddh, const float* dh_
                        dgh, dh);
     return check_launch("gru_cell_bwd");
 }
-extern "C" int ekaid_lstm_cell_fwd(const float* gx, const float* gh, const float* c, int B, int H, float* h2, float* c2,
+extern "C" int ekaid_lstm_cell_fwd(const float* gx, const float* gh, int ldgh, const float* c, int B, int H, float* h2, float* c2,
                                    float* save, void* stream) {
-    hipLaunchKernelGGL(lstm_cell_fwd_kernel, g1((long long)B * H), dim3(256), 0, ST, gx, gh, c, B, H, h2, c2, save);
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, g1((long long)B * H), dim3(256), 0, ST, gx, gh, ldgh, c, B, H, h2, c2, save);
     return check_launch("lstm_cell_fwd");
 }
-extern "C" int ekaid_lstm_cell_bwd(const float* dh2, const float* dc2, const float* save, const float* c, const float* c2, int B,
-                                   int H, float* dgates, float* dc, void* stream) {
-    hipLaunchKernelGGL(lstm_cell_bwd_kernel, g1((long long)B * H), dim3(256), 0, ST, dh2, dc2, save, c, c2, B, H, dgates, dc);
+extern "C" int ekaid_lstm_cell_bwd(const float* dh2, const float* dh2b, const float* dc2, const float* save, const float* c,
+                                   const float* c2, int B, int H, float* dgates, int lddg, float* dc, void* stream) {
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, g1((long long)B * H), dim3(256), 0, ST, dh2, dh2b, dc2, save, c, c2, B, H, dgates, lddg,
+                       dc);
     return check_launch("lstm_cell_bwd");
 }

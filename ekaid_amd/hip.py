@@ -36,6 +36,7 @@ class GemmDesc(Structure):
         ('accumulate', c_int), ('bias', c_void_p),
         ('R', c_void_p), ('ldr', c_int), ('rdiv', c_int), ('rowmask', c_void_p),
         ('act', c_int),
+        ('drop_p', c_float), ('drop_seed', c_uint64),
     ]
 
 
@@ -74,8 +75,10 @@ SIGNATURES = {
     'ekaid_embedding_bwd': [P, L, P, P, I, I, I, I, L, P, P],
     'ekaid_gru_cell_fwd': [P, I, P, I, P, I, I, I, P, I, P, P],
     'ekaid_gru_cell_bwd': [P, I, P, P, P, I, I, I, P, I, P, P, P],
-    'ekaid_lstm_cell_fwd': [P, P, P, I, I, P, P, P, P],
-    'ekaid_lstm_cell_bwd': [P, P, P, P, P, I, I, P, P, P],
+    'ekaid_lstm_cell_fwd': [P, P, I, P, I, I, P, P, P, P],
+    'ekaid_lstm_cell_bwd': [P, P, P, P, P, P, I, I, P, I, P, P],
+    'ekaid_bias_act_drop': [P, I, P, I, I, I, F, U64, P, P],
+    'ekaid_drop_act_bwd': [P, P, I, I, I, I, F, U64, P, I, P],
     'ekaid_softmax_fwd': [P, P, L, I, I, P],
     'ekaid_softmax_bwd': [P, P, P, L, I, I, P],
     'ekaid_mix3_fwd': [P, P, P, P, I, I, P, P],

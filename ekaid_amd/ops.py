@@ -53,7 +53,7 @@ def _rows2d(t):
 # --------------------------------------------------------------------------- #
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=None,
          accumulate=False, bias=None, R=None, ldr=0, rdiv=1, rowmask=None, act=ACT_NONE,
-         batch=(1, 1), strides=(0, 0, 0, 0, 0, 0), a_off=0, b_off=0, c_off=0):
+         batch=(1, 1), strides=(0, 0, 0, 0, 0, 0), a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_seed=0):
     """C = act(alpha * op(A) op(B) [+C] [+bias] [+R]) on raw device buffers (element offsets a_off..)."""
     d = GemmDesc()
     d.A = A.data_ptr() + 4 * a_off
@@ -73,6 +73,8 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=N
     d.rdiv = rdiv
     d.rowmask = ptr(rowmask)
     d.act = act
+    d.drop_p = drop_p
+    d.drop_seed = drop_seed
     L = hip.lib()
     need = L.ekaid_gemm_workspace_bytes(ctypes.byref(d))
     ws = hip.workspace(need, C.device) if need else None
@@ -733,7 +735,7 @@ class LSTMCellFn(Function):
         B, H = c.shape
         h2, c2 = torch.empty_like(c), torch.empty_like(c)
         save = torch.empty(B, 4 * H, device=c.device, dtype=torch.float32)
-        check(hip.lib().ekaid_lstm_cell_fwd(ptr(gx), ptr(gh), ptr(c), B, H, ptr(h2), ptr(c2), ptr(save), stream()),
+        check(hip.lib().ekaid_lstm_cell_fwd(ptr(gx), ptr(gh), 4 * H, ptr(c), B, H, ptr(h2), ptr(c2), ptr(save), stream()),
               'lstm_cell_fwd')
         ctx.save_for_backward(save, c, c2)
         return h2, c2
@@ -744,9 +746,9 @@ class LSTMCellFn(Function):
         B, H = c.shape
         dg = torch.empty(B, 4 * H, device=c.device, dtype=torch.float32)
         dc = torch.empty_like(c)
-        check(hip.lib().ekaid_lstm_cell_bwd(ptr(_c(dh2)) if dh2 is not None else None,
+        check(hip.lib().ekaid_lstm_cell_bwd(ptr(_c(dh2)) if dh2 is not None else None, None,
                                             ptr(_c(dc2)) if dc2 is not None else None, ptr(save), ptr(c), ptr(c2), B, H,
-                                            ptr(dg), ptr(dc), stream()), 'lstm_cell_bwd')
+                                            ptr(dg), 4 * H, ptr(dc), stream()), 'lstm_cell_bwd')
         return dg, dg, dc
 
 

@@ -54,6 +54,14 @@ def _drop(x, y, n, p, seed, xoff=0, yoff=0):
 
 
 class SpeakerSeqFn(Function):
+    """Layout of the per-step "h_lang projection" block (width NW = 4R + R + G1 + 4R):
+        [0, 4R)          h_lang_{t-1} . W_ih_att[:, E:]^T   -> += h_att_{t-1} . W_hh_att^T + b_hh   = att-LSTM hidden-side gates
+        [4R, 5R)         h_lang_{t-1} . W_pos1^T                                                   = pos1 pre-activation
+        [5R, 5R+G1)      h_lang_{t-1} . W_g1[:, :R]^T       -> += ppos . W_g1[:, R:2R]^T += att . W_g1[:, 2R:]^T + b, relu, dropout
+        [5R+G1, NW)      h_lang_{t-1} . W_hh_lang^T         -> += gated . W_ih_lang[:, We:]^T + b_hh = lang-LSTM hidden-side gates
+    All four products share the operand h_lang_{t-1}, so they are ONE GEMM against the row-concatenated weight
+    ``Wcat`` (NW x R); in the backward pass the four gradient blocks are laid out the same way (``DCAT``), so that
+    d h_lang_{t-1} = DCAT_t . Wcat is again one GEMM and the weight gradients read column slices of DCAT."""
 
     @staticmethod
     def forward(ctx, bef, aft, diff, tok_tb, p_lm, p_pos, training, *params):
@@ -65,6 +73,8 @@ class SpeakerSeqFn(Function):
         A = bef.shape[1]
         E, R, We, V = w_e.shape[0], whh_a.shape[1], emb.shape[1], w_lo.shape[0]
         G1 = w_g1.shape[0]                        # 2R + A
+        NW = 9 * R + G1
+        oP1, oG1, oGL = 4 * R, 5 * R, 5 * R + G1   # column offsets inside the NW-wide block
         dev = bef.device
         L = hip.lib()
         f32 = dict(device=dev, dtype=torch.float32)
@@ -80,7 +90,7 @@ class SpeakerSeqFn(Function):
         _nt(diff, 0, A, w_e, A, 3 * A, embed_pre, 0, E, B, E, A, acc=True)
         _nt(aft, 0, A, w_e, 2 * A, 3 * A, embed_pre, 0, E, B, E, A, bias=b_e, acc=True, act=ACT_RELU)
         ED = torch.empty(T, B, E, **f32)
-        for t in range(T):                        # dropout mask differs per step (index offset folded into the seed)
+        for t in range(T):                        # dropout mask differs per step (step index folded into the seed)
             _drop(embed_pre, ED, B * E, p, seeds['ed'] + t, 0, t * B * E)
         Xr = torch.empty(T, B, We, **f32)
         check(L.ekaid_embedding_fwd(tok_tb.data_ptr(), TB, ptr(emb), We, ptr(Xr), We, 0, 1, stream()), 'embedding_fwd')
@@ -90,6 +100,8 @@ class SpeakerSeqFn(Function):
         _nt(ED, 0, E, wih_a, 0, E + R, GXA, 0, 4 * R, TB, 4 * R, E, bias=bih_a)
         GXL = torch.empty(T, B, 4 * R, **f32)     # lang-LSTM input-side gates: word part + b_ih
         _nt(Xd, 0, We, wih_l, 0, We + A, GXL, 0, 4 * R, TB, 4 * R, We, bias=bih_l)
+        # row-concatenated weights applied to h_lang_{t-1} (a copy, no arithmetic)
+        Wcat = torch.cat([wih_a[:, E:], w_p1, w_g1[:, :R], whh_l], 0).contiguous()          # (NW, R)
 
         HA = torch.zeros(T + 1, B, R, **f32)      # h of the module-attention LSTM, HA[0] = 0
         CA = torch.zeros(T + 1, B, R, **f32)
@@ -97,57 +109,52 @@ class SpeakerSeqFn(Function):
         CL = torch.zeros(T + 1, B, R, **f32)
         SA = torch.empty(T, B, 4 * R, **f32)      # gate activations (i,f,g,o)
         SL = torch.empty(T, B, 4 * R, **f32)
+        HLW = torch.empty(T, B, NW, **f32)        # see class docstring; the G1 block ends up holding dropout(relu(gate1x))
         MW = torch.empty(T, B, 3, **f32)
         VP = torch.empty(T, B, R, **f32)          # dropout(relu(pos1(h_lang)))
         DP = torch.empty(T, B, 16, **f32)         # dropout(weight_pos(vpos))   (= output_pos of the core)
         PW = torch.empty(T, B, 16, **f32)
         PP = torch.empty(T, B, R, **f32)
         AT = torch.empty(T, B, A, **f32)
-        G1D = torch.empty(T, B, G1, **f32)
         GT = torch.empty(T, B, A, **f32)          # gate (sigmoid)
         GA = torch.empty(T, B, A, **f32)          # gated att feat
-        gh = torch.empty(B, 4 * R, **f32)
         tmp3 = torch.empty(B, 3, **f32)
-        tmpR = torch.empty(B, R, **f32)
-        tmp16 = torch.empty(B, 16, **f32)
-        tmpG = torch.empty(B, G1, **f32)
 
         for t in range(T):
             o_prev, o_t = t * B * R, (t + 1) * B * R
-            # 1. module-attention LSTM: gates = GXA[t] + h_lang_{t-1} W_ih[:, E:]^T + h_att_{t-1} W_hh^T + b_hh
-            _nt(HL, o_prev, R, wih_a, E, E + R, gh, 0, 4 * R, B, 4 * R, R)
-            _nt(HA, o_prev, R, whh_a, 0, R, gh, 0, 4 * R, B, 4 * R, R, bias=bhh_a, acc=True)
-            check(L.ekaid_lstm_cell_fwd(GXA.data_ptr() + 4 * t * B * 4 * R, ptr(gh), CA.data_ptr() + 4 * o_prev, B, R,
-                                        HA.data_ptr() + 4 * o_t, CA.data_ptr() + 4 * o_t,
+            ow = t * B * NW
+            sv, sd, sg = seeds_t[t]
+            # 0. everything h_lang_{t-1} feeds, in one GEMM
+            _nt(HL, o_prev, R, Wcat, 0, R, HLW, ow, NW, B, NW, R)
+            # 1. module-attention LSTM: gates = GXA[t] + (block 0 += h_att_{t-1} W_hh^T + b_hh)
+            _nt(HA, o_prev, R, whh_a, 0, R, HLW, ow, NW, B, 4 * R, R, bias=bhh_a, acc=True)
+            check(L.ekaid_lstm_cell_fwd(GXA.data_ptr() + 4 * t * B * 4 * R, HLW.data_ptr() + 4 * ow, NW,
+                                        CA.data_ptr() + 4 * o_prev, B, R, HA.data_ptr() + 4 * o_t, CA.data_ptr() + 4 * o_t,
                                         SA.data_ptr() + 4 * t * B * 4 * R, stream()), 'lstm_cell_fwd')
             # 2. module weights
             _nt(HA, o_t, R, w_fc, 0, R, tmp3, 0, 3, B, 3, R, bias=b_fc)
             check(L.ekaid_softmax_fwd(ptr(tmp3), MW.data_ptr() + 4 * t * B * 3, B, 3, 0, stream()), 'softmax_fwd')
-            # 3. POS branch
-            sv, sd, sg = seeds_t[t]
-            _nt(HL, o_prev, R, w_p1, 0, R, tmpR, 0, R, B, R, R, bias=b_p1, act=ACT_RELU)
-            _drop(tmpR, VP, B * R, p, sv, 0, t * B * R)
-            _nt(VP, t * B * R, R, w_wp, 0, R, tmp16, 0, 16, B, 16, R, bias=b_wp)
-            _drop(tmp16, DP, B * 16, p5, sd, 0, t * B * 16)
+            # 3. POS branch: vpos = dropout(relu(block 1 + b)); dpos = dropout(W vpos + b) in the GEMM epilogue
+            check(L.ekaid_bias_act_drop(HLW.data_ptr() + 4 * (ow + oP1), NW, ptr(b_p1), B, R, ACT_RELU, p, sv,
+                                        VP.data_ptr() + 4 * t * B * R, stream()), 'bias_act_drop')
+            gemm(VP, w_wp, DP, B, 16, R, R, R, 16, 0, 1, bias=b_wp, a_off=t * B * R, c_off=t * B * 16, drop_p=p5, drop_seed=sd)
             check(L.ekaid_softmax_fwd(DP.data_ptr() + 4 * t * B * 16, PW.data_ptr() + 4 * t * B * 16, B, 16, 0, stream()),
                   'softmax_fwd')
             _nt(PW, t * B * 16, 16, w_p2, 0, 16, PP, t * B * R, R, B, R, 16, bias=b_p2)
             # 4. attended feature
             check(L.ekaid_mix3_fwd(MW.data_ptr() + 4 * t * B * 3, ptr(bef), ptr(diff), ptr(aft), B, A,
                                    AT.data_ptr() + 4 * t * B * A, stream()), 'mix3_fwd')
-            # 5. gate MLP on [h_lang_{t-1} | ppos | att]
-            _nt(HL, o_prev, R, w_g1, 0, G1, tmpG, 0, G1, B, G1, R)
-            _nt(PP, t * B * R, R, w_g1, R, G1, tmpG, 0, G1, B, G1, R, acc=True)
-            _nt(AT, t * B * A, A, w_g1, 2 * R, G1, tmpG, 0, G1, B, G1, A, bias=b_g1, acc=True, act=ACT_RELU)
-            _drop(tmpG, G1D, B * G1, p, sg, 0, t * B * G1)
-            _nt(G1D, t * B * G1, G1, w_g2, 0, G1, GT, t * B * A, A, B, A, G1, bias=b_g2, act=ACT_SIGMOID)
+            # 5. gate MLP: block 2 += ppos W[:, R:2R]^T += att W[:, 2R:]^T + b, relu, dropout (in place, last epilogue)
+            _nt(PP, t * B * R, R, w_g1, R, G1, HLW, ow + oG1, NW, B, G1, R, acc=True)
+            gemm(AT, w_g1, HLW, B, G1, A, A, G1, NW, 0, 1, accumulate=True, bias=b_g1, act=ACT_RELU, a_off=t * B * A,
+                 b_off=2 * R, c_off=ow + oG1, drop_p=p, drop_seed=sg)
+            _nt(HLW, ow + oG1, NW, w_g2, 0, G1, GT, t * B * A, A, B, A, G1, bias=b_g2, act=ACT_SIGMOID)
             check(L.ekaid_mul(GT.data_ptr() + 4 * t * B * A, AT.data_ptr() + 4 * t * B * A, GA.data_ptr() + 4 * t * B * A,
                               B * A, stream()), 'mul')
-            # 6. language LSTM: gates = GXL[t] + gated W_ih[:, We:]^T + h_lang_{t-1} W_hh^T + b_hh
-            _nt(GA, t * B * A, A, wih_l, We, We + A, gh, 0, 4 * R, B, 4 * R, A)
-            _nt(HL, o_prev, R, whh_l, 0, R, gh, 0, 4 * R, B, 4 * R, R, bias=bhh_l, acc=True)
-            check(L.ekaid_lstm_cell_fwd(GXL.data_ptr() + 4 * t * B * 4 * R, ptr(gh), CL.data_ptr() + 4 * o_prev, B, R,
-                                        HL.data_ptr() + 4 * o_t, CL.data_ptr() + 4 * o_t,
+            # 6. language LSTM: gates = GXL[t] + (block 3 += gated W_ih[:, We:]^T + b_hh)
+            _nt(GA, t * B * A, A, wih_l, We, We + A, HLW, ow + oGL, NW, B, 4 * R, A, bias=bhh_l, acc=True)
+            check(L.ekaid_lstm_cell_fwd(GXL.data_ptr() + 4 * t * B * 4 * R, HLW.data_ptr() + 4 * (ow + oGL), NW,
+                                        CL.data_ptr() + 4 * o_prev, B, R, HL.data_ptr() + 4 * o_t, CL.data_ptr() + 4 * o_t,
                                         SL.data_ptr() + 4 * t * B * 4 * R, stream()), 'lstm_cell_fwd')
 
         # ---- time-batched head: dropout(h_lang) -> logit -> log-softmax;  log-softmax of the POS logits
@@ -162,17 +169,19 @@ class SpeakerSeqFn(Function):
 
         ctx.dims = (T, B, A, E, R, We, V, G1)
         ctx.pp = (p, p5, seeds, seeds_t)
-        ctx.save_for_backward(bef, aft, diff, tok_tb, embed_pre, ED, Xr, Xd, HA, CA, HL, CL, SA, SL, MW, VP, DP, PW, PP, AT,
-                              G1D, GT, GA, HO, logp, logpos, emb, w_e, wih_a, whh_a, w_fc, w_p1, w_wp, w_p2, w_g1, w_g2,
-                              wih_l, whh_l, w_lo)
+        ctx.save_for_backward(bef, aft, diff, tok_tb, embed_pre, ED, Xd, HA, CA, HL, CL, SA, SL, MW, VP, PW, PP, AT,
+                              HLW, GT, GA, HO, logp, logpos, emb, w_e, wih_a, whh_a, w_fc, w_wp, w_p2, w_g1, w_g2,
+                              wih_l, w_lo, Wcat)
         ctx.mark_non_differentiable(MW)
         return logp, logpos, MW
 
     @staticmethod
     def backward(ctx, dlogp, dlogpos, _dmw):
-        (bef, aft, diff, tok_tb, embed_pre, ED, Xr, Xd, HA, CA, HL, CL, SA, SL, MW, VP, DP, PW, PP, AT, G1D, GT, GA, HO,
-         logp, logpos, emb, w_e, wih_a, whh_a, w_fc, w_p1, w_wp, w_p2, w_g1, w_g2, wih_l, whh_l, w_lo) = ctx.saved_tensors
+        (bef, aft, diff, tok_tb, embed_pre, ED, Xd, HA, CA, HL, CL, SA, SL, MW, VP, PW, PP, AT, HLW, GT, GA, HO,
+         logp, logpos, emb, w_e, wih_a, whh_a, w_fc, w_wp, w_p2, w_g1, w_g2, wih_l, w_lo, Wcat) = ctx.saved_tensors
         T, B, A, E, R, We, V, G1 = ctx.dims
+        NW = 9 * R + G1
+        oP1, oG1, oGL = 4 * R, 5 * R, 5 * R + G1
         p, p5, seeds, seeds_t = ctx.pp
         dev = bef.device
         L = hip.lib()
@@ -194,13 +203,10 @@ class SpeakerSeqFn(Function):
         if dlogpos is not None:
             check(L.ekaid_softmax_bwd(ptr(logpos), ptr(dlogpos.contiguous()), ptr(dDPl), TB, 16, 1, stream()), 'softmax_bwd')
 
-        DGA = torch.empty(T, B, 4 * R, **f32)     # pre-activation gate gradients, all steps (for the batched wgrads)
-        DGL = torch.empty(T, B, 4 * R, **f32)
+        DCAT = torch.empty(T, B, NW, **f32)       # [d att gates | d pos1 pre-act | d gate1x pre-act | d lang gates] per step
         DZFC = torch.empty(T, B, 3, **f32)
-        DZP1 = torch.empty(T, B, R, **f32)
         DWP = torch.empty(T, B, 16, **f32)
         DPP = torch.empty(T, B, R, **f32)
-        DZ1 = torch.empty(T, B, G1, **f32)
         DZ2 = torch.empty(T, B, A, **f32)
         d_bef = torch.zeros(B, A, **f32)
         d_diff = torch.zeros(B, A, **f32)
@@ -215,42 +221,31 @@ class SpeakerSeqFn(Function):
         t_BA = torch.empty(B, A, **f32)
         t_BA2 = torch.empty(B, A, **f32)
         t_BG = torch.empty(B, G1, **f32)
-        t_BG2 = torch.empty(B, G1, **f32)
         t_BR = torch.empty(B, R, **f32)
-        t_BR2 = torch.empty(B, R, **f32)
         t_B16 = torch.empty(B, 16, **f32)
         t_B16b = torch.empty(B, 16, **f32)
         t_B3 = torch.empty(B, 3, **f32)
 
-        def axpy_into(dst, src, n):               # dst += src
-            check(L.ekaid_axpby(ptr(dst), ptr(src), ptr(dst), n, 1.0, 1.0, stream()), 'axpby')
-
         for t in range(T - 1, -1, -1):
             o_prev, o_t = t * B * R, (t + 1) * B * R
+            ow = t * B * NW
             sv, sd, sg = seeds_t[t]
-            # total gradient on h_lang_t: carry + output path
-            check(L.ekaid_axpby(ptr(dh_l), dHLo.data_ptr() + 4 * t * B * R, ptr(dh_l), B * R, 1.0, 1.0, stream()), 'axpby')
-            # 6'. language LSTM
-            check(L.ekaid_lstm_cell_bwd(ptr(dh_l), ptr(dc_l), SL.data_ptr() + 4 * t * B * 4 * R, CL.data_ptr() + 4 * o_prev,
-                                        CL.data_ptr() + 4 * o_t, B, R, DGL.data_ptr() + 4 * t * B * 4 * R, ptr(dc_tmp),
-                                        stream()), 'lstm_cell_bwd')
+            # 6'. language LSTM (upstream on h_lang_t = carry + output path)
+            check(L.ekaid_lstm_cell_bwd(ptr(dh_l), dHLo.data_ptr() + 4 * t * B * R, ptr(dc_l), SL.data_ptr() + 4 * t * B * 4 * R,
+                                        CL.data_ptr() + 4 * o_prev, CL.data_ptr() + 4 * o_t, B, R,
+                                        DCAT.data_ptr() + 4 * (ow + oGL), NW, ptr(dc_tmp), stream()), 'lstm_cell_bwd')
             dc_l, dc_tmp = dc_tmp, dc_l
-            og = t * B * 4 * R
-            _nn(DGL, og, 4 * R, whh_l, 0, R, dh_l_prev, 0, R, B, R, 4 * R)                       # -> h_lang_{t-1}
-            _nn(DGL, og, 4 * R, wih_l, We, We + A, t_BA, 0, A, B, A, 4 * R)                      # d gated
+            _nn(DCAT, ow + oGL, NW, wih_l, We, We + A, t_BA, 0, A, B, A, 4 * R)                  # d gated
             # 5'. gated = gate * att ; gate = sigmoid(W_g2 g1d + b)
             check(L.ekaid_mul(ptr(t_BA), AT.data_ptr() + 4 * t * B * A, ptr(t_BA2), B * A, stream()), 'mul')   # d gate
             check(L.ekaid_act_bwd(ptr(t_BA2), GT.data_ptr() + 4 * t * B * A, DZ2.data_ptr() + 4 * t * B * A, B * A,
                                   ACT_SIGMOID, stream()), 'act_bwd')
             check(L.ekaid_mul(ptr(t_BA), GT.data_ptr() + 4 * t * B * A, ptr(t_BA2), B * A, stream()), 'mul')   # d att (part 1)
             _nn(DZ2, t * B * A, A, w_g2, 0, G1, t_BG, 0, G1, B, G1, A)                            # d g1d
-            _drop(t_BG, t_BG2, B * G1, p, sg)
-            check(L.ekaid_act_bwd(ptr(t_BG2), G1D.data_ptr() + 4 * t * B * G1, DZ1.data_ptr() + 4 * t * B * G1, B * G1,
-                                  ACT_RELU, stream()), 'act_bwd')
-            oz1 = t * B * G1
-            _nn(DZ1, oz1, G1, w_g1, 0, G1, dh_l_prev, 0, R, B, R, G1, acc=True)                   # -> h_lang_{t-1}
-            _nn(DZ1, oz1, G1, w_g1, R, G1, DPP, t * B * R, R, B, R, G1)                           # d ppos
-            _nn(DZ1, oz1, G1, w_g1, 2 * R, G1, t_BA2, 0, A, B, A, G1, acc=True)                   # d att (total)
+            check(L.ekaid_drop_act_bwd(ptr(t_BG), HLW.data_ptr() + 4 * (ow + oG1), NW, B, G1, ACT_RELU, p, sg,
+                                       DCAT.data_ptr() + 4 * (ow + oG1), NW, stream()), 'drop_act_bwd')
+            _nn(DCAT, ow + oG1, NW, w_g1, R, G1, DPP, t * B * R, R, B, R, G1)                     # d ppos
+            _nn(DCAT, ow + oG1, NW, w_g1, 2 * R, G1, t_BA2, 0, A, B, A, G1, acc=True)             # d att (total)
             # 4'. att = mix3(mw, bef, diff, aft)
             check(L.ekaid_mix3_bwd(MW.data_ptr() + 4 * t * B * 3, ptr(bef), ptr(diff), ptr(aft), ptr(t_BA2), B, A, ptr(t_B3),
                                    ptr(d_bef), ptr(d_diff), ptr(d_aft), 1, stream()), 'mix3_bwd')
@@ -262,42 +257,39 @@ class SpeakerSeqFn(Function):
                   'axpby')
             _drop(t_B16b, DWP, B * 16, p5, sd, 0, t * B * 16)                                     # d weight_pos output
             _nn(DWP, t * B * 16, 16, w_wp, 0, R, t_BR, 0, R, B, R, 16)                            # d vpos (post-dropout)
-            _drop(t_BR, t_BR2, B * R, p, sv)
-            check(L.ekaid_act_bwd(ptr(t_BR2), VP.data_ptr() + 4 * t * B * R, DZP1.data_ptr() + 4 * t * B * R, B * R,
-                                  ACT_RELU, stream()), 'act_bwd')
-            _nn(DZP1, t * B * R, R, w_p1, 0, R, dh_l_prev, 0, R, B, R, R, acc=True)               # -> h_lang_{t-1}
+            check(L.ekaid_drop_act_bwd(ptr(t_BR), VP.data_ptr() + 4 * t * B * R, R, B, R, ACT_RELU, p, sv,
+                                       DCAT.data_ptr() + 4 * (ow + oP1), NW, stream()), 'drop_act_bwd')
             # 2'. module weights
             check(L.ekaid_softmax_bwd(MW.data_ptr() + 4 * t * B * 3, ptr(t_B3), DZFC.data_ptr() + 4 * t * B * 3, B, 3, 0,
                                       stream()), 'softmax_bwd')
             _nn(DZFC, t * B * 3, 3, w_fc, 0, R, dh_a, 0, R, B, R, 3, acc=True)                    # += into h_att_t gradient
             # 1'. module-attention LSTM
-            check(L.ekaid_lstm_cell_bwd(ptr(dh_a), ptr(dc_a), SA.data_ptr() + 4 * t * B * 4 * R, CA.data_ptr() + 4 * o_prev,
-                                        CA.data_ptr() + 4 * o_t, B, R, DGA.data_ptr() + 4 * t * B * 4 * R, ptr(dc_tmp),
-                                        stream()), 'lstm_cell_bwd')
+            check(L.ekaid_lstm_cell_bwd(ptr(dh_a), None, ptr(dc_a), SA.data_ptr() + 4 * t * B * 4 * R, CA.data_ptr() + 4 * o_prev,
+                                        CA.data_ptr() + 4 * o_t, B, R, DCAT.data_ptr() + 4 * ow, NW, ptr(dc_tmp), stream()),
+                  'lstm_cell_bwd')
             dc_a, dc_tmp = dc_tmp, dc_a
-            _nn(DGA, og, 4 * R, whh_a, 0, R, dh_a_prev, 0, R, B, R, 4 * R)                        # -> h_att_{t-1}
-            _nn(DGA, og, 4 * R, wih_a, E, E + R, dh_l_prev, 0, R, B, R, 4 * R, acc=True)          # -> h_lang_{t-1}
+            _nn(DCAT, ow, NW, whh_a, 0, R, dh_a_prev, 0, R, B, R, 4 * R)                          # -> h_att_{t-1}
+            # 0'. everything that flowed out of h_lang_{t-1}: one GEMM against the concatenated weight
+            _nn(DCAT, ow, NW, Wcat, 0, R, dh_l_prev, 0, R, B, R, NW)
             dh_l, dh_l_prev = dh_l_prev, dh_l
             dh_a, dh_a_prev = dh_a_prev, dh_a
 
-        # ---- time-batched weight gradients (K = T*B) and input gradients
-        g = {}
-        HLp, HAp, HAn = HL, HA, HA                 # HL[0:T] = previous h_lang; HA[1:T+1] = new h_att (offset B*R)
+        # ---- time-batched weight gradients (K = T*B) and input gradients; DCAT column blocks with ld = NW
         d_wih_a = torch.empty_like(wih_a)
-        _tn(DGA, 4 * R, ED, E, d_wih_a, 0, E + R, 4 * R, E, TB)
-        _tn(DGA, 4 * R, HLp, R, d_wih_a, E, E + R, 4 * R, R, TB)
+        _tn(DCAT, NW, ED, E, d_wih_a, 0, E + R, 4 * R, E, TB)
+        _tn(DCAT, NW, HL, R, d_wih_a, E, E + R, 4 * R, R, TB)
         d_whh_a = torch.empty_like(whh_a)
-        _tn(DGA, 4 * R, HAp, R, d_whh_a, 0, R, 4 * R, R, TB)
+        _tn(DCAT, NW, HA, R, d_whh_a, 0, R, 4 * R, R, TB)
         d_b_a = torch.empty(4 * R, **f32)
-        _colsum(DGA, TB, 4 * R, d_b_a)
+        check(L.ekaid_colsum(ptr(DCAT), TB, 4 * R, NW, ptr(d_b_a), stream()), 'colsum')
         d_w_fc = torch.empty_like(w_fc)
-        _tn(DZFC, 3, HAn, R, d_w_fc, 0, R, 3, R, TB, xoff=B * R)
+        _tn(DZFC, 3, HA, R, d_w_fc, 0, R, 3, R, TB, xoff=B * R)
         d_b_fc = torch.empty(3, **f32)
         _colsum(DZFC, TB, 3, d_b_fc)
-        d_w_p1 = torch.empty_like(w_p1)
-        _tn(DZP1, R, HLp, R, d_w_p1, 0, R, R, R, TB)
+        d_w_p1 = torch.empty(R, R, **f32)
+        _tn(DCAT, NW, HL, R, d_w_p1, 0, R, R, R, TB, doff=oP1)
         d_b_p1 = torch.empty(R, **f32)
-        _colsum(DZP1, TB, R, d_b_p1)
+        check(L.ekaid_colsum(DCAT.data_ptr() + 4 * oP1, TB, R, NW, ptr(d_b_p1), stream()), 'colsum')
         d_w_wp = torch.empty_like(w_wp)
         _tn(DWP, 16, VP, R, d_w_wp, 0, R, 16, R, TB)
         d_b_wp = torch.empty(16, **f32)
@@ -307,25 +299,25 @@ class SpeakerSeqFn(Function):
         d_b_p2 = torch.empty(R, **f32)
         _colsum(DPP, TB, R, d_b_p2)
         d_w_g1 = torch.empty_like(w_g1)
-        _tn(DZ1, G1, HLp, R, d_w_g1, 0, G1, G1, R, TB)
-        _tn(DZ1, G1, PP, R, d_w_g1, R, G1, G1, R, TB)
-        _tn(DZ1, G1, AT, A, d_w_g1, 2 * R, G1, G1, A, TB)
+        _tn(DCAT, NW, HL, R, d_w_g1, 0, G1, G1, R, TB, doff=oG1)
+        _tn(DCAT, NW, PP, R, d_w_g1, R, G1, G1, R, TB, doff=oG1)
+        _tn(DCAT, NW, AT, A, d_w_g1, 2 * R, G1, G1, A, TB, doff=oG1)
         d_b_g1 = torch.empty(G1, **f32)
-        _colsum(DZ1, TB, G1, d_b_g1)
+        check(L.ekaid_colsum(DCAT.data_ptr() + 4 * oG1, TB, G1, NW, ptr(d_b_g1), stream()), 'colsum')
         d_w_g2 = torch.empty_like(w_g2)
-        _tn(DZ2, A, G1D, G1, d_w_g2, 0, G1, A, G1, TB)
+        _tn(DZ2, A, HLW, NW, d_w_g2, 0, G1, A, G1, TB, xoff=oG1)                                  # input = dropout(relu(gate1x)) block
         d_b_g2 = torch.empty(A, **f32)
         _colsum(DZ2, TB, A, d_b_g2)
         d_wih_l = torch.empty_like(wih_l)
-        _tn(DGL, 4 * R, Xd, We, d_wih_l, 0, We + A, 4 * R, We, TB)
-        _tn(DGL, 4 * R, GA, A, d_wih_l, We, We + A, 4 * R, A, TB)
-        d_whh_l = torch.empty_like(whh_l)
-        _tn(DGL, 4 * R, HLp, R, d_whh_l, 0, R, 4 * R, R, TB)
+        _tn(DCAT, NW, Xd, We, d_wih_l, 0, We + A, 4 * R, We, TB, doff=oGL)
+        _tn(DCAT, NW, GA, A, d_wih_l, We, We + A, 4 * R, A, TB, doff=oGL)
+        d_whh_l = torch.empty(4 * R, R, **f32)
+        _tn(DCAT, NW, HL, R, d_whh_l, 0, R, 4 * R, R, TB, doff=oGL)
         d_b_l = torch.empty(4 * R, **f32)
-        _colsum(DGL, TB, 4 * R, d_b_l)
+        check(L.ekaid_colsum(DCAT.data_ptr() + 4 * oGL, TB, 4 * R, NW, ptr(d_b_l), stream()), 'colsum')
         # embed path: dED = DGA . W_ih_att[:, :E]; per-step dropout backward; sum over t; relu; Linear(3A -> E)
         dED = torch.empty(T, B, E, **f32)
-        _nn(DGA, 0, 4 * R, wih_a, 0, E + R, dED, 0, E, TB, E, 4 * R)
+        _nn(DCAT, 0, NW, wih_a, 0, E + R, dED, 0, E, TB, E, 4 * R)
         for t in range(T):
             _drop(dED, dED, B * E, p, seeds['ed'] + t, t * B * E, t * B * E)
         d_epre = torch.empty(B, E, **f32)
@@ -343,7 +335,7 @@ class SpeakerSeqFn(Function):
         _nn(d_ez, 0, E, w_e, 2 * A, 3 * A, d_aft, 0, A, B, A, E, acc=True)
         # word path: dXd = DGL . W_ih_lang[:, :We]; dropout backward; relu + table scatter-add
         dX = torch.empty(T, B, We, **f32)
-        _nn(DGL, 0, 4 * R, wih_l, 0, We + A, dX, 0, We, TB, We, 4 * R)
+        _nn(DCAT, oGL, NW, wih_l, 0, We + A, dX, 0, We, TB, We, 4 * R)
         _drop(dX, dX, TB * We, p, seeds['xt'])
         d_emb = torch.zeros_like(emb)
         check(L.ekaid_embedding_bwd(tok_tb.data_ptr(), TB, ptr(emb), ptr(dX), We, We, 0, 1, -1, ptr(d_emb), stream()),

@@ -39,7 +39,7 @@ const char* ekaid_last_error(void);
 
 /* ------------------------------------------------------------------------------------------
  * Dense contraction on the fp32 matrix cores.
- *   C = act( alpha * alpha_dev[0] * op(A).op(B)  [+ C]  [+ bias[n]]  [+ rowmask[m] * R[m / rdiv][n]] )
+ *   C = dropout( act( alpha * alpha_dev[0] * op(A).op(B)  [+ C]  [+ bias[n]]  [+ rowmask[m] * R[m / rdiv][n]] ) )
  * transA=0: A is [M][K]; transA=1: A is [K][M].  transB=1: B is [N][K]; transB=0: B is [K][N].
  * Two batch dimensions (batch1 x batch2) with element strides; batch index z -> (z / batch2, z % batch2).
  * ref: every nn.Linear / FCNet / matmul on the path -- modules.py:195-196,278-303,
@@ -64,6 +64,8 @@ typedef struct ekaid_gemm {
     int rdiv;
     const float* rowmask;   /* optional [M] multiplier of the residual row */
     int act;
+    float drop_p;           /* > 0: dropout of the activated output, keep(seed, m * N + n) / (1 - p) */
+    uint64_t drop_seed;
 } ekaid_gemm_t;
 
 size_t ekaid_gemm_workspace_bytes(const ekaid_gemm_t* g);
@@ -166,10 +168,19 @@ int ekaid_gru_cell_fwd(const float* gi, int ldgi, const float* gh, int ldgh, con
                        float* hnew, int ldhn, float* save, void* stream);
 int ekaid_gru_cell_bwd(const float* dhnew, int lddh, const float* dh_carry, const float* save, const float* h, int ldh,
                        int B, int H, float* dgi, int lddgi, float* dgh, float* dh, void* stream);
-int ekaid_lstm_cell_fwd(const float* gx, const float* gh, const float* c, int B, int H, float* h2, float* c2,
+int ekaid_lstm_cell_fwd(const float* gx, const float* gh, int ldgh, const float* c, int B, int H, float* h2, float* c2,
                         float* save, void* stream);
-int ekaid_lstm_cell_bwd(const float* dh2, const float* dc2, const float* save, const float* c, const float* c2, int B,
-                        int H, float* dgates, float* dc, void* stream);
+/* upstream gradient on h2 = dh2 + dh2b (either may be NULL); dgates written with leading dim lddg */
+int ekaid_lstm_cell_bwd(const float* dh2, const float* dh2b, const float* dc2, const float* save, const float* c,
+                        const float* c2, int B, int H, float* dgates, int lddg, float* dc, void* stream);
+
+/* out[r][c] = dropout(act(x[r*ldx + c] + bias[c]))   (contiguous out; mask index r*cols + c)
+ * drop_act_bwd: out[r*ldo + c] = dy[r][c] * keep(seed, r*cols + c)/(1-p) * act'(y[r*ldy + c])  (y = activation output,
+ * possibly after the same dropout: a dropped element has zero gradient either way) */
+int ekaid_bias_act_drop(const float* x, int ldx, const float* bias, int rows, int cols, int act, float p, uint64_t seed,
+                        float* out, void* stream);
+int ekaid_drop_act_bwd(const float* dy, const float* y, int ldy, int rows, int cols, int act, float p, uint64_t seed,
+                       float* out, int ldo, void* stream);
 
 /* row softmax / log-softmax.  ref: dynamic_speaker_change_pos.py:61-63,71,238-239, modules.py:65 */
 int ekaid_softmax_fwd(const float* x, float* y, long long rows, int cols, int log_mode, void* stream);
