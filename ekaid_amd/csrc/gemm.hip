@@ -168,6 +168,51 @@ __device__ __forceinline__ void loader_mask(const TileLoader<NV>& L, f32x4* r, i
     }
 }
 
+// epilogue shared by the MFMA kernels.  C/D map of the 32x32 MFMA: col = lane&31, row = (t&3) + 8*(t>>2) + 4*(lane>>5)
+template <int TM, int TN>
+__device__ __forceinline__ void write_tiles(const GemmArgs& g, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int r, int h, int z) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    const bool slab = g.splitk > 1;
+    float* C;
+    int ldc;
+    if (slab) {
+        C = g.ws + (long long)z * g.M * g.N;
+        ldc = g.N;
+    } else {
+        const long long z1 = z / g.nb2, z2 = z % g.nb2;
+        C = g.C + z1 * g.sC1 + z2 * g.sC2;
+        ldc = g.ldc;
+    }
+    const float alpha = g.e.alpha_dev ? g.e.alpha * g.e.alpha_dev[0] : g.e.alpha;
+    const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+    auto store_tiles = [&](auto checked) {
+        constexpr bool CHECK = decltype(checked)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) {
+                const int n = n0 + wn + 32 * jj + r;
+                if (CHECK && n >= g.N) continue;
+                const int mb = m0 + wm + 32 * i + 4 * h;
+                float* cp0 = C + (long long)mb * ldc + n;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int dm = (t & 3) + 8 * (t >> 2);
+                    if (CHECK && mb + dm >= g.M) continue;
+                    float* cp = cp0 + (long long)dm * ldc;
+                    if (slab) {
+                        *cp = acc[i][jj][t];
+                    } else {
+                        const float cold = g.e.beta ? *cp : 0.f;
+                        *cp = epilogue(acc[i][jj][t], cold, mb + dm, n, g.e, alpha);
+                    }
+                }
+            }
+    };
+    if (full) store_tiles(std::false_type{});
+    else store_tiles(std::true_type{});
+}
+
 #ifndef EKAID_LB_HALF
 #define EKAID_LB_HALF 4
 #endif
@@ -326,46 +371,201 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : (TM * TN == 2 ? EKAID_LB_H
         else mainloop(std::true_type{});
     }
 
-    // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (t&3) + 8*(t>>2) + 4*(lane>>5)
-    const bool slab = g.splitk > 1;
-    float* C;
-    int ldc;
-    if (slab) {
-        C = g.ws + (long long)z * g.M * g.N;
-        ldc = g.N;
+    write_tiles<TM, TN>(g, acc, m0, n0, wm, wn, r, h, z);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// f32 GEMM on the bf16 matrix pipe ("3-way exact split", 6 products).
+//
+// gfx950 runs v_mfma_f32_32x32x2_f32 at 1/16 of the bf16 MFMA rate.  An f32 value is EXACTLY the sum of three bf16
+// values  a = a_h + a_m + a_l  (8 + 8 + 8 significant bits, obtained by truncation, every residual is exact in f32), so
+//     a * b = a_h b_h + (a_h b_m + a_m b_h) + (a_m b_m + a_h b_l + a_l b_h) + [a_m b_l + a_l b_m + a_l b_l]
+// where each kept product of two bf16 values is exact in the f32 accumulator of v_mfma_f32_32x32x16_bf16 and the
+// dropped bracket is below 2^-23 |a b| -- the size of ONE f32 rounding of the product.  Six bf16 MFMAs (6 x 32 cycles
+// per 32x32x16 block) replace eight f32 MFMAs (8 x 64 cycles): 2.67x the matrix throughput at f32-level accuracy
+// (measured against float64 in tests/test_hip_ops.py::test_gemm_split_accuracy: same error as the f32 pipe).
+//
+// Staging: global f32 -> registers (same loaders as above) -> split at LDS-store time into three bf16 planes.
+//   k-contiguous operand : plane image [row][KB] bf16, row stride 2*KB + 16 B; fragment = one ds_read_b128 per plane
+//                          (lane (r, h) takes k = 8h .. 8h+7 of row r: the operand map of the 32x32x16 MFMA)
+//   m/n-contiguous operand: plane image [k][rows] bf16 exactly as it lies in memory (8-byte stores, no transpose);
+//                          fragment = two ds_read_b64_tr_b16 per plane (the LDS hardware transposes 4 k x 16 rows
+//                          per 16-lane group); row stride 2*rows + 64 B puts the 4 k-rows of a read on disjoint banks
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// four f32 -> three planes of four bf16 (truncation split; h + m + l == v exactly for finite v)
+__device__ __forceinline__ void split4(const f32x4& v, u32x2& H, u32x2& M, u32x2& L) {
+    unsigned u[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        u[e] = __float_as_uint(v[e]);
+        const float r1 = v[e] - __uint_as_float(u[e] & 0xFFFF0000u);
+        m[e] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(m[e] & 0xFFFF0000u);
+        l[e] = __float_as_uint(r2);
+    }
+    // pack the upper halves of two words: result = (x0 >> 16) | (x1 & 0xFFFF0000)
+    H[0] = __builtin_amdgcn_perm(u[1], u[0], 0x07060302u); H[1] = __builtin_amdgcn_perm(u[3], u[2], 0x07060302u);
+    M[0] = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u); M[1] = __builtin_amdgcn_perm(m[3], m[2], 0x07060302u);
+    L[0] = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u); L[1] = __builtin_amdgcn_perm(l[3], l[2], 0x07060302u);
+}
+
+template <bool A_KC, bool B_KC, int TM, int TN, int KB>
+__global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : (TM * TN == 2 ? 2 : 4))) void gemm_split_kernel(GemmArgs g) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int A_RS = A_KC ? 2 * KB + 16 : 2 * BM + 64;          // row stride of one plane image, bytes
+    constexpr int B_RS = B_KC ? 2 * KB + 16 : 2 * BN + 64;
+    constexpr int A_PLANE = (A_KC ? BM : KB) * A_RS;
+    constexpr int B_PLANE = (B_KC ? BN : KB) * B_RS;
+    constexpr int A_BYTES = 3 * A_PLANE;
+    constexpr int A_V4 = BM * KB / 4 / 256;
+    constexpr int B_V4 = BN * KB / 4 / 256;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char* const ldsA = reinterpret_cast<char*>(lds);
+    char* const ldsB = ldsA + A_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = (wave >> 1) * (32 * TM), wn = (wave & 1) * (32 * TN);
+
+    const int nwg = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    }
+    const int m0 = (bid / g.tiles_n) * BM, n0 = (bid % g.tiles_n) * BN;
+
+    const int z = blockIdx.z;
+    const float* A = g.A; const float* B = g.B;
+    int kbeg = 0, kend = g.K;
+    if (g.splitk > 1) {
+        kbeg = z * g.k_per_split;
+        kend = min(g.K, kbeg + g.k_per_split);
     } else {
         const long long z1 = z / g.nb2, z2 = z % g.nb2;
-        C = g.C + z1 * g.sC1 + z2 * g.sC2;
-        ldc = g.ldc;
+        A += z1 * g.sA1 + z2 * g.sA2;
+        B += z1 * g.sB1 + z2 * g.sB2;
     }
-    const float alpha = g.e.alpha_dev ? g.e.alpha * g.e.alpha_dev[0] : g.e.alpha;
-    const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N);
-    auto store_tiles = [&](auto checked) {
-        constexpr bool CHECK = decltype(checked)::value;
+    const bool vecA = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (((A_KC ? g.K : g.M) & 3) == 0);
+    const bool vecB = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (((B_KC ? g.K : g.N) & 3) == 0);
+
+    f32x16 acc[TM][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int jj = 0; jj < TN; ++jj) {
-                const int n = n0 + wn + 32 * jj + r;
-                if (CHECK && n >= g.N) continue;
-                const int mb = m0 + wm + 32 * i + 4 * h;
-                float* cp0 = C + (long long)mb * ldc + n;
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const int dm = (t & 3) + 8 * (t >> 2);
-                    if (CHECK && mb + dm >= g.M) continue;
-                    float* cp = cp0 + (long long)dm * ldc;
-                    if (slab) {
-                        *cp = acc[i][jj][t];
-                    } else {
-                        const float cold = g.e.beta ? *cp : 0.f;
-                        *cp = epilogue(acc[i][jj][t], cold, mb + dm, n, g.e, alpha);
-                    }
-                }
-            }
+            for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
+
+    f32x4 ra[A_V4], rb[B_V4];
+    TileLoader<A_V4> LA;
+    TileLoader<B_V4> LB;
+    loader_init<A_KC, BM, A_V4, KB>(LA, A, g.lda, m0, g.M, g.K, tid, vecA);
+    loader_init<B_KC, BN, B_V4, KB>(LB, B, g.ldb, n0, g.N, g.K, tid, vecB);
+
+    int kload = kbeg;
+    const bool ragged = ((kend - kbeg) % KB) != 0 || !vecA || !vecB ||
+                        (!A_KC && (m0 + BM > g.M)) || (!B_KC && (n0 + BN > g.N));
+    auto lstore = [&](bool need_mask) {
+        if (need_mask) {
+            loader_mask<A_KC, BM, A_V4, KB>(LA, ra, kload, kend, tid);
+            loader_mask<B_KC, BN, B_V4, KB>(LB, rb, kload, kend, tid);
+        }
+#pragma unroll
+        for (int i = 0; i < A_V4; ++i) {
+            const int idx = tid + i * 256;
+            const int off = A_KC ? (idx / (KB / 4)) * A_RS + 8 * (idx % (KB / 4)) : (idx / (BM / 4)) * A_RS + 8 * (idx % (BM / 4));
+            u32x2 H, M, L;
+            split4(ra[i], H, M, L);
+            *reinterpret_cast<u32x2*>(ldsA + off) = H;
+            *reinterpret_cast<u32x2*>(ldsA + A_PLANE + off) = M;
+            *reinterpret_cast<u32x2*>(ldsA + 2 * A_PLANE + off) = L;
+        }
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i) {
+            const int idx = tid + i * 256;
+            const int off = B_KC ? (idx / (KB / 4)) * B_RS + 8 * (idx % (KB / 4)) : (idx / (BN / 4)) * B_RS + 8 * (idx % (BN / 4));
+            u32x2 H, M, L;
+            split4(rb[i], H, M, L);
+            *reinterpret_cast<u32x2*>(ldsB + off) = H;
+            *reinterpret_cast<u32x2*>(ldsB + B_PLANE + off) = M;
+            *reinterpret_cast<u32x2*>(ldsB + 2 * B_PLANE + off) = L;
+        }
     };
-    if (full) store_tiles(std::false_type{});
-    else store_tiles(std::true_type{});
+    // per-lane base offsets of the fragment reads (bytes inside a plane)
+    //   KC: row (w + r), k bytes 16h (+ 32 per 16-k chunk)
+    //   MC: transposed read: lane 4q+p of a 16-lane group addresses k-row q, rows 4p..4p+3 of the group's 16 rows
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+    const int a_base = A_KC ? (wm + r) * A_RS + 16 * h : (8 * h + tq) * A_RS + 2 * (wm + 16 * tg + 4 * tp);
+    const int b_base = B_KC ? (wn + r) * B_RS + 16 * h : (8 * h + tq) * B_RS + 2 * (wn + 16 * tg + 4 * tp);
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+    auto frag = [&](const char* plane, int base, int tile, int chunk, bool kc, int rs) -> bf16x8 {
+        if (kc) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(plane + base + tile * 32 * rs + 32 * chunk);
+            return __builtin_bit_cast(bf16x8, v);
+        } else {
+            const char* p = plane + base + 64 * tile + 16 * chunk * rs;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 4 * rs));
+            const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            return __builtin_bit_cast(bf16x8, v);
+        }
+    };
+    auto compute = [&]() {
+#pragma unroll
+        for (int c = 0; c < KB / 16; ++c) {
+            bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) fa[i][p] = frag(ldsA + p * A_PLANE, a_base, i, c, A_KC, A_RS);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) fb[j][p] = frag(ldsB + p * B_PLANE, b_base, j, c, B_KC, B_RS);
+            // smallest terms first
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+    auto mainloop = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        auto gload = [&](int k0) {
+            kload = k0;
+            loader_fetch<A_KC, BM, A_V4, KB, FAST>(LA, ra, g.lda, k0, g.K, g.M, m0, tid, vecA);
+            loader_fetch<B_KC, BN, B_V4, KB, FAST>(LB, rb, g.ldb, k0, g.K, g.N, n0, tid, vecB);
+        };
+        gload(kbeg);
+        lstore(!FAST);
+        __syncthreads();
+        for (int k0 = kbeg; k0 < kend; k0 += KB) {
+            const bool more = (k0 + KB) < kend;
+            if (more) gload(k0 + KB);
+            compute();
+            __syncthreads();
+            if (more) { lstore(!FAST); __syncthreads(); }
+        }
+    };
+    if (kbeg < kend) {
+        if (ragged) mainloop(std::false_type{});
+        else mainloop(std::true_type{});
+    }
+    write_tiles<TM, TN>(g, acc, m0, n0, wm, wn, r, h, z);
 }
 
 // "Direct" variant for the recurrent GEMMs (M = batch rows, a few hundred): the whole problem is ~128 MFMAs per
@@ -663,6 +863,27 @@ static int launch(const GemmArgs& a, int batch, hipStream_t st) {
     return EKAID_OK;
 }
 
+template <bool A_KC, bool B_KC, int TM, int TN, int KB>
+static int launch_split(const GemmArgs& a, int batch, hipStream_t st) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr size_t lds = 3 * ((A_KC ? BM * (2 * KB + 16) : KB * (2 * BM + 64)) + (B_KC ? BN * (2 * KB + 16) : KB * (2 * BN + 64)));
+    auto kern = gemm_split_kernel<A_KC, B_KC, TM, TN, KB>;
+    if (lds > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                (void)hipGetLastError();
+                set_error("gemm: cannot raise the dynamic LDS limit to %zu bytes", lds);
+                return EKAID_ERR_LAUNCH;
+            }
+            attr_set = true;
+        }
+    }
+    dim3 grid(a.tiles_m * a.tiles_n, 1, a.splitk > 1 ? a.splitk : batch);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+    return EKAID_OK;
+}
+
 template <bool A_KC, bool B_KC>
 static int launch_skinny(const GemmArgs& a, int batch, hipStream_t st) {
     dim3 grid(a.tiles_m * a.tiles_n, 1, a.splitk > 1 ? a.splitk : batch);
@@ -675,6 +896,16 @@ static int launch_direct(const GemmArgs& a, int batch, hipStream_t st) {
     dim3 grid(a.tiles_m * a.tiles_n, 1, a.splitk > 1 ? a.splitk : batch);
     hipLaunchKernelGGL((gemm_direct_kernel<B_KC>), grid, dim3(256), 0, st, a);
     return EKAID_OK;
+}
+
+// arithmetic of the MFMA kernels: 0 = v_mfma_f32_32x32x2_f32, 1 = exact 3-way bf16 split (6 x v_mfma_f32_32x32x16_bf16)
+static int g_gemm_mode = -1;
+static int gemm_mode() {
+    if (g_gemm_mode < 0) {
+        const char* m = getenv("EKAID_GEMM_MODE");
+        g_gemm_mode = (m && (m[0] == 'f' || m[0] == '0')) ? 0 : 1;
+    }
+    return g_gemm_mode;
 }
 
 static int plan_splitk(int tiles, int K, int batch, long long MN, int BK) {
@@ -735,6 +966,13 @@ static void plan(const ekaid_gemm_t* d, int& TMN, int& splitk, int& tiles_m, int
 
 using namespace ekaid;
 
+extern "C" int ekaid_set_gemm_mode(int mode) {
+    if (mode != 0 && mode != 1) { set_error("ekaid_set_gemm_mode: mode must be 0 (f32 MFMA) or 1 (bf16 3-way split)"); return EKAID_ERR_ARG; }
+    g_gemm_mode = mode;
+    return EKAID_OK;
+}
+extern "C" int ekaid_get_gemm_mode(void) { return gemm_mode(); }
+
 extern "C" size_t ekaid_gemm_workspace_bytes(const ekaid_gemm_t* d) {
     if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
     int TMN, splitk, tm, tn;
@@ -779,6 +1017,14 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     const int batch = d->batch1 * d->batch2;
     const bool akc = !d->transA, bkc = d->transB != 0;
     int rc;
+    if (gemm_mode() == 1 && TMN >= 1 && TMN <= 4) {
+#define EKAID_LAUNCH_SPLIT(AK, BKC) (TMN == 2 ? launch_split<AK, BKC, 2, 2, 32>(a, batch, st) : TMN == 1 ? launch_split<AK, BKC, 1, 1, 32>(a, batch, st) \
+                                     : TMN == 3 ? launch_split<AK, BKC, 2, 1, 32>(a, batch, st) : launch_split<AK, BKC, 1, 2, 32>(a, batch, st))
+        if (akc && bkc) rc = EKAID_LAUNCH_SPLIT(true, true);
+        else if (akc && !bkc) rc = EKAID_LAUNCH_SPLIT(true, false);
+        else rc = EKAID_LAUNCH_SPLIT(false, false);
+#undef EKAID_LAUNCH_SPLIT
+    } else {
 #define EKAID_LAUNCH(AK, BKC) (TMN == 2 ? launch<AK, BKC, 2, 2, BK_BIG>(a, batch, st) : TMN == 1 ? launch<AK, BKC, 1, 1, BK_SMALL>(a, batch, st) \
                                : TMN == 3 ? launch<AK, BKC, 2, 1, BK_HALF>(a, batch, st) : TMN == 4 ? launch<AK, BKC, 1, 2, BK_HALF>(a, batch, st) \
                                : TMN == 5 ? launch_direct<BKC>(a, batch, st) \
@@ -787,6 +1033,7 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     else if (akc && !bkc) rc = EKAID_LAUNCH(true, false);
     else rc = EKAID_LAUNCH(false, false);
 #undef EKAID_LAUNCH
+    }
     if (rc) return rc;
     rc = check_launch("gemm_mfma_kernel");
     if (rc) return rc;

@@ -12,7 +12,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_lon
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libekaid_hip.so')
+LIB_PATH = os.environ.get('EKAID_HIP_LIB') or os.path.join(_HERE, 'lib', 'libekaid_hip.so')   # env: A/B builds
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 ERR_UNSUPPORTED = -3
@@ -47,6 +47,8 @@ SIGNATURES = {
     'ekaid_version': [],
     'ekaid_last_error': [],
     'ekaid_gemm_workspace_bytes': [POINTER(GemmDesc)],
+    'ekaid_set_gemm_mode': [I],
+    'ekaid_get_gemm_mode': [],
     'ekaid_gemm_f32': [POINTER(GemmDesc), P, c_size_t, P],
     'ekaid_wn_scale_fwd': [P, P, L, P, P, P],
     'ekaid_wn_scale_bwd': [P, P, P, P, L, P, I, P, P],

@@ -22,6 +22,19 @@ _seed_base = 1238
 _seed_counter = 0
 
 
+GEMM_F32_MFMA, GEMM_BF16_SPLIT = 0, 1
+
+
+def set_gemm_mode(mode):
+    """Arithmetic of every GEMM on the path (include/ekaid_hip.h: ekaid_set_gemm_mode): GEMM_F32_MFMA or
+    GEMM_BF16_SPLIT (exact 3-way bf16 split, six bf16 MFMA products, f32 accumulation; the default)."""
+    hip.check(hip.lib().ekaid_set_gemm_mode(int(mode)), 'set_gemm_mode')
+
+
+def get_gemm_mode():
+    return int(hip.lib().ekaid_get_gemm_mode())
+
+
 def manual_seed(seed):
     global _seed_base, _seed_counter
     _seed_base = int(seed)

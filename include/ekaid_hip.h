@@ -71,6 +71,18 @@ typedef struct ekaid_gemm {
 size_t ekaid_gemm_workspace_bytes(const ekaid_gemm_t* g);
 int ekaid_gemm_f32(const ekaid_gemm_t* g, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Arithmetic of ekaid_gemm_f32 (process-wide; both take and return f32 and accumulate in f32):
+ *   EKAID_GEMM_F32_MFMA   (0)  v_mfma_f32_32x32x2_f32, an exact f32 fma chain;
+ *   EKAID_GEMM_BF16_SPLIT (1)  every f32 operand element is split EXACTLY into three bf16 values (8+8+8 significant
+ *                              bits) and the six products above 2^-24 relative are formed on v_mfma_f32_32x32x16_bf16
+ *                              with f32 accumulation: f32-level accuracy (dropped terms < 2^-23 |a.b| per product) at
+ *                              2.67x the matrix rate.  Default; the environment variable EKAID_GEMM_MODE=f32 selects 0.
+ * Inputs must be finite in mode 1 (an Inf operand gives NaN where mode 0 gives Inf). */
+#define EKAID_GEMM_F32_MFMA 0
+#define EKAID_GEMM_BF16_SPLIT 1
+int ekaid_set_gemm_mode(int mode);
+int ekaid_get_gemm_mode(void);
+
 /* ------------------------------------------------------------------------------------------
  * Weight normalisation, dim=None:  W = v * g / ||v||_F.   ref: fc.py:26-33 (weight_norm(Linear, dim=None))
  * fwd: scale_out[0] = g / ||v||,  norm_out[0] = ||v||.

@@ -45,9 +45,19 @@ GEMM_SHAPES = [
 ]
 
 
+@pytest.fixture(params=['bf16x3', 'f32'])
+def gemm_arith(request):
+    """Run a test under both GEMM arithmetics (exact bf16 split on the bf16 matrix pipe / f32 MFMA)."""
+    from ekaid_amd import ops
+    old = ops.get_gemm_mode()
+    ops.set_gemm_mode(ops.GEMM_BF16_SPLIT if request.param == 'bf16x3' else ops.GEMM_F32_MFMA)
+    yield request.param
+    ops.set_gemm_mode(old)
+
+
 @pytest.mark.parametrize('M,N,K', GEMM_SHAPES)
 @pytest.mark.parametrize('mode', ['nt', 'nn', 'tn'])
-def test_gemm_variants(M, N, K, mode):
+def test_gemm_variants(M, N, K, mode, gemm_arith):
     from ekaid_amd import ops
     A = rnd(M, K, seed=1)
     B = rnd(K, N, seed=2)
@@ -61,6 +71,71 @@ def test_gemm_variants(M, N, K, mode):
     C = torch.full((M, N), float('nan'), device=DEV)
     ops.gemm(a.to(DEV), b.to(DEV), C, M, N, K, lda, ldb, N, ta, tb)
     check(C, want, 2e-6 * max(1.0, math.sqrt(K) / 4), 'gemm %s %dx%dx%d' % (mode, M, N, K))
+
+
+@pytest.mark.parametrize('mode', ['nt', 'nn', 'tn'])
+@pytest.mark.parametrize('M,N,K', [(512, 384, 1024), (256, 2048, 512), (4608, 1024, 2048), (1000, 600, 4096)])
+def test_gemm_split_accuracy(M, N, K, mode):
+    """The 3-way bf16 split is f32-accurate: against float64, its error is no larger than 1.5x the error of the f32
+    MFMA (an exact f32 fma chain) on the same data -- including data with a wide dynamic range."""
+    from ekaid_amd import ops
+    g = torch.Generator().manual_seed(77)
+    A = torch.randn(M, K, generator=g) * torch.exp(3 * torch.randn(M, 1, generator=g))
+    B = torch.randn(K, N, generator=g) * torch.exp(3 * torch.randn(1, N, generator=g))
+    want = A.double() @ B.double()
+    scale = (A.double().abs() @ B.double().abs())          # per-element condition scale
+    if mode == 'nt':
+        a, b, ta, tb, lda, ldb = A, B.t().contiguous(), 0, 1, K, K
+    elif mode == 'nn':
+        a, b, ta, tb, lda, ldb = A, B, 0, 0, K, N
+    else:
+        a, b, ta, tb, lda, ldb = A.t().contiguous(), B, 1, 0, M, N
+    a, b = a.to(DEV), b.to(DEV)
+    errs = {}
+    old = ops.get_gemm_mode()
+    try:
+        for name, m in (('f32', ops.GEMM_F32_MFMA), ('bf16x3', ops.GEMM_BF16_SPLIT)):
+            ops.set_gemm_mode(m)
+            C = torch.empty(M, N, device=DEV)
+            ops.gemm(a, b, C, M, N, K, lda, ldb, N, ta, tb)
+            e = (C.double().cpu() - want).abs() / scale
+            errs[name] = (float(e.max()), float(e.mean()))
+    finally:
+        ops.set_gemm_mode(old)
+    print('gemm accuracy %s %dx%dx%d: f32 max %.2e mean %.2e | bf16x3 max %.2e mean %.2e' % (
+        mode, M, N, K, errs['f32'][0], errs['f32'][1], errs['bf16x3'][0], errs['bf16x3'][1]))
+    assert errs['bf16x3'][0] <= 1.5 * errs['f32'][0] + 1e-9
+    assert errs['bf16x3'][1] <= 1.5 * errs['f32'][1] + 1e-10
+    assert errs['bf16x3'][0] < 2e-6
+
+
+def test_gemm_split_is_exact_on_bf16_representable_products():
+    """Integer-valued operands whose products and sums are exact in f32: both arithmetics must be bit-identical
+    to the integer result (catches any wrong lane/k mapping of the bf16 fragments and the transposed LDS reads)."""
+    from ekaid_amd import ops
+    g = torch.Generator().manual_seed(5)
+    # (M, N, K, |A| bound, |B| bound): bound_A * bound_B * K <= 2^24 keeps every partial sum exact in f32;
+    # 2^18-sized integers need all three bf16 planes of that operand
+    for (M, N, K, amax, bmax) in [(128, 128, 32, 1 << 18, 2), (192, 320, 32, 2, 1 << 18), (77, 45, 24, 1 << 18, 2),
+                                  (256, 192, 64, 4000, 60), (130, 70, 96, 50, 3000)]:
+        A = torch.randint(-amax, amax + 1, (M, K), generator=g).float()
+        B = torch.randint(-bmax, bmax + 1, (K, N), generator=g).float()
+        want = (A.double() @ B.double()).float()
+        for mode in ('nt', 'nn', 'tn'):
+            if mode == 'nt':
+                a, b, ta, tb, lda, ldb = A, B.t().contiguous(), 0, 1, K, K
+            elif mode == 'nn':
+                a, b, ta, tb, lda, ldb = A, B, 0, 0, K, N
+            else:
+                a, b, ta, tb, lda, ldb = A.t().contiguous(), B, 1, 0, M, N
+            old = ops.get_gemm_mode()
+            try:
+                ops.set_gemm_mode(ops.GEMM_BF16_SPLIT)
+                C = torch.empty(M, N, device=DEV)
+                ops.gemm(a.to(DEV), b.to(DEV), C, M, N, K, lda, ldb, N, ta, tb)
+            finally:
+                ops.set_gemm_mode(old)
+            assert torch.equal(C.cpu(), want), (mode, M, N, K, float((C.cpu() - want).abs().max()))
 
 
 def test_gemm_epilogue_and_strides():
