@@ -31,6 +31,7 @@ import torch.distributed as dist  # noqa: E402
 
 FLOP_PER_PAIR_TRAIN = 15.39e9     # algorithmic fwd+bwd work per QA pair (N=36, D=2048, T=16)
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_BF16_MFMA_TFLOPS = 2516.6    # MI355X_MICROARCH.md: dense bf16 MFMA peak (16x the f32-input rate, no sparsity)
 SHAPE = dict(N=36, D=2048, Lq=20, T=16, seq_length=90, V=148)
 
 
@@ -195,6 +196,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_val = float(loss.item())
+    # host-side cost of issuing one step (GPU idle at the start, no synchronisation inside): the lower bound the
+    # launch path puts on the step time
+    torch.cuda.synchronize()
+    th = time.perf_counter()
+    train_step(cfg, cd, sp, opt, b, T, args.graph)
+    host_issue_ms = (time.perf_counter() - th) * 1e3
+    torch.cuda.synchronize()
 
     # ---- roofline of the dominant kernel family: HIP events around every GEMM launch, two extra steps
     roof = None
@@ -223,14 +231,24 @@ def main():
         for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
             if n1 != 'start':
                 phases[n1] = round(phases.get(n1, 0.0) + e0.elapsed_time(e1) / 2, 3)
-        roof = {'bound': 'mfma', 'kernel': 'ekaid::gemm_mfma_kernel (v_mfma_f32_32x32x2_f32)',
-                'achieved': round(fl / (ms * 1e-3) / 1e12, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+        alg = fl / (ms * 1e-3) / 1e12             # algorithmic f32 TFLOP/s of the GEMM family (2*M*N*K per call)
+        split = ops.get_gemm_mode() == ops.GEMM_BF16_SPLIT
+        # bf16-split arithmetic executes SIX bf16 MFMA products per algorithmic f32 product: the roofline is the bf16
+        # matrix pipe and `achieved` counts the executed bf16 flops; the f32-MFMA arithmetic is priced on the f32 pipe
+        executed, peak = (6.0 * alg, PEAK_BF16_MFMA_TFLOPS) if split else (alg, PEAK_F32_MFMA_TFLOPS)
+        path_alg = FLOP_PER_PAIR_TRAIN * per_gpu * args.steps / elapsed / 1e12
+        roof = {'bound': 'mfma',
+                'kernel': ('ekaid::gemm_split_kernel (f32 operands split exactly into 3 bf16, 6 x v_mfma_f32_32x32x16_bf16 '
+                           'per product block, f32 accumulate)') if split else 'ekaid::gemm_mfma_kernel (v_mfma_f32_32x32x2_f32)',
+                'achieved': round(executed, 3), 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': round(executed / peak, 4), 'traffic': None,
+                'executed_flop_per_algorithmic_flop': 6 if split else 1,
+                'algorithmic_f32_tflops': round(alg, 3), 'f32_mfma_peak_tflops': PEAK_F32_MFMA_TFLOPS,
                 'launches_per_step': len(rec) // 2, 'gemm_ms_per_step': round(ms / 2, 3),
                 'gemm_flop_per_step': fl / 2,
                 'large_gemm_tflops': round(sum(r[1] for r in big) / (sum(r[0] for r in big) * 1e-3) / 1e12, 3) if big else None,
-                'path_algorithmic_tflops': round(FLOP_PER_PAIR_TRAIN * per_gpu * world * args.steps / elapsed / 1e12, 3),
-                'path_frac_of_peak': round(FLOP_PER_PAIR_TRAIN * per_gpu * args.steps / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+                'path_algorithmic_tflops': round(path_alg * world, 3),
+                'path_frac_of_peak': round(path_alg * (6 if split else 1) / peak, 4)}
     if world > 1:
         dist.barrier()
 
@@ -242,7 +260,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32', 'gemm_arithmetic': 'bf16x3-exact-split (6 MFMA products, f32 accumulate)' if ops.get_gemm_mode() == ops.GEMM_BF16_SPLIT else 'f32-mfma',
+            'data': 'synthetic',
             'config': {'workload': 'BASELINE.json configs[%d]: synthetic 36-region x 2-image graphs, 2048-d ROI features, '
                                    '20-token questions, 16 decode steps, graph=%s, train step (fwd+bwd+all-reduce+Adam), '
                                    'dropout %s' % (2 if world == 1 else 3, args.graph, 'off' if args.eval else 'on'),
@@ -251,6 +270,7 @@ def main():
                        'params_total': 87290418, 'loss': round(loss_val, 5)},
             'roofline': roof,
             'phases_ms': phases if rank == 0 else None,
+            'host_issue_ms_per_step': round(host_issue_ms, 3),
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, cd, sp, args.cpu_batch, args.graph)

@@ -213,6 +213,18 @@ __device__ __forceinline__ void write_tiles(const GemmArgs& g, f32x16 (&acc)[TM]
     else store_tiles(std::true_type{});
 }
 
+#ifndef EKAID_SPLIT_OCC_BIG
+#define EKAID_SPLIT_OCC_BIG 3
+#endif
+#ifndef EKAID_SPLIT_OCC_SMALL
+#define EKAID_SPLIT_OCC_SMALL 4
+#endif
+#ifndef EKAID_SPLIT_KB_SMALL
+#define EKAID_SPLIT_KB_SMALL 32
+#endif
+#ifndef EKAID_SPLIT_PF_SMALL
+#define EKAID_SPLIT_PF_SMALL 1
+#endif
 #ifndef EKAID_LB_HALF
 #define EKAID_LB_HALF 4
 #endif
@@ -386,11 +398,13 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : (TM * TN == 2 ? EKAID_LB_H
 // (measured against float64 in tests/test_hip_ops.py::test_gemm_split_accuracy: same error as the f32 pipe).
 //
 // Staging: global f32 -> registers (same loaders as above) -> split at LDS-store time into three bf16 planes.
-//   k-contiguous operand : plane image [row][KB] bf16, row stride 2*KB + 16 B; fragment = one ds_read_b128 per plane
+//   k-contiguous operand : plane image [row][KB] bf16; fragment = one ds_read_b128 per plane
 //                          (lane (r, h) takes k = 8h .. 8h+7 of row r: the operand map of the 32x32x16 MFMA)
 //   m/n-contiguous operand: plane image [k][rows] bf16 exactly as it lies in memory (8-byte stores, no transpose);
 //                          fragment = two ds_read_b64_tr_b16 per plane (the LDS hardware transposes 4 k x 16 rows
-//                          per 16-lane group); row stride 2*rows + 64 B puts the 4 k-rows of a read on disjoint banks
+//                          per 16-lane group)
+// Both images are unpadded and XOR-swizzled (kc_store_off / mc_store_off below): 48 KiB for the 128x128 tile, so
+// three workgroups share a CU.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -414,16 +428,49 @@ __device__ __forceinline__ void split4(const f32x4& v, u32x2& H, u32x2& M, u32x2
     L[0] = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u); L[1] = __builtin_amdgcn_perm(l[3], l[2], 0x07060302u);
 }
 
-template <bool A_KC, bool B_KC, int TM, int TN, int KB>
-__global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : (TM * TN == 2 ? 2 : 4))) void gemm_split_kernel(GemmArgs g) {
+// LDS plane images, unpadded with XOR swizzles so that every access below is bank-conflict free (K-step KB = 32/64/128):
+//   k-contiguous: [row][KB/8 slots of 16 B]; slot s of row R sits at slot s ^ key(R), key(R) = (R / (128/KB)) mod (KB/8).
+//                 ds_read_b128 serves 16 lanes (16 rows, distinct mod 16) per cycle; 2*KB-byte rows put 128/KB rows on
+//                 one 256-B bank row, the key spreads the rows that share a bank row position over the slots.
+//   m-contiguous: [k][BT/32 chunks of 64 B]; chunk ch of k-row k sits at ch ^ (k & 3) (128-wide tile, 256-B rows) or
+//                 ch ^ ((k >> 1) & 1) (64-wide tile, 128-B rows): the 4 k-rows a transposed read gathers per half-wave
+//                 land on 4 different 64-B bank groups.
+template <int KB>
+__device__ __forceinline__ int kc_key(int row) { return (row / (128 / KB)) & (KB / 8 - 1); }
+template <int KB>
+__device__ __forceinline__ int kc_store_off(int idx) {        // idx: row = idx / (KB/4), float4 c4 = idx % (KB/4) (k = 4 c4)
+    const int row = idx / (KB / 4), c4 = idx % (KB / 4);
+    return row * (2 * KB) + 16 * ((c4 >> 1) ^ kc_key<KB>(row)) + 8 * (c4 & 1);
+}
+template <int KB>
+__device__ __forceinline__ int kc_read_off(int row, int slot) { return row * (2 * KB) + 16 * (slot ^ kc_key<KB>(row)); }
+template <int BT>
+__device__ __forceinline__ int mc_store_off(int idx) {        // idx: k-row = idx / (BT/4), float4 c4 (rows 4 c4 ..)
+    const int k = idx / (BT / 4), c4 = idx % (BT / 4);
+    const int key = BT == 128 ? (k & 3) : ((k >> 1) & 1);
+    return k * (2 * BT) + 64 * ((c4 >> 3) ^ key) + 8 * (c4 & 7);
+}
+template <int BT>
+__device__ __forceinline__ int mc_read_off(int k, int row0, int tg, int tp) {   // row0: first of the tile's 32 rows
+    const int key = BT == 128 ? (k & 3) : ((k >> 1) & 1);
+    return k * (2 * BT) + 64 * ((row0 >> 5) ^ key) + 32 * tg + 8 * tp;
+}
+
+// PF = K-steps of global loads kept in flight (1: the next step's loads hide under this step's MFMAs -- enough for the
+// large tiles; 2: for the 64x64 tile, whose 12 MFMAs per 32-deep step are far shorter than a load round trip)
+template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF>
+__global__ __launch_bounds__(256, (TM * TN >= 4 ? EKAID_SPLIT_OCC_BIG : (TM * TN == 2 ? 2 : EKAID_SPLIT_OCC_SMALL))) void gemm_split_kernel(GemmArgs g) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int A_RS = A_KC ? 2 * KB + 16 : 2 * BM + 64;          // row stride of one plane image, bytes
-    constexpr int B_RS = B_KC ? 2 * KB + 16 : 2 * BN + 64;
+    static_assert(KB == 32 || KB == 64 || KB == 128, "K-step");
+    static_assert(PF == 1 || PF == 2, "prefetch depth");
+    constexpr int A_RS = A_KC ? 2 * KB : 2 * BM;          // row stride of one plane image, bytes (no padding: XOR swizzles)
+    constexpr int B_RS = B_KC ? 2 * KB : 2 * BN;
     constexpr int A_PLANE = (A_KC ? BM : KB) * A_RS;
     constexpr int B_PLANE = (B_KC ? BN : KB) * B_RS;
     constexpr int A_BYTES = 3 * A_PLANE;
     constexpr int A_V4 = BM * KB / 4 / 256;
     constexpr int B_V4 = BN * KB / 4 / 256;
+    constexpr int NCH = KB / 16;                          // 16-k MFMA chunks per K-step
     extern __shared__ __attribute__((aligned(16))) float lds[];
     char* const ldsA = reinterpret_cast<char*>(lds);
     char* const ldsB = ldsA + A_BYTES;
@@ -463,26 +510,27 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : (TM * TN == 2 ? 2 : 4))) v
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
 
-    f32x4 ra[A_V4], rb[B_V4];
+    f32x4 ra[PF][A_V4], rb[PF][B_V4];        // PF register sets, always indexed statically
+    int kload[PF];
     TileLoader<A_V4> LA;
     TileLoader<B_V4> LB;
     loader_init<A_KC, BM, A_V4, KB>(LA, A, g.lda, m0, g.M, g.K, tid, vecA);
     loader_init<B_KC, BN, B_V4, KB>(LB, B, g.ldb, n0, g.N, g.K, tid, vecB);
 
-    int kload = kbeg;
     const bool ragged = ((kend - kbeg) % KB) != 0 || !vecA || !vecB ||
                         (!A_KC && (m0 + BM > g.M)) || (!B_KC && (n0 + BN > g.N));
-    auto lstore = [&](bool need_mask) {
+    auto lstore = [&](auto set_tag, bool need_mask) {
+        constexpr int S = decltype(set_tag)::value;
         if (need_mask) {
-            loader_mask<A_KC, BM, A_V4, KB>(LA, ra, kload, kend, tid);
-            loader_mask<B_KC, BN, B_V4, KB>(LB, rb, kload, kend, tid);
+            loader_mask<A_KC, BM, A_V4, KB>(LA, ra[S], kload[S], kend, tid);
+            loader_mask<B_KC, BN, B_V4, KB>(LB, rb[S], kload[S], kend, tid);
         }
 #pragma unroll
         for (int i = 0; i < A_V4; ++i) {
             const int idx = tid + i * 256;
-            const int off = A_KC ? (idx / (KB / 4)) * A_RS + 8 * (idx % (KB / 4)) : (idx / (BM / 4)) * A_RS + 8 * (idx % (BM / 4));
+            const int off = A_KC ? kc_store_off<KB>(idx) : mc_store_off<BM>(idx);
             u32x2 H, M, L;
-            split4(ra[i], H, M, L);
+            split4(ra[S][i], H, M, L);
             *reinterpret_cast<u32x2*>(ldsA + off) = H;
             *reinterpret_cast<u32x2*>(ldsA + A_PLANE + off) = M;
             *reinterpret_cast<u32x2*>(ldsA + 2 * A_PLANE + off) = L;
@@ -490,45 +538,51 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : (TM * TN == 2 ? 2 : 4))) v
 #pragma unroll
         for (int i = 0; i < B_V4; ++i) {
             const int idx = tid + i * 256;
-            const int off = B_KC ? (idx / (KB / 4)) * B_RS + 8 * (idx % (KB / 4)) : (idx / (BN / 4)) * B_RS + 8 * (idx % (BN / 4));
+            const int off = B_KC ? kc_store_off<KB>(idx) : mc_store_off<BN>(idx);
             u32x2 H, M, L;
-            split4(rb[i], H, M, L);
+            split4(rb[S][i], H, M, L);
             *reinterpret_cast<u32x2*>(ldsB + off) = H;
             *reinterpret_cast<u32x2*>(ldsB + B_PLANE + off) = M;
             *reinterpret_cast<u32x2*>(ldsB + 2 * B_PLANE + off) = L;
         }
     };
-    // per-lane base offsets of the fragment reads (bytes inside a plane)
-    //   KC: row (w + r), k bytes 16h (+ 32 per 16-k chunk)
-    //   MC: transposed read: lane 4q+p of a 16-lane group addresses k-row q, rows 4p..4p+3 of the group's 16 rows
+    // per-lane offsets of the fragment reads (bytes inside a plane): see the image layouts above
     const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
-    const int a_base = A_KC ? (wm + r) * A_RS + 16 * h : (8 * h + tq) * A_RS + 2 * (wm + 16 * tg + 4 * tp);
-    const int b_base = B_KC ? (wn + r) * B_RS + 16 * h : (8 * h + tq) * B_RS + 2 * (wn + 16 * tg + 4 * tp);
+    int a_off[TM][NCH], b_off[TN][NCH];          // [tile][16-k chunk]
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            a_off[i][c] = A_KC ? kc_read_off<KB>(wm + 32 * i + r, 2 * c + h) : mc_read_off<BM>(16 * c + 8 * h + tq, wm + 32 * i, tg, tp);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            b_off[j][c] = B_KC ? kc_read_off<KB>(wn + 32 * j + r, 2 * c + h) : mc_read_off<BN>(16 * c + 8 * h + tq, wn + 32 * j, tg, tp);
     typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
-    auto frag = [&](const char* plane, int base, int tile, int chunk, bool kc, int rs) -> bf16x8 {
+    auto frag = [&](const char* plane, int off, bool kc, int rs) -> bf16x8 {
         if (kc) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(plane + base + tile * 32 * rs + 32 * chunk);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(plane + off);
             return __builtin_bit_cast(bf16x8, v);
         } else {
-            const char* p = plane + base + 64 * tile + 16 * chunk * rs;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 4 * rs));
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(plane + off));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(plane + off + 4 * rs));   // k + 4: same swizzle key
             const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             return __builtin_bit_cast(bf16x8, v);
         }
     };
     auto compute = [&]() {
 #pragma unroll
-        for (int c = 0; c < KB / 16; ++c) {
+        for (int c = 0; c < NCH; ++c) {
             bf16x8 fa[TM][3], fb[TN][3];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) fa[i][p] = frag(ldsA + p * A_PLANE, a_base, i, c, A_KC, A_RS);
+                for (int p = 0; p < 3; ++p) fa[i][p] = frag(ldsA + p * A_PLANE, a_off[i][c], A_KC, A_RS);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) fb[j][p] = frag(ldsB + p * B_PLANE, b_base, j, c, B_KC, B_RS);
+                for (int p = 0; p < 3; ++p) fb[j][p] = frag(ldsB + p * B_PLANE, b_off[j][c], B_KC, B_RS);
             // smallest terms first
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -545,20 +599,46 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : (TM * TN == 2 ? 2 : 4))) v
     };
     auto mainloop = [&](auto fast_tag) {
         constexpr bool FAST = decltype(fast_tag)::value;
-        auto gload = [&](int k0) {
-            kload = k0;
-            loader_fetch<A_KC, BM, A_V4, KB, FAST>(LA, ra, g.lda, k0, g.K, g.M, m0, tid, vecA);
-            loader_fetch<B_KC, BN, B_V4, KB, FAST>(LB, rb, g.ldb, k0, g.K, g.N, n0, tid, vecB);
+        auto gload = [&](auto set_tag, int k0) {
+            constexpr int S = decltype(set_tag)::value;
+            kload[S] = k0;
+            loader_fetch<A_KC, BM, A_V4, KB, FAST>(LA, ra[S], g.lda, k0, g.K, g.M, m0, tid, vecA);
+            loader_fetch<B_KC, BN, B_V4, KB, FAST>(LB, rb[S], g.ldb, k0, g.K, g.N, n0, tid, vecB);
         };
-        gload(kbeg);
-        lstore(!FAST);
-        __syncthreads();
-        for (int k0 = kbeg; k0 < kend; k0 += KB) {
-            const bool more = (k0 + KB) < kend;
-            if (more) gload(k0 + KB);
-            compute();
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, PF - 1>;
+        if constexpr (PF == 1) {
+            gload(S0{}, kbeg);
+            lstore(S0{}, !FAST);
             __syncthreads();
-            if (more) { lstore(!FAST); __syncthreads(); }
+            for (int k0 = kbeg; k0 < kend; k0 += KB) {
+                const bool more = (k0 + KB) < kend;
+                if (more) gload(S0{}, k0 + KB);
+                compute();
+                __syncthreads();
+                if (more) { lstore(S0{}, !FAST); __syncthreads(); }
+            }
+        } else {
+            // two K-steps in flight; the loop is unrolled by two so that both register sets are indexed statically.
+            // The loads are issued UNCONDITIONALLY (addresses are clamped into the matrix, a step beyond kend is
+            // fetched and dropped): a load under a branch makes the compiler wait vmcnt(0) at the next LDS store,
+            // which would drain the younger set as well and undo the second step in flight.
+            gload(S0{}, kbeg);
+            gload(S1{}, kbeg + KB);
+            lstore(S0{}, !FAST);
+            __syncthreads();
+            for (int k0 = kbeg; k0 < kend; k0 += 2 * KB) {
+                gload(S0{}, k0 + 2 * KB);                             // set 1 still holds step k0 + KB
+                compute();
+                __syncthreads();
+                if (k0 + KB >= kend) break;
+                lstore(S1{}, !FAST);
+                __syncthreads();
+                gload(S1{}, k0 + 3 * KB);
+                compute();
+                __syncthreads();
+                if (k0 + 2 * KB < kend) { lstore(S0{}, !FAST); __syncthreads(); }
+            }
         }
     };
     if (kbeg < kend) {
@@ -863,11 +943,11 @@ static int launch(const GemmArgs& a, int batch, hipStream_t st) {
     return EKAID_OK;
 }
 
-template <bool A_KC, bool B_KC, int TM, int TN, int KB>
+template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF>
 static int launch_split(const GemmArgs& a, int batch, hipStream_t st) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr size_t lds = 3 * ((A_KC ? BM * (2 * KB + 16) : KB * (2 * BM + 64)) + (B_KC ? BN * (2 * KB + 16) : KB * (2 * BN + 64)));
-    auto kern = gemm_split_kernel<A_KC, B_KC, TM, TN, KB>;
+    constexpr size_t lds = 3 * 2 * KB * (BM + BN);      // three bf16 planes per operand, unpadded
+    auto kern = gemm_split_kernel<A_KC, B_KC, TM, TN, KB, PF>;
     if (lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -930,7 +1010,8 @@ static void plan(const ekaid_gemm_t* d, int& TMN, int& splitk, int& tiles_m, int
     TMN = (d->M >= 512 && d->N >= 128) ? 2 : 1;
     // tall outputs with few column tiles (forward/dgrad of the 1024-wide layers, M = 2*B*N rows): 128x64 tiles run
     // 4-5 workgroups per CU and quantise better than 128x128 (measured 94 -> 104 TF NT, 114 -> 122 TF NN at N = 1024)
-    if (TMN == 2 && batch == 1 && d->M >= 4096 && d->N <= 2048) TMN = 3;
+    // (f32 MFMA kernel only: the bf16-split kernel runs 3 workgroups of 128x128 per CU and is faster with them)
+    if (TMN == 2 && batch == 1 && d->M >= 4096 && d->N <= 2048 && gemm_mode() == 0) TMN = 3;
     // skinny problems (recurrent GEMMs, M = batch rows): if 64x64 tiles cannot give every CU two workgroups,
     // use 32x32 tiles with the K-step split across the four waves (TMN = 0)
     // (measured: not faster than 64x64 tiles with the 128-deep K-step + split-K, so only on request)
@@ -959,7 +1040,7 @@ static void plan(const ekaid_gemm_t* d, int& TMN, int& splitk, int& tiles_m, int
             splitk = sk < 1 ? 1 : sk;
         }
     } else
-    splitk = plan_splitk(tiles_m * tiles_n, d->K, batch, (long long)d->M * d->N, TMN >= 2 ? BK_BIG : BK_SMALL);
+    splitk = plan_splitk(tiles_m * tiles_n, d->K, batch, (long long)d->M * d->N, TMN >= 2 ? BK_BIG : (gemm_mode() == 1 && TMN == 1 ? EKAID_SPLIT_KB_SMALL : BK_SMALL));
 }
 
 }  // namespace ekaid
@@ -1002,7 +1083,7 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     plan(d, TMN, a.splitk, a.tiles_m, a.tiles_n);
     if (d->K == 0) a.splitk = 1;
     a.ws = nullptr;
-    const int BK = TMN == 5 ? 64 : (TMN == 3 || TMN == 4 ? BK_HALF : (TMN >= 2 ? BK_BIG : BK_SMALL));
+    const int BK = TMN == 5 ? 64 : (TMN == 3 || TMN == 4 ? BK_HALF : (TMN >= 2 ? BK_BIG : (gemm_mode() == 1 && TMN == 1 ? EKAID_SPLIT_KB_SMALL : BK_SMALL)));
     a.k_per_split = cdiv(cdiv(d->K, BK), a.splitk) * BK;
     if (a.splitk > 1) {
         const size_t need = (size_t)a.splitk * d->M * d->N * sizeof(float);
@@ -1018,8 +1099,9 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     const bool akc = !d->transA, bkc = d->transB != 0;
     int rc;
     if (gemm_mode() == 1 && TMN >= 1 && TMN <= 4) {
-#define EKAID_LAUNCH_SPLIT(AK, BKC) (TMN == 2 ? launch_split<AK, BKC, 2, 2, 32>(a, batch, st) : TMN == 1 ? launch_split<AK, BKC, 1, 1, 32>(a, batch, st) \
-                                     : TMN == 3 ? launch_split<AK, BKC, 2, 1, 32>(a, batch, st) : launch_split<AK, BKC, 1, 2, 32>(a, batch, st))
+#define EKAID_LAUNCH_SPLIT(AK, BKC) (TMN == 2 ? launch_split<AK, BKC, 2, 2, 32, 1>(a, batch, st) \
+                                     : TMN == 1 ? launch_split<AK, BKC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL>(a, batch, st) \
+                                     : TMN == 3 ? launch_split<AK, BKC, 2, 1, 32, 1>(a, batch, st) : launch_split<AK, BKC, 1, 2, 32, 1>(a, batch, st))
         if (akc && bkc) rc = EKAID_LAUNCH_SPLIT(true, true);
         else if (akc && !bkc) rc = EKAID_LAUNCH_SPLIT(true, false);
         else rc = EKAID_LAUNCH_SPLIT(false, false);

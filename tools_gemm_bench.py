@@ -2,8 +2,12 @@
 import glob, os, sys, ctypes, torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from ekaid_amd import hip, ops
-SHAPES = [('nt', 256, 2048, 1024), ('nn', 256, 512, 2048), ('nn', 256, 1024, 2048), ('nt', 256, 3072, 1024), ('nt', 18432, 1024, 1024), ('nt', 18432, 1024, 4096), ('nn', 18432, 1024, 1024), ('nn', 18432, 4096, 1024),
-          ('tn', 1024, 1024, 18432), ('tn', 1024, 4096, 18432), ('nt', 256, 2048, 512), ('nt', 256, 2048, 2048), ('tn', 2048, 512, 256)]
+BIG = [('nt', 18432, 1024, 1024), ('nt', 18432, 1024, 4096), ('nn', 18432, 1024, 1024), ('nn', 18432, 4096, 1024),
+       ('tn', 1024, 1024, 18432), ('tn', 1024, 4096, 18432)]
+SMALL = [('nt', 256, 6656, 512), ('nt', 256, 2048, 512), ('nt', 256, 2048, 1024), ('nt', 256, 1024, 2048), ('nt', 256, 3072, 1024),
+         ('nn', 256, 512, 6656), ('nn', 256, 512, 2048), ('nn', 256, 1024, 2048), ('nn', 256, 2048, 1024), ('nn', 256, 1024, 3072)]
+SHAPES = SMALL if os.environ.get('GEMM_BENCH_SET') == 'small' else (BIG if os.environ.get('GEMM_BENCH_SET') == 'big' else BIG + SMALL)
+US = os.environ.get('GEMM_BENCH_US')          # print microseconds per call instead of TFLOP/s
 def run(lib):
     res = []
     for mode, M, N, K in SHAPES:
@@ -17,10 +21,14 @@ def run(lib):
         e0.record()
         for _ in range(n): f()
         e1.record(); torch.cuda.synchronize()
-        res.append(2.0 * M * N * K * n / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+        res.append(e0.elapsed_time(e1) * 1e3 / n if US else 2.0 * M * N * K * n / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+        if os.environ.get('GEMM_BENCH_CHECK'):
+            a2 = A.view(K, M).t() if ta else A.view(M, K); b2 = B.view(N, K).t() if tb else B.view(K, N)
+            err = float((C.view(M, N) - a2 @ b2).abs().max() / (a2 @ b2).abs().max())
+            assert err < 1e-4, (mode, M, N, K, err)
     return res
 print('%-22s' % 'variant' + ''.join('%14s' % ('%s %dx%dx%d' % s)[:13] for s in SHAPES))
-for path in sorted(glob.glob(os.path.join(os.path.dirname(hip.LIB_PATH), 'libekaid_v*.so'))):
+for path in sorted(glob.glob(os.path.join(os.path.dirname(hip.LIB_PATH), 'libekaid_v*.so'))) or [hip.LIB_PATH]:
     hip._lib = None
     hip._lib = hip.load(path)
     print('%-22s' % os.path.basename(path) + ''.join('%14.1f' % x for x in run(hip._lib)), flush=True)
