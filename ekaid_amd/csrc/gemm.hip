@@ -216,6 +216,12 @@ __device__ __forceinline__ void write_tiles(const GemmArgs& g, f32x16 (&acc)[TM]
 #ifndef EKAID_SPLIT_OCC_BIG
 #define EKAID_SPLIT_OCC_BIG 3
 #endif
+#ifndef EKAID_SPLIT_ABLATE
+#define EKAID_SPLIT_ABLATE 0
+#endif
+#ifndef EKAID_SPLIT_PIPE_BIG
+#define EKAID_SPLIT_PIPE_BIG true
+#endif
 #ifndef EKAID_SPLIT_OCC_SMALL
 #define EKAID_SPLIT_OCC_SMALL 4
 #endif
@@ -405,6 +411,9 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : (TM * TN == 2 ? EKAID_LB_H
 //                          per 16-lane group)
 // Both images are unpadded and XOR-swizzled (kc_store_off / mc_store_off below): 48 KiB for the 128x128 tile, so
 // three workgroups share a CU.
+#ifndef EKAID_SPLIT_ABLATE
+#define EKAID_SPLIT_ABLATE 0
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -413,6 +422,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // four f32 -> three planes of four bf16 (truncation split; h + m + l == v exactly for finite v)
 __device__ __forceinline__ void split4(const f32x4& v, u32x2& H, u32x2& M, u32x2& L) {
+#if EKAID_SPLIT_ABLATE == 2              // timing-only: no split arithmetic (three copies of the raw words)
+    H[0] = __float_as_uint(v[0]); H[1] = __float_as_uint(v[1]); M[0] = __float_as_uint(v[2]); M[1] = __float_as_uint(v[3]); L = H;
+    return;
+#endif
     unsigned u[4], m[4], l[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -458,8 +471,9 @@ __device__ __forceinline__ int mc_read_off(int k, int row0, int tg, int tp) {   
 
 // PF = K-steps of global loads kept in flight (1: the next step's loads hide under this step's MFMAs -- enough for the
 // large tiles; 2: for the 64x64 tile, whose 12 MFMAs per 32-deep step are far shorter than a load round trip)
-template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF>
+template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE>
 __global__ __launch_bounds__(256, (TM * TN >= 4 ? EKAID_SPLIT_OCC_BIG : (TM * TN == 2 ? 2 : EKAID_SPLIT_OCC_SMALL))) void gemm_split_kernel(GemmArgs g) {
+    static_assert(!PIPE || (KB == 32 && PF == 1), "the pipelined loop shares the 32-deep LDS footprint");
     constexpr int BM = 64 * TM, BN = 64 * TN;
     static_assert(KB == 32 || KB == 64 || KB == 128, "K-step");
     static_assert(PF == 1 || PF == 2, "prefetch depth");
@@ -517,7 +531,28 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? EKAID_SPLIT_OCC_BIG : (TM * TN
     loader_init<A_KC, BM, A_V4, KB>(LA, A, g.lda, m0, g.M, g.K, tid, vecA);
     loader_init<B_KC, BN, B_V4, KB>(LB, B, g.ldb, n0, g.N, g.K, tid, vecB);
 
-    const bool ragged = ((kend - kbeg) % KB) != 0 || !vecA || !vecB ||
+    // FAST path operand fetch: buffer loads.  The per-thread byte offsets are computed once; the K advance is a scalar
+    // (soffset) -- no vector ALU work per K-step (the split already uses ~3.7 VALU slots per MFMA) -- and rows beyond the
+    // matrix end read as zero through the descriptor's bounds check.
+    const long long spanA = A_KC ? ((long long)(g.M - 1) * g.lda + g.K) : ((long long)(g.K - 1) * g.lda + g.M);
+    const long long spanB = B_KC ? ((long long)(g.N - 1) * g.ldb + g.K) : ((long long)(g.K - 1) * g.ldb + g.N);
+    const bool buf_ok = spanA < (1ll << 29) && spanB < (1ll << 29);           // 32-bit byte offsets
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(min(spanA, (1ll << 29)) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(min(spanB, (1ll << 29)) * 4), 0x00020000);
+    unsigned voffA[A_V4], voffB[B_V4];
+#pragma unroll
+    for (int i = 0; i < A_V4; ++i) {
+        const int idx = tid + i * 256;
+        voffA[i] = A_KC ? ((unsigned)(m0 + idx / (KB / 4)) * (unsigned)g.lda + 4u * (idx % (KB / 4))) * 4u
+                        : ((unsigned)(idx / (BM / 4)) * (unsigned)g.lda + (unsigned)m0 + 4u * (idx % (BM / 4))) * 4u;
+    }
+#pragma unroll
+    for (int i = 0; i < B_V4; ++i) {
+        const int idx = tid + i * 256;
+        voffB[i] = B_KC ? ((unsigned)(n0 + idx / (KB / 4)) * (unsigned)g.ldb + 4u * (idx % (KB / 4))) * 4u
+                        : ((unsigned)(idx / (BN / 4)) * (unsigned)g.ldb + (unsigned)n0 + 4u * (idx % (BN / 4))) * 4u;
+    }
+    const bool ragged = ((kend - kbeg) % KB) != 0 || !vecA || !vecB || !buf_ok ||
                         (!A_KC && (m0 + BM > g.M)) || (!B_KC && (n0 + BN > g.N));
     auto lstore = [&](auto set_tag, bool need_mask) {
         constexpr int S = decltype(set_tag)::value;
@@ -602,8 +637,19 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? EKAID_SPLIT_OCC_BIG : (TM * TN
         auto gload = [&](auto set_tag, int k0) {
             constexpr int S = decltype(set_tag)::value;
             kload[S] = k0;
-            loader_fetch<A_KC, BM, A_V4, KB, FAST>(LA, ra[S], g.lda, k0, g.K, g.M, m0, tid, vecA);
-            loader_fetch<B_KC, BN, B_V4, KB, FAST>(LB, rb[S], g.ldb, k0, g.K, g.N, n0, tid, vecB);
+            if constexpr (FAST) {
+                const unsigned soA = (A_KC ? (unsigned)k0 : (unsigned)k0 * (unsigned)g.lda) * 4u;
+                const unsigned soB = (B_KC ? (unsigned)k0 : (unsigned)k0 * (unsigned)g.ldb) * 4u;
+#pragma unroll
+                for (int i = 0; i < A_V4; ++i)
+                    ra[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, voffA[i], soA, 0));
+#pragma unroll
+                for (int i = 0; i < B_V4; ++i)
+                    rb[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, voffB[i], soB, 0));
+            } else {
+                loader_fetch<A_KC, BM, A_V4, KB, FAST>(LA, ra[S], g.lda, k0, g.K, g.M, m0, tid, vecA);
+                loader_fetch<B_KC, BN, B_V4, KB, FAST>(LB, rb[S], g.ldb, k0, g.K, g.N, n0, tid, vecB);
+            }
         };
         using S0 = std::integral_constant<int, 0>;
         using S1 = std::integral_constant<int, PF - 1>;
@@ -613,10 +659,27 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? EKAID_SPLIT_OCC_BIG : (TM * TN
             __syncthreads();
             for (int k0 = kbeg; k0 < kend; k0 += KB) {
                 const bool more = (k0 + KB) < kend;
+#if EKAID_SPLIT_ABLATE == 1          // timing-only ablations (results are wrong): 1 = no global loads after the first tile
+                (void)more;
+                compute();
+                __syncthreads();
+                if (more) { lstore(S0{}, !FAST); __syncthreads(); }
+#elif EKAID_SPLIT_ABLATE == 3        // 3 = no conversion / LDS stores after the first tile
+                if (more) gload(S0{}, k0 + KB);
+                compute();
+                __syncthreads();
+#elif EKAID_SPLIT_ABLATE == 4        // 4 = no MFMA phase
+                if (more) gload(S0{}, k0 + KB);
+                __syncthreads();
+                if (more) { lstore(S0{}, !FAST); __syncthreads(); }
+#elif EKAID_SPLIT_ABLATE == 5        // 5 = MFMA phase only
+                compute();
+#else
                 if (more) gload(S0{}, k0 + KB);
                 compute();
                 __syncthreads();
                 if (more) { lstore(S0{}, !FAST); __syncthreads(); }
+#endif
             }
         } else {
             // two K-steps in flight; the loop is unrolled by two so that both register sets are indexed statically.
@@ -641,8 +704,130 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? EKAID_SPLIT_OCC_BIG : (TM * TN
             }
         }
     };
+    // ---- software-pipelined K loop (aligned, unragged problems; KB = 32): the LDS is used as TWO 16-deep stages.  In
+    // stage s every wave multiplies out stage buffer s%2 while it converts the raw registers of stage s+1 into the other
+    // buffer and has the loads of stage s+2 / s+3 in flight: one barrier per 16 k, and every wave carries MFMA and
+    // vector-ALU work at the same time (with separate load / convert / multiply phases the co-resident workgroups of
+    // a CU run their phases in step: measured 48 % MFMA busy + 35 % VALU busy with next to no overlap).
+    auto pipelined = [&]() {
+        constexpr int KS = 16;
+        constexpr int PA = BM * KS / 4 / 256, PB = BN * KS / 4 / 256;       // float4 per thread per stage
+        constexpr int SA_RS = A_KC ? 2 * KS : 2 * BM, SB_RS = B_KC ? 2 * KS : 2 * BN;
+        constexpr int SA_PLANE = (A_KC ? BM : KS) * SA_RS, SB_PLANE = (B_KC ? BN : KS) * SB_RS;
+        constexpr int STAGE_BYTES = 3 * (SA_PLANE + SB_PLANE);
+        unsigned vA[PA], vB[PB];
+        int stA[PA], stB[PB];                 // LDS store offsets inside a plane
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int idx = tid + i * 256;
+            if (A_KC) {
+                const int row = idx >> 2, c4 = idx & 3;
+                vA[i] = ((unsigned)(m0 + row) * (unsigned)g.lda + 4u * c4) * 4u;
+                stA[i] = row * 32 + 16 * ((c4 >> 1) ^ ((row >> 3) & 1)) + 8 * (c4 & 1);
+            } else {
+                vA[i] = ((unsigned)(idx / (BM / 4)) * (unsigned)g.lda + (unsigned)m0 + 4u * (idx % (BM / 4))) * 4u;
+                stA[i] = mc_store_off<BM>(idx);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int idx = tid + i * 256;
+            if (B_KC) {
+                const int row = idx >> 2, c4 = idx & 3;
+                vB[i] = ((unsigned)(n0 + row) * (unsigned)g.ldb + 4u * c4) * 4u;
+                stB[i] = row * 32 + 16 * ((c4 >> 1) ^ ((row >> 3) & 1)) + 8 * (c4 & 1);
+            } else {
+                vB[i] = ((unsigned)(idx / (BN / 4)) * (unsigned)g.ldb + (unsigned)n0 + 4u * (idx % (BN / 4))) * 4u;
+                stB[i] = mc_store_off<BN>(idx);
+            }
+        }
+        // fragment read offsets inside a stage plane: k-contiguous rows are 32 B (two 16-B slots, key = (row >> 3) & 1)
+        int fA[TM], fB[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            fA[i] = A_KC ? (wm + 32 * i + r) * 32 + 16 * (h ^ (((wm + 32 * i + r) >> 3) & 1)) : mc_read_off<BM>(8 * h + tq, wm + 32 * i, tg, tp);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            fB[j] = B_KC ? (wn + 32 * j + r) * 32 + 16 * (h ^ (((wn + 32 * j + r) >> 3) & 1)) : mc_read_off<BN>(8 * h + tq, wn + 32 * j, tg, tp);
+
+        f32x4 pa[2][PA], pb[2][PB];
+        auto gload16 = [&](auto set_tag, int stage) {
+            constexpr int S = decltype(set_tag)::value;
+            const unsigned k = (unsigned)(kbeg + KS * stage);
+            const unsigned soA = (A_KC ? k : k * (unsigned)g.lda) * 4u, soB = (B_KC ? k : k * (unsigned)g.ldb) * 4u;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) pa[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, vA[i], soA, 0));
+#pragma unroll
+            for (int i = 0; i < PB; ++i) pb[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, vB[i], soB, 0));
+        };
+        auto cvt1 = [&](const f32x4& v, char* base, int plane, int off) {
+            u32x2 H, M, L;
+            split4(v, H, M, L);
+            *reinterpret_cast<u32x2*>(base + off) = H;
+            *reinterpret_cast<u32x2*>(base + plane + off) = M;
+            *reinterpret_cast<u32x2*>(base + 2 * plane + off) = L;
+        };
+        // one stage: multiply out buffer `cur`, convert register set S into buffer `cur ^ 1`
+        auto stage = [&](auto set_tag, int cur, bool convert) {
+            constexpr int S = decltype(set_tag)::value;
+            char* const cA = ldsA + cur * STAGE_BYTES;
+            char* const cB = cA + 3 * SA_PLANE;
+            char* const nA = ldsA + (cur ^ 1) * STAGE_BYTES;
+            char* const nB = nA + 3 * SA_PLANE;
+            bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) fa[i][p] = frag(cA + p * SA_PLANE, fA[i], A_KC, SA_RS);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) fb[j][p] = frag(cB + p * SB_PLANE, fB[j], B_KC, SB_RS);
+            constexpr int NCV = PA + PB;                        // conversions to spread over the TM*TN product groups
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                    if (convert) {
+                        const int grp = i * TN + j;
+#pragma unroll
+                        for (int c = 0; c < NCV; ++c) {
+                            if (c * (TM * TN) / NCV != grp) continue;
+                            if (c < PA) cvt1(pa[S][c], nA, SA_PLANE, stA[c]);
+                            else cvt1(pb[S][c - PA], nB, SB_PLANE, stB[c - PA]);
+                        }
+                    }
+                }
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        const int nst = (kend - kbeg) / KS;        // even: (kend - kbeg) % 32 == 0 on this path
+        gload16(S0{}, 0);
+        gload16(S1{}, 1);
+#pragma unroll
+        for (int c = 0; c < PA; ++c) cvt1(pa[0][c], ldsA, SA_PLANE, stA[c]);
+#pragma unroll
+        for (int c = 0; c < PB; ++c) cvt1(pb[0][c], ldsA + 3 * SA_PLANE, SB_PLANE, stB[c]);
+        gload16(S0{}, 2);
+        __syncthreads();
+        for (int s0 = 0; s0 < nst; s0 += 2) {
+            stage(S1{}, 0, true);                  // buffer 0 = stage s0; registers set 1 = stage s0+1 -> buffer 1
+            gload16(S1{}, s0 + 3);
+            __syncthreads();
+            stage(S0{}, 1, s0 + 2 < nst);          // buffer 1 = stage s0+1; set 0 = stage s0+2 -> buffer 0
+            gload16(S0{}, s0 + 4);
+            __syncthreads();
+        }
+    };
     if (kbeg < kend) {
         if (ragged) mainloop(std::false_type{});
+        else if constexpr (PIPE) pipelined();
         else mainloop(std::true_type{});
     }
     write_tiles<TM, TN>(g, acc, m0, n0, wm, wn, r, h, z);
@@ -943,11 +1128,11 @@ static int launch(const GemmArgs& a, int batch, hipStream_t st) {
     return EKAID_OK;
 }
 
-template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF>
+template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE>
 static int launch_split(const GemmArgs& a, int batch, hipStream_t st) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr size_t lds = 3 * 2 * KB * (BM + BN);      // three bf16 planes per operand, unpadded
-    auto kern = gemm_split_kernel<A_KC, B_KC, TM, TN, KB, PF>;
+    auto kern = gemm_split_kernel<A_KC, B_KC, TM, TN, KB, PF, PIPE>;
     if (lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -1099,9 +1284,9 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     const bool akc = !d->transA, bkc = d->transB != 0;
     int rc;
     if (gemm_mode() == 1 && TMN >= 1 && TMN <= 4) {
-#define EKAID_LAUNCH_SPLIT(AK, BKC) (TMN == 2 ? launch_split<AK, BKC, 2, 2, 32, 1>(a, batch, st) \
-                                     : TMN == 1 ? launch_split<AK, BKC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL>(a, batch, st) \
-                                     : TMN == 3 ? launch_split<AK, BKC, 2, 1, 32, 1>(a, batch, st) : launch_split<AK, BKC, 1, 2, 32, 1>(a, batch, st))
+#define EKAID_LAUNCH_SPLIT(AK, BKC) (TMN == 2 ? launch_split<AK, BKC, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG>(a, batch, st) \
+                                     : TMN == 1 ? launch_split<AK, BKC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL, false>(a, batch, st) \
+                                     : TMN == 3 ? launch_split<AK, BKC, 2, 1, 32, 1, false>(a, batch, st) : launch_split<AK, BKC, 1, 2, 32, 1, false>(a, batch, st))
         if (akc && bkc) rc = EKAID_LAUNCH_SPLIT(true, true);
         else if (akc && !bkc) rc = EKAID_LAUNCH_SPLIT(true, false);
         else rc = EKAID_LAUNCH_SPLIT(false, false);
