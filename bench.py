@@ -84,6 +84,21 @@ def train_step(cfg, cd, sp, opt, b, T, graph, marks=None):
     return loss
 
 
+def pmc_traffic(split):
+    """HBM bytes per launch of the dominant GEMM shape from the committed rocprofv3 --pmc summary (PMC counters cannot
+    be read inside this process; the summary is produced by tools_pmc_run.sh, FETCH_SIZE doubled as the gfx950 guide
+    prescribes).  None when the summary for the active arithmetic is not in profiles/."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_gemm_split_nn_18432x1024x1024.json')
+    if not split or not os.path.exists(path):
+        return None
+    d = json.load(open(path))['derived']
+    return {'shape': 'nn 18432x1024x1024 (28 launches per step)',
+            'fetch_bytes_per_launch': d['hbm_fetch_bytes_per_launch_corrected'],
+            'write_bytes_per_launch': d['hbm_write_bytes_per_launch'],
+            'algorithmic_bytes_per_launch': d['algorithmic_read_bytes_per_launch'] + d['algorithmic_write_bytes_per_launch'],
+            'source': 'profiles/r01_pmc_gemm_split_nn_18432x1024x1024.json'}
+
+
 def cpu_baseline(cfg, cd, sp, batch_size, graph):
     """Oracle train fwd+bwd on the host cores, bounded sample (1 warm-up + timed iterations, <= ~25 s)."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -241,7 +256,7 @@ def main():
                 'kernel': ('ekaid::gemm_split_kernel (f32 operands split exactly into 3 bf16, 6 x v_mfma_f32_32x32x16_bf16 '
                            'per product block, f32 accumulate)') if split else 'ekaid::gemm_mfma_kernel (v_mfma_f32_32x32x2_f32)',
                 'achieved': round(executed, 3), 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': round(executed / peak, 4), 'traffic': None,
+                'frac': round(executed / peak, 4), 'traffic': pmc_traffic(split),
                 'executed_flop_per_algorithmic_flop': 6 if split else 1,
                 'algorithmic_f32_tflops': round(alg, 3), 'f32_mfma_peak_tflops': PEAK_F32_MFMA_TFLOPS,
                 'launches_per_step': len(rec) // 2, 'gemm_ms_per_step': round(ms / 2, 3),
