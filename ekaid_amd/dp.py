@@ -152,6 +152,8 @@ class FlatAdam(GradBuckets):
     def step(self):
         self.finish()
         hip.require_cuda(self.pflat)
+        if getattr(self, '_pending_state', None) is not None:
+            self._apply_pending_state()
         if self.m is None:
             self.m = torch.zeros_like(self.pflat)
             self.v = torch.zeros_like(self.pflat)
@@ -160,8 +162,50 @@ class FlatAdam(GradBuckets):
                                             self.total, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count,
                                             1.0 / self.world, hip.stream()), 'adam_step')
 
-    def state_dict(self):
-        return {'step': self.step_count, 'lr': self.lr, 'm': self.m, 'v': self.v}
+    # ------------------------------------------------------------------ checkpointing (SURVEY f-4)
+    def state_dict(self, named_parameters=None):
+        """Optimizer state keyed by parameter NAME (robust against the flat layout, which depends on the order in
+        which the first backward finishes gradients).  ``named_parameters``: iterable of (name, parameter) covering the
+        optimised modules.  The reference saves no optimizer state at all (train_mimic.py:283-287), so a resumed
+        reference run restarts Adam's moments; this one continues bit-exactly."""
+        out = {'step': self.step_count, 'lr': self.lr, 'betas': self.betas, 'eps': self.eps,
+               'exp_avg': {}, 'exp_avg_sq': {}}
+        if self.m is None or named_parameters is None:
+            return out
+        names = {id(p): n for n, p in named_parameters}
+        for p, o in zip(self.live, self.offsets):
+            n = names.get(id(p))
+            if n is None:
+                raise KeyError('FlatAdam.state_dict: a live parameter is missing from named_parameters')
+            k = p.numel()
+            out['exp_avg'][n] = self.m[o:o + k].view(p.shape).detach().cpu().clone()
+            out['exp_avg_sq'][n] = self.v[o:o + k].view(p.shape).detach().cpu().clone()
+        return out
+
+    def load_state_dict(self, state, named_parameters):
+        """Restore ``state_dict`` output.  The moments are applied when the flat storage exists (after the first
+        backward of the resumed run), i.e. before the first ``step()``."""
+        self.step_count = int(state['step'])
+        self.lr = float(state['lr'])
+        self._pending_state = (state, {n: p for n, p in named_parameters})
+        if self.built:
+            self._apply_pending_state()
+
+    def _apply_pending_state(self):
+        state, by_name = self._pending_state
+        self._pending_state = None
+        if not state['exp_avg']:
+            return
+        self.m = torch.zeros_like(self.pflat)
+        self.v = torch.zeros_like(self.pflat)
+        where = {id(p): o for p, o in zip(self.live, self.offsets)}
+        for n, t in state['exp_avg'].items():
+            p = by_name[n]
+            if id(p) not in where:
+                raise KeyError('FlatAdam.load_state_dict: %s has optimizer state but received no gradient' % n)
+            o, k = where[id(p)], p.numel()
+            self.m[o:o + k].copy_(t.reshape(-1).to(self.m.device))
+            self.v[o:o + k].copy_(state['exp_avg_sq'][n].reshape(-1).to(self.v.device))
 
 
 # --------------------------------------------------------------------------- Q-C under data parallelism

@@ -41,6 +41,16 @@ def manual_seed(seed):
     _seed_counter = 0
 
 
+def seed_state():
+    """(base, counter) of the dropout seed stream -- part of a resumable checkpoint."""
+    return (_seed_base, _seed_counter)
+
+
+def set_seed_state(state):
+    global _seed_base, _seed_counter
+    _seed_base, _seed_counter = int(state[0]), int(state[1])
+
+
 def next_seed():
     global _seed_counter
     _seed_counter += 1

@@ -418,3 +418,65 @@ def test_batch_of_one_and_empty_image_flag():
                                            adj1[3], ones['d_bb'], ones['q_bb'], batch['question'])
     for a, r, n in zip(outs, ref, ('pred', 'att_bef', 'att_aft', 'feat_bef', 'feat_aft', 'feat_diff')):
         close(a, r, 1e-4, 'empty_image ' + n)
+
+
+def test_resume_with_optimizer_state_continues_the_run():
+    """SURVEY f-4: parameters + Adam moments/step + dropout seed stream saved after 2 steps and restored into fresh
+    modules give, after 2 more steps, the parameters of an uninterrupted 4-step run (to the run-to-run noise of the
+    float-atomic bias-gradient / embedding-gradient sums, ~1e-7), while a resume WITHOUT the optimizer state -- what
+    the reference's checkpoints allow, train_mimic.py:283-287 -- lands ~lr away."""
+    import io
+    from ekaid_amd import ops
+    from ekaid_amd.dp import FlatAdam
+    batch = make_batch(**SMALL)
+    lr = 1e-3
+
+    def named(cd, sp):
+        return [('cd.' + n, q) for n, q in cd.named_parameters()] + [('sp.' + n, q) for n, q in sp.named_parameters()]
+
+    def steps(cfg, cd, sp, opt, n):
+        for _ in range(n):
+            opt.zero_grad()
+            hip_step(cfg, cd, sp, batch, 'mode2', 'all')[0].backward()
+            opt.step()
+
+    cfg, cd, sp = small_models('all', device=DEV)
+    cd.train(); sp.train()
+    ops.manual_seed(11)
+    opt = FlatAdam([cd, sp], lr=lr)
+    steps(cfg, cd, sp, opt, 4)
+    want = {n: q.detach().clone() for n, q in named(cd, sp)}
+
+    cfg, cd, sp = small_models('all', device=DEV)
+    cd.train(); sp.train()
+    ops.manual_seed(11)
+    opt = FlatAdam([cd, sp], lr=lr)
+    steps(cfg, cd, sp, opt, 2)
+    buf = io.BytesIO()
+    torch.save({'cd': cd.state_dict(), 'sp': sp.state_dict(), 'opt': opt.state_dict(named(cd, sp)),
+                'seeds': ops.seed_state()}, buf)
+
+    def resume(with_optimizer_state):
+        buf.seek(0)
+        ck = torch.load(buf, weights_only=False)
+        cfg, cd2, sp2 = small_models('all', device=DEV)
+        cd2.load_state_dict(ck['cd']); sp2.load_state_dict(ck['sp'])
+        cd2.train(); sp2.train()
+        ops.manual_seed(999)                               # overwritten by the restored stream
+        opt2 = FlatAdam([cd2, sp2], lr=5e-2 if with_optimizer_state else lr)
+        if with_optimizer_state:
+            opt2.load_state_dict(ck['opt'], named(cd2, sp2))
+        ops.set_seed_state(ck['seeds'])
+        steps(cfg, cd2, sp2, opt2, 2)
+        live = {id(q) for q in opt2.live}
+        # parameters whose true gradient is exactly zero move by +-lr on numerical noise under Adam: not comparable
+        g1 = load_golden('f1_all')
+        noisy = set(negligible_grad_names(g1['grad_names'], g1['grad_rows']))
+        return opt2, max(float((q.detach() - want[n]).abs().max()) for n, q in named(cd2, sp2)
+                         if id(q) in live and n not in noisy)
+
+    opt2, err = resume(True)
+    assert opt2.step_count == 4 and opt2.lr == lr
+    assert err <= 2e-5, 'resumed run is %.2e away from the uninterrupted one' % err      # Adam amplifies the ~1e-8 gradient noise of small-gradient entries
+    _, err_no_state = resume(False)
+    assert err_no_state >= 0.2 * lr, 'control: dropping the optimizer state should be visible (%.2e)' % err_no_state

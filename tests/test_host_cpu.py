@@ -143,3 +143,59 @@ def test_decode_sequence_and_checkpoint_layout(tmp_path):
     cfg2, cd2, sp2 = small_models('semantic')
     cd2.load_state_dict(ck['change_detector_state'])
     sp2.load_state_dict(ck['speaker_state'])
+
+
+# --------------------------------------------------------------------------- SURVEY f-3 / f-4 (host logic)
+def test_exact_match_accuracy_total_open_closed():
+    """acc() of evaluate_score.py:216-251: positional pairing, 'what has changed' items skipped, closed = gt in
+    {yes, no}, exact string equality."""
+    from ekaid_amd.evaluate_score import acc_from_lists
+    gt = [{'question': 'is there edema?', 'caption': 'yes'},
+          {'question': 'is there edema?', 'caption': 'no'},
+          {'question': 'where is the opacity?', 'caption': 'left lower lobe'},
+          {'question': 'what has changed compared to the reference image?', 'caption': 'the edema is new'},
+          {'question': 'what level is the effusion?', 'caption': 'small'},
+          {'question': 'is there a pneumothorax?', 'caption': 'no'}]
+    pr = [{'caption': 'yes'}, {'caption': 'yes'}, {'caption': 'left lower lobe'}, {'caption': 'the edema is new'},
+          {'caption': 'moderate'}, {'caption': 'no'}]
+    total, opened, closed = acc_from_lists(gt, pr)
+    assert total == pytest.approx(3 / 5) and opened == pytest.approx(1 / 2) and closed == pytest.approx(2 / 3)
+    import json, tempfile, os
+    from ekaid_amd.evaluate_score import acc
+    with tempfile.TemporaryDirectory() as d:
+        json.dump({'annotations': gt}, open(os.path.join(d, 'gt.json'), 'w'))
+        json.dump(pr, open(os.path.join(d, 'pr.json'), 'w'))
+        assert acc(os.path.join(d, 'pr.json'), os.path.join(d, 'gt.json')) == (total, opened, closed)
+    with pytest.raises(ValueError):
+        acc_from_lists(gt, pr[:2])
+
+
+def test_flat_adam_state_round_trip_is_layout_independent():
+    """Optimizer state is saved per parameter NAME and restored into a flat layout built in a different order."""
+    import torch
+    from ekaid_amd.dp import FlatAdam
+    torch.manual_seed(0)
+
+    def make():
+        return torch.nn.ModuleDict({'a': torch.nn.Linear(3, 5), 'b': torch.nn.Linear(5, 2), 'dead': torch.nn.Linear(2, 2)})
+    m1, m2 = make(), make()
+    m2.load_state_dict(m1.state_dict())
+    x = torch.randn(4, 3)
+    o1 = FlatAdam([m1], lr=1e-3)
+    m1['b'](m1['a'](x)).sum().backward()              # completion order: b then a
+    o1.build()
+    o1.m, o1.v, o1.step_count = torch.randn_like(o1.pflat), torch.rand_like(o1.pflat), 7
+    sd = o1.state_dict(list(m1.named_parameters()))
+    assert set(sd['exp_avg']) == {'a.weight', 'a.bias', 'b.weight', 'b.bias'} and sd['step'] == 7
+    o2 = FlatAdam([m2], lr=5e-4)
+    h = m2['a'](x)
+    (m2['b'](h).sum() + 0 * h.sum()).backward()
+    o2.order.reverse()                                # force a different flat layout
+    o2.build()
+    o2.load_state_dict(sd, list(m2.named_parameters()))
+    assert o2.step_count == 7 and o2.lr == 1e-3
+    names2 = {id(p): n for n, p in m2.named_parameters()}
+    for p, o in zip(o2.live, o2.offsets):
+        n, k = names2[id(p)], p.numel()
+        assert torch.equal(o2.m[o:o + k].view(p.shape), sd['exp_avg'][n])
+        assert torch.equal(o2.v[o:o + k].view(p.shape), sd['exp_avg_sq'][n])

@@ -114,6 +114,7 @@ def main():
     D = cfg.model.change_detector.feat_dim - 2
     change_detector = ChangeDetector(cfg, vocab)
     speaker = DynamicSpeaker(cfg, V)
+    ck = None
     if args.resume:
         ck = load_checkpoint(args.checkpoint)
         change_detector.load_state_dict(ck['change_detector_state'])
@@ -133,7 +134,15 @@ def main():
     shape = dict(N=args.nodes, D=D, Lq=20, T=args.answer_steps, seq_length=cfg.model.speaker.seq_length, V=V)
     iters_per_epoch = 50
 
+    def named():
+        return [('cd.' + n, q) for n, q in change_detector.named_parameters()] + \
+               [('sp.' + n, q) for n, q in speaker.named_parameters()]
+
     t, epoch = 0, 0
+    if ck is not None and 'optimizer_state' in ck:      # a checkpoint of this framework: continue where it stopped
+        optimizer.load_state_dict(ck['optimizer_state'], named())
+        t, epoch = int(ck['iteration']), int(ck['epoch'])
+        ops.set_seed_state(ck['dropout_seed_state'])
     set_mode('train', [change_detector, speaker])
     loss_avg = AverageMeter()
     while t < cfg.train.max_iter:
@@ -141,7 +150,7 @@ def main():
             print('Starting epoch %d' % epoch)
         if epoch > 0 and epoch % o.step_size == 0:
             optimizer.lr = o.lr * (o.gamma ** (epoch // o.step_size))          # StepLR (train_mimic.py:174-177,190)
-        for i in range(iters_per_epoch):
+        for i in range(t - epoch * iters_per_epoch if 0 <= t - epoch * iters_per_epoch < iters_per_epoch else 0, iters_per_epoch):
             if t >= cfg.train.max_iter:
                 break
             t0 = time.time()
@@ -168,8 +177,11 @@ def main():
                                         'avg_total_loss': loss_avg.avg}, time.time() - t0)
             if t % cfg.train.snapshot_interval == 0 or t == cfg.train.max_iter:
                 if rank == 0:
+                    # the reference's three keys (train_mimic.py:283-287) + what a true resume needs
                     checkpoint = {'change_detector_state': change_detector.state_dict(),
-                                  'speaker_state': speaker.state_dict(), 'model_cfg': cfg}
+                                  'speaker_state': speaker.state_dict(), 'model_cfg': cfg,
+                                  'optimizer_state': optimizer.state_dict(named()), 'iteration': t, 'epoch': epoch,
+                                  'dropout_seed_state': ops.seed_state()}
                     save_checkpoint(checkpoint, os.path.join(snapshot_dir, 'checkpoint_%d.pt' % t))
                 set_mode('eval', [change_detector, speaker])
                 with torch.no_grad():
