@@ -817,12 +817,31 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? EKAID_SPLIT_OCC_BIG : (TM * TN
         gload16(S0{}, 2);
         __syncthreads();
         for (int s0 = 0; s0 < nst; s0 += 2) {
+#if EKAID_SPLIT_ABLATE == 6            // timing-only: no conversion / LDS stores in the stages
+            stage(S1{}, 0, false);
+            gload16(S1{}, s0 + 3);
+            __syncthreads();
+            stage(S0{}, 1, false);
+            gload16(S0{}, s0 + 4);
+            __syncthreads();
+#elif EKAID_SPLIT_ABLATE == 7          // timing-only: no barriers
+            stage(S1{}, 0, true);
+            gload16(S1{}, s0 + 3);
+            stage(S0{}, 1, s0 + 2 < nst);
+            gload16(S0{}, s0 + 4);
+#elif EKAID_SPLIT_ABLATE == 8          // timing-only: no global loads in the loop
+            stage(S1{}, 0, true);
+            __syncthreads();
+            stage(S0{}, 1, s0 + 2 < nst);
+            __syncthreads();
+#else
             stage(S1{}, 0, true);                  // buffer 0 = stage s0; registers set 1 = stage s0+1 -> buffer 1
             gload16(S1{}, s0 + 3);
             __syncthreads();
             stage(S0{}, 1, s0 + 2 < nst);          // buffer 1 = stage s0+1; set 0 = stage s0+2 -> buffer 0
             gload16(S0{}, s0 + 4);
             __syncthreads();
+#endif
         }
     };
     if (kbeg < kend) {
