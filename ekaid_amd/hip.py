@@ -81,6 +81,11 @@ SIGNATURES = {
     'ekaid_lstm_cell_bwd': [P, P, P, P, P, P, I, I, P, I, P, P],
     'ekaid_bias_act_drop': [P, I, P, I, I, I, F, U64, P, P],
     'ekaid_drop_act_bwd': [P, P, I, I, I, I, F, U64, P, I, P],
+    'ekaid_spk_modmix_fwd': [P, I, I, P, P, P, P, P, I, P, P, P, I, P],
+    'ekaid_spk_modmix_bwd': [P, P, P, P, I, I, P, I, P, P, P, I, P, P, P, P, P, P],
+    'ekaid_spk_pos_fwd': [P, I, P, I, I, P, P, I, P, P, F, U64, F, U64, P, P, P, P, I, P],
+    'ekaid_spk_pos_bwd': [P, I, P, P, I, I, P, P, P, I, F, U64, F, U64, P, P, I, P],
+    'ekaid_spk_gate_bwd': [P, P, P, L, P, P],
     'ekaid_softmax_fwd': [P, P, L, I, I, P],
     'ekaid_softmax_bwd': [P, P, P, L, I, I, P],
     'ekaid_mix3_fwd': [P, P, P, P, I, I, P, P],

@@ -114,11 +114,10 @@ class SpeakerSeqFn(Function):
         VP = torch.empty(T, B, R, **f32)          # dropout(relu(pos1(h_lang)))
         DP = torch.empty(T, B, 16, **f32)         # dropout(weight_pos(vpos))   (= output_pos of the core)
         PW = torch.empty(T, B, 16, **f32)
-        PP = torch.empty(T, B, R, **f32)
+        PA = torch.empty(T, B, R + A, **f32)      # [pos_feat | att_feat]: the two trailing inputs of the gate MLP, one GEMM operand
         AT = torch.empty(T, B, A, **f32)
         GT = torch.empty(T, B, A, **f32)          # gate (sigmoid)
         GA = torch.empty(T, B, A, **f32)          # gated att feat
-        tmp3 = torch.empty(B, 3, **f32)
 
         for t in range(T):
             o_prev, o_t = t * B * R, (t + 1) * B * R
@@ -131,23 +130,20 @@ class SpeakerSeqFn(Function):
             check(L.ekaid_lstm_cell_fwd(GXA.data_ptr() + 4 * t * B * 4 * R, HLW.data_ptr() + 4 * ow, NW,
                                         CA.data_ptr() + 4 * o_prev, B, R, HA.data_ptr() + 4 * o_t, CA.data_ptr() + 4 * o_t,
                                         SA.data_ptr() + 4 * t * B * 4 * R, stream()), 'lstm_cell_fwd')
-            # 2. module weights
-            _nt(HA, o_t, R, w_fc, 0, R, tmp3, 0, 3, B, 3, R, bias=b_fc)
-            check(L.ekaid_softmax_fwd(ptr(tmp3), MW.data_ptr() + 4 * t * B * 3, B, 3, 0, stream()), 'softmax_fwd')
-            # 3. POS branch: vpos = dropout(relu(block 1 + b)); dpos = dropout(W vpos + b) in the GEMM epilogue
-            check(L.ekaid_bias_act_drop(HLW.data_ptr() + 4 * (ow + oP1), NW, ptr(b_p1), B, R, ACT_RELU, p, sv,
-                                        VP.data_ptr() + 4 * t * B * R, stream()), 'bias_act_drop')
-            gemm(VP, w_wp, DP, B, 16, R, R, R, 16, 0, 1, bias=b_wp, a_off=t * B * R, c_off=t * B * 16, drop_p=p5, drop_seed=sd)
-            check(L.ekaid_softmax_fwd(DP.data_ptr() + 4 * t * B * 16, PW.data_ptr() + 4 * t * B * 16, B, 16, 0, stream()),
-                  'softmax_fwd')
-            _nt(PW, t * B * 16, 16, w_p2, 0, 16, PP, t * B * R, R, B, R, 16, bias=b_p2)
-            # 4. attended feature
-            check(L.ekaid_mix3_fwd(MW.data_ptr() + 4 * t * B * 3, ptr(bef), ptr(diff), ptr(aft), B, A,
-                                   AT.data_ptr() + 4 * t * B * A, stream()), 'mix3_fwd')
-            # 5. gate MLP: block 2 += ppos W[:, R:2R]^T += att W[:, 2R:]^T + b, relu, dropout (in place, last epilogue)
-            _nt(PP, t * B * R, R, w_g1, R, G1, HLW, ow + oG1, NW, B, G1, R, acc=True)
-            gemm(AT, w_g1, HLW, B, G1, A, A, G1, NW, 0, 1, accumulate=True, bias=b_g1, act=ACT_RELU, a_off=t * B * A,
-                 b_off=2 * R, c_off=ow + oG1, drop_p=p, drop_seed=sg)
+            # 2.+4. module weights and attended feature: fc -> softmax(3) -> mix of (bef, diff, aft), one kernel;
+            #        att goes to AT[t] and to the right part of PA[t]
+            check(L.ekaid_spk_modmix_fwd(HA.data_ptr() + 4 * o_t, B, R, ptr(w_fc), ptr(b_fc), ptr(bef), ptr(diff), ptr(aft), A,
+                                         MW.data_ptr() + 4 * t * B * 3, AT.data_ptr() + 4 * t * B * A,
+                                         PA.data_ptr() + 4 * (t * B * (R + A) + R), R + A, stream()), 'spk_modmix_fwd')
+            # 3. POS chain: relu/dropout(block 1 + b) -> weight_pos -> dropout -> softmax -> pos2, one kernel;
+            #    pos_feat goes to the left part of PA[t]
+            check(L.ekaid_spk_pos_fwd(HLW.data_ptr() + 4 * (ow + oP1), NW, ptr(b_p1), B, R, ptr(w_wp), ptr(b_wp), 16, ptr(w_p2),
+                                      ptr(b_p2), p, sv, p5, sd, VP.data_ptr() + 4 * t * B * R, DP.data_ptr() + 4 * t * B * 16,
+                                      PW.data_ptr() + 4 * t * B * 16, PA.data_ptr() + 4 * t * B * (R + A), R + A, stream()),
+                  'spk_pos_fwd')
+            # 5. gate MLP: block 2 += [pos_feat | att] W[:, R:]^T + b, relu, dropout (in place, GEMM epilogue)
+            gemm(PA, w_g1, HLW, B, G1, R + A, R + A, G1, NW, 0, 1, accumulate=True, bias=b_g1, act=ACT_RELU,
+                 a_off=t * B * (R + A), b_off=R, c_off=ow + oG1, drop_p=p, drop_seed=sg)
             _nt(HLW, ow + oG1, NW, w_g2, 0, G1, GT, t * B * A, A, B, A, G1, bias=b_g2, act=ACT_SIGMOID)
             check(L.ekaid_mul(GT.data_ptr() + 4 * t * B * A, AT.data_ptr() + 4 * t * B * A, GA.data_ptr() + 4 * t * B * A,
                               B * A, stream()), 'mul')
@@ -169,7 +165,7 @@ class SpeakerSeqFn(Function):
 
         ctx.dims = (T, B, A, E, R, We, V, G1)
         ctx.pp = (p, p5, seeds, seeds_t)
-        ctx.save_for_backward(bef, aft, diff, tok_tb, embed_pre, ED, Xd, HA, CA, HL, CL, SA, SL, MW, VP, PW, PP, AT,
+        ctx.save_for_backward(bef, aft, diff, tok_tb, embed_pre, ED, Xd, HA, CA, HL, CL, SA, SL, MW, VP, PW, PA, AT,
                               HLW, GT, GA, HO, logp, logpos, emb, w_e, wih_a, whh_a, w_fc, w_wp, w_p2, w_g1, w_g2,
                               wih_l, w_lo, Wcat)
         ctx.mark_non_differentiable(MW)
@@ -177,7 +173,7 @@ class SpeakerSeqFn(Function):
 
     @staticmethod
     def backward(ctx, dlogp, dlogpos, _dmw):
-        (bef, aft, diff, tok_tb, embed_pre, ED, Xd, HA, CA, HL, CL, SA, SL, MW, VP, PW, PP, AT, HLW, GT, GA, HO,
+        (bef, aft, diff, tok_tb, embed_pre, ED, Xd, HA, CA, HL, CL, SA, SL, MW, VP, PW, PA, AT, HLW, GT, GA, HO,
          logp, logpos, emb, w_e, wih_a, whh_a, w_fc, w_wp, w_p2, w_g1, w_g2, wih_l, w_lo, Wcat) = ctx.saved_tensors
         T, B, A, E, R, We, V, G1 = ctx.dims
         NW = 9 * R + G1
@@ -206,7 +202,7 @@ class SpeakerSeqFn(Function):
         DCAT = torch.empty(T, B, NW, **f32)       # [d att gates | d pos1 pre-act | d gate1x pre-act | d lang gates] per step
         DZFC = torch.empty(T, B, 3, **f32)
         DWP = torch.empty(T, B, 16, **f32)
-        DPP = torch.empty(T, B, R, **f32)
+        DPA = torch.empty(T, B, R + A, **f32)     # [d pos_feat | d att_feat (gate-MLP path)] per step, one dgrad GEMM
         DZ2 = torch.empty(T, B, A, **f32)
         d_bef = torch.zeros(B, A, **f32)
         d_diff = torch.zeros(B, A, **f32)
@@ -219,12 +215,7 @@ class SpeakerSeqFn(Function):
         dh_a_prev = torch.empty(B, R, **f32)
         dc_tmp = torch.empty(B, R, **f32)
         t_BA = torch.empty(B, A, **f32)
-        t_BA2 = torch.empty(B, A, **f32)
         t_BG = torch.empty(B, G1, **f32)
-        t_BR = torch.empty(B, R, **f32)
-        t_B16 = torch.empty(B, 16, **f32)
-        t_B16b = torch.empty(B, 16, **f32)
-        t_B3 = torch.empty(B, 3, **f32)
 
         for t in range(T - 1, -1, -1):
             o_prev, o_t = t * B * R, (t + 1) * B * R
@@ -236,33 +227,24 @@ class SpeakerSeqFn(Function):
                                         DCAT.data_ptr() + 4 * (ow + oGL), NW, ptr(dc_tmp), stream()), 'lstm_cell_bwd')
             dc_l, dc_tmp = dc_tmp, dc_l
             _nn(DCAT, ow + oGL, NW, wih_l, We, We + A, t_BA, 0, A, B, A, 4 * R)                  # d gated
-            # 5'. gated = gate * att ; gate = sigmoid(W_g2 g1d + b)
-            check(L.ekaid_mul(ptr(t_BA), AT.data_ptr() + 4 * t * B * A, ptr(t_BA2), B * A, stream()), 'mul')   # d gate
-            check(L.ekaid_act_bwd(ptr(t_BA2), GT.data_ptr() + 4 * t * B * A, DZ2.data_ptr() + 4 * t * B * A, B * A,
-                                  ACT_SIGMOID, stream()), 'act_bwd')
-            check(L.ekaid_mul(ptr(t_BA), GT.data_ptr() + 4 * t * B * A, ptr(t_BA2), B * A, stream()), 'mul')   # d att (part 1)
+            # 5'. gated = gate * att ; gate = sigmoid(W_g2 g1d + b):  d z2 = d gated * att * gate'
+            check(L.ekaid_spk_gate_bwd(ptr(t_BA), AT.data_ptr() + 4 * t * B * A, GT.data_ptr() + 4 * t * B * A, B * A,
+                                       DZ2.data_ptr() + 4 * t * B * A, stream()), 'spk_gate_bwd')
             _nn(DZ2, t * B * A, A, w_g2, 0, G1, t_BG, 0, G1, B, G1, A)                            # d g1d
             check(L.ekaid_drop_act_bwd(ptr(t_BG), HLW.data_ptr() + 4 * (ow + oG1), NW, B, G1, ACT_RELU, p, sg,
                                        DCAT.data_ptr() + 4 * (ow + oG1), NW, stream()), 'drop_act_bwd')
-            _nn(DCAT, ow + oG1, NW, w_g1, R, G1, DPP, t * B * R, R, B, R, G1)                     # d ppos
-            _nn(DCAT, ow + oG1, NW, w_g1, 2 * R, G1, t_BA2, 0, A, B, A, G1, acc=True)             # d att (total)
-            # 4'. att = mix3(mw, bef, diff, aft)
-            check(L.ekaid_mix3_bwd(MW.data_ptr() + 4 * t * B * 3, ptr(bef), ptr(diff), ptr(aft), ptr(t_BA2), B, A, ptr(t_B3),
-                                   ptr(d_bef), ptr(d_diff), ptr(d_aft), 1, stream()), 'mix3_bwd')
-            # 3'. POS branch
-            _nn(DPP, t * B * R, R, w_p2, 0, 16, t_B16, 0, 16, B, 16, R)                           # d pos_weights
-            check(L.ekaid_softmax_bwd(PW.data_ptr() + 4 * t * B * 16, ptr(t_B16), ptr(t_B16b), B, 16, 0, stream()),
-                  'softmax_bwd')
-            check(L.ekaid_axpby(ptr(t_B16b), dDPl.data_ptr() + 4 * t * B * 16, ptr(t_B16b), B * 16, 1.0, 1.0, stream()),
-                  'axpby')
-            _drop(t_B16b, DWP, B * 16, p5, sd, 0, t * B * 16)                                     # d weight_pos output
-            _nn(DWP, t * B * 16, 16, w_wp, 0, R, t_BR, 0, R, B, R, 16)                            # d vpos (post-dropout)
-            check(L.ekaid_drop_act_bwd(ptr(t_BR), VP.data_ptr() + 4 * t * B * R, R, B, R, ACT_RELU, p, sv,
-                                       DCAT.data_ptr() + 4 * (ow + oP1), NW, stream()), 'drop_act_bwd')
-            # 2'. module weights
-            check(L.ekaid_softmax_bwd(MW.data_ptr() + 4 * t * B * 3, ptr(t_B3), DZFC.data_ptr() + 4 * t * B * 3, B, 3, 0,
-                                      stream()), 'softmax_bwd')
-            _nn(DZFC, t * B * 3, 3, w_fc, 0, R, dh_a, 0, R, B, R, 3, acc=True)                    # += into h_att_t gradient
+            # [d pos_feat | d att (gate-MLP path)] = d gate1x . W_g1[:, R:]   (one GEMM, N = R + A)
+            _nn(DCAT, ow + oG1, NW, w_g1, R, G1, DPA, t * B * (R + A), R + A, B, R + A, G1)
+            # 4'.+2'. att = mix3(mw, bef, diff, aft); d att = gate-MLP path + d gated * gate; module weights: softmax, fc
+            check(L.ekaid_spk_modmix_bwd(MW.data_ptr() + 4 * t * B * 3, ptr(bef), ptr(diff), ptr(aft), B, A,
+                                         DPA.data_ptr() + 4 * (t * B * (R + A) + R), R + A, ptr(t_BA), GT.data_ptr() + 4 * t * B * A,
+                                         ptr(w_fc), R, DZFC.data_ptr() + 4 * t * B * 3, ptr(d_bef), ptr(d_diff), ptr(d_aft),
+                                         ptr(dh_a), stream()), 'spk_modmix_bwd')
+            # 3'. POS chain
+            check(L.ekaid_spk_pos_bwd(DPA.data_ptr() + 4 * t * B * (R + A), R + A, PW.data_ptr() + 4 * t * B * 16,
+                                      dDPl.data_ptr() + 4 * t * B * 16, B, 16, ptr(w_p2), ptr(w_wp), VP.data_ptr() + 4 * t * B * R, R,
+                                      p, sv, p5, sd, DWP.data_ptr() + 4 * t * B * 16, DCAT.data_ptr() + 4 * (ow + oP1), NW,
+                                      stream()), 'spk_pos_bwd')
             # 1'. module-attention LSTM
             check(L.ekaid_lstm_cell_bwd(ptr(dh_a), None, ptr(dc_a), SA.data_ptr() + 4 * t * B * 4 * R, CA.data_ptr() + 4 * o_prev,
                                         CA.data_ptr() + 4 * o_t, B, R, DCAT.data_ptr() + 4 * ow, NW, ptr(dc_tmp), stream()),
@@ -295,13 +277,12 @@ class SpeakerSeqFn(Function):
         d_b_wp = torch.empty(16, **f32)
         _colsum(DWP, TB, 16, d_b_wp)
         d_w_p2 = torch.empty_like(w_p2)
-        _tn(DPP, R, PW, 16, d_w_p2, 0, 16, R, 16, TB)
+        _tn(DPA, R + A, PW, 16, d_w_p2, 0, 16, R, 16, TB)
         d_b_p2 = torch.empty(R, **f32)
-        _colsum(DPP, TB, R, d_b_p2)
+        check(L.ekaid_colsum(ptr(DPA), TB, R, R + A, ptr(d_b_p2), stream()), 'colsum')
         d_w_g1 = torch.empty_like(w_g1)
         _tn(DCAT, NW, HL, R, d_w_g1, 0, G1, G1, R, TB, doff=oG1)
-        _tn(DCAT, NW, PP, R, d_w_g1, R, G1, G1, R, TB, doff=oG1)
-        _tn(DCAT, NW, AT, A, d_w_g1, 2 * R, G1, G1, A, TB, doff=oG1)
+        _tn(DCAT, NW, PA, R + A, d_w_g1, R, G1, G1, R + A, TB, doff=oG1)
         d_b_g1 = torch.empty(G1, **f32)
         check(L.ekaid_colsum(DCAT.data_ptr() + 4 * oG1, TB, G1, NW, ptr(d_b_g1), stream()), 'colsum')
         d_w_g2 = torch.empty_like(w_g2)

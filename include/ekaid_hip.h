@@ -186,6 +186,35 @@ int ekaid_lstm_cell_fwd(const float* gx, const float* gh, int ldgh, const float*
 int ekaid_lstm_cell_bwd(const float* dh2, const float* dh2b, const float* dc2, const float* save, const float* c,
                         const float* c2, int B, int H, float* dgates, int lddg, float* dc, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused row-local chains of one decoder step (one workgroup per batch row).
+ * ref: DynamicCore.forward, dynamic_speaker_change_pos.py:104-125 and its autograd backward.
+ *
+ * spk_modmix_fwd : mw = softmax(h . w_fc^T + b_fc) over the 3 modules (:104-106); att = mw0*bef + mw1*diff + mw2*aft
+ *                  (:108-113), written to `att` (contiguous, B x A) and, if att2 != NULL, to att2 (leading dim ld2).
+ * spk_modmix_bwd : d_att = d_att_a[b*lda + k] (+ d_gated*gate if d_gated != NULL: the product rule of gated = gate*att);
+ *                  d_bef/d_diff/d_aft += mw_c * d_att; dz_out = softmax backward of <d_att, feat_c>; dh += dz . w_fc.
+ * spk_pos_fwd    : v = dropout(relu(x + b1), p_v) (mask index b*R + k); dpos = dropout(w_wp v + b_wp, p_d) (mask index
+ *                  b*P + j); pw = softmax(dpos); pp = w_p2 pw + b_p2 (:115-121).  Saves vp (= v), dp (= dpos), pw; pp is
+ *                  written with leading dim ldpp.  R <= 2048, P <= 64.
+ * spk_pos_bwd    : inverse chain: dpp (leading dim lddpp) -> dwp_out (B x P, gradient at the weight_pos output before
+ *                  its dropout's mask was applied in forward, i.e. after dropout backward) and dx_out (gradient at the
+ *                  pos1 pre-activation, leading dim lddx); dhead (B x P, may be NULL) is added at dpos.
+ * spk_gate_bwd   : dz = d_gated * att * gate * (1 - gate)     (gated = sigmoid(z) * att, :122-125)
+ * ------------------------------------------------------------------------------------------ */
+int ekaid_spk_modmix_fwd(const float* h, int B, int R, const float* w_fc, const float* b_fc, const float* bef, const float* diff,
+                         const float* aft, int A, float* mw, float* att, float* att2, int ld2, void* stream);
+int ekaid_spk_modmix_bwd(const float* mw, const float* bef, const float* diff, const float* aft, int B, int A,
+                         const float* d_att_a, int lda, const float* d_gated, const float* gate, const float* w_fc, int R,
+                         float* dz_out, float* d_bef, float* d_diff, float* d_aft, float* dh, void* stream);
+int ekaid_spk_pos_fwd(const float* x, int ldx, const float* b1, int B, int R, const float* w_wp, const float* b_wp, int P,
+                      const float* w_p2, const float* b_p2, float p_v, uint64_t seed_v, float p_d, uint64_t seed_d,
+                      float* vp, float* dp, float* pw, float* pp, int ldpp, void* stream);
+int ekaid_spk_pos_bwd(const float* dpp, int lddpp, const float* pw, const float* dhead, int B, int P, const float* w_p2,
+                      const float* w_wp, const float* vp, int R, float p_v, uint64_t seed_v, float p_d, uint64_t seed_d,
+                      float* dwp_out, float* dx_out, int lddx, void* stream);
+int ekaid_spk_gate_bwd(const float* d_gated, const float* att, const float* gate, long long n, float* dz, void* stream);
+
 /* out[r][c] = dropout(act(x[r*ldx + c] + bias[c]))   (contiguous out; mask index r*cols + c)
  * drop_act_bwd: out[r*ldo + c] = dy[r][c] * keep(seed, r*cols + c)/(1-p) * act'(y[r*ldy + c])  (y = activation output,
  * possibly after the same dropout: a dropped element has zero gradient either way) */

@@ -502,3 +502,136 @@ def test_gat_attention_fused_and_composed(N, M, A, H, direction, with_geo):
         gg = _grads([out], ins_g)
         for n, a, r in zip(('dq', 'dk', 'dS', 'dlbias', 'dgeo'), gg, gr):
             check(a, r.float(), 5e-5, '%s %s' % (n, impl))
+
+
+# --------------------------------------------------------------------------- fused decoder-step chains (speaker.hip)
+def _stream():
+    from ekaid_amd import hip
+    return hip.stream()
+
+
+@pytest.mark.parametrize('B,R,A', [(5, 64, 96), (256, 512, 1024), (1, 300, 40)])
+def test_spk_modmix_fwd_bwd(B, R, A):
+    """fc -> softmax(3) -> mix3 and its backward (incl. the gated-product term and both accumulations) vs float64."""
+    from ekaid_amd import hip
+    L = hip.lib()
+    h, w_fc, b_fc = rnd(B, R, seed=1), rnd(3, R, seed=2, scale=0.2), rnd(3, seed=3)
+    feats = [rnd(B, A, seed=4 + i) for i in range(3)]
+    hd, wd, bd = h.double().requires_grad_(), w_fc.double(), b_fc.double()
+    fd = [f.double().requires_grad_() for f in feats]
+    z = hd @ wd.t() + bd
+    z.retain_grad()
+    mwd = torch.softmax(z, 1)
+    attd = mwd[:, 0:1] * fd[0] + mwd[:, 1:2] * fd[1] + mwd[:, 2:3] * fd[2]
+    g = [t.to(DEV) for t in (h, w_fc, b_fc, *feats)]
+    mw = torch.empty(B, 3, device=DEV)
+    att = torch.empty(B, A, device=DEV)
+    wide = torch.full((B, A + 7), float('nan'), device=DEV)
+    hip.check(L.ekaid_spk_modmix_fwd(hip.ptr(g[0]), B, R, hip.ptr(g[1]), hip.ptr(g[2]), hip.ptr(g[3]), hip.ptr(g[4]), hip.ptr(g[5]), A,
+                                     hip.ptr(mw), hip.ptr(att), wide.data_ptr() + 4 * 7, A + 7, _stream()), 'fwd')
+    check(mw, mwd, 2e-6, 'module weights')
+    check(att, attd, 2e-6, 'attended feature')
+    assert torch.equal(wide[:, 7:], att) and torch.isnan(wide[:, :7]).all()
+    # backward: d_att = d_att_a (strided) + d_gated * gate
+    d_a, d_g, gate = rnd(B, A + 3, seed=20), rnd(B, A, seed=21), torch.sigmoid(rnd(B, A, seed=22))
+    d_att = d_a[:, 3:].double() + d_g.double() * gate.double()
+    attd.backward(d_att)
+    dz = torch.empty(B, 3, device=DEV)
+    acc0 = [rnd(B, A, seed=30 + i) for i in range(3)]
+    dh0 = rnd(B, R, seed=40)
+    dacc = [t.clone().to(DEV) for t in acc0]
+    dh = dh0.clone().to(DEV)
+    d_a_dev, d_g_dev, gate_dev = d_a.to(DEV), d_g.to(DEV), gate.to(DEV)      # keep the device copies alive across the call
+    hip.check(L.ekaid_spk_modmix_bwd(hip.ptr(mw), hip.ptr(g[3]), hip.ptr(g[4]), hip.ptr(g[5]), B, A, d_a_dev.data_ptr() + 4 * 3, A + 3,
+                                     hip.ptr(d_g_dev), hip.ptr(gate_dev), hip.ptr(g[1]), R, hip.ptr(dz), hip.ptr(dacc[0]),
+                                     hip.ptr(dacc[1]), hip.ptr(dacc[2]), hip.ptr(dh), _stream()), 'bwd')
+    check(dz, z.grad, 3e-5, 'd logits')        # s_c - <mw, s> cancels
+    for i in range(3):
+        check(dacc[i], acc0[i].double() + fd[i].grad, 5e-6, 'd feat %d (accumulated)' % i)
+    check(dh, dh0.double() + hd.grad, 5e-6, 'd h (accumulated)')
+
+
+@pytest.mark.parametrize('B,R,P', [(7, 64, 16), (256, 512, 16), (3, 100, 5)])
+def test_spk_pos_chain_fwd_bwd_vs_float64(B, R, P):
+    """relu(x+b) -> weight_pos -> softmax -> pos2 and its backward, dropout off, strided in/out, vs float64."""
+    from ekaid_amd import hip
+    L = hip.lib()
+    x, b1 = rnd(B, R + 5, seed=1), rnd(R, seed=2)
+    w_wp, b_wp, w_p2, b_p2 = rnd(P, R, seed=3, scale=0.3), rnd(P, seed=4), rnd(R, P, seed=5), rnd(R, seed=6)
+    xd = x[:, 5:].double().requires_grad_()
+    v = torch.relu(xd + b1.double())
+    v.retain_grad()
+    dposd = v @ w_wp.double().t() + b_wp.double()
+    dposd.retain_grad()
+    pwd = torch.softmax(dposd, 1)
+    ppd = pwd @ w_p2.double().t() + b_p2.double()
+    dev = lambda t: t.to(DEV)
+    xg = dev(x)
+    vp, dp, pw = torch.empty(B, R, device=DEV), torch.empty(B, P, device=DEV), torch.empty(B, P, device=DEV)
+    pp = torch.full((B, R + 2), float('nan'), device=DEV)
+    W = [dev(t) for t in (b1, w_wp, b_wp, w_p2, b_p2)]
+    hip.check(L.ekaid_spk_pos_fwd(xg.data_ptr() + 4 * 5, R + 5, hip.ptr(W[0]), B, R, hip.ptr(W[1]), hip.ptr(W[2]), P, hip.ptr(W[3]),
+                                  hip.ptr(W[4]), 0.0, 1, 0.0, 2, hip.ptr(vp), hip.ptr(dp), hip.ptr(pw), hip.ptr(pp), R + 2, _stream()),
+              'pos fwd')
+    check(vp, v, 1e-6, 'vpos'); check(dp, dposd, 3e-6, 'dpos'); check(pw, pwd, 3e-6, 'pos weights')
+    check(pp[:, :R], ppd, 3e-6, 'pos feat')
+    assert torch.isnan(pp[:, R:]).all()
+    dpp, dhead = rnd(B, R + 4, seed=9), rnd(B, P, seed=10)
+    ppd.backward(dpp[:, :R].double(), retain_graph=True)
+    dposd.backward(dhead.double())
+    dwp = torch.empty(B, P, device=DEV)
+    dx = torch.full((B, R + 1), float('nan'), device=DEV)
+    dpp_dev, dhead_dev = dev(dpp), dev(dhead)
+    hip.check(L.ekaid_spk_pos_bwd(hip.ptr(dpp_dev), R + 4, hip.ptr(pw), hip.ptr(dhead_dev), B, P, hip.ptr(W[3]), hip.ptr(W[1]),
+                                  hip.ptr(vp), R, 0.0, 1, 0.0, 2, hip.ptr(dwp), hip.ptr(dx), R + 1, _stream()), 'pos bwd')
+    check(dwp, dposd.grad, 5e-6, 'd weight_pos output')
+    check(dx[:, :R], xd.grad, 5e-6, 'd pos1 pre-activation')
+    assert torch.isnan(dx[:, R:]).all()
+
+
+def test_spk_pos_chain_with_dropout_equals_the_unfused_kernel_sequence():
+    """With both dropouts on, the fused chain reproduces the sequence of stand-alone kernels it replaces (same
+    counter-based masks: (seed_v, b*R + k) and (seed_d, b*P + j)), forward and backward."""
+    from ekaid_amd import hip, ops
+    from ekaid_amd.hip import ACT_RELU
+    from ekaid_amd.speaker_seq import _nt, _nn, _drop
+    L = hip.lib()
+    B, R, P, pv, pd, sv, sd = 64, 256, 16, 0.3, 0.5, 1234567, 7654321
+    dev = lambda t: t.to(DEV)
+    x, b1 = dev(rnd(B, R, seed=1)), dev(rnd(R, seed=2))
+    w_wp, b_wp, w_p2, b_p2 = dev(rnd(P, R, seed=3, scale=0.3)), dev(rnd(P, seed=4)), dev(rnd(R, P, seed=5)), dev(rnd(R, seed=6))
+    e = lambda *s: torch.empty(*s, device=DEV)
+    vp, dp, pw, pp = e(B, R), e(B, P), e(B, P), e(B, R)
+    hip.check(L.ekaid_spk_pos_fwd(hip.ptr(x), R, hip.ptr(b1), B, R, hip.ptr(w_wp), hip.ptr(b_wp), P, hip.ptr(w_p2), hip.ptr(b_p2),
+                                  pv, sv, pd, sd, hip.ptr(vp), hip.ptr(dp), hip.ptr(pw), hip.ptr(pp), R, _stream()), 'fused fwd')
+    vp2, dp2, pw2, pp2 = e(B, R), e(B, P), e(B, P), e(B, R)
+    hip.check(L.ekaid_bias_act_drop(hip.ptr(x), R, hip.ptr(b1), B, R, ACT_RELU, pv, sv, hip.ptr(vp2), _stream()), 'bias_act_drop')
+    ops.gemm(vp2, w_wp, dp2, B, P, R, R, R, P, 0, 1, bias=b_wp, drop_p=pd, drop_seed=sd)
+    hip.check(L.ekaid_softmax_fwd(hip.ptr(dp2), hip.ptr(pw2), B, P, 0, _stream()), 'softmax')
+    _nt(pw2, 0, P, w_p2, 0, P, pp2, 0, R, B, R, P, bias=b_p2)
+    assert torch.equal(vp, vp2) and 0.2 < float((vp == 0).float().mean()) < 0.9
+    check(dp, dp2, 3e-6, 'dpos'); check(pw, pw2, 3e-6, 'pos weights'); check(pp, pp2, 3e-6, 'pos feat')
+    assert torch.equal(dp == 0, dp2 == 0) and float((dp == 0).float().mean()) > 0.2
+    dpp, dhead = dev(rnd(B, R, seed=9)), dev(rnd(B, P, seed=10))
+    dwp, dx = e(B, P), e(B, R)
+    hip.check(L.ekaid_spk_pos_bwd(hip.ptr(dpp), R, hip.ptr(pw), hip.ptr(dhead), B, P, hip.ptr(w_p2), hip.ptr(w_wp), hip.ptr(vp), R,
+                                  pv, sv, pd, sd, hip.ptr(dwp), hip.ptr(dx), R, _stream()), 'fused bwd')
+    t16, t16b, dwp2, tR, dx2 = e(B, P), e(B, P), e(B, P), e(B, R), e(B, R)
+    _nn(dpp, 0, R, w_p2, 0, P, t16, 0, P, B, P, R)
+    hip.check(L.ekaid_softmax_bwd(hip.ptr(pw), hip.ptr(t16), hip.ptr(t16b), B, P, 0, _stream()), 'softmax_bwd')
+    hip.check(L.ekaid_axpby(hip.ptr(t16b), hip.ptr(dhead), hip.ptr(t16b), B * P, 1.0, 1.0, _stream()), 'axpby')
+    _drop(t16b, dwp2, B * P, pd, sd)
+    _nn(dwp2, 0, P, w_wp, 0, R, tR, 0, R, B, R, P)
+    hip.check(L.ekaid_drop_act_bwd(hip.ptr(tR), hip.ptr(vp), R, B, R, ACT_RELU, pv, sv, hip.ptr(dx2), R, _stream()), 'drop_act_bwd')
+    check(dwp, dwp2, 5e-6, 'd weight_pos output'); check(dx, dx2, 5e-6, 'd pos1 pre-activation')
+    assert torch.equal(dx == 0, dx2 == 0)
+
+
+def test_spk_gate_bwd():
+    from ekaid_amd import hip
+    n = 256 * 1024 + 3
+    d, a, g = rnd(n, seed=1), rnd(n, seed=2), torch.sigmoid(rnd(n, seed=3))
+    out = torch.empty(n, device=DEV)
+    dd, ad, gd = d.to(DEV), a.to(DEV), g.to(DEV)
+    hip.check(hip.lib().ekaid_spk_gate_bwd(hip.ptr(dd), hip.ptr(ad), hip.ptr(gd), n, hip.ptr(out), _stream()), 'gate')
+    check(out, d.double() * a.double() * g.double() * (1 - g.double()), 1e-6, 'gate derivative')
