@@ -1197,6 +1197,7 @@ static int plan_splitk(int tiles, int K, int batch, long long MN, int BK) {
     static const char* tgt = getenv("EKAID_GEMM_SPLIT_TARGET");   // tuning aid
     const int target = tgt ? atoi(tgt) : 768;     // ~3 workgroups per CU (the register budget admits 3 per SIMD)
     if (tiles * 4 >= target * 3) return 1;
+    if (tiles >= 256 && gemm_mode() == 1) return 1;    // one workgroup per CU already: a 2-way split + reduce kernel measured no faster (256x6656x512: 23 vs 24 us)
     int s = (target + tiles - 1) / tiles;
     const int ksteps = cdiv(K, BK);
     static const char* mk = getenv("EKAID_GEMM_MIN_KSTEPS");     // tuning aid
