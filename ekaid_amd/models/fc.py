@@ -13,6 +13,8 @@ import torch.nn as nn
 from .. import ops
 from ..hip import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
 
+import os
+_UNFUSED_INPUT_DROPOUT = bool(os.environ.get('EKAID_UNFUSED_INPUT_DROPOUT'))
 _ACT_CODE = {None: ACT_NONE, '': ACT_NONE, 'ReLU': ACT_RELU, 'Tanh': ACT_TANH, 'Sigmoid': ACT_SIGMOID}
 
 
@@ -46,8 +48,10 @@ class WNLinear(nn.Module):
         self.weight_v = nn.Parameter(lin.weight.detach().clone())
         self.in_features, self.out_features = in_dim, out_dim
 
-    def forward(self, xs, act=ACT_NONE):
-        return ops.wn_linear(xs, self.weight_v, self.weight_g, self.bias, act)
+    def forward(self, xs, act=ACT_NONE, drops=None):
+        """``drops``: per-input dropout probabilities applied to the inputs inside the linear node (the FCNet's
+        Dropout layer; its backward then rides in the dgrad GEMM epilogue)."""
+        return ops.wn_linear(xs, self.weight_v, self.weight_g, self.bias, act, drops)
 
     def extra_repr(self):
         return 'in_features=%d, out_features=%d, bias=%s' % (self.in_features, self.out_features,
@@ -64,7 +68,7 @@ class FCNet(nn.Module):
         layers = []
         for i in range(len(dims) - 1):
             if 0 < dropout:
-                layers.append(nn.Dropout(dropout))           # marker: applied through ops.dropout
+                layers.append(nn.Dropout(dropout))           # marker: applied inside the following linear node
             layers.append(WNLinear(dims[i], dims[i + 1], bias=bias))
             if '' != act and act is not None:
                 layers.append(getattr(nn, act)())            # marker: fused into the GEMM epilogue
@@ -73,16 +77,19 @@ class FCNet(nn.Module):
 
     def forward(self, x):
         """``x``: tensor or tuple of tensors (feature-axis concatenation)."""
+        pending = 0.0                                        # dropout of the layer input, applied inside the linear node
         for layer in self.main:
             if isinstance(layer, nn.Dropout):
-                if isinstance(x, (tuple, list)):
-                    x = tuple(t.tensor if isinstance(t, PreDropped) else ops.dropout(t, layer.p, self.training) for t in x)
-                else:
-                    x = ops.dropout(x, layer.p, self.training)
+                pending = float(layer.p) if self.training else 0.0
             elif isinstance(layer, WNLinear):
-                if isinstance(x, (tuple, list)):
-                    x = tuple(t.tensor if isinstance(t, PreDropped) else t for t in x)
-                x = layer(x, self.act)
+                xs = x if isinstance(x, (tuple, list)) else (x,)
+                if _UNFUSED_INPUT_DROPOUT and pending > 0.0:     # A/B aid: dropout as a node of its own
+                    xs = tuple(t if isinstance(t, PreDropped) else ops.dropout(t, pending, True) for t in xs)
+                    pending = 0.0
+                drops = tuple(0.0 if isinstance(t, PreDropped) else pending for t in xs)
+                xs = tuple(t.tensor if isinstance(t, PreDropped) else t for t in xs)
+                x = layer(xs if len(xs) > 1 else xs[0], self.act, drops)
+                pending = 0.0
         return x
 
     def input_dropout(self):

@@ -150,11 +150,24 @@ class LinearFn(Function):
     ref: fc.py:15-49, modules.py:195,278-303, dynamic_speaker_change_pos.py:98-125."""
 
     @staticmethod
-    def forward(ctx, W, b, scale, act, *xs):
+    def forward(ctx, W, b, scale, act, drops, *xs):
+        """``drops``: None, or one dropout probability per input (0 = none): the FCNet's input dropout (fc.py:36-37)
+        applied here so that its backward is the epilogue of the dgrad GEMM instead of a pass of its own."""
         require_cuda(W, *xs)
         N, Ktot = W.shape
         W = _c(W)
         xs2, lds = zip(*[_rows2d(x) for x in xs])
+        xs2, lds = list(xs2), list(lds)
+        seeds = [0] * len(xs2)
+        if drops is not None:
+            for i, pd in enumerate(drops):
+                if pd > 0.0:
+                    x = xs2[i] if lds[i] == xs2[i].shape[1] else xs2[i].contiguous()    # mask index = flat index
+                    xd = torch.empty_like(x)
+                    seeds[i] = next_seed()
+                    check(hip.lib().ekaid_dropout(ptr(x), ptr(xd), x.numel(), float(pd), seeds[i], stream()), 'dropout')
+                    xs2[i], lds[i] = xd, xd.shape[1]
+        ctx.drops, ctx.seeds = drops, seeds
         M = xs2[0].shape[0]
         assert sum(x.shape[1] for x in xs2) == Ktot, 'input widths do not add up to in_features'
         y = torch.empty(M, N, device=W.device, dtype=torch.float32)
@@ -199,9 +212,11 @@ class LinearFn(Function):
         off = 0
         for i, x in enumerate(xs2):
             K = x.shape[1]
-            if need[4 + i]:
+            if need[5 + i]:
                 dx = torch.empty(M, K, device=W.device, dtype=torch.float32)
-                gemm(dz, W, dx, M, K, N, N, Ktot, K, 0, 0, alpha_dev=scale, b_off=off)
+                pd = ctx.drops[i] if ctx.drops is not None else 0.0
+                gemm(dz, W, dx, M, K, N, N, Ktot, K, 0, 0, alpha_dev=scale, b_off=off,
+                     drop_p=float(pd), drop_seed=ctx.seeds[i])          # input-dropout backward in the epilogue
                 dxs.append(dx.view(*ctx.lead[i], K))
             else:
                 dxs.append(None)
@@ -218,13 +233,15 @@ class LinearFn(Function):
                 dscale = torch.empty((), device=W.device, dtype=torch.float32)
                 check(L.ekaid_scale_dot(ptr(dW), ptr(W), ptr(scale), dW.numel(), ptr(dscale), stream()),
                       'scale_dot')
-        return (dW, db, dscale, None) + tuple(dxs)
+        return (dW, db, dscale, None, None) + tuple(dxs)
 
 
-def linear(xs, W, b=None, scale=None, act=ACT_NONE):
+def linear(xs, W, b=None, scale=None, act=ACT_NONE, drops=None):
     if isinstance(xs, torch.Tensor):
         xs = (xs,)
-    return LinearFn.apply(W, b, scale, act, *xs)
+    if drops is not None and not any(d > 0.0 for d in drops):
+        drops = None
+    return LinearFn.apply(W, b, scale, act, drops, *xs)
 
 
 class LinearRowStackFn(Function):
@@ -311,8 +328,8 @@ class WNScaleFn(Function):
         return dv, dg.view(g.shape)
 
 
-def wn_linear(xs, v, g, b=None, act=ACT_NONE):
-    return linear(xs, v, b, WNScaleFn.apply(v, g), act)
+def wn_linear(xs, v, g, b=None, act=ACT_NONE, drops=None):
+    return linear(xs, v, b, WNScaleFn.apply(v, g), act, drops)
 
 
 # --------------------------------------------------------------------------- #
