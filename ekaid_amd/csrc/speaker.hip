@@ -152,15 +152,22 @@ __global__ __launch_bounds__(256) void spk_pos_bwd_kernel(const float* dpp, int 
     const int b = blockIdx.x, tid = threadIdx.x;
     for (int k = tid; k < R; k += 256) sd[k] = dpp[(long long)b * lddpp + k];
     __syncthreads();
-    const int l = tid & 15, jg = tid >> 4;
-    for (int j0 = 0; j0 < P; j0 += 16) {
-        const int j = j0 + jg;
+    // dpw_j = sum_k dpp[k] * w_p2[k][j]: thread (kq, j) walks rows k = kq, kq + 256/PG, .. so that a wave reads whole
+    // 64-byte rows of w_p2 (P = 16: 4 rows per 16 lanes... coalesced), partial sums combined through LDS
+    __shared__ float sp[256];
+    {
+        const int PG = P <= 16 ? 16 : (P <= 32 ? 32 : 64);        // lanes per row of w_p2
+        const int j = tid % PG, kq = tid / PG, KQ = 256 / PG;
         float s = 0.f;
         if (j < P)
-            for (int k = l; k < R; k += 16) s += sd[k] * w_p2[(long long)k * P + j];
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
-        if (j < P && l == 0) sg[j] = s;
+            for (int k = kq; k < R; k += KQ) s += sd[k] * w_p2[(long long)k * P + j];
+        sp[tid] = s;
+        __syncthreads();
+        if (tid < P) {
+            float t = 0.f;
+            for (int q = 0; q < KQ; ++q) t += sp[q * PG + tid];
+            sg[tid] = t;
+        }
     }
     __syncthreads();
     if (tid == 0) {
