@@ -251,11 +251,11 @@ __global__ __launch_bounds__(256) void masked_softmax_bwd_kernel(const float* P,
 // s = 0 sin / 1 cos, t = frequency index; dim_mat[t] = 1000^(8t/fd) is the reference's float32 table, built on the host
 // with the same torch expression (mimic_utils.py:195-197) so that no device powf rounding enters the argument.
 __global__ __launch_bounds__(256) void geom_embed_kernel(const double* bb, const float* dim_mat, int R, int N, int M, int fd, float* out) {
+    // one thread per (pair, component): the log-geometry value is computed once and fanned out to the fd/8 frequencies
     const int nf = fd / 8;
-    const long long total = (long long)R * N * M * 4 * nf;
+    const long long total = (long long)R * N * M * 4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int t = (int)(i % nf);
-        long long rest = i / nf;
+        long long rest = i;
         const int comp = (int)(rest % 4); rest /= 4;
         const int j = (int)(rest % M); rest /= M;
         const int ii = (int)(rest % N);
@@ -276,10 +276,14 @@ __global__ __launch_bounds__(256) void geom_embed_kernel(const double* bb, const
         } else {
             v = log(hi / hj);
         }
-        const double arg = (100.0 * v) / (double)dim_mat[t];
         float* o = out + (((r * N + ii) * M + j) * (long long)fd) + comp * (2 * nf);
-        o[t] = (float)sin(arg);
-        o[nf + t] = (float)cos(arg);
+        for (int t = 0; t < nf; ++t) {
+            const double arg = (100.0 * v) / (double)dim_mat[t];
+            double sn, cs;
+            sincos(arg, &sn, &cs);
+            o[t] = (float)sn;
+            o[nf + t] = (float)cs;
+        }
     }
 }
 
@@ -348,9 +352,9 @@ extern "C" int ekaid_masked_softmax_bwd(const float* P, const float* dP, const f
 }
 extern "C" int ekaid_geom_embed(const double* bb, const float* dim_mat, int R, int N, int M, int feat_dim, float* out, void* stream) {
     if (feat_dim % 8) { set_error("geom_embed: feat_dim %% 8 != 0"); return EKAID_ERR_ARG; }
-    const long long total = (long long)R * N * M * 4 * (feat_dim / 8);
+    const long long total = (long long)R * N * M * 4;
     long long b = (total + 255) / 256;
-    if (b > 4096) b = 4096;
+    if (b > 8192) b = 8192;
     if (b < 1) b = 1;
     hipLaunchKernelGGL(geom_embed_kernel, dim3((unsigned)b), dim3(256), 0, ST, bb, dim_mat, R, N, M, feat_dim, out);
     return check_launch("geom_embed");
