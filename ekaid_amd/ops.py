@@ -8,6 +8,8 @@ HIP device -- there is no CPU fallback (the CPU restatement is ``oracle/``, test
 import ctypes
 import math
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -133,7 +135,13 @@ def gemm_profile_end():
 # --------------------------------------------------------------------------- #
 # linear layers:  y = act( scale * sum_i x_i W[:, K_i]^T + b )
 # --------------------------------------------------------------------------- #
-TRANSPOSE_MIN_ROWS = 4096     # forward GEMMs with at least this many rows read a transposed copy of the weight
+TRANSPOSE_MIN_ROWS = int(os.environ.get('EKAID_TRANSPOSE_MIN_ROWS', 4096))     # f32-MFMA arithmetic only: forward GEMMs with at least this many
+                                                                            # rows read a transposed copy of the weight (n-contiguous staging was
+                                                                            # 10 % faster there; the bf16-split kernel is indifferent: measured)
+
+
+def _use_transposed(M):
+    return M >= TRANSPOSE_MIN_ROWS and get_gemm_mode() == GEMM_F32_MFMA
 
 
 def weight_transposed(W):
@@ -171,7 +179,7 @@ class LinearFn(Function):
         M = xs2[0].shape[0]
         assert sum(x.shape[1] for x in xs2) == Ktot, 'input widths do not add up to in_features'
         y = torch.empty(M, N, device=W.device, dtype=torch.float32)
-        Wt = weight_transposed(W) if M >= TRANSPOSE_MIN_ROWS else None
+        Wt = weight_transposed(W) if _use_transposed(M) else None
         off = 0
         for i, (x, ld) in enumerate(zip(xs2, lds)):
             last = i == len(xs2) - 1
@@ -257,7 +265,7 @@ class LinearRowStackFn(Function):
         Ms = [x.shape[0] for x in xs2]
         y = torch.empty(sum(Ms), N, device=W.device, dtype=torch.float32)
         r0 = 0
-        Wt = weight_transposed(W) if sum(Ms) >= TRANSPOSE_MIN_ROWS else None
+        Wt = weight_transposed(W) if _use_transposed(sum(Ms)) else None
         for x, ld, M in zip(xs2, lds, Ms):
             if Wt is not None:
                 gemm(x, Wt, y, M, N, K, ld, N, N, 0, 0, bias=b, c_off=r0 * N)
