@@ -258,7 +258,8 @@ def main():
                 'achieved': round(executed, 3), 'peak': peak, 'unit': 'TFLOP/s',
                 'frac': round(executed / peak, 4), 'traffic': pmc_traffic(split),
                 'executed_flop_per_algorithmic_flop': 6 if split else 1,
-                'algorithmic_f32_tflops': round(alg, 3), 'f32_mfma_peak_tflops': PEAK_F32_MFMA_TFLOPS,
+                'algorithmic_f32_tflops': round(alg, 3), 'algorithmic_peak_tflops': round(peak / (6 if split else 1), 1),
+                'f32_mfma_peak_tflops': PEAK_F32_MFMA_TFLOPS,
                 'launches_per_step': len(rec) // 2, 'gemm_ms_per_step': round(ms / 2, 3),
                 'gemm_flop_per_step': fl / 2,
                 'large_gemm_tflops': round(sum(r[1] for r in big) / (sum(r[0] for r in big) * 1e-3) / 1e12, 3) if big else None,
