@@ -138,6 +138,61 @@ def test_gemm_split_is_exact_on_bf16_representable_products():
             assert torch.equal(C.cpu(), want), (mode, M, N, K, float((C.cpu() - want).abs().max()))
 
 
+def test_gemm_randomised_layouts_alignments_and_epilogues(gemm_arith):
+    """60 seeded random problems per arithmetic: ragged and tile-aligned sizes (the aligned ones take the buffer-load /
+    software-pipelined path), leading dimensions with and without 16-byte alignment, misaligned base offsets,
+    accumulate / bias / activation / scalar combinations, all three operand layouts -- against float64."""
+    from ekaid_amd import ops
+    from ekaid_amd.hip import ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID
+    rng = np.random.RandomState(2024)
+    acts = {ACT_NONE: lambda t: t, ACT_RELU: torch.relu, ACT_TANH: torch.tanh, ACT_SIGMOID: torch.sigmoid}
+    for case in range(60):
+        aligned = case % 3 == 0
+        if aligned:
+            M, N, K = (int(rng.choice([128, 256, 384, 512, 640])), int(rng.choice([128, 256, 384])), int(rng.choice([32, 64, 96, 256, 512])))
+        else:
+            M, N, K = int(rng.randint(1, 700)), int(rng.randint(1, 400)), int(rng.randint(1, 600))
+        mode = ['nt', 'nn', 'tn'][case % 3 if not aligned else (case // 3) % 3]
+        pad = 0 if aligned else int(rng.choice([0, 1, 3, 4]))
+        off = 0 if aligned else int(rng.choice([0, 1, 4]))
+        A = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32))
+        B = torch.from_numpy(rng.standard_normal((K, N)).astype(np.float32))
+
+        def stage(mat):                       # row-major storage with a padded leading dim and a base offset
+            r, c = mat.shape
+            buf = torch.full((off + r * (c + pad),), float('nan'))
+            buf[off:].view(r, c + pad)[:, :c] = mat
+            return buf.to(DEV), c + pad
+        if mode == 'nt':
+            (a, lda), (b, ldb), ta, tb = stage(A), stage(B.t().contiguous()), 0, 1
+        elif mode == 'nn':
+            (a, lda), (b, ldb), ta, tb = stage(A), stage(B), 0, 0
+        else:
+            (a, lda), (b, ldb), ta, tb = stage(A.t().contiguous()), stage(B), 1, 0
+        acc, with_bias = bool(rng.randint(2)), bool(rng.randint(2))
+        act = int(rng.choice([ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID]))
+        alpha = float(rng.choice([1.0, 0.5, -2.0]))
+        ldc = N + (0 if aligned else int(rng.choice([0, 2, 4])))
+        C0 = torch.from_numpy(rng.standard_normal((M, ldc)).astype(np.float32))
+        bias = torch.from_numpy(rng.standard_normal(N).astype(np.float32))
+        C = C0.clone().to(DEV)
+        bias_dev = bias.to(DEV)
+        ops.gemm(a, b, C, M, N, K, lda, ldb, ldc, ta, tb, alpha=alpha, accumulate=acc, bias=bias_dev if with_bias else None,
+                 act=act, a_off=off, b_off=off)
+        want = alpha * (A.double() @ B.double())
+        if acc:
+            want = want + C0[:, :N].double()
+        if with_bias:
+            want = want + bias.double()
+        want = acts[act](want)
+        what = 'case %d %s %dx%dx%d pad %d off %d acc %d bias %d act %d alpha %g' % (case, mode, M, N, K, pad, off, acc, with_bias, act, alpha)
+        scale = float((A.double().abs() @ B.double().abs()).max()) * abs(alpha) + 1.0
+        err = float((C[:, :N].double().cpu() - want).abs().max())
+        assert err <= 4e-6 * scale, '%s: abs err %.3e vs scale %.3e' % (what, err, scale)
+        if ldc > N:
+            assert torch.equal(C[:, N:].cpu(), C0[:, N:]), what + ': wrote outside the N columns'
+
+
 def test_gemm_epilogue_and_strides():
     from ekaid_amd import ops
     from ekaid_amd.hip import ACT_RELU, ACT_SIGMOID, ACT_TANH
