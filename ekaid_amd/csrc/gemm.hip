@@ -852,233 +852,6 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? EKAID_SPLIT_OCC_BIG : (TM * TN
     write_tiles<TM, TN>(g, acc, m0, n0, wm, wn, r, h, z);
 }
 
-// "Direct" variant for the recurrent GEMMs (M = batch rows, a few hundred): the whole problem is ~128 MFMAs per
-// SIMD, i.e. ONE K-step of the tiled kernel, so LDS staging + barriers are pure overhead.  Here every wave owns one
-// 32x32 output tile and streams its A and B fragments straight from global memory (L2/MALL-resident activations and
-// weights) into MFMA operand registers -- no LDS, no barrier, loads of the next 64-deep chunk in flight under the
-// MFMAs of the current one.  Workgroup = 4 waves = a 64x64 block of tiles (the two waves of a row share A lines in
-// L1, the two of a column share B lines).  A must be k-contiguous (transA = 0).
-template <bool B_KC>
-__global__ __launch_bounds__(256) void gemm_direct_kernel(GemmArgs g) {
-    constexpr int U = 8;                          // 8-k groups per chunk (64 k)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int bid = blockIdx.x;
-    const int m0 = (bid / g.tiles_n) * 64 + (wave >> 1) * 32, n0 = (bid % g.tiles_n) * 64 + (wave & 1) * 32;
-    const int z = blockIdx.z;
-    const float* A = g.A; const float* B = g.B;
-    int kbeg = 0, kend = g.K;
-    if (g.splitk > 1) {
-        kbeg = z * g.k_per_split;
-        kend = min(g.K, kbeg + g.k_per_split);
-    } else {
-        const long long z1 = z / g.nb2, z2 = z % g.nb2;
-        A += z1 * g.sA1 + z2 * g.sA2;
-        B += z1 * g.sB1 + z2 * g.sB2;
-    }
-    const bool vecA = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((g.K & 3) == 0);
-    const bool vecB = B_KC && ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((g.K & 3) == 0);
-    const float* arow = A + (long long)min(m0 + r, g.M - 1) * g.lda;
-    const float* brow = B_KC ? B + (long long)min(n0 + r, g.N - 1) * g.ldb : B + min(n0 + r, g.N - 1);
-    f32x16 acc;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) acc[t] = 0.f;
-    f32x4 a[2][U], b[2][U];
-    // fragment of 8-k group at k: lane half h supplies k + 4h .. k + 4h + 3 (same permutation for A and B)
-    auto fetch = [&](int kc, f32x4* fa, f32x4* fb) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int k = kc + 8 * u + 4 * h;
-            if (vecA) fa[u] = *reinterpret_cast<const f32x4*>(arow + min(k, g.K - 4));
-            else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) fa[u][e] = arow[min(k + e, g.K - 1)];
-            }
-            if (B_KC) {
-                if (vecB) fb[u] = *reinterpret_cast<const f32x4*>(brow + min(k, g.K - 4));
-                else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) fb[u][e] = brow[min(k + e, g.K - 1)];
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) fb[u][e] = brow[(long long)min(k + e, g.K - 1) * g.ldb];
-            }
-        }
-    };
-    auto mask = [&](int kc, f32x4* fa) {          // zero the A side beyond kend: kills the product for every ragged k
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int k = kc + 8 * u + 4 * h;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) fa[u][e] = (k + e < kend) ? fa[u][e] : 0.f;
-        }
-    };
-    if (kbeg < kend) {
-        fetch(kbeg, a[0], b[0]);
-        for (int kc = kbeg; kc < kend; kc += 16 * U) {
-            // two chunks per trip so that the register sets are indexed statically
-            if (kc + 8 * U < kend) fetch(kc + 8 * U, a[1], b[1]);
-            if (kc + 8 * U > kend) mask(kc, a[0]);
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][u][j], b[0][u][j], acc, 0, 0, 0);
-            if (kc + 8 * U < kend) {
-                if (kc + 16 * U < kend) fetch(kc + 16 * U, a[0], b[0]);
-                if (kc + 16 * U > kend) mask(kc + 8 * U, a[1]);
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][u][j], b[1][u][j], acc, 0, 0, 0);
-            }
-        }
-    }
-    const bool slab = g.splitk > 1;
-    float* C;
-    int ldc;
-    if (slab) { C = g.ws + (long long)z * g.M * g.N; ldc = g.N; }
-    else {
-        const long long z1 = z / g.nb2, z2 = z % g.nb2;
-        C = g.C + z1 * g.sC1 + z2 * g.sC2;
-        ldc = g.ldc;
-    }
-    const float alpha = g.e.alpha_dev ? g.e.alpha * g.e.alpha_dev[0] : g.e.alpha;
-    const int n = n0 + r;
-    if (n < g.N) {
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int m = m0 + (t & 3) + 8 * (t >> 2) + 4 * h;
-            if (m >= g.M) continue;
-            float* cp = C + (long long)m * ldc + n;
-            if (slab) *cp = acc[t];
-            else {
-                const float cold = g.e.beta ? *cp : 0.f;
-                *cp = epilogue(acc[t], cold, m, n, g.e, alpha);
-            }
-        }
-    }
-}
-
-// "Skinny" variant for the recurrent GEMMs (M = batch rows): 32x32 output tile per workgroup, the four waves
-// split every K-step (wave w contracts the k-groups 8w..8w+7 (+32, ...) of each KB-deep step for the whole tile)
-// and their partial accumulators are summed through LDS.  4x more workgroups than the 64x64 tiling for the same
-// problem and no slab round trip through HBM.
-template <bool A_KC, bool B_KC, int KB>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
-    constexpr int BT = 32;
-    constexpr int NVS = BT * KB / 4 / 256;
-    constexpr int A_ELEMS = A_KC ? BT * (KB + LDS_PAD) : KB * (BT + LDS_PAD);
-    constexpr int B_ELEMS = B_KC ? BT * (KB + LDS_PAD) : KB * (BT + LDS_PAD);
-    constexpr int STAGE = A_ELEMS + B_ELEMS;
-    __shared__ __attribute__((aligned(16))) float lds[(STAGE > 4 * 16 * 64 ? STAGE : 4 * 16 * 64)];
-    float* As = lds;
-    float* Bs = lds + A_ELEMS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int bid = blockIdx.x;
-    const int m0 = (bid / g.tiles_n) * BT, n0 = (bid % g.tiles_n) * BT;
-    const int z = blockIdx.z;
-    const float* A = g.A; const float* B = g.B;
-    int kbeg = 0, kend = g.K;
-    if (g.splitk > 1) {
-        kbeg = z * g.k_per_split;
-        kend = min(g.K, kbeg + g.k_per_split);
-    } else {
-        const long long z1 = z / g.nb2, z2 = z % g.nb2;
-        A += z1 * g.sA1 + z2 * g.sA2;
-        B += z1 * g.sB1 + z2 * g.sB2;
-    }
-    const bool vecA = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (((A_KC ? g.K : g.M) & 3) == 0);
-    const bool vecB = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (((B_KC ? g.K : g.N) & 3) == 0);
-    f32x16 acc;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) acc[t] = 0.f;
-    f32x4 ra[NVS], rb[NVS];
-    TileLoader<NVS> LA, LB;
-    loader_init<A_KC, BT, NVS, KB>(LA, A, g.lda, m0, g.M, g.K, tid, vecA);
-    loader_init<B_KC, BT, NVS, KB>(LB, B, g.ldb, n0, g.N, g.K, tid, vecB);
-    int kload = kbeg;
-    auto gload = [&](int k0) {
-        kload = k0;
-        loader_fetch<A_KC, BT, NVS, KB, false>(LA, ra, g.lda, k0, g.K, g.M, m0, tid, vecA);
-        loader_fetch<B_KC, BT, NVS, KB, false>(LB, rb, g.ldb, k0, g.K, g.N, n0, tid, vecB);
-    };
-    auto lstore = [&]() {
-        loader_mask<A_KC, BT, NVS, KB>(LA, ra, kload, kend, tid);
-        loader_mask<B_KC, BT, NVS, KB>(LB, rb, kload, kend, tid);
-#pragma unroll
-        for (int i = 0; i < NVS; ++i) {
-            const int idx = tid + i * 256;
-            if (A_KC) *reinterpret_cast<f32x4*>(&As[(idx / (KB / 4)) * (KB + LDS_PAD) + 4 * (idx % (KB / 4))]) = ra[i];
-            else *reinterpret_cast<f32x4*>(&As[(idx / (BT / 4)) * (BT + LDS_PAD) + 4 * (idx % (BT / 4))]) = ra[i];
-            if (B_KC) *reinterpret_cast<f32x4*>(&Bs[(idx / (KB / 4)) * (KB + LDS_PAD) + 4 * (idx % (KB / 4))]) = rb[i];
-            else *reinterpret_cast<f32x4*>(&Bs[(idx / (BT / 4)) * (BT + LDS_PAD) + 4 * (idx % (BT / 4))]) = rb[i];
-        }
-    };
-    if (kbeg < kend) {
-        gload(kbeg);
-        lstore();
-        __syncthreads();
-        for (int k0 = kbeg; k0 < kend; k0 += KB) {
-            const bool more = (k0 + KB) < kend;
-            if (more) gload(k0 + KB);
-#pragma unroll
-            for (int kq = 0; kq < KB; kq += 32) {
-                const int kb = kq + 8 * wave;
-                f32x4 a, b;
-                if (A_KC) a = *reinterpret_cast<const f32x4*>(&As[r * (KB + LDS_PAD) + kb + 4 * h]);
-                else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) a[j] = As[(kb + 4 * h + j) * (BT + LDS_PAD) + r];
-                }
-                if (B_KC) b = *reinterpret_cast<const f32x4*>(&Bs[r * (KB + LDS_PAD) + kb + 4 * h]);
-                else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) b[j] = Bs[(kb + 4 * h + j) * (BT + LDS_PAD) + r];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
-            }
-            __syncthreads();
-            if (more) { lstore(); __syncthreads(); }
-        }
-    }
-    // cross-wave reduction through LDS: red[wave][t][lane]
-    float* red = lds;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) red[(wave * 16 + t) * 64 + lane] = acc[t];
-    __syncthreads();
-    const bool slab = g.splitk > 1;
-    float* C;
-    int ldc;
-    if (slab) { C = g.ws + (long long)z * g.M * g.N; ldc = g.N; }
-    else {
-        const long long z1 = z / g.nb2, z2 = z % g.nb2;
-        C = g.C + z1 * g.sC1 + z2 * g.sC2;
-        ldc = g.ldc;
-    }
-    const float alpha = g.e.alpha_dev ? g.e.alpha * g.e.alpha_dev[0] : g.e.alpha;
-    // thread -> 4 consecutive lanes (= 4 consecutive columns) of one accumulator register t
-    const int e0 = tid * 4, t = e0 >> 6, l0 = e0 & 63;
-    const int m = m0 + (t & 3) + 8 * (t >> 2) + 4 * (l0 >> 5);
-    if (m < g.M) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int n = n0 + ((l0 + c) & 31);
-            if (n >= g.N) continue;
-            const float v = red[(0 * 16 + t) * 64 + l0 + c] + red[(1 * 16 + t) * 64 + l0 + c] +
-                            red[(2 * 16 + t) * 64 + l0 + c] + red[(3 * 16 + t) * 64 + l0 + c];
-            float* cp = C + (long long)m * ldc + n;
-            if (slab) *cp = v;
-            else {
-                const float cold = g.e.beta ? *cp : 0.f;
-                *cp = epilogue(v, cold, m, n, g.e, alpha);
-            }
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, float* C, int M, int N, int ldc,
                                                             int splitk, Epi e) {
     const long long total = (long long)M * N;
@@ -1168,20 +941,6 @@ static int launch_split(const GemmArgs& a, int batch, hipStream_t st) {
     return EKAID_OK;
 }
 
-template <bool A_KC, bool B_KC>
-static int launch_skinny(const GemmArgs& a, int batch, hipStream_t st) {
-    dim3 grid(a.tiles_m * a.tiles_n, 1, a.splitk > 1 ? a.splitk : batch);
-    hipLaunchKernelGGL((gemm_skinny_kernel<A_KC, B_KC, BK_SMALL>), grid, dim3(256), 0, st, a);
-    return EKAID_OK;
-}
-
-template <bool B_KC>
-static int launch_direct(const GemmArgs& a, int batch, hipStream_t st) {
-    dim3 grid(a.tiles_m * a.tiles_n, 1, a.splitk > 1 ? a.splitk : batch);
-    hipLaunchKernelGGL((gemm_direct_kernel<B_KC>), grid, dim3(256), 0, st, a);
-    return EKAID_OK;
-}
-
 // arithmetic of the MFMA kernels: 0 = v_mfma_f32_32x32x2_f32, 1 = exact 3-way bf16 split (6 x v_mfma_f32_32x32x16_bf16)
 static int g_gemm_mode = -1;
 static int gemm_mode() {
@@ -1217,34 +976,12 @@ static void plan(const ekaid_gemm_t* d, int& TMN, int& splitk, int& tiles_m, int
     // 4-5 workgroups per CU and quantise better than 128x128 (measured 94 -> 104 TF NT, 114 -> 122 TF NN at N = 1024)
     // (f32 MFMA kernel only: the bf16-split kernel runs 3 workgroups of 128x128 per CU and is faster with them)
     if (TMN == 2 && batch == 1 && d->M >= 4096 && d->N <= 2048 && gemm_mode() == 0) TMN = 3;
-    // skinny problems (recurrent GEMMs, M = batch rows): if 64x64 tiles cannot give every CU two workgroups,
-    // use 32x32 tiles with the K-step split across the four waves (TMN = 0)
-    // (measured: not faster than 64x64 tiles with the 128-deep K-step + split-K, so only on request)
-    static const char* skinny = getenv("EKAID_GEMM_SKINNY");
-    if (skinny && TMN == 1 && (long long)cdiv(d->M, 64) * cdiv(d->N, 64) * batch < 512 && d->K >= 64) TMN = 0;
-    // recurrent GEMMs (a few hundred rows, k-contiguous A): LDS-free direct-fragment kernel (TMN = 5)
-    // (measured 28 TF vs 49 TF for the LDS-staged 64x64 kernel at 256x2048x1024: fragment-shaped global loads are
-    //  TA-bound -- kept for experiments only)
-    static const char* direct = getenv("EKAID_GEMM_DIRECT");
-    if (direct && TMN == 1 && !d->transA && d->M <= 1024 && d->K >= 64 && (long long)cdiv(d->M, 64) * cdiv(d->N, 64) * batch <= 1024) TMN = 5;
-    static const char* force = getenv("EKAID_GEMM_TILE");         // tuning aid: "0" / "1" / "2"
-    if (force && force[0] >= '0' && force[0] <= '5' && (force[0] < '3' || (force[0] < '5' && TMN == 2) || (force[0] == '5' && !d->transA && TMN <= 1)))
-        TMN = force[0] - '0';
-    const int bm = TMN == 0 ? 32 : (TMN == 4 || TMN == 5 ? 64 : (TMN == 3 ? 128 : 64 * TMN));
-    const int bn = TMN == 0 ? 32 : (TMN == 3 || TMN == 5 ? 64 : (TMN == 4 ? 128 : 64 * TMN));
+    static const char* force = getenv("EKAID_GEMM_TILE");         // tuning aid: "1" (64x64), "2" (128x128), "3" (128x64), "4" (64x128)
+    if (force && force[0] >= '1' && force[0] <= '4' && (force[0] < '3' || TMN == 2)) TMN = force[0] - '0';
+    const int bm = TMN == 4 ? 64 : (TMN == 3 ? 128 : 64 * TMN);
+    const int bn = TMN == 3 ? 64 : (TMN == 4 ? 128 : 64 * TMN);
     tiles_m = cdiv(d->M, bm);
     tiles_n = cdiv(d->N, bn);
-    if (TMN == 5) {
-        // 4 waves per tile-block: aim at ~4 waves per SIMD chip-wide (1024 workgroups), at least 128 k per split
-        splitk = 1;
-        if (batch == 1) {
-            const int blocks = tiles_m * tiles_n;
-            int sk = 1024 / (blocks > 0 ? blocks : 1);
-            const int kmax = d->K / 128;
-            sk = sk > kmax ? kmax : sk;
-            splitk = sk < 1 ? 1 : sk;
-        }
-    } else
     splitk = plan_splitk(tiles_m * tiles_n, d->K, batch, (long long)d->M * d->N, TMN >= 2 ? BK_BIG : (gemm_mode() == 1 && TMN == 1 ? EKAID_SPLIT_KB_SMALL : BK_SMALL));
 }
 
@@ -1288,7 +1025,7 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     plan(d, TMN, a.splitk, a.tiles_m, a.tiles_n);
     if (d->K == 0) a.splitk = 1;
     a.ws = nullptr;
-    const int BK = TMN == 5 ? 64 : (TMN == 3 || TMN == 4 ? BK_HALF : (TMN >= 2 ? BK_BIG : (gemm_mode() == 1 && TMN == 1 ? EKAID_SPLIT_KB_SMALL : BK_SMALL)));
+    const int BK = (TMN == 3 || TMN == 4 ? BK_HALF : (TMN >= 2 ? BK_BIG : (gemm_mode() == 1 && TMN == 1 ? EKAID_SPLIT_KB_SMALL : BK_SMALL)));
     a.k_per_split = cdiv(cdiv(d->K, BK), a.splitk) * BK;
     if (a.splitk > 1) {
         const size_t need = (size_t)a.splitk * d->M * d->N * sizeof(float);
@@ -1313,9 +1050,7 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
 #undef EKAID_LAUNCH_SPLIT
     } else {
 #define EKAID_LAUNCH(AK, BKC) (TMN == 2 ? launch<AK, BKC, 2, 2, BK_BIG>(a, batch, st) : TMN == 1 ? launch<AK, BKC, 1, 1, BK_SMALL>(a, batch, st) \
-                               : TMN == 3 ? launch<AK, BKC, 2, 1, BK_HALF>(a, batch, st) : TMN == 4 ? launch<AK, BKC, 1, 2, BK_HALF>(a, batch, st) \
-                               : TMN == 5 ? launch_direct<BKC>(a, batch, st) \
-                                        : launch_skinny<AK, BKC>(a, batch, st))
+                               : TMN == 3 ? launch<AK, BKC, 2, 1, BK_HALF>(a, batch, st) : launch<AK, BKC, 1, 2, BK_HALF>(a, batch, st))
     if (akc && bkc) rc = EKAID_LAUNCH(true, true);
     else if (akc && !bkc) rc = EKAID_LAUNCH(true, false);
     else rc = EKAID_LAUNCH(false, false);
