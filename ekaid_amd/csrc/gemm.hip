@@ -1,4 +1,8 @@
-// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, k-ordered fma chain).
+// f32 GEMM on the CDNA4 matrix cores, two arithmetics behind one entry point (ekaid_gemm_f32):
+//   gemm_split_kernel (default): exact 3-way bf16 split of every operand element, six v_mfma_f32_32x32x16_bf16
+//                                products per f32 product, f32 accumulation (described further down);
+//   gemm_mfma_kernel           : v_mfma_f32_32x32x2_f32, an exact k-ordered f32 fma chain (EKAID_GEMM_MODE=f32).
+// Both share the tiling, the operand loaders, the split-K planner and the epilogue.
 //
 // C[M,N] = epilogue( alpha * op(A)[M,K] . op(B)[K,N] )     row-major everywhere
 //   transA = 0 : A stored [M][K] (k-contiguous)      transA = 1 : A stored [K][M] (m-contiguous)
@@ -32,15 +36,6 @@ namespace ekaid {
 #ifndef BK_SMALL
 #define BK_SMALL 32    // K-step of the 64x64 / 32x32 kernels: their loop is load-latency bound (16 MFMAs per wave per
                        // 32-deep step), so one iteration carries 4x the bytes in flight (measured: 50 -> 90 TF at M = 256)
-#endif
-#ifndef EKAID_GEMM_DBUF
-#define EKAID_GEMM_DBUF 0
-#endif
-#ifndef EKAID_GEMM_FRAGPF
-#define EKAID_GEMM_FRAGPF 0
-#endif
-#ifndef EKAID_GEMM_SETPRIO
-#define EKAID_GEMM_SETPRIO 0
 #endif
 #define LDS_PAD 4
 
@@ -242,7 +237,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : (TM * TN == 2 ? EKAID_LB_H
     constexpr int B_ELEMS = B_KC ? BN * (KB + LDS_PAD) : KB * (BN + LDS_PAD);
     constexpr int A_V4 = BM * KB / 4 / 256;     // float4 per thread per tile
     constexpr int B_V4 = BN * KB / 4 / 256;
-    extern __shared__ __attribute__((aligned(16))) float lds[];      // 2 x (A tile | B tile), double buffered
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // A tile | B tile
     constexpr int STAGE = A_ELEMS + B_ELEMS;
 
     const int tid = threadIdx.x;
@@ -902,7 +897,7 @@ static int launch(const GemmArgs& a, int batch, hipStream_t st) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int A_ELEMS = A_KC ? BM * (KB + LDS_PAD) : KB * (BM + LDS_PAD);
     constexpr int B_ELEMS = B_KC ? BN * (KB + LDS_PAD) : KB * (BN + LDS_PAD);
-    constexpr size_t lds = (EKAID_GEMM_DBUF ? 2 : 1) * (A_ELEMS + B_ELEMS) * sizeof(float);
+    constexpr size_t lds = (A_ELEMS + B_ELEMS) * sizeof(float);
     auto kern = gemm_mfma_kernel<A_KC, B_KC, TM, TN, KB>;
     if (lds > 64 * 1024) {
         static bool attr_set = false;            // once per instantiation (first call happens outside graph capture)
