@@ -73,6 +73,7 @@ class SpeakerSeqFn(Function):
         A = bef.shape[1]
         E, R, We, V = w_e.shape[0], whh_a.shape[1], emb.shape[1], w_lo.shape[0]
         G1 = w_g1.shape[0]                        # 2R + A
+        NP = w_wp.shape[0]                        # POS classes (16)
         NW = 9 * R + G1
         oP1, oG1, oGL = 4 * R, 5 * R, 5 * R + G1   # column offsets inside the NW-wide block
         dev = bef.device
@@ -112,8 +113,8 @@ class SpeakerSeqFn(Function):
         HLW = torch.empty(T, B, NW, **f32)        # see class docstring; the G1 block ends up holding dropout(relu(gate1x))
         MW = torch.empty(T, B, 3, **f32)
         VP = torch.empty(T, B, R, **f32)          # dropout(relu(pos1(h_lang)))
-        DP = torch.empty(T, B, 16, **f32)         # dropout(weight_pos(vpos))   (= output_pos of the core)
-        PW = torch.empty(T, B, 16, **f32)
+        DP = torch.empty(T, B, NP, **f32)         # dropout(weight_pos(vpos))   (= output_pos of the core)
+        PW = torch.empty(T, B, NP, **f32)
         PA = torch.empty(T, B, R + A, **f32)      # [pos_feat | att_feat]: the two trailing inputs of the gate MLP, one GEMM operand
         AT = torch.empty(T, B, A, **f32)
         GT = torch.empty(T, B, A, **f32)          # gate (sigmoid)
@@ -137,9 +138,9 @@ class SpeakerSeqFn(Function):
                                          PA.data_ptr() + 4 * (t * B * (R + A) + R), R + A, stream()), 'spk_modmix_fwd')
             # 3. POS chain: relu/dropout(block 1 + b) -> weight_pos -> dropout -> softmax -> pos2, one kernel;
             #    pos_feat goes to the left part of PA[t]
-            check(L.ekaid_spk_pos_fwd(HLW.data_ptr() + 4 * (ow + oP1), NW, ptr(b_p1), B, R, ptr(w_wp), ptr(b_wp), 16, ptr(w_p2),
-                                      ptr(b_p2), p, sv, p5, sd, VP.data_ptr() + 4 * t * B * R, DP.data_ptr() + 4 * t * B * 16,
-                                      PW.data_ptr() + 4 * t * B * 16, PA.data_ptr() + 4 * t * B * (R + A), R + A, stream()),
+            check(L.ekaid_spk_pos_fwd(HLW.data_ptr() + 4 * (ow + oP1), NW, ptr(b_p1), B, R, ptr(w_wp), ptr(b_wp), NP, ptr(w_p2),
+                                      ptr(b_p2), p, sv, p5, sd, VP.data_ptr() + 4 * t * B * R, DP.data_ptr() + 4 * t * B * NP,
+                                      PW.data_ptr() + 4 * t * B * NP, PA.data_ptr() + 4 * t * B * (R + A), R + A, stream()),
                   'spk_pos_fwd')
             # 5. gate MLP: block 2 += [pos_feat | att] W[:, R:]^T + b, relu, dropout (in place, GEMM epilogue)
             gemm(PA, w_g1, HLW, B, G1, R + A, R + A, G1, NW, 0, 1, accumulate=True, bias=b_g1, act=ACT_RELU,
@@ -160,8 +161,8 @@ class SpeakerSeqFn(Function):
         _nt(HO, 0, R, w_lo, 0, R, logits, 0, V, TB, V, R, bias=b_lo)
         logp = torch.empty(T, B, V, **f32)
         check(L.ekaid_softmax_fwd(ptr(logits), ptr(logp), TB, V, 1, stream()), 'softmax_fwd')
-        logpos = torch.empty(T, B, 16, **f32)
-        check(L.ekaid_softmax_fwd(ptr(DP), ptr(logpos), TB, 16, 1, stream()), 'softmax_fwd')
+        logpos = torch.empty(T, B, NP, **f32)
+        check(L.ekaid_softmax_fwd(ptr(DP), ptr(logpos), TB, NP, 1, stream()), 'softmax_fwd')
 
         ctx.dims = (T, B, A, E, R, We, V, G1)
         ctx.pp = (p, p5, seeds, seeds_t)
@@ -176,6 +177,7 @@ class SpeakerSeqFn(Function):
         (bef, aft, diff, tok_tb, embed_pre, ED, Xd, HA, CA, HL, CL, SA, SL, MW, VP, PW, PA, AT, HLW, GT, GA, HO,
          logp, logpos, emb, w_e, wih_a, whh_a, w_fc, w_wp, w_p2, w_g1, w_g2, wih_l, w_lo, Wcat) = ctx.saved_tensors
         T, B, A, E, R, We, V, G1 = ctx.dims
+        NP = w_wp.shape[0]
         NW = 9 * R + G1
         oP1, oG1, oGL = 4 * R, 5 * R, 5 * R + G1
         p, p5, seeds, seeds_t = ctx.pp
@@ -195,13 +197,13 @@ class SpeakerSeqFn(Function):
         _nn(dlogits, 0, V, w_lo, 0, R, dHO, 0, R, TB, R, V)
         dHLo = torch.empty(T, B, R, **f32)        # gradient reaching h_lang_t through the output dropout
         _drop(dHO, dHLo, TB * R, p, seeds['out'])
-        dDPl = torch.zeros(T, B, 16, **f32)       # gradient reaching dpos through log_softmax(output_pos)
+        dDPl = torch.zeros(T, B, NP, **f32)       # gradient reaching dpos through log_softmax(output_pos)
         if dlogpos is not None:
-            check(L.ekaid_softmax_bwd(ptr(logpos), ptr(dlogpos.contiguous()), ptr(dDPl), TB, 16, 1, stream()), 'softmax_bwd')
+            check(L.ekaid_softmax_bwd(ptr(logpos), ptr(dlogpos.contiguous()), ptr(dDPl), TB, NP, 1, stream()), 'softmax_bwd')
 
         DCAT = torch.empty(T, B, NW, **f32)       # [d att gates | d pos1 pre-act | d gate1x pre-act | d lang gates] per step
         DZFC = torch.empty(T, B, 3, **f32)
-        DWP = torch.empty(T, B, 16, **f32)
+        DWP = torch.empty(T, B, NP, **f32)
         DPA = torch.empty(T, B, R + A, **f32)     # [d pos_feat | d att_feat (gate-MLP path)] per step, one dgrad GEMM
         DZ2 = torch.empty(T, B, A, **f32)
         d_bef = torch.zeros(B, A, **f32)
@@ -241,9 +243,9 @@ class SpeakerSeqFn(Function):
                                          ptr(w_fc), R, DZFC.data_ptr() + 4 * t * B * 3, ptr(d_bef), ptr(d_diff), ptr(d_aft),
                                          ptr(dh_a), stream()), 'spk_modmix_bwd')
             # 3'. POS chain
-            check(L.ekaid_spk_pos_bwd(DPA.data_ptr() + 4 * t * B * (R + A), R + A, PW.data_ptr() + 4 * t * B * 16,
-                                      dDPl.data_ptr() + 4 * t * B * 16, B, 16, ptr(w_p2), ptr(w_wp), VP.data_ptr() + 4 * t * B * R, R,
-                                      p, sv, p5, sd, DWP.data_ptr() + 4 * t * B * 16, DCAT.data_ptr() + 4 * (ow + oP1), NW,
+            check(L.ekaid_spk_pos_bwd(DPA.data_ptr() + 4 * t * B * (R + A), R + A, PW.data_ptr() + 4 * t * B * NP,
+                                      dDPl.data_ptr() + 4 * t * B * NP, B, NP, ptr(w_p2), ptr(w_wp), VP.data_ptr() + 4 * t * B * R, R,
+                                      p, sv, p5, sd, DWP.data_ptr() + 4 * t * B * NP, DCAT.data_ptr() + 4 * (ow + oP1), NW,
                                       stream()), 'spk_pos_bwd')
             # 1'. module-attention LSTM
             check(L.ekaid_lstm_cell_bwd(ptr(dh_a), None, ptr(dc_a), SA.data_ptr() + 4 * t * B * 4 * R, CA.data_ptr() + 4 * o_prev,
@@ -273,11 +275,11 @@ class SpeakerSeqFn(Function):
         d_b_p1 = torch.empty(R, **f32)
         check(L.ekaid_colsum(DCAT.data_ptr() + 4 * oP1, TB, R, NW, ptr(d_b_p1), stream()), 'colsum')
         d_w_wp = torch.empty_like(w_wp)
-        _tn(DWP, 16, VP, R, d_w_wp, 0, R, 16, R, TB)
-        d_b_wp = torch.empty(16, **f32)
-        _colsum(DWP, TB, 16, d_b_wp)
+        _tn(DWP, NP, VP, R, d_w_wp, 0, R, NP, R, TB)
+        d_b_wp = torch.empty(NP, **f32)
+        _colsum(DWP, TB, NP, d_b_wp)
         d_w_p2 = torch.empty_like(w_p2)
-        _tn(DPA, R + A, PW, 16, d_w_p2, 0, 16, R, 16, TB)
+        _tn(DPA, R + A, PW, NP, d_w_p2, 0, NP, R, NP, TB)
         d_b_p2 = torch.empty(R, **f32)
         check(L.ekaid_colsum(ptr(DPA), TB, R, R + A, ptr(d_b_p2), stream()), 'colsum')
         d_w_g1 = torch.empty_like(w_g1)
