@@ -482,7 +482,9 @@ def test_resume_with_optimizer_state_continues_the_run():
         return opt2, (sq / cnt) ** 0.5
 
     opt2, err = resume(True)
+    print('resume rms difference: %.3e (limit %.1e)' % (err, 0.01 * lr))
     assert opt2.step_count == 4 and opt2.lr == lr
     assert err <= 0.01 * lr, 'resumed run is %.2e (rms) away from the uninterrupted one' % err
     _, err_no_state = resume(False)
+    print('resume without optimizer state: %.3e (must exceed %.1e)' % (err_no_state, 0.1 * lr))
     assert err_no_state >= 0.1 * lr, 'control: dropping the optimizer state should be visible (%.2e rms)' % err_no_state
