@@ -189,7 +189,12 @@ def main():
                    betas=(0.9, 0.999), eps=1e-8)
     host_batch = make_batch(B=per_gpu, seed=1238, rank=rank, **SHAPE)
     T = DynamicSpeaker.count_steps(host_batch['labels'], SHAPE['seq_length'])   # host-side: no device sync per step
+    torch.cuda.synchronize()
+    th2d = time.perf_counter()
     b = {k: v.to(dev) for k, v in host_batch.items()}                  # inputs resident in HBM before the clock starts
+    torch.cuda.synchronize()
+    h2d_ms = (time.perf_counter() - th2d) * 1e3                        # pageable host -> device copy of one batch (reported, never in `value`)
+    h2d_bytes = sum(v.numel() * v.element_size() for v in host_batch.values())
     ops.manual_seed(1238 + rank)
 
     for _ in range(args.warmup):
@@ -287,6 +292,10 @@ def main():
             'roofline': roof,
             'phases_ms': phases if rank == 0 else None,
             'host_issue_ms_per_step': round(host_issue_ms, 3),
+            'h2d': {'ms_per_batch': round(h2d_ms, 3), 'bytes_per_batch': h2d_bytes,
+                    'note': 'pageable host memory, first transfer of the process, not overlapped; the reference layout '
+                            '(f64 100x100 label matrices); not part of value',
+                    'value_if_serialised': round(per_gpu * world / (elapsed / args.steps + h2d_ms * 1e-3), 2)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, cd, sp, args.cpu_batch, args.graph)
