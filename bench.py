@@ -86,7 +86,7 @@ def train_step(cfg, cd, sp, opt, b, T, graph, marks=None):
 
 def pmc_traffic(split):
     """HBM bytes per launch of the dominant GEMM shape from the committed rocprofv3 --pmc summary (PMC counters cannot
-    be read inside this process; the summary is produced by tools_pmc_run.sh, FETCH_SIZE doubled as the gfx950 guide
+    be read inside this process; the summary is produced by tools/pmc_run.sh, FETCH_SIZE doubled as the gfx950 guide
     prescribes).  None when the summary for the active arithmetic is not in profiles/."""
     path = os.path.join(ROOT, 'profiles', 'r01_pmc_gemm_split_nn_18432x1024x1024.json')
     if not split or not os.path.exists(path):

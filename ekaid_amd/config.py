@@ -69,6 +69,7 @@ def default_cfg():
             'vocab_json': './data/vocab_mimic_VQA.json',
             'splits_json': './data/splits.json',
             'h5_label_file': './data/labels.h5',
+            'h5_feature_file': '',        # extension: '' = the path hard-coded in the reference (rcc_dataset_pos_mimic.py:95)
             'feature_mode': 'location',
             'train': {'batch_size': 128, 'seq_per_img': 1, 'max_samples': None,
                       'empty_image': False},

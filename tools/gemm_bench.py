@@ -1,6 +1,6 @@
 """GEMM micro-benchmark over library variants (tuning aid, not part of the product)."""
 import glob, os, sys, ctypes, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ekaid_amd import hip, ops
 BIG = [('nt', 18432, 1024, 1024), ('nt', 18432, 1024, 4096), ('nn', 18432, 1024, 1024), ('nn', 18432, 4096, 1024),
        ('tn', 1024, 1024, 18432), ('tn', 1024, 4096, 18432)]

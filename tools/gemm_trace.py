@@ -1,7 +1,7 @@
 """Run a list of GEMM shapes back to back (tuning aid; use under rocprofv3 --kernel-trace and read per-dispatch
-durations with tools_gemm_trace_read.py).  Shapes: argv = mode,M,N,K ..."""
+durations with tools/gemm_trace_read.py).  Shapes: argv = mode,M,N,K ..."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ekaid_amd import hip, ops
 shapes = [tuple(a.split(',')) for a in sys.argv[1:]]
 REP = 12

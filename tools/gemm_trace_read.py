@@ -1,4 +1,4 @@
-"""Summarise a rocprofv3 kernel-trace CSV produced around tools_gemm_trace.py: per consecutive run of identical
+"""Summarise a rocprofv3 kernel-trace CSV produced around tools/gemm_trace.py: per consecutive run of identical
 (kernel, grid) dispatches print count / median duration."""
 import csv, sys, statistics, re
 rows = list(csv.DictReader(open(sys.argv[1])))

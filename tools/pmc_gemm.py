@@ -1,6 +1,6 @@
 """One GEMM shape launched a few times (PMC collection target; tuning aid)."""
 import sys, os, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ekaid_amd import hip, ops
 hip.load()
 mode, M, N, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])

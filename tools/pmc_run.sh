@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over one GEMM shape (tuning aid).  usage: tools_pmc_run.sh <outdir> <mode> <M> <N> <K>
+# PMC passes over one GEMM shape (tuning aid).  usage: tools/pmc_run.sh <outdir> <mode> <M> <N> <K>
 # (a group the hardware cannot collect in one pass makes rocprofv3 abort and hang: every pass runs under timeout)
 # Each counter group is its own rocprofv3 run (kernel-trace + pmc only), as the pool requires.
 out=$1; shift
@@ -13,5 +13,5 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_A
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   [ $i -lt $first ] && continue
-  timeout 150 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/g$i -o p -- python3 tools_pmc_gemm.py "$@" > $out.g$i.log 2>&1
+  timeout 150 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/g$i -o p -- python3 tools/pmc_gemm.py "$@" > $out.g$i.log 2>&1
 done
