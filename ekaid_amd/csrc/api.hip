@@ -1,8 +1,10 @@
 // Error bookkeeping + version for libekaid_hip.so.
 #include "common.h"
 #include "../../include/ekaid_hip.h"
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 namespace ekaid {
 static thread_local char g_err[512] = "";
@@ -22,7 +24,71 @@ int check_launch(const char* what) {
     }
     return EKAID_OK;
 }
+
+// ---- per-device state: the only mutable state of the library besides the thread-local error string.  Every field is
+// an atomic, so calls from different host threads / on different streams never race on it.
+constexpr int MAX_DEVICES = 64, ATTR_SLOTS = 64;
+struct DeviceState {
+    std::atomic<int> ready{0};
+    std::atomic<int> gemm_mode{-1};
+    std::atomic<const unsigned long long*> epoch{nullptr};
+    std::atomic<bool> attr[ATTR_SLOTS];
+};
+static DeviceState g_dev[MAX_DEVICES];
+
+static int default_gemm_mode() {
+    const char* m = getenv("EKAID_GEMM_MODE");
+    return (m && (m[0] == 'f' || m[0] == '0')) ? 0 : 1;
+}
+DeviceState& device_state() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; }
+    DeviceState& s = g_dev[(d < 0 || d >= MAX_DEVICES) ? 0 : d];
+    int expected = 0;
+    if (s.ready.compare_exchange_strong(expected, 1)) {
+        int unset = -1;
+        s.gemm_mode.compare_exchange_strong(unset, default_gemm_mode());
+    }
+    return s;
+}
+int gemm_mode() {
+    DeviceState& s = device_state();
+    int m = s.gemm_mode.load();
+    if (m < 0) { m = default_gemm_mode(); s.gemm_mode.store(m); }
+    return m;
+}
+int set_gemm_mode(int mode) { device_state().gemm_mode.store(mode); return EKAID_OK; }
+const unsigned long long* dropout_epoch_ptr() { return device_state().epoch.load(std::memory_order_relaxed); }
+bool func_attr_once(int slot) {
+    if (slot < 0 || slot >= ATTR_SLOTS) return true;
+    bool expected = false;
+    return device_state().attr[slot].compare_exchange_strong(expected, true);
+}
+
+__global__ void epoch_advance_kernel(unsigned long long* e, unsigned long long by) { e[0] += by; }
 }  // namespace ekaid
+
+extern "C" int ekaid_init(int device_id) {
+    if (device_id < 0 || device_id >= ekaid::MAX_DEVICES) { ekaid::set_error("ekaid_init: bad device id %d", device_id); return EKAID_ERR_ARG; }
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess || hipSetDevice(device_id) != hipSuccess) {
+        (void)hipGetLastError();
+        ekaid::set_error("ekaid_init: cannot select device %d", device_id);
+        return EKAID_ERR_ARG;
+    }
+    (void)ekaid::device_state();
+    (void)hipSetDevice(cur);
+    return EKAID_OK;
+}
+extern "C" int ekaid_set_dropout_epoch_ptr(const unsigned long long* epoch_dev) {
+    ekaid::device_state().epoch.store(epoch_dev);
+    return EKAID_OK;
+}
+extern "C" int ekaid_dropout_epoch_advance(unsigned long long* epoch_dev, unsigned long long by, void* stream) {
+    if (!epoch_dev) { ekaid::set_error("ekaid_dropout_epoch_advance: null pointer"); return EKAID_ERR_ARG; }
+    hipLaunchKernelGGL(ekaid::epoch_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, epoch_dev, by);
+    return ekaid::check_launch("dropout_epoch_advance");
+}
 
 extern "C" int ekaid_version(void) { return EKAID_ABI_VERSION; }
 extern "C" const char* ekaid_last_error(void) { return ekaid::g_err; }

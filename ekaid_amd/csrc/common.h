@@ -16,6 +16,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// per-device state (api.hip): created by ekaid_init(device) or on first use of a device; no other mutable globals
+struct DeviceState;
+DeviceState& device_state();                       // of the calling thread's current HIP device
+int gemm_mode();                                   // 0 = f32 MFMA, 1 = exact bf16 split (per device)
+int set_gemm_mode(int mode);
+const unsigned long long* dropout_epoch_ptr();     // device word folded into every dropout seed, or NULL
+bool func_attr_once(int slot);                     // true exactly once per (device, slot): "raise the LDS limit" bookkeeping
+
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3 };
 
 __device__ __forceinline__ float act_apply(float v, int act) {
@@ -53,6 +61,21 @@ __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, floa
     float u = (float)(hash_u32(seed, idx) >> 8) * (1.0f / 16777216.0f);   // [0,1)
     return u < p ? 0.f : inv_keep;
 }
+// A dropout site's seed as the kernels see it: the caller's 64-bit seed plus an optional DEVICE-resident epoch word
+// (ekaid_set_dropout_epoch_ptr).  A captured hipGraph freezes every by-value seed; the epoch word is advanced by a
+// kernel inside the graph (ekaid_dropout_epoch_advance), so every replay draws fresh masks while the forward and the
+// backward launches of one replay still agree.  epoch pointer NULL (the default) = the seed alone.
+struct DropSeed {
+    uint64_t s;
+    const unsigned long long* ep;
+};
+__device__ __forceinline__ uint64_t drop_seed_value(const DropSeed& d) {
+    return d.ep ? d.s + (uint64_t)d.ep[0] * 0x9E3779B97F4A7C15ull : d.s;
+}
+__device__ __forceinline__ float dropout_scale(const DropSeed& d, uint64_t idx, float p, float inv_keep) {
+    if (p <= 0.f) return 1.f;
+    return dropout_scale(drop_seed_value(d), idx, p, inv_keep);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -71,5 +94,9 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 }
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace ekaid
+#define DS(seed) (ekaid::DropSeed{(uint64_t)(seed), ekaid::dropout_epoch_ptr()})
+namespace ekaid {
 
 }  // namespace ekaid

@@ -298,14 +298,12 @@ static int launch_fused(const float* q, const float* k, const float* S, const fl
                         float* outT, hipStream_t st) {
     auto kern = gat_fused_fwd_kernel<VEC, MMAX>;
     if (lds > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (func_attr_once(MMAX == 40 ? 48 : 49)) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 (void)hipGetLastError();
                 set_error("gat_fused_fwd: cannot raise dynamic LDS limit to %zu bytes", lds);
                 return EKAID_ERR_UNSUPPORTED;
             }
-            attr_set = true;
         }
     }
     hipLaunchKernelGGL(kern, dim3(R), dim3(256), lds, st, q, k, S, cond, lbias, geo, N, M, A, H, dir, DC, P, outT);

@@ -51,6 +51,7 @@ struct Epi {
     int act;
     float drop_p, drop_inv;     // fused dropout of the activated output: mask index = m * N + n
     unsigned long long drop_seed;
+    const unsigned long long* drop_epoch;   // device word folded into drop_seed (ekaid_set_dropout_epoch_ptr) or NULL
     int n_cols;
 };
 
@@ -64,7 +65,7 @@ __device__ __forceinline__ float epilogue(float acc, float cold, int m, int n, c
         v += r;
     }
     v = act_apply(v, e.act);
-    if (e.drop_p > 0.f) v *= dropout_scale(e.drop_seed, (uint64_t)m * e.n_cols + n, e.drop_p, e.drop_inv);
+    if (e.drop_p > 0.f) v *= dropout_scale(DropSeed{e.drop_seed, e.drop_epoch}, (uint64_t)m * e.n_cols + n, e.drop_p, e.drop_inv);
     return v;
 }
 
@@ -900,14 +901,13 @@ static int launch(const GemmArgs& a, int batch, hipStream_t st) {
     constexpr size_t lds = (A_ELEMS + B_ELEMS) * sizeof(float);
     auto kern = gemm_mfma_kernel<A_KC, B_KC, TM, TN, KB>;
     if (lds > 64 * 1024) {
-        static bool attr_set = false;            // once per instantiation (first call happens outside graph capture)
-        if (!attr_set) {
+        constexpr int slot = (A_KC ? 1 : 0) + (B_KC ? 2 : 0) + 4 * (TM - 1) + 8 * (TN - 1);       // once per device and instantiation
+        if (func_attr_once(slot)) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
                 (void)hipGetLastError();
                 set_error("gemm: cannot raise the dynamic LDS limit to %zu bytes", lds);
                 return EKAID_ERR_LAUNCH;
             }
-            attr_set = true;
         }
     }
     dim3 grid(a.tiles_m * a.tiles_n, 1, a.splitk > 1 ? a.splitk : batch);
@@ -921,14 +921,13 @@ static int launch_split(const GemmArgs& a, int batch, hipStream_t st) {
     constexpr size_t lds = 3 * 2 * KB * (BM + BN);      // three bf16 planes per operand, unpadded
     auto kern = gemm_split_kernel<A_KC, B_KC, TM, TN, KB, PF, PIPE>;
     if (lds > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        constexpr int slot = 16 + (A_KC ? 1 : 0) + (B_KC ? 2 : 0) + 4 * (TM - 1) + 8 * (TN - 1);
+        if (func_attr_once(slot)) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
                 (void)hipGetLastError();
                 set_error("gemm: cannot raise the dynamic LDS limit to %zu bytes", lds);
                 return EKAID_ERR_LAUNCH;
             }
-            attr_set = true;
         }
     }
     dim3 grid(a.tiles_m * a.tiles_n, 1, a.splitk > 1 ? a.splitk : batch);
@@ -936,15 +935,8 @@ static int launch_split(const GemmArgs& a, int batch, hipStream_t st) {
     return EKAID_OK;
 }
 
-// arithmetic of the MFMA kernels: 0 = v_mfma_f32_32x32x2_f32, 1 = exact 3-way bf16 split (6 x v_mfma_f32_32x32x16_bf16)
-static int g_gemm_mode = -1;
-static int gemm_mode() {
-    if (g_gemm_mode < 0) {
-        const char* m = getenv("EKAID_GEMM_MODE");
-        g_gemm_mode = (m && (m[0] == 'f' || m[0] == '0')) ? 0 : 1;
-    }
-    return g_gemm_mode;
-}
+// arithmetic of the MFMA kernels: 0 = v_mfma_f32_32x32x2_f32, 1 = exact 3-way bf16 split (6 x v_mfma_f32_32x32x16_bf16);
+// kept in the per-device state (api.hip: gemm_mode / set_gemm_mode)
 
 static int plan_splitk(int tiles, int K, int batch, long long MN, int BK) {
     if (batch > 1) return 1;
@@ -986,8 +978,7 @@ using namespace ekaid;
 
 extern "C" int ekaid_set_gemm_mode(int mode) {
     if (mode != 0 && mode != 1) { set_error("ekaid_set_gemm_mode: mode must be 0 (f32 MFMA) or 1 (bf16 3-way split)"); return EKAID_ERR_ARG; }
-    g_gemm_mode = mode;
-    return EKAID_OK;
+    return set_gemm_mode(mode);
 }
 extern "C" int ekaid_get_gemm_mode(void) { return gemm_mode(); }
 
@@ -1015,7 +1006,7 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     a.sC1 = d->strideC1; a.sC2 = d->strideC2; a.nb2 = d->batch2;
     a.e.alpha = d->alpha; a.e.alpha_dev = d->alpha_dev; a.e.beta = d->accumulate; a.e.bias = d->bias;
     a.e.R = d->R; a.e.ldr = d->ldr; a.e.rdiv = d->rdiv < 1 ? 1 : d->rdiv; a.e.rowmask = d->rowmask; a.e.act = d->act;
-    a.e.drop_p = d->drop_p; a.e.drop_inv = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f; a.e.drop_seed = d->drop_seed; a.e.n_cols = d->N;
+    a.e.drop_p = d->drop_p; a.e.drop_inv = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f; a.e.drop_seed = d->drop_seed; a.e.drop_epoch = dropout_epoch_ptr(); a.e.n_cols = d->N;
     int TMN;
     plan(d, TMN, a.splitk, a.tiles_m, a.tiles_n);
     if (d->K == 0) a.splitk = 1;

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* dy, const flo
     GS_LOOP(i, n) dz[i] = dy[i] * act_grad_from_out(y[i], act);
 }
 __global__ __launch_bounds__(256) void dropout_kernel(const float* x, float* y, long long n, float p, float inv_keep,
-                                                      uint64_t seed) {
+                                                      DropSeed seed) {
     GS_LOOP(i, n) y[i] = x[i] * dropout_scale(seed, (uint64_t)i, p, inv_keep);
 }
 __global__ __launch_bounds__(256) void axpby_kernel(const float* x, const float* y, float* out, long long n, float a, float b) {
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void mul_kernel(const float* x, const float* y
     GS_LOOP(i, n) out[i] = x[i] * y[i];
 }
 __global__ __launch_bounds__(256) void expand_rows_kernel(const float* q, const float* mask, long long rows, int group,
-                                                          int qrows, int cols, float* out, float p, float inv_keep, uint64_t seed) {
+                                                          int qrows, int cols, float* out, float p, float inv_keep, DropSeed seed) {
     const long long n = rows * cols;
     GS_LOOP(i, n) {
         const long long r = i / cols;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void expand_rows_kernel(const float* q, const 
 }
 __global__ __launch_bounds__(256) void expand_rows_bwd_kernel(const float* dout, const float* mask, long long rows,
                                                               int group, int qrows, int cols, float* dq, float p, float inv_keep,
-                                                              uint64_t seed) {
+                                                              DropSeed seed) {
     const long long G = rows / group;            // row groups; group g reads q row (g % qrows)
     const long long n = (long long)qrows * cols;
     GS_LOOP(i, n) {
@@ -155,14 +155,14 @@ __global__ __launch_bounds__(256) void expand_rows_bwd_kernel(const float* dout,
     }
 }
 __global__ __launch_bounds__(256) void residual_relu2_fwd_kernel(const float* v, const float* o, float* vnew, long long n,
-                                                                 float p, float inv_keep, uint64_t seed) {
+                                                                 float p, float inv_keep, DropSeed seed) {
     GS_LOOP(i, n) {
         const float t = (o[i] + o[i]) * dropout_scale(seed, (uint64_t)i, p, inv_keep);
         vnew[i] = v[i] + (t > 0.f ? t : 0.f);
     }
 }
 __global__ __launch_bounds__(256) void residual_relu2_bwd_kernel(const float* o, const float* dvnew, float* d_o, long long n,
-                                                                 float p, float inv_keep, uint64_t seed) {
+                                                                 float p, float inv_keep, DropSeed seed) {
     GS_LOOP(i, n) {
         const float k = dropout_scale(seed, (uint64_t)i, p, inv_keep);
         const float t = (o[i] + o[i]) * k;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void residual_relu2_bwd_kernel(const float* o,
 // n = rep * n1 elements of c2/g2
 __global__ __launch_bounds__(256) void gate_fuse_fwd_kernel(const float* c2, const float* g2, const float* c1, const float* g1,
                                                             float* out, long long n, long long n1, float p, float inv_keep,
-                                                            uint64_t seed_c, uint64_t seed_g) {
+                                                            DropSeed seed_c, DropSeed seed_g) {
     GS_LOOP(i, n) {
         const long long j = i % n1;
         const float c = tanhf(c2[i] + c1[j]) * dropout_scale(seed_c, (uint64_t)i, p, inv_keep);
@@ -183,8 +183,8 @@ __global__ __launch_bounds__(256) void gate_fuse_fwd_kernel(const float* c2, con
 }
 __global__ __launch_bounds__(256) void gate_fuse_bwd_kernel(const float* c2, const float* g2, const float* c1, const float* g1,
                                                             const float* dout, float* dc2, float* dg2, float* dc1, float* dg1,
-                                                            long long n, long long n1, float p, float inv_keep, uint64_t seed_c,
-                                                            uint64_t seed_g) {
+                                                            long long n, long long n1, float p, float inv_keep, DropSeed seed_c,
+                                                            DropSeed seed_g) {
     GS_LOOP(j, n1) {
         float sc = 0.f, sg = 0.f;
         for (long long i = j; i < n; i += n1) {
@@ -388,7 +388,12 @@ __global__ __launch_bounds__(256) void nll_bwd_kernel(const int64_t* target, int
     }
 }
 
-__global__ void nll_finish_kernel(const float* sums, float* loss) { loss[0] = sums[0] / sums[1]; }
+// denom (optional): replaces the local sum of the mask -- the global-batch mask sum / world size under data parallelism,
+// so that the average of the per-rank losses is the reference's loss over the global batch (utils/utils.py:213-214)
+__global__ void nll_finish_kernel(float* sums, const float* denom, float* loss) {
+    if (denom) sums[1] = denom[0];
+    loss[0] = sums[0] / sums[1];
+}
 __global__ __launch_bounds__(256) void total_loss_kernel(const float* sl, const float* a, const float* b, long long n, float coef,
                                                          float* out) {
     float s = 0.f;
@@ -475,6 +480,28 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
     }
 }
 
+// Adam whose step counter and hyper-parameters live on the DEVICE (graph-capturable: a captured launch of the by-value
+// form would freeze the bias correction and the learning rate).  state[0] = step (incremented here, as a float-exact
+// integer < 2^24 steps... stored as int), hyper = {lr, beta1, beta2, eps, grad_scale}.
+__global__ void adam_prep_kernel(int* step, const float* hyper, float* derived) {
+    const int t = step[0] + 1;
+    step[0] = t;
+    const double b1 = hyper[1], b2 = hyper[2];
+    derived[0] = (float)((double)hyper[0] / (1.0 - pow(b1, (double)t)));
+    derived[1] = (float)(1.0 / sqrt(1.0 - pow(b2, (double)t)));
+}
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* p, const float* g, float* m, float* v, long long n, const float* hyper,
+                                                       const float* derived) {
+    const float lr_bc1 = derived[0], inv_sqrt_bc2 = derived[1], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], gscale = hyper[4];
+    GS_LOOP(i, n) {
+        const float gr = g[i] * gscale;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gr;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gr * gr;
+        m[i] = mi; v[i] = vi;
+        p[i] -= lr_bc1 * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+}
+
 // scratch for the two-stage weight-norm reductions: per-workgroup partials of sumsq / dot (two slots of 2048 doubles),
 // summed in a fixed order by the finish kernels (deterministic, no atomics, no zero-fill).  One buffer per process
 // (= per device), used by stream-ordered calls on one stream; allocated at first use (outside any graph capture:
@@ -539,7 +566,7 @@ extern "C" int ekaid_act_bwd(const float* dy, const float* y, float* dz, long lo
 }
 extern "C" int ekaid_dropout(const float* x, float* y, long long n, float p, uint64_t seed, void* stream) {
     if (p < 0.f || p >= 1.f) { set_error("dropout: p=%f out of range", p); return EKAID_ERR_ARG; }
-    hipLaunchKernelGGL(dropout_kernel, grid1d(n), dim3(256), 0, ST, x, y, n, p, INVK(p), seed);
+    hipLaunchKernelGGL(dropout_kernel, grid1d(n), dim3(256), 0, ST, x, y, n, p, INVK(p), DS(seed));
     return check_launch("dropout");
 }
 extern "C" int ekaid_axpby(const float* x, const float* y, float* out, long long n, float a, float b, void* stream) {
@@ -558,28 +585,28 @@ extern "C" int ekaid_rowsum(const float* x, long long rows, int cols, float* out
 extern "C" int ekaid_expand_rows_fwd(const float* q, const float* mask, long long rows, int group, int qrows, int cols, float* out,
                                      float p, uint64_t seed, void* stream) {
     if (group < 1 || qrows < 1 || rows % group) { set_error("expand_rows: rows %% group != 0"); return EKAID_ERR_ARG; }
-    hipLaunchKernelGGL(expand_rows_kernel, grid1d(rows * cols), dim3(256), 0, ST, q, mask, rows, group, qrows, cols, out, p, INVK(p), seed);
+    hipLaunchKernelGGL(expand_rows_kernel, grid1d(rows * cols), dim3(256), 0, ST, q, mask, rows, group, qrows, cols, out, p, INVK(p), DS(seed));
     return check_launch("expand_rows_fwd");
 }
 extern "C" int ekaid_expand_rows_bwd(const float* dout, const float* mask, long long rows, int group, int qrows, int cols, float* dq,
                                      float p, uint64_t seed, void* stream) {
     if (group < 1 || qrows < 1 || rows % group) { set_error("expand_rows: rows %% group != 0"); return EKAID_ERR_ARG; }
     hipLaunchKernelGGL(expand_rows_bwd_kernel, grid1d((long long)qrows * cols), dim3(256), 0, ST, dout, mask, rows, group, qrows, cols, dq,
-                       p, INVK(p), seed);
+                       p, INVK(p), DS(seed));
     return check_launch("expand_rows_bwd");
 }
 extern "C" int ekaid_residual_relu2_fwd(const float* v, const float* o, float* vnew, long long n, float p, uint64_t seed, void* stream) {
-    hipLaunchKernelGGL(residual_relu2_fwd_kernel, grid1d(n), dim3(256), 0, ST, v, o, vnew, n, p, INVK(p), seed);
+    hipLaunchKernelGGL(residual_relu2_fwd_kernel, grid1d(n), dim3(256), 0, ST, v, o, vnew, n, p, INVK(p), DS(seed));
     return check_launch("residual_relu2_fwd");
 }
 extern "C" int ekaid_residual_relu2_bwd(const float* o, const float* dvnew, float* d_o, long long n, float p, uint64_t seed, void* stream) {
-    hipLaunchKernelGGL(residual_relu2_bwd_kernel, grid1d(n), dim3(256), 0, ST, o, dvnew, d_o, n, p, INVK(p), seed);
+    hipLaunchKernelGGL(residual_relu2_bwd_kernel, grid1d(n), dim3(256), 0, ST, o, dvnew, d_o, n, p, INVK(p), DS(seed));
     return check_launch("residual_relu2_bwd");
 }
 extern "C" int ekaid_gate_fuse_fwd(const float* c2, const float* g2, const float* c1, const float* g1, float* out, long long n,
                                    long long n1, float p, uint64_t seed_c, uint64_t seed_g, void* stream) {
     if (n1 < 1 || n % n1) { set_error("gate_fuse: n %% n1 != 0"); return EKAID_ERR_ARG; }
-    hipLaunchKernelGGL(gate_fuse_fwd_kernel, grid1d(n), dim3(256), 0, ST, c2, g2, c1, g1, out, n, n1, p, INVK(p), seed_c, seed_g);
+    hipLaunchKernelGGL(gate_fuse_fwd_kernel, grid1d(n), dim3(256), 0, ST, c2, g2, c1, g1, out, n, n1, p, INVK(p), DS(seed_c), DS(seed_g));
     return check_launch("gate_fuse_fwd");
 }
 extern "C" int ekaid_gate_fuse_bwd(const float* c2, const float* g2, const float* c1, const float* g1, const float* dout, float* dc2,
@@ -587,7 +614,7 @@ extern "C" int ekaid_gate_fuse_bwd(const float* c2, const float* g2, const float
                                    uint64_t seed_g, void* stream) {
     if (n1 < 1 || n % n1) { set_error("gate_fuse: n %% n1 != 0"); return EKAID_ERR_ARG; }
     hipLaunchKernelGGL(gate_fuse_bwd_kernel, grid1d(n1), dim3(256), 0, ST, c2, g2, c1, g1, dout, dc2, dg2, dc1, dg1, n, n1, p, INVK(p),
-                       seed_c, seed_g);
+                       DS(seed_c), DS(seed_g));
     return check_launch("gate_fuse_bwd");
 }
 extern "C" int ekaid_weighted_pool_fwd(const float* w, const float* x, int G, int n, int C, float* out, void* stream) {
@@ -636,9 +663,9 @@ extern "C" int ekaid_mix3_bwd(const float* w, const float* a, const float* b, co
     return check_launch("mix3_bwd");
 }
 extern "C" int ekaid_nll_fwd(const float* logp, const int64_t* target, int ld_target, const float* mask, int ld_mask, int B, int T,
-                             int V, float* sums, float* loss_out, void* stream) {
+                             int V, const float* denom_dev, float* sums, float* loss_out, void* stream) {
     hipLaunchKernelGGL(nll_fwd_kernel, grid1d((long long)B * T), dim3(256), 0, ST, logp, target, ld_target, mask, ld_mask, B, T, V, sums);
-    hipLaunchKernelGGL(nll_finish_kernel, dim3(1), dim3(1), 0, ST, (const float*)sums, loss_out);
+    hipLaunchKernelGGL(nll_finish_kernel, dim3(1), dim3(1), 0, ST, sums, denom_dev, loss_out);
     return check_launch("nll_fwd");
 }
 extern "C" int ekaid_total_loss_fwd(const float* speaker_loss, const float* att_bef, const float* att_aft, long long n, float coef,
@@ -676,10 +703,20 @@ extern "C" int ekaid_adam_step(float* p, const float* g, float* m, float* v, lon
                        (float)(1.0 / sqrt(bc2)), grad_scale);
     return check_launch("adam_step");
 }
-extern "C" int ekaid_process_matrix(const void* adj, int is_int64, int B, int S, int N, int L, float* out, void* stream) {
+extern "C" int ekaid_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* hyper_dev, int* step_dev,
+                                   float* derived_dev, void* stream) {
+    if (!hyper_dev || !step_dev || !derived_dev) { set_error("adam_step_dev: null state pointer"); return EKAID_ERR_ARG; }
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, ST, step_dev, hyper_dev, derived_dev);
+    hipLaunchKernelGGL(adam_dev_kernel, grid1d(n), dim3(256), 0, ST, p, g, m, v, n, hyper_dev, (const float*)derived_dev);
+    return check_launch("adam_step_dev");
+}
+extern "C" int ekaid_process_matrix(const void* adj, int label_type, int B, int S, int N, int L, float* out, void* stream) {
     if (N > S || N < 1 || L < 1) { set_error("process_matrix: bad dims N=%d S=%d L=%d", N, S, L); return EKAID_ERR_ARG; }
+    if (label_type < 0 || label_type > 2) { set_error("process_matrix: label_type must be 0 (f64), 1 (i64) or 2 (i8)"); return EKAID_ERR_ARG; }
     const long long n = (long long)B * N * N * L;
-    if (is_int64)
+    if (label_type == 2)
+        hipLaunchKernelGGL(process_matrix_kernel<signed char>, grid1d(n), dim3(256), 0, ST, (const signed char*)adj, B, S, N, L, out);
+    else if (label_type == 1)
         hipLaunchKernelGGL(process_matrix_kernel<long long>, grid1d(n), dim3(256), 0, ST, (const long long*)adj, B, S, N, L, out);
     else
         hipLaunchKernelGGL(process_matrix_kernel<double>, grid1d(n), dim3(256), 0, ST, (const double*)adj, B, S, N, L, out);
@@ -754,7 +791,7 @@ extern "C" int ekaid_greedy_step(const float* logp, int B, int V, int t, int* un
 // ------------------------------------------------------------------ strided bias + activation + dropout, and its backward
 namespace ekaid {
 __global__ __launch_bounds__(256) void bias_act_drop_kernel(const float* x, int ldx, const float* bias, int rows, int cols, int act,
-                                                            float p, float inv_keep, uint64_t seed, float* out) {
+                                                            float p, float inv_keep, DropSeed seed, float* out) {
     const int n = rows * cols;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int r = i / cols, c = i - r * cols;
@@ -763,7 +800,7 @@ __global__ __launch_bounds__(256) void bias_act_drop_kernel(const float* x, int 
     }
 }
 __global__ __launch_bounds__(256) void drop_act_bwd_kernel(const float* dy, const float* y, int ldy, int rows, int cols, int act, float p,
-                                                           float inv_keep, uint64_t seed, float* out, int ldo) {
+                                                           float inv_keep, DropSeed seed, float* out, int ldo) {
     const int n = rows * cols;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int r = i / cols, c = i - r * cols;
@@ -775,12 +812,12 @@ __global__ __launch_bounds__(256) void drop_act_bwd_kernel(const float* dy, cons
 extern "C" int ekaid_bias_act_drop(const float* x, int ldx, const float* bias, int rows, int cols, int act, float p, uint64_t seed,
                                    float* out, void* stream) {
     hipLaunchKernelGGL(ekaid::bias_act_drop_kernel, ekaid::grid1d((long long)rows * cols), dim3(256), 0, ST, x, ldx, bias, rows, cols, act, p,
-                       INVK(p), seed, out);
+                       INVK(p), DS(seed), out);
     return ekaid::check_launch("bias_act_drop");
 }
 extern "C" int ekaid_drop_act_bwd(const float* dy, const float* y, int ldy, int rows, int cols, int act, float p, uint64_t seed,
                                   float* out, int ldo, void* stream) {
     hipLaunchKernelGGL(ekaid::drop_act_bwd_kernel, ekaid::grid1d((long long)rows * cols), dim3(256), 0, ST, dy, y, ldy, rows, cols, act, p,
-                       INVK(p), seed, out, ldo);
+                       INVK(p), DS(seed), out, ldo);
     return ekaid::check_launch("drop_act_bwd");
 }

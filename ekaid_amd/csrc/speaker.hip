@@ -93,8 +93,8 @@ __global__ __launch_bounds__(256) void spk_modmix_bwd_kernel(const float* mw, co
 // GEMM epilogue dropout, which this kernel replaces
 __global__ __launch_bounds__(256) void spk_pos_fwd_kernel(const float* x, int ldx, const float* b1, int R, const float* w_wp,
                                                           const float* b_wp, int P, const float* w_p2, const float* b_p2,
-                                                          float pv, float invv, uint64_t seed_v, float p5, float inv5,
-                                                          uint64_t seed_d, float* vp, float* dp, float* pw, float* pp, int ldpp) {
+                                                          float pv, float invv, DropSeed seed_v, float p5, float inv5,
+                                                          DropSeed seed_d, float* vp, float* dp, float* pw, float* pp, int ldpp) {
     __shared__ float sv[SPK_MAXR];
     __shared__ float sz[SPK_MAXP];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void spk_pos_fwd_kernel(const float* x, int ld
 // output vp) -> dx_out (R, leading dim lddx)
 __global__ __launch_bounds__(256) void spk_pos_bwd_kernel(const float* dpp, int lddpp, const float* pw, const float* dhead, int P,
                                                           const float* w_p2, const float* w_wp, const float* vp, int R, float pv,
-                                                          float invv, uint64_t seed_v, float p5, float inv5, uint64_t seed_d,
+                                                          float invv, DropSeed seed_v, float p5, float inv5, DropSeed seed_d,
                                                           float* dwp_out, float* dx_out, int lddx) {
     __shared__ float sd[SPK_MAXR];
     __shared__ float sg[SPK_MAXP];
@@ -225,8 +225,8 @@ extern "C" int ekaid_spk_pos_fwd(const float* x, int ldx, const float* b1, int B
                                  float* vp, float* dp, float* pw, float* pp, int ldpp, void* stream) {
     if (R > SPK_MAXR || P > SPK_MAXP) { set_error("ekaid_spk_pos_fwd: R <= %d and P <= %d required", SPK_MAXR, SPK_MAXP); return EKAID_ERR_UNSUPPORTED; }
     if (B <= 0) return EKAID_OK;
-    hipLaunchKernelGGL(spk_pos_fwd_kernel, dim3(B), dim3(256), 0, ST, x, ldx, b1, R, w_wp, b_wp, P, w_p2, b_p2, p_v, INVK(p_v), seed_v,
-                       p_d, INVK(p_d), seed_d, vp, dp, pw, pp, ldpp);
+    hipLaunchKernelGGL(spk_pos_fwd_kernel, dim3(B), dim3(256), 0, ST, x, ldx, b1, R, w_wp, b_wp, P, w_p2, b_p2, p_v, INVK(p_v), DS(seed_v),
+                       p_d, INVK(p_d), DS(seed_d), vp, dp, pw, pp, ldpp);
     return check_launch("spk_pos_fwd");
 }
 
@@ -236,7 +236,7 @@ extern "C" int ekaid_spk_pos_bwd(const float* dpp, int lddpp, const float* pw, c
     if (R > SPK_MAXR || P > SPK_MAXP) { set_error("ekaid_spk_pos_bwd: R <= %d and P <= %d required", SPK_MAXR, SPK_MAXP); return EKAID_ERR_UNSUPPORTED; }
     if (B <= 0) return EKAID_OK;
     hipLaunchKernelGGL(spk_pos_bwd_kernel, dim3(B), dim3(256), 0, ST, dpp, lddpp, pw, dhead, P, w_p2, w_wp, vp, R, p_v, INVK(p_v),
-                       seed_v, p_d, INVK(p_d), seed_d, dwp_out, dx_out, lddx);
+                       DS(seed_v), p_d, INVK(p_d), DS(seed_d), dwp_out, dx_out, lddx);
     return check_launch("spk_pos_bwd");
 }
 

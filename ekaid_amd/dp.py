@@ -18,6 +18,8 @@ buckets overlaps the rest of backward.  xGMI is point-to-point (7 links x ~153 G
 (default 32 MB) are preferred over many small ones.  The 1/world_size averaging is folded into the
 Adam kernel (``grad_scale``).
 """
+import hashlib
+
 import torch
 import torch.distributed as dist
 
@@ -33,6 +35,7 @@ class GradBuckets:
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.overlap = overlap
+        self.force_comm = False       # issue the collectives even at world size 1 (exercises the RCCL path on one GPU)
         self.built = False
         self.order = []             # parameters in first-backward completion order
         self._seen = set()
@@ -51,8 +54,11 @@ class GradBuckets:
             raise RuntimeError('a parameter outside the live set discovered on the first backward received a '
                                'gradient; rebuild GradBuckets (call reset())')
         self._pending[b] -= 1
-        if self._pending[b] == 0 and self.overlap and self.world > 1:
-            self._launch(b)
+        if self.overlap and self.comm_active():
+            # strictly in bucket order (bucket b only once 0..b-1 are out): every rank issues the same sequence of
+            # collectives even if autograd finishes two buckets in a different order on different ranks
+            while self._next < len(self.buckets) and self._pending[self._next] == 0:
+                self._launch(self._next)
 
     def build(self):
         """Freeze the live set (parameters whose .grad is set now) and move them into flat storage."""
@@ -91,10 +97,27 @@ class GradBuckets:
                 start, cur_bytes, members = end, 0, []
         self.built = True
         self._reset_pending()
+        self._check_layout_agreement()
+
+    def comm_active(self):
+        return self.world > 1 or self.force_comm
+
+    def _check_layout_agreement(self):
+        """Buckets are reduced by raw offset: all ranks must have derived the SAME flat layout (same live set, same
+        completion order, same cuts).  Compared through a digest of (shape, offset) per tensor + the bucket bounds."""
+        if self.world <= 1:
+            return
+        h = hashlib.sha256(repr(([tuple(p.shape) for p in self.live], self.offsets, self.buckets)).encode()).hexdigest()
+        all_h = [None] * self.world
+        dist.all_gather_object(all_h, h, group=self.group)
+        if any(x != h for x in all_h):
+            raise RuntimeError('GradBuckets: ranks disagree on the flat gradient layout (a parameter received a gradient '
+                               'on some ranks only, or backward finished gradients in a different order): %r' % (all_h,))
 
     def _reset_pending(self):
         self._pending = [n for (_, _, n) in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._next = 0
         self.handles = []
 
     def reset(self):
@@ -117,13 +140,14 @@ class GradBuckets:
             return
         s, e, _ = self.buckets[b]
         self._launched[b] = True
+        self._next = max(self._next, b + 1)
         self.handles.append(dist.all_reduce(self.gflat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Make every bucket's reduced SUM visible to the current stream (call after backward)."""
         if not self.built:
             self.build()
-        if self.world > 1:
+        if self.comm_active():
             for b in range(len(self.buckets)):
                 self._launch(b)
             for h in self.handles:
@@ -145,22 +169,59 @@ class FlatAdam(GradBuckets):
         for m in modules:
             params += list(m.parameters())
         super().__init__(params, process_group, bucket_mb, overlap)
-        self.lr, self.betas, self.eps = lr, betas, eps
-        self.step_count = 0
+        self._lr, self.betas, self.eps = lr, betas, eps
+        self._step_host = 0
         self.m = self.v = None
+        self._hyper = self._step_dev = self._derived = None
+
+    # The step counter and the hyper-parameters live in device memory (ekaid_adam_step_dev): a step captured into a
+    # hipGraph keeps counting and follows learning-rate changes made between replays.
+    def _device_state(self):
+        if self._hyper is None:
+            dev = self.pflat.device
+            self._hyper = torch.tensor([self._lr, self.betas[0], self.betas[1], self.eps, 1.0 / self.world],
+                                       dtype=torch.float32, device=dev)
+            self._step_dev = torch.tensor([self._step_host], dtype=torch.int32, device=dev)
+            self._derived = torch.zeros(2, dtype=torch.float32, device=dev)
+        return self._hyper, self._step_dev, self._derived
+
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        self._lr = float(value)
+        if self._hyper is not None:
+            self._hyper[0:1].copy_(torch.tensor([self._lr], dtype=torch.float32), non_blocking=False)
+
+    @property
+    def step_count(self):
+        """Number of updates applied so far (one device->host read when the counter lives on the device)."""
+        return int(self._step_dev.item()) if self._step_dev is not None else self._step_host
+
+    @step_count.setter
+    def step_count(self, value):
+        self._step_host = int(value)
+        if self._step_dev is not None:
+            self._step_dev.fill_(int(value))
 
     def step(self):
         self.finish()
+        self.apply_update()
+
+    def apply_update(self):
+        """The Adam kernel alone (gradients already reduced): what a captured step replays."""
         hip.require_cuda(self.pflat)
         if getattr(self, '_pending_state', None) is not None:
             self._apply_pending_state()
         if self.m is None:
             self.m = torch.zeros_like(self.pflat)
             self.v = torch.zeros_like(self.pflat)
-        self.step_count += 1
-        hip.check(hip.lib().ekaid_adam_step(hip.ptr(self.pflat), hip.ptr(self.gflat), hip.ptr(self.m), hip.ptr(self.v),
-                                            self.total, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count,
-                                            1.0 / self.world, hip.stream()), 'adam_step')
+        hyper, step, derived = self._device_state()
+        hip.check(hip.lib().ekaid_adam_step_dev(hip.ptr(self.pflat), hip.ptr(self.gflat), hip.ptr(self.m), hip.ptr(self.v),
+                                                self.total, hip.ptr(hyper), hip.ptr(step), hip.ptr(derived), hip.stream()),
+                  'adam_step_dev')
 
     # ------------------------------------------------------------------ checkpointing (SURVEY f-4)
     def state_dict(self, named_parameters=None):
@@ -206,6 +267,24 @@ class FlatAdam(GradBuckets):
             o, k = where[id(p)], p.numel()
             self.m[o:o + k].copy_(t.reshape(-1).to(self.m.device))
             self.v[o:o + k].copy_(state['exp_avg_sq'][n].reshape(-1).to(self.v.device))
+
+
+# --------------------------------------------------------------------------- loss weighting for ragged answers
+def loss_denominator(local_mask_sum, process_group=None):
+    """Denominator that makes data-parallel training reproduce the reference's loss over the GLOBAL batch.
+
+    The reference loss is ``-sum(logp * mask) / sum(mask)`` over the whole batch (utils/utils.py:213-214).  Each rank
+    computes its numerator locally and the optimiser averages the ranks' gradients (1/W); dividing every rank's
+    numerator by ``sum_over_ranks(mask sum) / W`` therefore yields exactly the gradient of the global-batch loss, also
+    when the ranks hold answers of different lengths.  ``local_mask_sum``: float or 1-element
+    tensor (host or device); returns a 1-element float32 tensor on the same device (one tiny all-reduce)."""
+    t = local_mask_sum if isinstance(local_mask_sum, torch.Tensor) else torch.tensor([float(local_mask_sum)])
+    t = t.detach().reshape(1).to(torch.float32).clone()
+    world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=process_group)
+        t /= world
+    return t
 
 
 # --------------------------------------------------------------------------- Q-C under data parallelism

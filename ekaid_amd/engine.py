@@ -1,0 +1,177 @@
+"""One training iteration of the difference-VQA path (reference ``train_mimic.py:209-269``) as a reusable object, eager or
+replayed from a captured hipGraph.
+
+Eager: ~1 350 kernel launches issued from Python through ctypes, ~14 ms of host time per step -- invisible at 256 pairs
+per GPU (34 ms of GPU work) but the floor of the strong-scaling points (32 pairs per GPU on 8 GPUs).  The C ABI is
+allocation- and synchronisation-free, so the whole step -- adjacency expansion, detector, decoder, loss,
+backward, Adam -- is captured ONCE per (batch, nodes, decode steps) shape with ``torch.cuda.graph`` (torch's allocator
+and autograd run at capture time only) and replayed with a single launch:
+  * inputs live in static buffers (one device copy per step);
+  * dropout: every site's seed is frozen in the graph, the device-resident epoch word advanced at the head of the graph
+    gives every replay fresh masks (include/ekaid_hip.h: ekaid_set_dropout_epoch_ptr);
+  * Adam's step counter / learning rate live on the device (ekaid_adam_step_dev);
+  * data parallel: the gradient all-reduce runs eagerly after the replay by default (``comm='eager'``: bucketed RCCL
+    calls + the Adam kernel, ~10 launches); ``comm='captured'`` keeps the overlapped hook-driven all-reduce inside the graph.
+"""
+import torch
+
+from . import hip, ops
+from .utils.mimic_utils import process_matrix
+from .utils.utils import LanguageModelCriterion, total_loss
+
+ADJ_KEYS = (('d_adj', 'spatial'), ('q_adj', 'spatial'), ('d_sem', 'semantic'), ('q_sem', 'semantic'))
+INPUT_KEYS = ('input_1', 'input_2', 'd_adj', 'q_adj', 'd_sem', 'q_sem', 'd_bb', 'q_bb', 'question', 'labels', 'masks')
+
+
+def forward_loss(cfg, cd, sp, b, T, graph='all', setting='mode2', denom=None, marks=None):
+    """adjacency expansion -> ChangeDetector -> teacher-forced DynamicSpeaker -> LM loss + attention regulariser.
+    ``b``: dict of tensors (ekaid_amd/synthetic.py keys).  Returns (total loss, speaker loss, detector outputs, logp)."""
+    N = b['input_1'].shape[1]
+    dev = b['input_1'].device
+
+    def mark(name):
+        if marks is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append((name, e))
+    adj = [process_matrix(b[k], cfg, N, dev, type=ty) for k, ty in ADJ_KEYS]
+    mark('adjacency')
+    outs = cd(b['input_1'], b['input_2'], adj[0], adj[1], adj[2], adj[3], b['d_bb'], b['q_bb'], b['question'],
+              setting=setting, graph=graph)
+    mark('detector_fwd')
+    logp, _ = sp._forward(outs[3], outs[4], outs[5], b['labels'], num_steps=T)
+    sp_loss = LanguageModelCriterion()(logp, b['labels'][:, 1:], b['masks'][:, 1:], denom=denom)
+    loss = total_loss(sp_loss, outs[1], outs[2])
+    mark('speaker_fwd_loss')
+    return loss, sp_loss, outs, logp
+
+
+class TrainStep:
+    """``step(batch, T, denom=None) -> (total loss, speaker loss)`` (device scalars; no host synchronisation)."""
+
+    def __init__(self, cfg, cd, sp, opt, graph='all', setting='mode2', use_graph=False, comm='eager', warmup=2):
+        if comm not in ('eager', 'captured'):
+            raise ValueError("comm must be 'eager' or 'captured'")
+        self.cfg, self.cd, self.sp, self.opt = cfg, cd, sp, opt
+        self.graph, self.setting = graph, setting
+        self.use_graph, self.comm, self.warmup = use_graph, comm, warmup
+        self._graphs = {}
+        self._pool = None
+        self._epoch = None
+        self.marks = None
+
+    def close(self):
+        """Drop the captured graphs and detach the dropout epoch word from the library."""
+        self._graphs = {}
+        if self._epoch is not None:
+            hip.check(hip.lib().ekaid_set_dropout_epoch_ptr(None), 'set_dropout_epoch_ptr')
+            self._epoch = None
+
+    # ------------------------------------------------------------------ eager
+    def _eager(self, b, T, denom):
+        marks = self.marks
+        if marks is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append(('start', e))
+        self.opt.zero_grad()
+        loss, sp_loss, _, _ = forward_loss(self.cfg, self.cd, self.sp, b, T, self.graph, self.setting, denom, marks)
+        loss.backward()
+        if marks is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append(('backward', e))
+        self.opt.step()
+        if marks is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append(('allreduce_wait_adam', e))
+        return loss, sp_loss
+
+    # ------------------------------------------------------------------ captured
+    def _epoch_word(self, dev):
+        if self._epoch is None:
+            self._epoch = torch.zeros(1, dtype=torch.int64, device=dev)
+            hip.check(hip.lib().ekaid_set_dropout_epoch_ptr(self._epoch.data_ptr()), 'set_dropout_epoch_ptr')
+        return self._epoch
+
+    def _body(self, static, T, denom):
+        hip.check(hip.lib().ekaid_dropout_epoch_advance(self._epoch.data_ptr(), 1, hip.stream()), 'dropout_epoch_advance')
+        self.opt.zero_grad()
+        loss, sp_loss, _, _ = forward_loss(self.cfg, self.cd, self.sp, static, T, self.graph, self.setting, denom)
+        loss.backward()
+        if self.comm == 'captured' or not self.opt.comm_active():
+            self.opt.step()
+        return loss, sp_loss
+
+    def _capture(self, b, T, denom):
+        dev = b['input_1'].device
+        self._epoch_word(dev)
+        static = {k: b[k].clone() for k in INPUT_KEYS}
+        sden = denom.clone() if denom is not None else None
+        overlap = self.opt.overlap
+        if self.comm == 'eager':
+            self.opt.overlap = False            # no collectives inside the capture
+        if not self.opt.built:
+            # one eager forward/backward (no update) fixes the flat parameter/gradient layout and applies a pending
+            # optimizer state (resume) BEFORE the snapshot below is taken
+            seed0 = ops.seed_state()
+            self.opt.zero_grad()
+            loss, _, _, _ = forward_loss(self.cfg, self.cd, self.sp, static, T, self.graph, self.setting, sden)
+            loss.backward()
+            self.opt.finish()
+            if getattr(self.opt, '_pending_state', None) is not None:
+                self.opt._apply_pending_state()
+            ops.set_seed_state(seed0)
+        # capture is transparent: the warm-up steps below really train, so weights, moments, step counter and the
+        # dropout epoch are put back afterwards
+        snap_p = self.opt.pflat.clone()
+        snap_m = self.opt.m.clone() if self.opt.m is not None else None
+        snap_v = self.opt.v.clone() if self.opt.v is not None else None
+        snap_step, snap_epoch = self.opt.step_count, self._epoch.clone()
+        seed_state = ops.seed_state()
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for _ in range(self.warmup):        # sizes every workspace, raises kernel attributes, warms the allocator
+                self._body(static, T, sden)
+                if self.comm == 'eager' and self.opt.comm_active():
+                    self.opt.step()
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize(dev)
+        ops.set_seed_state(seed_state)          # the capture draws the same site seeds as the first warm-up step
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self._pool):
+            loss, sp_loss = self._body(static, T, sden)
+        if self._pool is None:
+            self._pool = g.pool()
+        self.opt.pflat.copy_(snap_p)
+        if snap_m is not None:
+            self.opt.m.copy_(snap_m)
+            self.opt.v.copy_(snap_v)
+        elif self.opt.m is not None:
+            self.opt.m.zero_()
+            self.opt.v.zero_()
+        self.opt.step_count = snap_step
+        self._epoch.copy_(snap_epoch)
+        self.opt.overlap = overlap
+        return {'graph': g, 'static': static, 'denom': sden, 'loss': loss, 'sp_loss': sp_loss}
+
+    def __call__(self, b, T, denom=None):
+        if not self.use_graph:
+            return self._eager(b, T, denom)
+        key = (T, denom is not None) + tuple((k, tuple(b[k].shape), b[k].dtype) for k in INPUT_KEYS)
+        ent = self._graphs.get(key)
+        if ent is None:
+            ent = self._capture(b, T, denom)
+            self._graphs[key] = ent
+        for k in INPUT_KEYS:
+            ent['static'][k].copy_(b[k], non_blocking=True)
+        if denom is not None:
+            ent['denom'].copy_(denom, non_blocking=True)
+        ent['graph'].replay()
+        if self.comm == 'eager' and self.opt.comm_active():
+            self.opt.overlap = False
+            self.opt._reset_pending()
+            self.opt.step()                     # bucketed all-reduce (RCCL) + Adam, outside the graph
+        return ent['loss'], ent['sp_loss']

@@ -46,6 +46,9 @@ P, I, L, F, U64 = c_void_p, c_int, c_longlong, c_float, c_uint64
 SIGNATURES = {
     'ekaid_version': [],
     'ekaid_last_error': [],
+    'ekaid_init': [I],
+    'ekaid_set_dropout_epoch_ptr': [P],
+    'ekaid_dropout_epoch_advance': [P, U64, P],
     'ekaid_gemm_workspace_bytes': [POINTER(GemmDesc)],
     'ekaid_set_gemm_mode': [I],
     'ekaid_get_gemm_mode': [],
@@ -90,7 +93,7 @@ SIGNATURES = {
     'ekaid_softmax_bwd': [P, P, P, L, I, I, P],
     'ekaid_mix3_fwd': [P, P, P, P, I, I, P, P],
     'ekaid_mix3_bwd': [P, P, P, P, P, I, I, P, P, P, P, I, P],
-    'ekaid_nll_fwd': [P, P, I, P, I, I, I, I, P, P, P],
+    'ekaid_nll_fwd': [P, P, I, P, I, I, I, I, P, P, P, P],
     'ekaid_total_loss_fwd': [P, P, P, L, F, P, P],
     'ekaid_fill_scaled': [P, F, P, L, P],
     'ekaid_nll_bwd': [P, I, P, I, P, P, I, I, I, P, P],
@@ -100,6 +103,7 @@ SIGNATURES = {
     'ekaid_greedy_step': [P, I, I, I, P, P, P, P, I, P, P],
     'ekaid_transpose': [P, I, I, I, P, I, P],
     'ekaid_adam_step': [P, P, P, P, L, F, F, F, F, I, F, P],
+    'ekaid_adam_step_dev': [P, P, P, P, L, P, P, P, P],
 }
 _RESTYPES = {'ekaid_last_error': c_char_p, 'ekaid_gemm_workspace_bytes': c_size_t}
 

@@ -804,8 +804,8 @@ class LMLossFn(Function):
     """loss = -sum(logp[b,t,target[b,t]] * mask[b,t]) / sum(mask).  ref: utils/utils.py:208-216."""
 
     @staticmethod
-    def forward(ctx, logp, target, mask):
-        require_cuda(logp, target, mask)
+    def forward(ctx, logp, target, mask, denom):
+        require_cuda(logp, target, mask, denom)
         logp = _c(logp)
         B, T, V = logp.shape
         assert target.stride(1) == 1 and mask.stride(1) == 1 and target.dtype == torch.int64
@@ -813,7 +813,7 @@ class LMLossFn(Function):
         sums = torch.zeros(2, device=logp.device, dtype=torch.float32)
         loss = torch.empty((), device=logp.device, dtype=torch.float32)
         check(hip.lib().ekaid_nll_fwd(ptr(logp), target.data_ptr(), target.stride(0), mask.data_ptr(), mask.stride(0),
-                                      B, T, V, ptr(sums), ptr(loss), stream()), 'nll_fwd')
+                                      B, T, V, ptr(denom), ptr(sums), ptr(loss), stream()), 'nll_fwd')
         ctx.save_for_backward(target, mask, sums)
         ctx.shape = (B, T, V)
         return loss
@@ -825,11 +825,12 @@ class LMLossFn(Function):
         dlogp = torch.empty(B, T, V, device=sums.device, dtype=torch.float32)
         check(hip.lib().ekaid_nll_bwd(target.data_ptr(), target.stride(0), mask.data_ptr(), mask.stride(0), ptr(sums),
                                       ptr(_c(d)), B, T, V, ptr(dlogp), stream()), 'nll_bwd')
-        return dlogp, None, None
+        return dlogp, None, None, None
 
 
-def lm_loss(logp, target, mask):
-    return LMLossFn.apply(logp, target, mask)
+def lm_loss(logp, target, mask, denom=None):
+    """``denom``: optional device scalar that replaces sum(mask) (data-parallel loss weighting, include/ekaid_hip.h)."""
+    return LMLossFn.apply(logp, target, mask, denom)
 
 
 class TotalLossFn(Function):

@@ -15,14 +15,15 @@ def torch_broadcast_adj_matrix(adj_matrix, label_num=11, device=None):
 def process_matrix_labels(adj_matrix, num_objects, label_num, device=None):
     device = torch.device(device) if device is not None else adj_matrix.device
     adj = adj_matrix.to(device)
-    if adj.dtype not in (torch.float64, torch.int64):
+    if adj.dtype not in (torch.float64, torch.int64, torch.int8):
         adj = adj.to(torch.float64)
     adj = adj.contiguous()
+    label_type = {torch.float64: 0, torch.int64: 1, torch.int8: 2}[adj.dtype]
     hip.require_cuda(adj)
     B, S = adj.shape[0], adj.shape[1]
     assert adj.shape[2] == S
     out = torch.empty(B, num_objects, num_objects, label_num, device=device, dtype=torch.float32)
-    check(hip.lib().ekaid_process_matrix(adj.data_ptr(), int(adj.dtype == torch.int64), B, S, num_objects, label_num,
+    check(hip.lib().ekaid_process_matrix(adj.data_ptr(), label_type, B, S, num_objects, label_num,
                                          ptr(out), stream()), 'process_matrix')
     return out
 

@@ -26,10 +26,25 @@
 extern "C" {
 #endif
 
-#define EKAID_ABI_VERSION 1
+#define EKAID_ABI_VERSION 2
 
 int ekaid_version(void);
-const char* ekaid_last_error(void);
+const char* ekaid_last_error(void);        /* thread-local */
+
+/* Per-device state.  The library keeps exactly one small state record per HIP device (GEMM arithmetic selection,
+ * dropout epoch pointer, "kernel attribute already raised" flags), every field atomic: calls from different host
+ * threads or on different streams do not race.  ekaid_init(device) creates the record eagerly (it is also created on
+ * the first call made with that device current); all other entry points act on the calling thread's CURRENT device.
+ * The reference has no counterpart (single process, single GPU: train_mimic.py:2). */
+int ekaid_init(int device_id);
+
+/* Dropout under hipGraph replay.  Every dropout site takes its 64-bit seed BY VALUE, which a captured graph freezes.
+ * After ekaid_set_dropout_epoch_ptr(p) (p: one 64-bit word in device memory, NULL to switch off) every site of the
+ * current device uses  seed + p[0] * 0x9E3779B97F4A7C15  instead; ekaid_dropout_epoch_advance enqueues p[0] += by on a
+ * stream (put it at the head of the captured step): each replay draws fresh masks, forward and backward of one replay
+ * agree.  ref: the reference draws fresh masks every iteration through torch's global RNG (nn.Dropout, F.dropout). */
+int ekaid_set_dropout_epoch_ptr(const unsigned long long* epoch_dev);
+int ekaid_dropout_epoch_advance(unsigned long long* epoch_dev, unsigned long long by, void* stream);
 
 /* activation codes for fused epilogues */
 #define EKAID_ACT_NONE 0
@@ -71,7 +86,7 @@ typedef struct ekaid_gemm {
 size_t ekaid_gemm_workspace_bytes(const ekaid_gemm_t* g);
 int ekaid_gemm_f32(const ekaid_gemm_t* g, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Arithmetic of ekaid_gemm_f32 (process-wide; both take and return f32 and accumulate in f32):
+/* Arithmetic of ekaid_gemm_f32 (per device; both take and return f32 and accumulate in f32):
  *   EKAID_GEMM_F32_MFMA   (0)  v_mfma_f32_32x32x2_f32, an exact f32 fma chain;
  *   EKAID_GEMM_BF16_SPLIT (1)  every f32 operand element is split EXACTLY into three bf16 values (8+8+8 significant
  *                              bits) and the six products above 2^-24 relative are formed on v_mfma_f32_32x32x16_bf16
@@ -234,10 +249,12 @@ int ekaid_mix3_bwd(const float* w, const float* a, const float* b, const float* 
 
 /* masked NLL of teacher-forced log-probs.   ref: utils/utils.py:208-216
  * sums[0] = -sum logp[b][t][target[b][t]] * mask[b][t], sums[1] = sum mask  (t < T); caller zero-fills sums;
- * loss_out[0] = sums[0] / sums[1].
+ * loss_out[0] = sums[0] / sums[1].  denom_dev (optional device scalar): overrides sums[1] -- under data parallelism
+ * the caller passes (mask sum of the GLOBAL batch) / world_size, so that averaging the ranks' gradients reproduces the
+ * loss of the global batch when the ranks hold answers of different lengths.
  * bwd: dlogp[b][t][v] = -(v == target) * mask * gscale_dev[0] / sums[1]   (dlogp zero elsewhere, written in full) */
 int ekaid_nll_fwd(const float* logp, const int64_t* target, int ld_target, const float* mask, int ld_mask, int B, int T,
-                  int V, float* sums, float* loss_out, void* stream);
+                  int V, const float* denom_dev, float* sums, float* loss_out, void* stream);
 int ekaid_nll_bwd(const int64_t* target, int ld_target, const float* mask, int ld_mask, const float* sums,
                   const float* gscale_dev, int B, int T, int V, float* dlogp, void* stream);
 
@@ -253,9 +270,10 @@ int ekaid_layernorm_fwd(const float* x, const float* gamma, const float* beta, l
 int ekaid_layernorm_bwd(const float* x, const float* gamma, const float* save, const float* dy, long long rows, int cols,
                         float* dx, float* dgamma, float* dbeta, void* stream);
 
-/* integer-valued label matrix [B][S][S] (float64 as the reference collates it, or int64) -> one-hot float32
- * [B][N][N][L], channel l-1 = (label == l), cropped to the first N nodes.   ref: utils/mimic_utils.py:119-149 */
-int ekaid_process_matrix(const void* adj, int is_int64, int B, int S, int N, int L, float* out, void* stream);
+/* integer-valued label matrix [B][S][S] -> one-hot float32 [B][N][N][L], channel l-1 = (label == l), cropped to the
+ * first N nodes.  label_type: 0 = float64 (as the reference collates it), 1 = int64 (as stored in the HDF5 file),
+ * 2 = int8 (the compact form the data pipeline ships over PCIe).   ref: utils/mimic_utils.py:119-149 */
+int ekaid_process_matrix(const void* adj, int label_type, int B, int S, int N, int L, float* out, void* stream);
 
 /* One greedy decode step for the whole batch (sample_max = 1).   ref: dynamic_speaker_change_pos.py:316-352
  * logp [B][V]; forbids token 0 at t == 0; it/seq[:, t]/seq_logp[:, t] written; unfinished[B] updated in place;
@@ -272,6 +290,11 @@ int ekaid_transpose(const float* src, int R, int C, int ld_src, float* dst, int 
  * g is multiplied by grad_scale first (1/world_size after an all-reduce sum). */
 int ekaid_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                     float eps, int step, float grad_scale, void* stream);
+/* The same update with the step counter and the hyper-parameters in DEVICE memory, for hipGraph capture (a captured
+ * by-value launch would freeze the bias correction and the learning-rate schedule): step_dev[0] is incremented by the
+ * call, hyper_dev = {lr, beta1, beta2, eps, grad_scale}, derived_dev = 2 floats of scratch. */
+int ekaid_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* hyper_dev, int* step_dev,
+                        float* derived_dev, void* stream);
 
 #ifdef __cplusplus
 }

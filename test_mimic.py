@@ -2,7 +2,9 @@
 """Evaluation entry point -- counterpart of the reference's ``model/test_mimic.py`` (:25-152): load a checkpoint in the
 reference's layout, greedy-decode a test split on MI355X, write COCO-format captions.
 
-    python test_mimic.py -p experiments/temp/<run>/snapshots/checkpoint_20.pt --synthetic
+    python test_mimic.py -p experiments/temp/<run>/snapshots/checkpoint_20.pt                  # cfg.data.* HDF5 files
+    python test_mimic.py -p .../checkpoint_20.pt --data_dir /tmp/d                             # generated dataset
+    python test_mimic.py -p .../checkpoint_20.pt --synthetic                                   # seeded batches, no files
 
 Caption metrics (BLEU/METEOR/ROUGE-L/CIDEr through pycocoevalcap + Java) are outside the hot path and absent from
 this image; the script reports exact-match accuracy (reference evaluate_score.py:216-251) and writes the
@@ -20,7 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from ekaid_amd import hip                                                 # noqa: E402
-from ekaid_amd.config import cfg, merge_cfg_from_file, merge_into, MIMIC_YAML   # noqa: E402
+from ekaid_amd.config import cfg, default_cfg, merge_cfg_from_file, merge_into, MIMIC_YAML   # noqa: E402
 from ekaid_amd.models.dynamic_speaker_change_pos import DynamicSpeaker   # noqa: E402
 from ekaid_amd.models.modules import ChangeDetector                      # noqa: E402
 from ekaid_amd.synthetic import make_batch                               # noqa: E402
@@ -28,7 +30,7 @@ from ekaid_amd.utils.mimic_utils import process_matrix                   # noqa:
 from ekaid_amd.utils.utils import coco_gen_format_save, decode_sequence, load_checkpoint, set_mode  # noqa: E402
 
 
-def main():
+def main(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument('--cfg', default='')
     p.add_argument('-p', '--resume_checkpoint', type=str, required=True)
@@ -38,20 +40,35 @@ def main():
     p.add_argument('--synthetic', action='store_true')
     p.add_argument('--batches', type=int, default=4)
     p.add_argument('--nodes', type=int, default=52)
-    args = p.parse_args()
+    p.add_argument('--data_dir', default='')
+    p.add_argument('--split', default='test', choices=['test', 'val', 'train', 'all'])
+    p.add_argument('--exp_dir', default=None)
+    args = p.parse_args(argv)
+    cfg.clear()
+    cfg.update(default_cfg())
     if args.cfg:
         merge_cfg_from_file(args.cfg)
     else:
         merge_into(json.loads(json.dumps(MIMIC_YAML)), cfg)
     cfg.train.graph = args.graph
-    if not args.synthetic:
-        raise SystemExit('The MIMIC-Diff-VQA HDF5 reader (SURVEY.md section 8 f-1) is not part of this round; use --synthetic.')
+    cfg.data.feature_mode = args.feature_mode
+    if args.exp_dir:
+        cfg.exp_dir = args.exp_dir
+    if args.data_dir:
+        from ekaid_amd.datasets.generate import point_cfg_at
+        point_cfg_at(cfg, args.data_dir)
     device = torch.device('cuda', max(args.gpu, 0))
     torch.cuda.set_device(device)
     hip.load()
     ck = load_checkpoint(args.resume_checkpoint)
-    vocab = json.load(open(cfg.data.vocab_json)) if os.path.exists(cfg.data.vocab_json) else \
-        {'w%d' % i: i for i in range(1, 148)}
+    dataset = loader = None
+    if args.synthetic:
+        vocab = json.load(open(cfg.data.vocab_json)) if os.path.exists(cfg.data.vocab_json) else \
+            {'w%d' % i: i for i in range(1, 148)}
+    else:
+        from ekaid_amd.datasets import create_dataset
+        dataset, loader = create_dataset(cfg, args.split)
+        vocab = dataset.get_word_to_idx()
     idx_to_word = {i: w for w, i in vocab.items()}
     V = len(idx_to_word) + 1
     change_detector = ChangeDetector(cfg, vocab)
@@ -66,8 +83,13 @@ def main():
     D = cfg.model.change_detector.feat_dim - 2
     predictions, correct, total = {}, 0, 0
     t0 = time.time()
+    if loader is not None:
+        # the reference's loop (test_mimic.py:97-141) over the real split: device feed, detector, greedy decode
+        from train_mimic import evaluate
+        predictions, accuracy, total = evaluate(cfg, change_detector, speaker, loader, device, idx_to_word, args.graph)
+        correct = round(accuracy * total)
     with torch.no_grad():
-        for i in range(args.batches):
+        for i in range(args.batches if loader is None else 0):
             host = make_batch(B=cfg.data.test.batch_size, N=args.nodes, D=D, Lq=20, T=16,
                               seq_length=cfg.model.speaker.seq_length, V=V, seed=977 + i)
             b = {k: v.to(device) for k, v in host.items()}
@@ -88,6 +110,7 @@ def main():
     coco_gen_format_save(predictions, path)
     print(path)
     print('exact-match accuracy: %.4f (%d/%d)' % (correct / max(total, 1), correct, total))
+    return {'results_file': path, 'accuracy': correct / max(total, 1), 'n': total, 'predictions': predictions}
 
 
 if __name__ == '__main__':

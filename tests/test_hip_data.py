@@ -1,0 +1,159 @@
+"""GPU tests of this round's host-side additions: the real-data path end to end (generated HDF5 dataset of the real
+shapes -> reader -> compact device feed -> HIP path vs the CPU oracle; train_mimic.py / test_mimic.py without
+--synthetic), resume across snapshot / epoch boundaries, hipGraph replay vs eager, the RCCL code path on one GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope='module')
+def data_dir(tmp_path_factory):
+    from ekaid_amd.datasets.generate import make_dataset
+    return make_dataset(str(tmp_path_factory.mktemp('mimic')), n_images=24, n_pairs=90, nodes=52, D=1024, seed=3)
+
+
+def test_real_shape_batch_reader_to_hip_path_vs_oracle(data_dir):
+    """N = 52 regions, D = 1024, ragged answers: the batch the device feed delivers (int8 adjacency, pinned staging, side
+    stream) equals the collated reference-layout batch, and the HIP path on it matches the CPU oracle on the
+    reference-layout batch (log-probs <= 1e-3 of their range, identical argmax)."""
+    from common import build_models, oracle_params
+    from ekaid_amd.config import mimic_cfg
+    from ekaid_amd.datasets import create_dataset
+    from ekaid_amd.datasets.generate import point_cfg_at
+    from ekaid_amd.datasets.rcc_dataset_pos_mimic import DevicePrefetcher, batch_dict
+    from ekaid_amd.engine import forward_loss
+    from ekaid_amd.models.dynamic_speaker_change_pos import DynamicSpeaker
+    from oracle import ekaid_oracle as O
+    cfg = point_cfg_at(mimic_cfg(), data_dir)
+    cfg.data.feature_mode = 'both'
+    cfg.data.test.batch_size = 6
+    cfg.model.speaker.vocab_size = 148
+    ds, loader = create_dataset(cfg, 'test')
+    ref = batch_dict(ds[[0, 1, 2, 3, 4, 5]])
+    dev_batch = next(iter(DevicePrefetcher(loader, 'cuda')))
+    N = 52
+    assert dev_batch['input_1'].shape == (6, N, 1024) and dev_batch['d_adj'].dtype == torch.int8
+    for k in ('input_1', 'input_2', 'labels', 'masks', 'question', 'd_bb', 'q_bb', 'pos', 'pair_index'):
+        assert torch.equal(dev_batch[k].cpu(), ref[k]), k
+    for k in ('d_adj', 'q_adj', 'd_sem', 'q_sem'):
+        assert torch.equal(dev_batch[k].cpu().double(), ref[k][:, :N, :N]), k
+    lens = (ref['labels'] != 0).sum(1)
+    assert lens.min() < lens.max(), 'answers must be ragged for this test'
+    cd, sp = build_models(cfg, 147, 148, 'cuda')
+    T = DynamicSpeaker.count_steps(ref['labels'], cfg.model.speaker.seq_length)
+    with torch.no_grad():
+        loss, sp_loss, outs, logp = forward_loss(cfg, cd, sp, dev_batch, T, 'all', 'mode2')
+        lo, res = O.train_loss(oracle_params(cd), oracle_params(sp), cfg, ref, 'mode2', 'all')
+    got, want = logp[:, :T].cpu(), res['logp'][:, :T]
+    err = float((got - want).abs().max() / want.abs().max())
+    assert err < 1e-3, err
+    assert torch.equal(got.argmax(-1), want.argmax(-1))
+    assert abs(float(loss) - float(lo)) < 1e-4 * abs(float(lo))
+
+
+def test_entry_scripts_run_on_a_dataset_without_synthetic(data_dir, tmp_path):
+    """train_mimic.py then test_mimic.py on HDF5 files (no --synthetic): checkpoints in the reference layout, in-loop
+    evaluation json, greedy captions for every pair of the test split."""
+    import test_mimic
+    import train_mimic
+    out = train_mimic.main(['--data_dir', data_dir, '--max_iter', '5', '--batch_size', '8', '--snapshot_interval', '5',
+                            '--exp_dir', str(tmp_path), '--quiet', '--eval_batches', '1'])
+    assert out['iteration'] == 5 and np.isfinite(out['last']['total_loss'])
+    ck = os.path.join(out['snapshot_dir'], 'checkpoint_5.pt')
+    assert os.path.exists(ck) and os.path.exists(os.path.join(out['snapshot_dir'], 'checkpoint_best.pt'))
+    res = test_mimic.main(['-p', ck, '--data_dir', data_dir, '--exp_dir', str(tmp_path), '--feature_mode', 'both'])
+    n_test = len(json.load(open(os.path.join(data_dir, 'splits_mimic_VQA.json')))['test'])
+    rows = json.load(open(res['results_file']))
+    assert res['n'] == n_test == len(rows) and set(rows[0]) == {'caption', 'image_id'}
+
+
+def _weights(out):
+    return torch.cat([p.detach().reshape(-1).double().cpu() for m in (out['change_detector'], out['speaker'])
+                      for p in m.parameters()])
+
+
+@pytest.mark.parametrize('stop', [3, 4])
+def test_resumed_run_continues_the_uninterrupted_run(tmp_path, stop):
+    """7 iterations straight == ``stop`` iterations + checkpoint + --resume for the rest, with 3-iteration epochs and a
+    learning-rate decay every epoch: the snapshot lands on an epoch boundary (stop = 3) or mid-epoch (stop = 4); epoch
+    counter, StepLR phase, Adam moments and the dropout stream all carry over."""
+    import train_mimic
+    common = ['--synthetic', '--batch_size', '4', '--nodes', '12', '--answer_steps', '5', '--iters_per_epoch', '3',
+              '--step_size', '1', '--quiet', '--seed', '77']
+    a = train_mimic.main(common + ['--max_iter', '7', '--snapshot_interval', '100', '--exp_dir', str(tmp_path / 'a')])
+    b1 = train_mimic.main(common + ['--max_iter', str(stop), '--snapshot_interval', str(stop), '--exp_dir', str(tmp_path / 'b')])
+    ck = os.path.join(b1['snapshot_dir'], 'checkpoint_%d.pt' % stop)
+    b2 = train_mimic.main(common + ['--max_iter', '7', '--snapshot_interval', '100', '--exp_dir', str(tmp_path / 'c'),
+                                    '--resume', '1', '--checkpoint', ck])
+    assert a['epoch'] == b2['epoch'] == 3 and a['iteration'] == b2['iteration'] == 7
+    assert a['lr'] == b2['lr'] == pytest.approx(1e-4 * 0.1 ** 3)          # StepLR stepped at the start of epochs 0, 1, 2
+    wa, wb = _weights(a), _weights(b2)
+    drift = float((wa - wb).abs().max())
+    moved = float((wa - _weights(b1)).abs().max())
+    print('resume at %d: max |delta w| resumed vs straight %.3e, distance travelled after the snapshot %.3e' % (stop, drift, moved))
+    assert drift < 1e-2 * moved
+    assert a['last']['total_loss'] == pytest.approx(b2['last']['total_loss'], rel=1e-4)
+
+
+def test_graph_replay_equals_eager():
+    """Three training steps replayed from the captured hipGraph == the same three steps issued eagerly with the same
+    dropout sites and epochs (weights agree to float-atomic noise); consecutive replays draw different masks."""
+    from common import build_models
+    from ekaid_amd import ops
+    from ekaid_amd.config import bench_cfg
+    from ekaid_amd.dp import FlatAdam
+    from ekaid_amd.engine import TrainStep
+    from ekaid_amd.synthetic import make_batch
+    cfg = bench_cfg(D=256, seq_length=12)
+    host = make_batch(B=4, N=12, D=256, Lq=8, T=5, seq_length=12, V=148, seed=5)
+    b = {k: v.cuda() for k, v in host.items()}
+    T = 5
+    finals, losses = [], []
+    for mode in ('eager', 'graph'):
+        cd, sp = build_models(cfg, 147, 148, 'cuda', train=True)
+        opt = FlatAdam([cd, sp], lr=1e-3)
+        ts = TrainStep(cfg, cd, sp, opt, use_graph=(mode == 'graph'))
+        try:
+            ops.manual_seed(4242)
+            ls = []
+            if mode == 'eager':
+                ts._epoch_word(b['input_1'].device)
+                s0 = ops.seed_state()
+                for _ in range(3):
+                    ops.set_seed_state(s0)
+                    ls.append(float(ts._body(b, T, None)[0]))
+            else:
+                for _ in range(3):
+                    ls.append(float(ts(b, T)[0]))
+                assert opt.step_count == 3
+        finally:
+            ts.close()
+        finals.append(torch.cat([p.detach().reshape(-1).double().cpu() for p in list(cd.parameters()) + list(sp.parameters())]))
+        losses.append(ls)
+    assert losses[0] == pytest.approx(losses[1], rel=1e-5), losses
+    assert len(set(losses[1])) == 3
+    d = float((finals[0] - finals[1]).abs().max())
+    assert d < 1e-5, d
+
+
+def test_rccl_path_on_one_gpu(tmp_path):
+    """backend 'nccl' (= RCCL) with world_size 1 on this box: process-group init with device_id, bucketed async
+    all-reduce launched from the gradient hooks, wait, fused Adam -- eager and captured into the hipGraph -- must
+    reproduce the run without any collective."""
+    script = os.path.join(ROOT, 'tests', 'rccl_world1.py')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29871', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, script, str(tmp_path / 'out.json')], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.load(open(str(tmp_path / 'out.json')))
+    assert out['buckets'] > 1 and out['collectives'] > 0
+    assert out['max_delta_eager'] < 1e-6 and out['max_delta_graph'] < 1e-5, out

@@ -690,3 +690,75 @@ def test_spk_gate_bwd():
     dd, ad, gd = d.to(DEV), a.to(DEV), g.to(DEV)
     hip.check(hip.lib().ekaid_spk_gate_bwd(hip.ptr(dd), hip.ptr(ad), hip.ptr(gd), n, hip.ptr(out), _stream()), 'gate')
     check(out, d.double() * a.double() * g.double() * (1 - g.double()), 1e-6, 'gate derivative')
+
+
+def test_round2_kernels_int8_labels_loss_denominator_device_adam_dropout_epoch():
+    """The entry points added for the real-data feed, data-parallel loss weighting and hipGraph replay."""
+    from ekaid_amd import hip, ops
+    from ekaid_amd.hip import check as hcheck, ptr, stream
+    from ekaid_amd.utils.mimic_utils import process_matrix_labels
+    from oracle import ekaid_oracle as O
+    # int8 N x N label matrices (the compact PCIe form) == the reference's float64 100 x 100 path
+    lab = torch.randint(0, 12, (3, 100, 100))
+    want = O.process_matrix(lab.double(), 52, 11)
+    got = process_matrix_labels(lab[:, :52, :52].to(torch.int8).contiguous().to(DEV), 52, 11)
+    assert torch.equal(got.cpu(), want)
+    # LM loss with an external denominator: value and gradient scale with sum(mask) / denom
+    B, T, V = 4, 5, 19
+    logp = torch.log_softmax(rnd(B, T, V, seed=7), -1)
+    labels = torch.randint(1, V, (B, T + 1))
+    masks = torch.zeros(B, T + 1)
+    masks[:, :3] = 1
+    masks[1, :5] = 1
+    g0 = logp.to(DEV).requires_grad_(True)
+    l0 = ops.lm_loss(g0, labels.to(DEV)[:, 1:], masks.to(DEV)[:, 1:])
+    g1 = logp.to(DEV).requires_grad_(True)
+    denom = torch.tensor([7.5], device=DEV)
+    l1 = ops.lm_loss(g1, labels.to(DEV)[:, 1:], masks.to(DEV)[:, 1:], denom)
+    ratio = float(masks[:, 1:].sum()) / 7.5
+    assert float(l1) == pytest.approx(float(l0) * ratio, rel=1e-6)
+    d0, = torch.autograd.grad(l0, g0)
+    d1, = torch.autograd.grad(l1, g1)
+    check(d1, d0 * ratio, 1e-6, 'lm_loss gradient with external denominator')
+    # Adam with device-resident step / hyper-parameters vs torch.optim.Adam, learning rate changed between steps
+    p0, grads = rnd(1000, seed=46), [rnd(1000, seed=47), rnd(1000, seed=48), rnd(1000, seed=49)]
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], 1e-4, (0.9, 0.999), 1e-8)
+    pg, m, v = p0.clone().to(DEV), torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+    hyper = torch.tensor([1e-4, 0.9, 0.999, 1e-8, 0.5], device=DEV)
+    stepd = torch.zeros(1, dtype=torch.int32, device=DEV)
+    derived = torch.zeros(2, device=DEV)
+    for i, g in enumerate(grads):
+        if i == 2:
+            opt.param_groups[0]['lr'] = 3e-5
+            hyper[0] = 3e-5
+        pr.grad = g.clone()
+        opt.step()
+        hcheck(hip.lib().ekaid_adam_step_dev(ptr(pg), ptr((2 * g).to(DEV)), ptr(m), ptr(v), 1000, ptr(hyper), ptr(stepd),
+                                             ptr(derived), stream()), 'adam_dev')
+    assert int(stepd.item()) == 3
+    check(pg - p0.to(DEV), pr.detach() - p0, 1e-5, 'device-state adam delta after 3 steps')
+    # dropout epoch: NULL pointer = seed alone; with a pointer the mask is a function of (seed, epoch); GEMM epilogue too
+    x = torch.ones(1 << 16, device=DEV)
+    y0, y1, y2, y3 = (torch.empty_like(x) for _ in range(4))
+    L = hip.lib()
+    hcheck(L.ekaid_dropout(ptr(x), ptr(y0), x.numel(), 0.5, 1234, stream()), 'dropout')
+    epoch = torch.zeros(1, dtype=torch.int64, device=DEV)
+    try:
+        hcheck(L.ekaid_set_dropout_epoch_ptr(epoch.data_ptr()), 'set epoch')
+        hcheck(L.ekaid_dropout(ptr(x), ptr(y1), x.numel(), 0.5, 1234, stream()), 'dropout')
+        hcheck(L.ekaid_dropout_epoch_advance(epoch.data_ptr(), 1, stream()), 'advance')
+        hcheck(L.ekaid_dropout(ptr(x), ptr(y2), x.numel(), 0.5, 1234, stream()), 'dropout')
+        hcheck(L.ekaid_dropout(ptr(x), ptr(y3), x.numel(), 0.5, 1234, stream()), 'dropout')
+        A, Bm = rnd(64, 32, seed=1).to(DEV), rnd(48, 32, seed=2).to(DEV)
+        c1, c2 = torch.empty(64, 48, device=DEV), torch.empty(64, 48, device=DEV)
+        ops.gemm(A, Bm, c1, 64, 48, 32, 32, 32, 48, 0, 1, drop_p=0.5, drop_seed=99)
+        hcheck(L.ekaid_dropout_epoch_advance(epoch.data_ptr(), 1, stream()), 'advance')
+        ops.gemm(A, Bm, c2, 64, 48, 32, 32, 32, 48, 0, 1, drop_p=0.5, drop_seed=99)
+    finally:
+        hcheck(L.ekaid_set_dropout_epoch_ptr(None), 'unset epoch')
+    assert int(epoch.item()) == 2
+    assert torch.equal(y0, y1), 'epoch 0 must reproduce the plain seed'
+    assert torch.equal(y2, y3) and not torch.equal(y1, y2)
+    assert abs(float((y2 != 0).float().mean()) - 0.5) < 0.02 and abs(float(((y1 != 0) & (y2 != 0)).float().mean()) - 0.25) < 0.02
+    assert not torch.equal(c1 != 0, c2 != 0)

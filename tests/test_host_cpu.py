@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(hip.SIGNATURES), (declared ^ set(hip.SIGNATURES))
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.ekaid_version() == 1
+    assert lib.ekaid_version() == 2
 
 
 def test_ops_fail_loudly_without_the_hip_device():
@@ -199,3 +199,52 @@ def test_flat_adam_state_round_trip_is_layout_independent():
         n, k = names2[id(p)], p.numel()
         assert torch.equal(o2.m[o:o + k].view(p.shape), sd['exp_avg'][n])
         assert torch.equal(o2.v[o:o + k].view(p.shape), sd['exp_avg_sq'][n])
+
+
+def test_exact_match_accuracy_matches_the_reference_acc():
+    """tests/golden/acc_golden.json: ground-truth / prediction lists and what the imported reference ``acc()``
+    (evaluate_score.py:216-251) returned for them (tests/golden/make_acc_golden.py)."""
+    from ekaid_amd.evaluate_score import acc_from_lists
+    cases = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'acc_golden.json')))
+    assert len(cases) == 4
+    for c in cases:
+        assert list(acc_from_lists(c['annotations'], c['predictions'])) == c['expected']
+
+
+def test_checkpoints_interoperate_with_the_reference_config_class(tmp_path):
+    """The reference pickles ``model_cfg`` as ``utils.attr_dict.AttrDict`` (train_mimic.py:283-287): such a file loads
+    here without that module, and a file written here names that class, so the reference's ``torch.load`` resolves it."""
+    import sys
+    import types
+    from ekaid_amd.config import AttrDict as Ours
+    from ekaid_amd.utils.utils import load_checkpoint, save_checkpoint
+    pkg, mod = types.ModuleType('utils'), types.ModuleType('utils.attr_dict')
+
+    class AttrDict(dict):                    # stand-in for the reference class (same module path / name)
+        def __getattr__(self, n):
+            if n in self:
+                return self[n]
+            raise AttributeError(n)
+    AttrDict.__module__, AttrDict.__qualname__ = 'utils.attr_dict', 'AttrDict'
+    mod.AttrDict, pkg.attr_dict = AttrDict, mod
+    sys.modules['utils'], sys.modules['utils.attr_dict'] = pkg, mod
+    try:
+        c = AttrDict(model=AttrDict(x=3))
+        torch.save({'change_detector_state': {'w': torch.ones(2)}, 'speaker_state': {}, 'model_cfg': c},
+                   str(tmp_path / 'ref.pt'))
+    finally:
+        del sys.modules['utils'], sys.modules['utils.attr_dict']
+    ck = load_checkpoint(str(tmp_path / 'ref.pt'))
+    assert type(ck['model_cfg']) is Ours and ck['model_cfg'].model.x == 3 and type(ck['model_cfg'].model) is Ours
+    assert torch.equal(ck['change_detector_state']['w'], torch.ones(2))
+    save_checkpoint({'speaker_state': {}, 'model_cfg': mimic_cfg(), 'iteration': 3}, str(tmp_path / 'ours.pt'))
+    assert 'utils.attr_dict' not in sys.modules
+    raw = open(str(tmp_path / 'ours.pt'), 'rb').read()
+    assert b'utils.attr_dict' in raw and b'ekaid_amd.config' not in raw
+    sys.modules['utils'], sys.modules['utils.attr_dict'] = pkg, mod
+    try:
+        back = torch.load(str(tmp_path / 'ours.pt'), weights_only=False)          # what the reference does (utils.py:15)
+    finally:
+        del sys.modules['utils'], sys.modules['utils.attr_dict']
+    assert type(back['model_cfg']) is AttrDict and back['model_cfg'].model.change_detector.att_dim == 1024
+    assert load_checkpoint(str(tmp_path / 'ours.pt'))['iteration'] == 3

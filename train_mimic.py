@@ -3,17 +3,24 @@
 same loop order, same checkpoint dict ``{'change_detector_state', 'speaker_state', 'model_cfg'}``), running the
 difference-VQA path on MI355X through libekaid_hip.so.
 
-    python train_mimic.py --graph all --synthetic --max_iter 20                 # no dataset needed
-    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train_mimic.py --synthetic ...
+    python train_mimic.py --graph all                                          # the MIMIC-Diff-VQA HDF5 files of cfg.data.*
+    python -m ekaid_amd.datasets.generate --out /tmp/d && python train_mimic.py --data_dir /tmp/d --max_iter 40
+    python train_mimic.py --synthetic --max_iter 20                            # no files at all: seeded batches
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train_mimic.py ...
 
 Differences from the reference script (ref: train_mimic.py:1-386), all deliberate:
-  * one process per GPU with RCCL gradient all-reduce (the reference pins ``CUDA_VISIBLE_DEVICES=0``, :2);
-  * ``--synthetic`` feeds seeded synthetic batches of the yaml shapes; the real-data reader (HDF5,
-    rcc_dataset_pos_mimic.py:171-313) is the next scope row -- without ``--synthetic``
-    the script explains that and exits;
+  * one process per GPU with RCCL gradient all-reduce (the reference pins ``CUDA_VISIBLE_DEVICES=0``, :2); every GLOBAL
+    batch (``cfg.data.train.batch_size`` samples, drawn in the reference's order) is cut into contiguous per-rank slices,
+    and each rank's language-model loss is divided by (global mask sum / world) so that the averaged gradient is the
+    reference's global-batch gradient also for ragged answers (utils/utils.py:213-214);
+  * batches come through ``DevicePrefetcher``: int8 adjacency, pinned double buffers, copies on a side stream;
+  * ``--hip_graph`` replays the whole iteration from a captured hipGraph (ekaid_amd/engine.py);
   * no ``.item()`` synchronisation per iteration: losses are read only every ``log_interval`` iterations;
-  * the in-loop evaluation computes greedy answers and exact-match accuracy; BLEU/METEOR/CIDEr need pycocoevalcap
-    + Java (absent here) and stay delegated to the reference's ``evaluation.py``;
+  * the in-loop evaluation greedy-decodes the validation split and scores exact-match accuracy (evaluate_score.py:216-251);
+    BLEU/METEOR/CIDEr need pycocoevalcap + Java (absent here): the COCO-format json the reference's ``evaluation.py``
+    consumes is written next to it, and "best" is chosen by exact-match accuracy instead of BLEU-1 (:379-383);
+  * checkpoints additionally carry optimizer moments / step, iteration, epoch position, RNG state at the start of the
+    epoch and the dropout seed counter: ``--resume`` continues the run (the reference restarts Adam and the epoch);
   * ``--coef_sem/--coef_spa`` are accepted and, as in the reference (quirk Q-D, :53-54 vs modules.py:117-118),
     do not reach the model.
 """
@@ -32,17 +39,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from ekaid_amd import hip, ops                                            # noqa: E402
-from ekaid_amd.config import cfg, merge_cfg_from_file, merge_into, MIMIC_YAML   # noqa: E402
+from ekaid_amd.config import cfg, default_cfg, merge_cfg_from_file, merge_into, MIMIC_YAML   # noqa: E402
 from ekaid_amd.dp import FlatAdam, enable_global_question_attention      # noqa: E402
+from ekaid_amd.engine import TrainStep, forward_loss                     # noqa: E402
 from ekaid_amd.models.dynamic_speaker_change_pos import DynamicSpeaker   # noqa: E402
 from ekaid_amd.models.modules import AddSpatialInfo, ChangeDetector      # noqa: E402
-from ekaid_amd.synthetic import make_batch                               # noqa: E402
-from ekaid_amd.utils.mimic_utils import process_matrix                   # noqa: E402
-from ekaid_amd.utils.utils import (AverageMeter, LanguageModelCriterion, decode_sequence, load_checkpoint,  # noqa: E402
-                                   save_checkpoint, set_mode, total_loss)
+from ekaid_amd.synthetic import make_batch, slice_batch                  # noqa: E402
+from ekaid_amd.utils.utils import (AverageMeter, coco_gen_format_save, decode_sequence, load_checkpoint,  # noqa: E402
+                                   save_checkpoint, set_mode)
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument('--cfg', default='')
     p.add_argument('--setting', type=str, default='mode2')
@@ -56,18 +63,55 @@ def parse():
     p.add_argument('--coef_spa', type=float, default=0.333)
     p.add_argument('--lr', type=float, default=0.0001)
     # build-owned extensions
-    p.add_argument('--synthetic', action='store_true')
+    p.add_argument('--data_dir', default='', help='directory holding the four data files under their reference names')
+    p.add_argument('--synthetic', action='store_true', help='seeded synthetic batches, no files')
     p.add_argument('--max_iter', type=int, default=None)
-    p.add_argument('--batch_size', type=int, default=None)
+    p.add_argument('--batch_size', type=int, default=None, help='GLOBAL batch size')
+    p.add_argument('--snapshot_interval', type=int, default=None)
+    p.add_argument('--step_size', type=int, default=None, help='StepLR period in epochs')
+    p.add_argument('--iters_per_epoch', type=int, default=50, help='epoch length of the --synthetic stream')
     p.add_argument('--nodes', type=int, default=52, help='regions per image of the synthetic batches')
     p.add_argument('--answer_steps', type=int, default=16)
     p.add_argument('--global_qc', action='store_true', help='global-batch semantics for the question attention (Q-C)')
+    p.add_argument('--hip_graph', action='store_true', help='replay each iteration from a captured hipGraph')
+    p.add_argument('--eval_batches', type=int, default=None, help='cap on validation batches per in-loop evaluation')
     p.add_argument('--exp_dir', default=None)
-    return p.parse_args()
+    p.add_argument('--quiet', action='store_true')
+    return p.parse_args(argv)
 
 
-def main():
-    args = parse()
+def step_lr(base_lr, gamma, step_size, epoch):
+    """``StepLR`` as the reference drives it: ``lr_scheduler.step()`` at the START of every epoch, epoch 0 included
+    (train_mimic.py:174-177,190), so the rate in force during epoch e is ``base * gamma ** ((e + 1) // step_size)``."""
+    return base_lr * (gamma ** ((epoch + 1) // step_size))
+
+
+def evaluate(cfg, change_detector, speaker, loader, device, idx_to_word, graph, max_batches=None):
+    """Greedy decode of a split (train_mimic.py:292-362): {pair index: sentence}, exact-match accuracy."""
+    from ekaid_amd.datasets.rcc_dataset_pos_mimic import DevicePrefetcher
+    predictions, correct, total = {}, 0, 0
+    set_mode('eval', [change_detector, speaker])
+    with torch.no_grad():
+        for bi, b in enumerate(DevicePrefetcher(loader, device)):
+            if max_batches is not None and bi >= max_batches:
+                break
+            T = DynamicSpeaker.count_steps(b['_host_labels'], cfg.model.speaker.seq_length)
+            _, _, outs, _ = forward_loss(cfg, change_detector, speaker, b, T, graph, cfg.train.setting)
+            seq, _ = speaker._sample(outs[3], outs[4], outs[5], b['labels'], cfg, sample_max=1)
+            sents = decode_sequence(idx_to_word, seq)
+            gts = decode_sequence(idx_to_word, b['_host_labels'][:, 1:])
+            for j, s in enumerate(sents):
+                predictions[str(int(b['pair_index'][j]))] = s
+                correct += int(s == gts[j])
+                total += 1
+    set_mode('train', [change_detector, speaker])
+    return predictions, correct / max(total, 1), total
+
+
+def main(argv=None):
+    args = parse(argv)
+    cfg.clear()
+    cfg.update(default_cfg())              # the module-level cfg is a process global (as in the reference): start clean
     if args.cfg:
         merge_cfg_from_file(args.cfg)
     else:
@@ -80,35 +124,62 @@ def main():
         cfg.train.max_iter = args.max_iter
     if args.batch_size is not None:
         cfg.data.train.batch_size = args.batch_size
+    if args.snapshot_interval is not None:
+        cfg.train.snapshot_interval = args.snapshot_interval
+    if args.step_size is not None:
+        cfg.train.optim.step_size = args.step_size
     if args.exp_dir:
         cfg.exp_dir = args.exp_dir
-    if not args.synthetic:
-        raise SystemExit('The MIMIC-Diff-VQA HDF5 reader (SURVEY.md section 8 f-1) is not part of this round; run with '
-                         '--synthetic to train on seeded synthetic batches of the same shapes.')
+    if args.data_dir:
+        from ekaid_amd.datasets.generate import point_cfg_at
+        point_cfg_at(cfg, args.data_dir)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    own_pg = False
+    if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        own_pg = True
     hip.load()
+    hip.check(hip.lib().ekaid_init(local_rank), 'ekaid_init')
     random.seed(args.seed)
     np.random.seed(args.seed)
-    torch.manual_seed(args.seed)          # identical default initialisation on every rank
+    torch.manual_seed(args.seed)          # identical default initialisation and sample order on every rank
     ops.manual_seed(args.seed + rank)     # different dropout masks per rank
+    say = (lambda *a: None) if (args.quiet or rank != 0) else print
 
     exp_name = '%s_%s_%s_%s_%d' % (args.setting, args.feature_mode, args.graph, args.lr, args.seed)
     output_dir = os.path.join(cfg.exp_dir, 'temp', exp_name)
     snapshot_dir = os.path.join(output_dir, 'snapshots')
+    sent_dir = os.path.join(output_dir, 'eval_sents')
     if rank == 0:
         os.makedirs(snapshot_dir, exist_ok=True)
+        os.makedirs(sent_dir, exist_ok=True)
         json.dump(cfg, open(os.path.join(output_dir, 'cfg.json'), 'w'))
 
-    vocab = json.load(open(cfg.data.vocab_json)) if os.path.exists(cfg.data.vocab_json) else \
-        {'w%d' % i: i for i in range(1, 148)}
+    global_bs = cfg.data.train.batch_size
+    if global_bs % world:
+        raise SystemExit('global batch size %d is not divisible by the world size %d' % (global_bs, world))
+    per_gpu = global_bs // world
+    train_dataset = train_loader = val_loader = None
+    if args.synthetic:
+        vocab = json.load(open(cfg.data.vocab_json)) if os.path.exists(cfg.data.vocab_json) else \
+            {'w%d' % i: i for i in range(1, 148)}
+        iters_per_epoch = args.iters_per_epoch
+    else:
+        from ekaid_amd.datasets import create_dataset
+        for k in ('vocab_json', 'splits_json', 'h5_label_file'):
+            if not os.path.exists(cfg.data[k]):
+                raise SystemExit('data file %s (cfg.data.%s) not found: pass --data_dir, fix the config, or use --synthetic '
+                                 '(python -m ekaid_amd.datasets.generate writes a stand-in dataset)' % (cfg.data[k], k))
+        train_dataset, train_loader = create_dataset(cfg, 'train', rank=rank, world_size=world, drop_last=world > 1)
+        _, val_loader = create_dataset(cfg, 'test' if args.eval_target == 'test' else 'val')
+        vocab = train_dataset.get_word_to_idx()
+        iters_per_epoch = len(train_loader)
     idx_to_word = {i: w for w, i in vocab.items()}
     V = len(idx_to_word) + 1
     D = cfg.model.change_detector.feat_dim - 2
@@ -125,77 +196,114 @@ def main():
     if args.global_qc and world > 1:
         enable_global_question_attention(change_detector)
 
-    lang_criterion = LanguageModelCriterion()
     o = cfg.train.optim
     if o.type != 'adam':
         raise SystemExit('only the configured optimiser (adam, utils.py:96-99) is implemented')
     optimizer = FlatAdam([change_detector, speaker], lr=o.lr, betas=(o.alpha, o.beta), eps=o.epsilon)
-    per_gpu = cfg.data.train.batch_size // world if world > 1 else cfg.data.train.batch_size
+    step = TrainStep(cfg, change_detector, speaker, optimizer, args.graph, args.setting, use_graph=args.hip_graph)
     shape = dict(N=args.nodes, D=D, Lq=20, T=args.answer_steps, seq_length=cfg.model.speaker.seq_length, V=V)
-    iters_per_epoch = 50
 
     def named():
         return [('cd.' + n, q) for n, q in change_detector.named_parameters()] + \
                [('sp.' + n, q) for n, q in speaker.named_parameters()]
 
-    t, epoch = 0, 0
+    t, epoch, i0, best = 0, 0, 0, -1.0
+    epoch_rng = None
     if ck is not None and 'optimizer_state' in ck:      # a checkpoint of this framework: continue where it stopped
         optimizer.load_state_dict(ck['optimizer_state'], named())
-        t, epoch = int(ck['iteration']), int(ck['epoch'])
-        ops.set_seed_state(ck['dropout_seed_state'])
+        t, epoch, i0 = int(ck['iteration']), int(ck['epoch']), int(ck.get('iter_in_epoch', 0))
+        best = float(ck.get('best', -1.0))
+        ops.set_seed_state((args.seed + rank, int(ck['dropout_seed_counter'])))      # per-rank base, shared counter
+        epoch_rng = ck.get('epoch_rng_state')
+
+    def batches(epoch, skip):
+        """Device batches of one epoch, starting after ``skip`` iterations: (dict, host labels, loss denominator)."""
+        if args.synthetic:
+            for i in range(skip, iters_per_epoch):
+                host = make_batch(B=global_bs, seed=args.seed + 7919 * (epoch * iters_per_epoch + i), **shape)
+                msum = float(host['masks'][:, 1:].sum())
+                mine = slice_batch(host, rank * per_gpu, (rank + 1) * per_gpu)
+                b = {k: v.to(device, non_blocking=True) for k, v in mine.items()}
+                yield b, mine['labels'], msum
+            return
+        from ekaid_amd.datasets.rcc_dataset_pos_mimic import DevicePrefetcher
+        train_loader.rank_slice.skip = skip
+        for b in DevicePrefetcher(train_loader, device):
+            gidx = b['_meta']['global_indices']
+            yield b, b['_host_labels'], (train_dataset.mask_sum(gidx) if world > 1 else None)
+
     set_mode('train', [change_detector, speaker])
     loss_avg = AverageMeter()
+    last = {}
     while t < cfg.train.max_iter:
-        if rank == 0:
-            print('Starting epoch %d' % epoch)
-        if epoch > 0 and epoch % o.step_size == 0:
-            optimizer.lr = o.lr * (o.gamma ** (epoch // o.step_size))          # StepLR (train_mimic.py:174-177,190)
-        for i in range(t - epoch * iters_per_epoch if 0 <= t - epoch * iters_per_epoch < iters_per_epoch else 0, iters_per_epoch):
+        say('Starting epoch %d' % epoch)
+        optimizer.lr = step_lr(o.lr, o.gamma, o.step_size, epoch)
+        if epoch_rng is not None:
+            torch.set_rng_state(epoch_rng)                  # resumed mid-epoch: the sampler redraws the same permutation
+        rng_at_epoch_start = torch.get_rng_state()
+        epoch_rng = None
+        i = i0
+        for b, host_labels, msum in batches(epoch, i0):
             if t >= cfg.train.max_iter:
                 break
             t0 = time.time()
-            host = make_batch(B=per_gpu, seed=args.seed + 7919 * t, rank=rank, **shape)
-            steps = DynamicSpeaker.count_steps(host['labels'], shape['seq_length'])
-            b = {k: v.to(device, non_blocking=True) for k, v in host.items()}
-            optimizer.zero_grad()
-            N = b['input_1'].shape[1]
-            adj = [process_matrix(b[k], cfg, N, device, type=ty) for k, ty in
-                   (('d_adj', 'spatial'), ('q_adj', 'spatial'), ('d_sem', 'semantic'), ('q_sem', 'semantic'))]
-            outs = change_detector(b['input_1'], b['input_2'], adj[0], adj[1], adj[2], adj[3], b['d_bb'], b['q_bb'],
-                                   b['question'], setting=cfg.train.setting, graph=args.graph)
-            logp, _ = speaker._forward(outs[3], outs[4], outs[5], b['labels'], num_steps=steps)
-            speaker_loss = lang_criterion(logp, b['labels'][:, 1:], b['masks'][:, 1:])
-            loss = total_loss(speaker_loss, outs[1], outs[2])
-            loss.backward()
-            optimizer.step()
+            steps = DynamicSpeaker.count_steps(host_labels, shape['seq_length'])
+            denom = None
+            if world > 1 and msum is not None:
+                denom = torch.tensor([msum / world], dtype=torch.float32, device=device)
+            loss, speaker_loss = step(b, steps, denom)
             t += 1
+            i += 1
             if t % cfg.train.log_interval == 0 or t == cfg.train.max_iter:
                 val = float(loss.item())
                 loss_avg.update(val, 2 * per_gpu)
-                if rank == 0:
-                    print(epoch, i, t, {'speaker_loss': float(speaker_loss.item()), 'total_loss': val,
-                                        'avg_total_loss': loss_avg.avg}, time.time() - t0)
+                last = {'speaker_loss': float(speaker_loss.item()), 'total_loss': val, 'avg_total_loss': loss_avg.avg}
+                say(epoch, i - 1, t, last, time.time() - t0)
             if t % cfg.train.snapshot_interval == 0 or t == cfg.train.max_iter:
+                end_of_epoch = i >= iters_per_epoch
+                checkpoint = None
                 if rank == 0:
-                    # the reference's three keys (train_mimic.py:283-287) + what a true resume needs
+                    # the reference's three keys (train_mimic.py:283-287) + what a true resume needs; ``epoch`` /
+                    # ``iter_in_epoch`` name the NEXT iteration to run
                     checkpoint = {'change_detector_state': change_detector.state_dict(),
                                   'speaker_state': speaker.state_dict(), 'model_cfg': cfg,
-                                  'optimizer_state': optimizer.state_dict(named()), 'iteration': t, 'epoch': epoch,
-                                  'dropout_seed_state': ops.seed_state()}
+                                  'optimizer_state': optimizer.state_dict(named()), 'iteration': t,
+                                  'epoch': epoch + 1 if end_of_epoch else epoch, 'iter_in_epoch': 0 if end_of_epoch else i,
+                                  'epoch_rng_state': None if end_of_epoch else rng_at_epoch_start,
+                                  'dropout_seed_counter': ops.seed_state()[1], 'best': best}
                     save_checkpoint(checkpoint, os.path.join(snapshot_dir, 'checkpoint_%d.pt' % t))
-                set_mode('eval', [change_detector, speaker])
-                with torch.no_grad():
-                    seq, _ = speaker._sample(outs[3].detach(), outs[4].detach(), outs[5].detach(), b['labels'], cfg,
-                                             sample_max=1)
-                    pred = decode_sequence(idx_to_word, seq)
-                    gts = decode_sequence(idx_to_word, b['labels'][:, 1:])
-                    acc = sum(p == g for p, g in zip(pred, gts)) / max(len(gts), 1)
-                if rank == 0:
-                    print('eval at iter %d: exact-match accuracy %.4f (greedy decode of the current batch)' % (t, acc))
-                set_mode('train', [change_detector, speaker])
+                say('Running eval at iter %d' % t)
+                if val_loader is not None:
+                    if rank == 0:
+                        preds, acc, n = evaluate(cfg, change_detector, speaker, val_loader, device, idx_to_word, args.graph,
+                                                 args.eval_batches)
+                        coco_gen_format_save(preds, os.path.join(sent_dir, 'eval_results_%d.json' % t))
+                        say('eval at iter %d: exact-match accuracy %.4f over %d pairs' % (t, acc, n))
+                        last['eval_accuracy'] = acc
+                        if acc > best:
+                            best = acc
+                            checkpoint['best'] = best
+                            save_checkpoint(checkpoint, os.path.join(snapshot_dir, 'checkpoint_best.pt'))
+                            say('Best checkpoint saved')
+                    if world > 1:
+                        dist.barrier()
+                else:
+                    set_mode('eval', [change_detector, speaker])
+                    with torch.no_grad():
+                        _, _, outs, _ = forward_loss(cfg, change_detector, speaker, b, steps, args.graph, args.setting)
+                        seq, _ = speaker._sample(outs[3], outs[4], outs[5], b['labels'], cfg, sample_max=1)
+                        pred = decode_sequence(idx_to_word, seq)
+                        gts = decode_sequence(idx_to_word, host_labels[:, 1:])
+                        acc = sum(p == g for p, g in zip(pred, gts)) / max(len(gts), 1)
+                    say('eval at iter %d: exact-match accuracy %.4f (greedy decode of the current batch)' % (t, acc))
+                    set_mode('train', [change_detector, speaker])
+        i0 = 0
         epoch += 1
-    if world > 1:
+    torch.cuda.synchronize()
+    if own_pg:
         dist.destroy_process_group()
+    return {'iteration': t, 'epoch': epoch, 'lr': optimizer.lr, 'last': last, 'snapshot_dir': snapshot_dir,
+            'change_detector': change_detector, 'speaker': speaker, 'optimizer': optimizer}
 
 
 if __name__ == '__main__':
