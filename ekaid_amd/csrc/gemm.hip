@@ -1063,3 +1063,260 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     }
     return rc;
 }
+
+namespace ekaid {
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same 6-product arithmetic on PRE-SPLIT operands ("planes"): the three bf16 planes of an f32 tensor are produced
+// once, where the tensor is produced (ekaid_split_planes, the Adam kernel for the weights), instead of inside every K
+// loop that reads it.  In gemm_split_kernel the split costs 5.2 vector-ALU instructions per MFMA and the shared
+// vector-issue port is ~90 % subscribed (profiles/r01_pmc_gemm_split_nn_18432x1024x1024.json: MFMA busy 52 %); here the
+// K loop has no vector ALU work at all.
+//
+// Plane storage "P8": for a flat f32 array x[0..n), n % 8 == 0, every group of 8 consecutive elements becomes 48 bytes
+//     [ h(x[8g..8g+7]) : 8 x bf16 | m(...) : 8 x bf16 | l(...) : 8 x bf16 ],       h + m + l == x exactly (truncation split)
+// i.e. plane p of element e sits at byte 6 * (e & ~7) + 16 p + 2 (e & 7).  The mapping does not depend on the matrix shape,
+// so any row-major view whose leading dimension and offsets are multiples of 8 elements addresses its planes with the same
+// (row, column) arithmetic as the f32 data, and one 16-byte unit = 8 consecutive k (k-contiguous operand) or 8 consecutive
+// rows (m/n-contiguous operand) of one plane -- exactly the unit both LDS images are built from.
+//
+// Staging: buffer_load_dwordx4 ... lds (LDS-DMA, no VGPRs, no ds_write): one wave instruction fills 1 KiB of LDS, lane L the
+// 16 bytes at +16 L; the XOR swizzles of the images are applied on the per-lane SOURCE offset (the LDS side of an LDS-DMA is
+// lane-linear).  The K advance is the scalar soffset.  Images, fragment reads and the 24 MFMAs per 16-deep stage are those
+// of gemm_split_kernel's pipelined loop; 2 stage buffers of 24 KiB -> 48 KiB per workgroup, 3 workgroups per CU: while one
+// workgroup waits for its next stage the other two multiply.
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 3) void gemm_planes_kernel(GemmArgs g) {
+    constexpr int TM = 2, TN = 2, BM = 128, BN = 128, KS = 16;
+    constexpr int PLANE = 4096;                 // one plane image of one operand per stage: 128 rows x 32 B, or 16 k-rows x 256 B
+    constexpr int STAGE = 6 * PLANE;
+    constexpr int A_RS = A_KC ? 2 * KS : 2 * BM, B_RS = B_KC ? 2 * KS : 2 * BN;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char* const ldsb = reinterpret_cast<char*>(lds);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int nwg = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    }
+    const int m0 = (bid / g.tiles_n) * BM, n0 = (bid % g.tiles_n) * BN;
+    const int z = blockIdx.z;
+    int kbeg = 0, kend = g.K;
+    if (g.splitk > 1) {
+        kbeg = z * g.k_per_split;
+        kend = min(g.K, kbeg + g.k_per_split);
+    }
+    const long long spanA = A_KC ? ((long long)(g.M - 1) * g.lda + g.K) : ((long long)(g.K - 1) * g.lda + g.M);
+    const long long spanB = B_KC ? ((long long)(g.N - 1) * g.ldb + g.K) : ((long long)(g.K - 1) * g.ldb + g.N);
+    // raw buffer descriptors {base lo, base hi (stride 0), num_records in bytes, flags}: the LDS-DMA is issued from inline
+    // asm (below), which takes the descriptor as an SGPR quad
+    const unsigned long long pa = reinterpret_cast<unsigned long long>(g.A), pb = reinterpret_cast<unsigned long long>(g.B);
+    const u32x4 rsrcA = {(unsigned)pa, (unsigned)(pa >> 32) & 0xFFFFu, (unsigned)(6 * ((spanA + 7) & ~7ll)), 0x00020000u};
+    const u32x4 rsrcB = {(unsigned)pb, (unsigned)(pb >> 32) & 0xFFFFu, (unsigned)(6 * ((spanB + 7) & ~7ll)), 0x00020000u};
+    // this lane's 16-byte unit inside quarter `wave` of every plane image, as a byte offset into plane 0 of the P8 array
+    unsigned voA, voB;
+    {
+        const int rowk = 32 * wave + (lane >> 1), s = (lane & 1) ^ ((rowk >> 3) & 1);                  // k-contiguous image
+        const int km = 4 * wave + (lane >> 4), col = 32 * (((lane & 15) >> 2) ^ (km & 3)) + 8 * (lane & 3);   // m-contiguous image
+        voA = A_KC ? 6u * ((unsigned)(m0 + rowk) * (unsigned)g.lda + 8u * s) : 6u * ((unsigned)km * (unsigned)g.lda + (unsigned)(m0 + col));
+        voB = B_KC ? 6u * ((unsigned)(n0 + rowk) * (unsigned)g.ldb + 8u * s) : 6u * ((unsigned)km * (unsigned)g.ldb + (unsigned)(n0 + col));
+    }
+    const unsigned kstepA = A_KC ? 6u * KS : 6u * KS * (unsigned)g.lda;      // soffset advance per stage, bytes
+    const unsigned kstepB = B_KC ? 6u * KS : 6u * KS * (unsigned)g.ldb;
+    unsigned soA = (A_KC ? 6u : 6u * (unsigned)g.lda) * (unsigned)kbeg, soB = (B_KC ? 6u : 6u * (unsigned)g.ldb) * (unsigned)kbeg;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
+
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+    int fA[TM], fB[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+        fA[i] = A_KC ? (wm + 32 * i + r) * 32 + 16 * (h ^ (((wm + 32 * i + r) >> 3) & 1)) : mc_read_off<BM>(8 * h + tq, wm + 32 * i, tg, tp);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+        fB[j] = B_KC ? (wn + 32 * j + r) * 32 + 16 * (h ^ (((wn + 32 * j + r) >> 3) & 1)) : mc_read_off<BN>(8 * h + tq, wn + 32 * j, tg, tp);
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+    auto frag = [&](const char* plane, int off, bool kc, int rs) -> bf16x8 {
+        if (kc) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(plane + off);
+            return __builtin_bit_cast(bf16x8, v);
+        } else {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(plane + off));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(plane + off + 4 * rs));
+            const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            return __builtin_bit_cast(bf16x8, v);
+        }
+    };
+    // six LDS-DMA instructions per wave and stage: quarter `wave` of the three A and the three B plane images.  Inline asm on
+    // purpose: behind the builtin form hipcc waits vmcnt(0) before the next ds_read (it cannot tell the two stage buffers
+    // apart), which would drain the DMA it has just issued; an asm load is outside its bookkeeping and is waited for by the
+    // explicit s_waitcnt in the loop.  M0 (the LDS destination base) is saved and restored inside each statement.
+    const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) char*)ldsb) + 1024u * (unsigned)wave;
+#define EKAID_DMA16(RS, LDSADDR, VOFF, SOFF, IMM)                                                                           \
+    do {                                                                                                                     \
+        unsigned keep_;                                                                                                      \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen offset:" #IMM " lds\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_) : "s"(LDSADDR), "v"(VOFF), "s"(RS), "s"(SOFF) : "memory");                               \
+    } while (0)
+    auto issue = [&](unsigned stage_off) {
+        const unsigned d = lds_base + stage_off;
+        EKAID_DMA16(rsrcA, d + 0u * PLANE, voA, soA, 0);
+        EKAID_DMA16(rsrcA, d + 1u * PLANE, voA, soA, 16);
+        EKAID_DMA16(rsrcA, d + 2u * PLANE, voA, soA, 32);
+        EKAID_DMA16(rsrcB, d + 3u * PLANE, voB, soB, 0);
+        EKAID_DMA16(rsrcB, d + 4u * PLANE, voB, soB, 16);
+        EKAID_DMA16(rsrcB, d + 5u * PLANE, voB, soB, 32);
+        soA += kstepA;
+        soB += kstepB;
+    };
+    auto compute = [&](const char* buf) {
+        const char* const cA = buf;
+        const char* const cB = buf + 3 * PLANE;
+        bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fa[i][p] = frag(cA + p * PLANE, fA[i], A_KC, A_RS);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fb[j][p] = frag(cB + p * PLANE, fB[j], B_KC, B_RS);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {      // smallest terms first
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+            }
+    };
+    const int nst = (kend - kbeg) / KS;
+    if (nst > 0) {
+        issue(0u);
+        for (int s = 0; s < nst; ++s) {
+            // my DMA of stage s has landed -> barrier -> everybody's has, and everybody is done reading the other buffer
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const unsigned cur = (s & 1) ? (unsigned)STAGE : 0u;
+            if (s + 1 < nst) issue((unsigned)STAGE - cur);
+            compute(ldsb + cur);
+        }
+    }
+#undef EKAID_DMA16
+    write_tiles<TM, TN>(g, acc, m0, n0, wm, wn, r, h, z);
+}
+
+// f32 -> P8 planes (see above).  One thread per group of 8 elements: two 16-byte loads, three 16-byte stores.
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, long long ngroups, long long n, u32x4* __restrict__ out) {
+    for (long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += (long long)gridDim.x * blockDim.x) {
+        f32x4 v0, v1;
+        const long long e = gi * 8;
+        if (e + 8 <= n) {
+            v0 = *reinterpret_cast<const f32x4*>(x + e);
+            v1 = *reinterpret_cast<const f32x4*>(x + e + 4);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { v0[c] = e + c < n ? x[e + c] : 0.f; v1[c] = e + 4 + c < n ? x[e + 4 + c] : 0.f; }
+        }
+        u32x2 H0, M0, L0, H1, M1, L1;
+        split4(v0, H0, M0, L0);
+        split4(v1, H1, M1, L1);
+        u32x4* o = out + gi * 3;
+        o[0] = u32x4{H0[0], H0[1], H1[0], H1[1]};
+        o[1] = u32x4{M0[0], M0[1], M1[0], M1[1]};
+        o[2] = u32x4{L0[0], L0[1], L1[0], L1[1]};
+    }
+}
+
+}  // namespace ekaid
+using namespace ekaid;
+
+extern "C" int ekaid_split_planes(const float* x, long long n, void* planes, void* stream) {
+    if (n <= 0) return EKAID_OK;
+    if (!x || !planes || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(planes) & 15)) {
+        set_error("ekaid_split_planes: null or unaligned pointer (16-byte alignment required)");
+        return EKAID_ERR_ARG;
+    }
+    const long long ngroups = (n + 7) / 8;
+    long long blocks = (ngroups + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ngroups, n, (u32x4*)planes);
+    return check_launch("split_planes");
+}
+
+extern "C" int ekaid_gemm_planes(const ekaid_gemm_t* d, const void* A_planes, const void* B_planes, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    if (!d || !A_planes || !B_planes || !d->C) { set_error("ekaid_gemm_planes: null pointer"); return EKAID_ERR_ARG; }
+    if (d->transA && d->transB) { set_error("ekaid_gemm_planes: transA && transB unsupported"); return EKAID_ERR_UNSUPPORTED; }
+    if (d->M <= 0 || d->N <= 0) return EKAID_OK;
+    const bool akc = !d->transA, bkc = d->transB != 0;
+    const long long spanA = akc ? ((long long)(d->M - 1) * d->lda + d->K) : ((long long)(d->K - 1) * d->lda + d->M);
+    const long long spanB = bkc ? ((long long)(d->N - 1) * d->ldb + d->K) : ((long long)(d->K - 1) * d->ldb + d->N);
+    int TMN, splitk, tm, tn;
+    plan(d, TMN, splitk, tm, tn);
+    if (d->batch1 * d->batch2 != 1 || TMN != 2 || d->K < 16 || (d->K & 15) || (d->lda & 7) || (d->ldb & 7) ||
+        6 * (spanA + 8) >= (1ll << 32) || 6 * (spanB + 8) >= (1ll << 32) ||
+        (reinterpret_cast<uintptr_t>(A_planes) & 15) || (reinterpret_cast<uintptr_t>(B_planes) & 15)) {
+        set_error("ekaid_gemm_planes: shape outside the pre-split kernel's envelope (one batch, M >= 512, N >= 128, K %% 16 == 0, "
+                  "leading dimensions %% 8 == 0): M=%d N=%d K=%d lda=%d ldb=%d", d->M, d->N, d->K, d->lda, d->ldb);
+        return EKAID_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs a;
+    a.A = (const float*)A_planes; a.B = (const float*)B_planes; a.C = d->C;
+    a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
+    a.sA1 = a.sA2 = a.sB1 = a.sB2 = a.sC1 = a.sC2 = 0; a.nb2 = 1;
+    a.e.alpha = d->alpha; a.e.alpha_dev = d->alpha_dev; a.e.beta = d->accumulate; a.e.bias = d->bias;
+    a.e.R = d->R; a.e.ldr = d->ldr; a.e.rdiv = d->rdiv < 1 ? 1 : d->rdiv; a.e.rowmask = d->rowmask; a.e.act = d->act;
+    a.e.drop_p = d->drop_p; a.e.drop_inv = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f; a.e.drop_seed = d->drop_seed;
+    a.e.drop_epoch = dropout_epoch_ptr(); a.e.n_cols = d->N;
+    a.splitk = splitk; a.tiles_m = tm; a.tiles_n = tn; a.ws = nullptr;
+    a.k_per_split = cdiv(cdiv(d->K, BK_BIG), a.splitk) * BK_BIG;
+    if (a.splitk > 1) {
+        const size_t need = (size_t)a.splitk * d->M * d->N * sizeof(float);
+        if (!workspace || workspace_bytes < need) {
+            set_error("ekaid_gemm_planes: workspace too small (%zu < %zu)", workspace_bytes, need);
+            return EKAID_ERR_ARG;
+        }
+        a.ws = (float*)workspace;
+        a.splitk = cdiv(d->K, a.k_per_split);
+        if (a.splitk <= 1) { a.splitk = 1; a.ws = nullptr; a.k_per_split = cdiv(d->K, BK_BIG) * BK_BIG; }
+    }
+    dim3 grid(a.tiles_m * a.tiles_n, 1, a.splitk > 1 ? a.splitk : 1);
+    constexpr size_t lds = 2 * 6 * 4096;
+    if (akc && bkc) hipLaunchKernelGGL((gemm_planes_kernel<true, true>), grid, dim3(256), lds, st, a);
+    else if (akc && !bkc) hipLaunchKernelGGL((gemm_planes_kernel<true, false>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((gemm_planes_kernel<false, false>), grid, dim3(256), lds, st, a);
+    int rc = check_launch("gemm_planes_kernel");
+    if (rc) return rc;
+    if (a.splitk > 1) {
+        const long long total = (long long)d->M * d->N;
+        const bool vec_ok = (d->N % 4 == 0) && (d->ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->C) & 15) == 0) && total / 4 < (1ll << 30);
+        if (vec_ok) {
+            const int n4 = d->N / 4;
+            hipLaunchKernelGGL(splitk_reduce_vec_kernel<4>, dim3(cdiv((long long)d->M * n4, 256)), dim3(256), 0, st, a.ws, d->C, d->M, n4, d->ldc, a.splitk, a.e);
+        } else {
+            int blocks = cdiv(total, 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.ws, d->C, d->M, d->N, d->ldc, a.splitk, a.e);
+        }
+        rc = check_launch("splitk_reduce_kernel");
+    }
+    return rc;
+}

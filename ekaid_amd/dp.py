@@ -70,7 +70,7 @@ class GradBuckets:
         offs, total = [], 0
         for n in sizes:
             offs.append(total)
-            total += (n + 3) // 4 * 4                    # keep every tensor 16-byte aligned
+            total += (n + 7) // 8 * 8                    # every tensor starts on an 8-element group (16-byte aligned; P8 planes)
         self.total = total
         self.pflat = torch.zeros(total, device=dev, dtype=dt)
         self.gflat = torch.zeros(total, device=dev, dtype=dt)
@@ -98,6 +98,21 @@ class GradBuckets:
         self.built = True
         self._reset_pending()
         self._check_layout_agreement()
+        self.refresh_planes()
+
+    def refresh_planes(self):
+        """bf16 planes of the whole flat parameter buffer (ekaid_split_planes) for the pre-split GEMM kernel: one pass
+        over the weights per update instead of one split inside every K loop that reads them."""
+        if not self.pflat.is_cuda:
+            return
+        from . import ops
+        if not ops.USE_PLANES:
+            return
+        if getattr(self, 'planes', None) is None:
+            self.planes = torch.empty(6 * self.total, dtype=torch.uint8, device=self.pflat.device)
+        hip.check(hip.lib().ekaid_split_planes(hip.ptr(self.pflat), self.total, hip.ptr(self.planes), hip.stream()), 'split_planes')
+        for p, o in zip(self.live, self.offsets):
+            ops.register_weight_planes(p, self.planes[6 * o:6 * (o + (p.numel() + 7) // 8 * 8)], self.pflat)
 
     def comm_active(self):
         return self.world > 1 or self.force_comm
@@ -222,6 +237,7 @@ class FlatAdam(GradBuckets):
         hip.check(hip.lib().ekaid_adam_step_dev(hip.ptr(self.pflat), hip.ptr(self.gflat), hip.ptr(self.m), hip.ptr(self.v),
                                                 self.total, hip.ptr(hyper), hip.ptr(step), hip.ptr(derived), hip.stream()),
                   'adam_step_dev')
+        self.refresh_planes()
 
     # ------------------------------------------------------------------ checkpointing (SURVEY f-4)
     def state_dict(self, named_parameters=None):

@@ -47,7 +47,9 @@ def forward_loss(cfg, cd, sp, b, T, graph='all', setting='mode2', denom=None, ma
 
 
 class TrainStep:
-    """``step(batch, T, denom=None) -> (total loss, speaker loss)`` (device scalars; no host synchronisation)."""
+    """``step(batch, T, denom=None) -> (total loss, speaker loss)`` (device scalars; no host synchronisation).
+    With ``use_graph`` do not keep loss tensors of EARLIER eager steps of the same modules alive across the first call
+    of a new shape (they pin autograd nodes to the eager stream; see ``_capture``)."""
 
     def __init__(self, cfg, cd, sp, opt, graph='all', setting='mode2', use_graph=False, comm='eager', warmup=2):
         if comm not in ('eager', 'captured'):
@@ -112,16 +114,21 @@ class TrainStep:
         overlap = self.opt.overlap
         if self.comm == 'eager':
             self.opt.overlap = False            # no collectives inside the capture
+        s = torch.cuda.Stream(device=dev)
         if not self.opt.built:
             # one eager forward/backward (no update) fixes the flat parameter/gradient layout and applies a pending
-            # optimizer state (resume) BEFORE the snapshot below is taken
+            # optimizer state (resume) BEFORE the snapshot below is taken.  On the side stream, and its loss dropped at
+            # once: an autograd graph that outlives this block would pin AccumulateGrad nodes to another stream, and the
+            # capture would then try to synchronise with that stream (crash in hipStreamEndCapture).
             seed0 = ops.seed_state()
-            self.opt.zero_grad()
-            loss, _, _, _ = forward_loss(self.cfg, self.cd, self.sp, static, T, self.graph, self.setting, sden)
-            loss.backward()
-            self.opt.finish()
-            if getattr(self.opt, '_pending_state', None) is not None:
-                self.opt._apply_pending_state()
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                self.opt.zero_grad()
+                forward_loss(self.cfg, self.cd, self.sp, static, T, self.graph, self.setting, sden)[0].backward()
+                self.opt.finish()
+                if getattr(self.opt, '_pending_state', None) is not None:
+                    self.opt._apply_pending_state()
+            torch.cuda.current_stream(dev).wait_stream(s)
             ops.set_seed_state(seed0)
         # capture is transparent: the warm-up steps below really train, so weights, moments, step counter and the
         # dropout epoch are put back afterwards
@@ -130,7 +137,6 @@ class TrainStep:
         snap_v = self.opt.v.clone() if self.opt.v is not None else None
         snap_step, snap_epoch = self.opt.step_count, self._epoch.clone()
         seed_state = ops.seed_state()
-        s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
             for _ in range(self.warmup):        # sizes every workspace, raises kernel attributes, warms the allocator
@@ -146,6 +152,7 @@ class TrainStep:
         if self._pool is None:
             self._pool = g.pool()
         self.opt.pflat.copy_(snap_p)
+        self.opt.refresh_planes()
         if snap_m is not None:
             self.opt.m.copy_(snap_m)
             self.opt.v.copy_(snap_v)

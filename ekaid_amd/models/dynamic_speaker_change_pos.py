@@ -8,7 +8,7 @@ Same constructors, ``_forward`` / ``_sample`` / ``get_logprobs_state`` / ``get_m
     it every step, :98-99); its Dropout is still drawn per step;
   * ``torch.cat`` inputs of the LSTM cells / gate MLP are fed as split-K GEMMs, never materialised;
   * the teacher-forced loop length is found with ONE host synchronisation instead of one per step (:213).
-Not supported (outside the path): scheduled sampling (``ss_prob > 0``: inactive with the shipped
+Not supported (outside the path): multinomial / constrained sampling in ``_sample`` (the entry points decode greedily), scheduled sampling (``ss_prob > 0``: inactive with the shipped
 config, config.py:137), beam search (``beam_size > 1``: broken in the reference, :273).
 """
 import torch
@@ -190,7 +190,6 @@ class DynamicSpeaker(CaptionModel):
         self.module_weights = []
         sp = cfg.model.speaker if hasattr(cfg, 'model') else {}
         beam_size = sp.get('beam_size', 1)
-        temperature = sp.get('temperature', 1.0)
         decoding_constraint = sp.get('decoding_contraint', 0)
         if beam_size > 1:
             return self._sample_beam(feat_bef, feat_aft, feat_diff, cfg)
@@ -220,31 +219,7 @@ class DynamicSpeaker(CaptionModel):
                         seq_logprobs[:, first + 1:] = 0
                         break
             return seq, seq_logprobs
-        unfinished = None
-        for t in range(self.seq_length + 1):
-            logprobs, state, _ = self.get_logprobs_state(it, feat_bef, feat_aft, feat_diff, state, embed_pre)
-            logprobs = logprobs.detach()
-            if t == 0:
-                logprobs = logprobs.clone()
-                logprobs[:, 0] = float('-inf')                              # never sample NULL first (:319-322)
-            if decoding_constraint and t > 0:
-                tmp = logprobs.new_zeros(logprobs.size())
-                tmp.scatter_(1, seq[:, t - 1].unsqueeze(1), float('-inf'))
-                logprobs = logprobs + tmp
-            if t == self.seq_length:
-                break
-            if sample_max:
-                sample_logprobs, it = torch.max(logprobs, 1)
-                it = it.view(-1).long()
-            else:
-                prob_prev = torch.exp(logprobs) if temperature == 1.0 else torch.exp(logprobs / temperature)
-                it = torch.multinomial(prob_prev, 1)
-                sample_logprobs = logprobs.gather(1, it)
-                it = it.view(-1).long()
-            unfinished = (it > 0) if t == 0 else unfinished * (it > 0)
-            it = it * unfinished.type_as(it)
-            seq[:, t] = it
-            seq_logprobs[:, t] = sample_logprobs.view(-1)
-            if unfinished.sum() == 0:
-                break
-        return seq, seq_logprobs
+        raise NotImplementedError(
+            'DynamicSpeaker._sample: only greedy decoding (sample_max=1, no decoding constraint) is on the EKAID path -- it is '
+            'what test_mimic.py:119-122 and train_mimic.py:330 call; the multinomial / constrained branch of the reference '
+            '(dynamic_speaker_change_pos.py:309-357) is not reproduced')

@@ -76,10 +76,63 @@ def _rows2d(t):
 # --------------------------------------------------------------------------- #
 # raw GEMM
 # --------------------------------------------------------------------------- #
+# --------------------------------------------------------------------------- #
+# pre-split operands ("planes", include/ekaid_hip.h: ekaid_split_planes / ekaid_gemm_planes)
+# --------------------------------------------------------------------------- #
+USE_PLANES = os.environ.get('EKAID_GEMM_PLANES', '1') not in ('0', 'off', 'false')
+_weight_planes = {}          # data_ptr of a parameter -> (planes view, owner flat buffer, its version when refreshed)
+
+
+def split_planes(t):
+    """float32 tensor (contiguous) -> its three bf16 planes in P8 storage: uint8 tensor of 6 bytes per element."""
+    require_cuda(t)
+    t = _c(t)
+    n = t.numel()
+    out = torch.empty(6 * ((n + 7) // 8 * 8), dtype=torch.uint8, device=t.device)
+    check(hip.lib().ekaid_split_planes(ptr(t), n, ptr(out), stream()), 'split_planes')
+    return out
+
+
+def planes_of(t):
+    """Planes of a tensor that is not written again after its creation (activations, inputs, eval-mode weights): cached
+    on the tensor object and dropped with it; torch-visible in-place writes invalidate the cache through ``_version``."""
+    ent = getattr(t, '_ekaid_planes', None)
+    if ent is not None and ent[0] == t._version and ent[1] == t.data_ptr():
+        return ent[2]
+    pl = split_planes(t)
+    try:
+        t._ekaid_planes = (t._version, t.data_ptr(), pl)
+    except Exception:       # noqa: BLE001  (a tensor type that refuses attributes: just do not cache)
+        pass
+    return pl
+
+
+def register_weight_planes(param, planes_view, owner):
+    _weight_planes[param.data_ptr()] = (planes_view, owner, owner._version)
+
+
+def weight_planes(W):
+    """Planes of a weight: the slice of the optimizer's flat plane buffer (refreshed by every update, ekaid_amd/dp.py)
+    when the parameter lives there and has not been overwritten since, otherwise split on demand."""
+    ent = _weight_planes.get(W.data_ptr())
+    if ent is not None and ent[1]._version == ent[2]:
+        return ent[0]
+    return planes_of(W)
+
+
+def planes_ok(M, N, K, lda, ldb, batch=(1, 1), a_off=0, b_off=0):
+    """Shapes the pre-split kernel takes (mirrors the check in ekaid_gemm_planes)."""
+    return (USE_PLANES and batch == (1, 1) and M >= 512 and N >= 128 and K >= 16 and K % 16 == 0 and lda % 8 == 0 and
+            ldb % 8 == 0 and a_off % 8 == 0 and b_off % 8 == 0 and get_gemm_mode() == GEMM_BF16_SPLIT)
+
+
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=None,
          accumulate=False, bias=None, R=None, ldr=0, rdiv=1, rowmask=None, act=ACT_NONE,
-         batch=(1, 1), strides=(0, 0, 0, 0, 0, 0), a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_seed=0):
-    """C = act(alpha * op(A) op(B) [+C] [+bias] [+R]) on raw device buffers (element offsets a_off..)."""
+         batch=(1, 1), strides=(0, 0, 0, 0, 0, 0), a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_seed=0,
+         A_planes=None, B_planes=None):
+    """C = act(alpha * op(A) op(B) [+C] [+bias] [+R]) on raw device buffers (element offsets a_off..).
+    ``A_planes`` / ``B_planes``: P8 planes of the WHOLE buffers A / B (``split_planes``); when both are given and the
+    shape is inside the pre-split kernel's envelope the product runs on them (no conversion in the K loop)."""
     d = GemmDesc()
     d.A = A.data_ptr() + 4 * a_off
     d.B = B.data_ptr() + 4 * b_off
@@ -107,7 +160,15 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=N
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(L.ekaid_gemm_f32(ctypes.byref(d), ptr(ws), need, stream()), 'ekaid_gemm_f32')
+    done = False
+    if A_planes is not None and B_planes is not None and planes_ok(M, N, K, lda, ldb, batch, a_off, b_off):
+        rc = L.ekaid_gemm_planes(ctypes.byref(d), A_planes.data_ptr() + 6 * a_off, B_planes.data_ptr() + 6 * b_off, ptr(ws), need,
+                                 stream())
+        if rc != hip.ERR_UNSUPPORTED:
+            check(rc, 'ekaid_gemm_planes')
+            done = True
+    if not done:
+        check(L.ekaid_gemm_f32(ctypes.byref(d), ptr(ws), need, stream()), 'ekaid_gemm_f32')
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
@@ -181,16 +242,29 @@ class LinearFn(Function):
         y = torch.empty(M, N, device=W.device, dtype=torch.float32)
         Wt = weight_transposed(W) if _use_transposed(M) else None
         off = 0
+        xps = []
+        Wp = None
         for i, (x, ld) in enumerate(zip(xs2, lds)):
             last = i == len(xs2) - 1
             K = x.shape[1]
             if Wt is not None:      # B = W^T [K][N]: n-contiguous staging (512-byte row segments), the faster variant
                 gemm(x, Wt, y, M, N, K, ld, N, N, 0, 0, alpha_dev=scale, accumulate=i > 0,
                      bias=b if last else None, act=act if last else ACT_NONE, b_off=off * N)
+                xps.append(None)
             else:
+                xp = None
+                if planes_ok(M, N, K, ld, Ktot, b_off=off) and x.is_contiguous():
+                    # cache on the caller's tensor object when the 2-D view is the same memory (one split serves every
+                    # layer that reads this activation)
+                    src = xs[i] if (isinstance(xs[i], torch.Tensor) and xs[i].data_ptr() == x.data_ptr() and xs[i].is_contiguous()
+                                    and xs[i].numel() == x.numel()) else x
+                    xp = planes_of(src)
+                    Wp = weight_planes(W) if Wp is None else Wp
+                xps.append(xp)
                 gemm(x, W, y, M, N, K, ld, Ktot, N, 0, 1, alpha_dev=scale, accumulate=i > 0,
-                     bias=b if last else None, act=act if last else ACT_NONE, b_off=off)
+                     bias=b if last else None, act=act if last else ACT_NONE, b_off=off, A_planes=xp, B_planes=Wp)
             off += K
+        ctx.xps = xps
         ctx.act = act
         ctx.has_b = b is not None
         ctx.has_scale = scale is not None
@@ -216,6 +290,12 @@ class LinearFn(Function):
         if ctx.has_b and need[1]:
             db = torch.empty(N, device=W.device, dtype=torch.float32)
             check(L.ekaid_colsum(ptr(dz), M, N, N, ptr(db), stream()), 'colsum')
+        # the gradient dz feeds up to two products per input (dgrad as the k-contiguous A, wgrad as the m-contiguous A):
+        # split it once
+        dzp = Wp = None
+        if any(xp is not None for xp in ctx.xps):
+            dzp = split_planes(dz)
+            Wp = weight_planes(W)
         dxs = []
         off = 0
         for i, x in enumerate(xs2):
@@ -224,7 +304,8 @@ class LinearFn(Function):
                 dx = torch.empty(M, K, device=W.device, dtype=torch.float32)
                 pd = ctx.drops[i] if ctx.drops is not None else 0.0
                 gemm(dz, W, dx, M, K, N, N, Ktot, K, 0, 0, alpha_dev=scale, b_off=off,
-                     drop_p=float(pd), drop_seed=ctx.seeds[i])          # input-dropout backward in the epilogue
+                     drop_p=float(pd), drop_seed=ctx.seeds[i],          # input-dropout backward in the epilogue
+                     A_planes=dzp, B_planes=Wp if dzp is not None else None)
                 dxs.append(dx.view(*ctx.lead[i], K))
             else:
                 dxs.append(None)
@@ -233,9 +314,9 @@ class LinearFn(Function):
         if need[0] or (ctx.has_scale and need[2]):
             dW = torch.empty(N, Ktot, device=W.device, dtype=torch.float32)
             off = 0
-            for x, ld in zip(xs2, ctx.lds):
+            for x, ld, xp in zip(xs2, ctx.lds, ctx.xps):
                 K = x.shape[1]
-                gemm(dz, x, dW, N, K, M, N, ld, Ktot, 1, 0, c_off=off)
+                gemm(dz, x, dW, N, K, M, N, ld, Ktot, 1, 0, c_off=off, A_planes=dzp if xp is not None else None, B_planes=xp)
                 off += K
             if ctx.has_scale:
                 dscale = torch.empty((), device=W.device, dtype=torch.float32)
@@ -266,12 +347,21 @@ class LinearRowStackFn(Function):
         y = torch.empty(sum(Ms), N, device=W.device, dtype=torch.float32)
         r0 = 0
         Wt = weight_transposed(W) if _use_transposed(sum(Ms)) else None
+        xps = []
+        Wp = None
         for x, ld, M in zip(xs2, lds, Ms):
             if Wt is not None:
                 gemm(x, Wt, y, M, N, K, ld, N, N, 0, 0, bias=b, c_off=r0 * N)
+                xps.append(None)
             else:
-                gemm(x, W, y, M, N, K, ld, K, N, 0, 1, bias=b, c_off=r0 * N)
+                xp = None
+                if planes_ok(M, N, K, ld, K) and x.is_contiguous():
+                    xp = planes_of(x)
+                    Wp = weight_planes(W) if Wp is None else Wp
+                xps.append(xp)
+                gemm(x, W, y, M, N, K, ld, K, N, 0, 1, bias=b, c_off=r0 * N, A_planes=xp, B_planes=Wp)
             r0 += M
+        ctx.xps = xps
         ctx.save_for_backward(W, *xs2)
         ctx.lds, ctx.Ms, ctx.has_b = lds, Ms, b is not None
         ctx.lead = [x.shape[:-1] for x in xs]
@@ -292,8 +382,10 @@ class LinearRowStackFn(Function):
         if need[0]:
             dW = torch.empty(N, K, device=W.device, dtype=torch.float32)
             r0 = 0
+            dyp = split_planes(dy) if any(xp is not None for xp in ctx.xps) else None
             for i, (x, ld, M) in enumerate(zip(xs2, ctx.lds, ctx.Ms)):
-                gemm(dy, x, dW, N, K, M, N, ld, K, 1, 0, accumulate=i > 0, a_off=r0 * N)
+                gemm(dy, x, dW, N, K, M, N, ld, K, 1, 0, accumulate=i > 0, a_off=r0 * N,
+                     A_planes=dyp if ctx.xps[i] is not None else None, B_planes=ctx.xps[i])
                 r0 += M
         dxs = []
         r0 = 0

@@ -80,7 +80,7 @@ def test_bucketed_allreduce_matches_single_process(bucket_mb, overlap):
     for n in names0:
         k = want[n].numel()
         assert torch.allclose(flat[off:off + k], want[n].reshape(-1), atol=1e-5), n
-        off += (k + 3) // 4 * 4
+        off += (k + 7) // 8 * 8          # every tensor starts on an 8-element group (ekaid_amd/dp.py)
     # gather semantics
     assert gath0 == gath1 == [[0., 1., 2.], [3., 4., 5.], [10., 11., 12.], [13., 14., 15.]]
     assert ga0 == [[0., 2., 4.], [6., 8., 10.]] and ga1 == [[12., 14., 16.], [18., 20., 22.]]

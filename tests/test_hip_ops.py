@@ -762,3 +762,59 @@ def test_round2_kernels_int8_labels_loss_denominator_device_adam_dropout_epoch()
     assert torch.equal(y2, y3) and not torch.equal(y1, y2)
     assert abs(float((y2 != 0).float().mean()) - 0.5) < 0.02 and abs(float(((y1 != 0) & (y2 != 0)).float().mean()) - 0.25) < 0.02
     assert not torch.equal(c1 != 0, c2 != 0)
+
+
+@pytest.mark.parametrize('tA,tB,M,N,K', [(0, 1, 640, 256, 128), (0, 0, 1152, 384, 1024), (1, 0, 1024, 640, 2304),
+                                         (0, 1, 2304, 1024, 4096), (0, 1, 600, 200, 48), (1, 0, 512, 128, 18432)])
+def test_gemm_on_presplit_planes(tA, tB, M, N, K):
+    """ekaid_gemm_planes == ekaid_gemm_f32 (same six products per block, same order: bit-identical accumulators up to the
+    split-K slab order) and both within the f32 error of a float64 product; epilogue (bias, activation, accumulate) shared."""
+    from ekaid_amd import ops
+    from ekaid_amd.hip import ACT_RELU
+    g = torch.Generator().manual_seed(M + N + K)
+    scale_r = torch.exp(torch.randn(M if not tA else K, 1, generator=g))          # rows with a 3-decade dynamic range
+    A = (torch.randn(*((M, K) if not tA else (K, M)), generator=g) * scale_r).to(DEV)
+    B = torch.randn(*((N, K) if tB else (K, N)), generator=g).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    lda, ldb = A.shape[1], B.shape[1]
+    Ap, Bp = ops.split_planes(A), ops.split_planes(B)
+    assert Ap.numel() == 6 * A.numel()
+    c_f32, c_pl = torch.zeros(M, N, device=DEV), torch.zeros(M, N, device=DEV)
+    assert ops.planes_ok(M, N, K, lda, ldb)
+    ops.gemm(A, B, c_f32, M, N, K, lda, ldb, N, tA, tB, bias=bias, act=ACT_RELU)
+    ops.gemm(A, B, c_pl, M, N, K, lda, ldb, N, tA, tB, bias=bias, act=ACT_RELU, A_planes=Ap, B_planes=Bp)
+    A64 = (A.double().cpu().t() if tA else A.double().cpu())
+    B64 = (B.double().cpu().t() if tB else B.double().cpu())
+    ref = torch.relu(A64 @ B64 + bias.double().cpu())
+    mag = A64.abs() @ B64.abs() + bias.double().cpu().abs()
+    e_pl = float(((c_pl.double().cpu() - ref).abs() / mag).max())
+    e_f32 = float(((c_f32.double().cpu() - ref).abs() / mag).max())
+    assert e_pl <= max(1.5 * e_f32, 2e-7), (e_pl, e_f32)
+    assert float((c_pl - c_f32).abs().max()) <= 4e-6 * float(mag.max()), 'the two staging paths compute the same products'
+    # accumulate into C
+    c2 = c_pl.clone()
+    ops.gemm(A, B, c2, M, N, K, lda, ldb, N, tA, tB, accumulate=True, A_planes=Ap, B_planes=Bp)
+    want = c_pl.double().cpu() + A64 @ B64
+    assert float(((c2.double().cpu() - want).abs() / (mag + c_pl.double().cpu().abs())).max()) < 3e-7
+
+
+def test_gemm_planes_exact_on_integers_and_views():
+    """Integer-valued operands that need all three planes reproduce the exact integer product (lane maps of the LDS-DMA
+    staging, swizzles and fragment reads), also through column-offset views of wider buffers (offsets % 8 == 0)."""
+    from ekaid_amd import ops
+    g = torch.Generator().manual_seed(3)
+    M, N, K, off = 1024, 256, 64, 16
+    Awide = torch.randint(-2000000, 2000000, (M, K + 2 * off), generator=g).float().to(DEV)      # 21 significant bits
+    Bwide = torch.randint(-3, 4, (N, K + off), generator=g).float().to(DEV)
+    Ap, Bp = ops.split_planes(Awide), ops.split_planes(Bwide)
+    C = torch.empty(M, N, device=DEV)
+    ops.gemm(Awide, Bwide, C, M, N, K, K + 2 * off, K + off, N, 0, 1, a_off=off, b_off=off, A_planes=Ap, B_planes=Bp)
+    want = Awide[:, off:off + K].double().cpu() @ Bwide[:, off:off + K].double().cpu().t()
+    assert float(want.abs().max()) < 2 ** 31
+    assert torch.equal(C.double().cpu(), want)
+    # planes round trip: hi + mid + lo == x bit for bit
+    x = torch.randn(4099, generator=g).to(DEV) * 1e3
+    pl = ops.split_planes(x).cpu().view(torch.int16).view(-1, 3, 8)
+    parts = (pl.to(torch.int32) << 16).view(torch.float32)
+    back = (parts[:, 0] + parts[:, 1] + parts[:, 2]).reshape(-1)[:4099]
+    assert torch.equal(back, x.cpu())
