@@ -1068,31 +1068,36 @@ namespace ekaid {
 
 // ------------------------------------------------------------------------------------------------------------------
 // The same 6-product arithmetic on PRE-SPLIT operands ("planes"): the three bf16 planes of an f32 tensor are produced
-// once, where the tensor is produced (ekaid_split_planes, the Adam kernel for the weights), instead of inside every K
-// loop that reads it.  In gemm_split_kernel the split costs 5.2 vector-ALU instructions per MFMA and the shared
+// once, where the tensor is produced (ekaid_split_planes; for the weights once per optimizer step), instead of inside
+// every K loop that reads it.  In gemm_split_kernel the split costs 5.2 vector-ALU instructions per MFMA and the shared
 // vector-issue port is ~90 % subscribed (profiles/r01_pmc_gemm_split_nn_18432x1024x1024.json: MFMA busy 52 %); here the
 // K loop has no vector ALU work at all.
 //
-// Plane storage "P8": for a flat f32 array x[0..n), n % 8 == 0, every group of 8 consecutive elements becomes 48 bytes
-//     [ h(x[8g..8g+7]) : 8 x bf16 | m(...) : 8 x bf16 | l(...) : 8 x bf16 ],       h + m + l == x exactly (truncation split)
-// i.e. plane p of element e sits at byte 6 * (e & ~7) + 16 p + 2 (e & 7).  The mapping does not depend on the matrix shape,
-// so any row-major view whose leading dimension and offsets are multiples of 8 elements addresses its planes with the same
-// (row, column) arithmetic as the f32 data, and one 16-byte unit = 8 consecutive k (k-contiguous operand) or 8 consecutive
-// rows (m/n-contiguous operand) of one plane -- exactly the unit both LDS images are built from.
+// Plane storage: PLANE-MAJOR -- three bf16 arrays (hi, mid, lo; hi + mid + lo == x exactly, truncation split) laid out
+// exactly like the f32 array, `plane_stride` bytes apart.  Any row-major view of the f32 buffer addresses its planes with
+// the same (row, column) arithmetic, 2 bytes per element.
 //
-// Staging: buffer_load_dwordx4 ... lds (LDS-DMA, no VGPRs, no ds_write): one wave instruction fills 1 KiB of LDS, lane L the
-// 16 bytes at +16 L; the XOR swizzles of the images are applied on the per-lane SOURCE offset (the LDS side of an LDS-DMA is
-// lane-linear).  The K advance is the scalar soffset.  Images, fragment reads and the 24 MFMAs per 16-deep stage are those
-// of gemm_split_kernel's pipelined loop; 2 stage buffers of 24 KiB -> 48 KiB per workgroup, 3 workgroups per CU: while one
-// workgroup waits for its next stage the other two multiply.
+// Staging: buffer_load_dwordx4 ... lds (LDS-DMA: no VGPRs, no ds_write).  One wave instruction fills 1 KiB of LDS, lane L
+// the 16 bytes at +16 L (= 8 consecutive k of a k-contiguous operand, or 8 consecutive rows of an m/n-contiguous one); the
+// XOR swizzles of the LDS images (kc_store_off / mc_store_off above) are applied on the per-lane SOURCE offset, because
+// the LDS side of an LDS-DMA is lane-linear.  K advance and plane selection ride in the scalar offset.  The loads are
+// issued from inline asm: behind the builtin form hipcc waits vmcnt(0) before the next ds_read (it cannot tell the ring
+// slots apart) and would drain the DMA it has just issued; asm loads are outside its bookkeeping and are retired by the
+// counted s_waitcnt in the loop.  NBUF ring slots of one KS-deep stage each; stage s+NBUF-1 is issued right after the
+// barrier that opens stage s (everybody has then finished reading the slot it overwrites).
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256, 3) void gemm_planes_kernel(GemmArgs g) {
-    constexpr int TM = 2, TN = 2, BM = 128, BN = 128, KS = 16;
-    constexpr int PLANE = 4096;                 // one plane image of one operand per stage: 128 rows x 32 B, or 16 k-rows x 256 B
+template <bool A_KC, bool B_KC, int KS, int NBUF, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_planes_kernel(GemmArgs g, unsigned long long strideA, unsigned long long strideB) {
+    constexpr int TM = 2, TN = 2, BM = 128, BN = 128;
+    constexpr int NCH = KS / 16;                      // 16-k MFMA chunks per stage
+    constexpr int PLANE = 128 * KS * 2;               // bytes of one plane image of one operand per stage
     constexpr int STAGE = 6 * PLANE;
+    constexpr int NI = PLANE / 4096;                  // LDS-DMA instructions per wave and plane image (1 KiB each, 4 waves)
+    constexpr int NDMA = 6 * NI;                      // per wave and stage
     constexpr int A_RS = A_KC ? 2 * KS : 2 * BM, B_RS = B_KC ? 2 * KS : 2 * BN;
+    static_assert(KS == 16 || KS == 32, "stage depth");
+    static_assert(NBUF == 2 || NBUF == 3, "ring slots");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     char* const ldsb = reinterpret_cast<char*>(lds);
 
@@ -1113,24 +1118,28 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_kernel(GemmArgs g) {
         kbeg = z * g.k_per_split;
         kend = min(g.K, kbeg + g.k_per_split);
     }
+    // raw buffer descriptors {base lo, base hi (stride 0), num_records in bytes, flags}, covering all three planes
     const long long spanA = A_KC ? ((long long)(g.M - 1) * g.lda + g.K) : ((long long)(g.K - 1) * g.lda + g.M);
     const long long spanB = B_KC ? ((long long)(g.N - 1) * g.ldb + g.K) : ((long long)(g.K - 1) * g.ldb + g.N);
-    // raw buffer descriptors {base lo, base hi (stride 0), num_records in bytes, flags}: the LDS-DMA is issued from inline
-    // asm (below), which takes the descriptor as an SGPR quad
     const unsigned long long pa = reinterpret_cast<unsigned long long>(g.A), pb = reinterpret_cast<unsigned long long>(g.B);
-    const u32x4 rsrcA = {(unsigned)pa, (unsigned)(pa >> 32) & 0xFFFFu, (unsigned)(6 * ((spanA + 7) & ~7ll)), 0x00020000u};
-    const u32x4 rsrcB = {(unsigned)pb, (unsigned)(pb >> 32) & 0xFFFFu, (unsigned)(6 * ((spanB + 7) & ~7ll)), 0x00020000u};
-    // this lane's 16-byte unit inside quarter `wave` of every plane image, as a byte offset into plane 0 of the P8 array
-    unsigned voA, voB;
-    {
-        const int rowk = 32 * wave + (lane >> 1), s = (lane & 1) ^ ((rowk >> 3) & 1);                  // k-contiguous image
-        const int km = 4 * wave + (lane >> 4), col = 32 * (((lane & 15) >> 2) ^ (km & 3)) + 8 * (lane & 3);   // m-contiguous image
-        voA = A_KC ? 6u * ((unsigned)(m0 + rowk) * (unsigned)g.lda + 8u * s) : 6u * ((unsigned)km * (unsigned)g.lda + (unsigned)(m0 + col));
-        voB = B_KC ? 6u * ((unsigned)(n0 + rowk) * (unsigned)g.ldb + 8u * s) : 6u * ((unsigned)km * (unsigned)g.ldb + (unsigned)(n0 + col));
+    const u32x4 rsrcA = {(unsigned)pa, (unsigned)(pa >> 32) & 0xFFFFu, (unsigned)(2 * strideA + 2 * (unsigned long long)spanA), 0x00020000u};
+    const u32x4 rsrcB = {(unsigned)pb, (unsigned)(pb >> 32) & 0xFFFFu, (unsigned)(2 * strideB + 2 * (unsigned long long)spanB), 0x00020000u};
+    // this lane's 16-byte units: instruction q of a plane image covers units [64 (wave + 4 q), +64) of the image
+    unsigned voA[NI], voB[NI];
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+        const int u = 64 * (wave + 4 * q) + lane;
+        // k-contiguous image [128 rows][KS/8 slots]: physical slot -> logical slot through the row's key
+        const int rowk = u / (KS / 8), sl = (u % (KS / 8)) ^ kc_key<KS>(rowk);
+        // m-contiguous image [KS k-rows][16 units of 8 rows]: 64-byte chunks XOR-ed with k & 3
+        const int km = u >> 4, c = u & 15, col = 32 * ((c >> 2) ^ (km & 3)) + 8 * (c & 3);
+        voA[q] = A_KC ? 2u * ((unsigned)(m0 + rowk) * (unsigned)g.lda + 8u * sl) : 2u * ((unsigned)km * (unsigned)g.lda + (unsigned)(m0 + col));
+        voB[q] = B_KC ? 2u * ((unsigned)(n0 + rowk) * (unsigned)g.ldb + 8u * sl) : 2u * ((unsigned)km * (unsigned)g.ldb + (unsigned)(n0 + col));
     }
-    const unsigned kstepA = A_KC ? 6u * KS : 6u * KS * (unsigned)g.lda;      // soffset advance per stage, bytes
-    const unsigned kstepB = B_KC ? 6u * KS : 6u * KS * (unsigned)g.ldb;
-    unsigned soA = (A_KC ? 6u : 6u * (unsigned)g.lda) * (unsigned)kbeg, soB = (B_KC ? 6u : 6u * (unsigned)g.ldb) * (unsigned)kbeg;
+    const unsigned kstepA = A_KC ? 2u * KS : 2u * KS * (unsigned)g.lda;      // soffset advance per stage, bytes
+    const unsigned kstepB = B_KC ? 2u * KS : 2u * KS * (unsigned)g.ldb;
+    unsigned soA = (A_KC ? 2u : 2u * (unsigned)g.lda) * (unsigned)kbeg, soB = (B_KC ? 2u : 2u * (unsigned)g.ldb) * (unsigned)kbeg;
+    const unsigned psA = (unsigned)strideA, psB = (unsigned)strideB;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -1141,13 +1150,17 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_kernel(GemmArgs g) {
             for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
 
     const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
-    int fA[TM], fB[TN];
+    int fA[TM][NCH], fB[TN][NCH];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
-        fA[i] = A_KC ? (wm + 32 * i + r) * 32 + 16 * (h ^ (((wm + 32 * i + r) >> 3) & 1)) : mc_read_off<BM>(8 * h + tq, wm + 32 * i, tg, tp);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            fA[i][c] = A_KC ? kc_read_off<KS>(wm + 32 * i + r, 2 * c + h) : mc_read_off<BM>(16 * c + 8 * h + tq, wm + 32 * i, tg, tp);
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-        fB[j] = B_KC ? (wn + 32 * j + r) * 32 + 16 * (h ^ (((wn + 32 * j + r) >> 3) & 1)) : mc_read_off<BN>(8 * h + tq, wn + 32 * j, tg, tp);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            fB[j][c] = B_KC ? kc_read_off<KS>(wn + 32 * j + r, 2 * c + h) : mc_read_off<BN>(16 * c + 8 * h + tq, wn + 32 * j, tg, tp);
     typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
     auto frag = [&](const char* plane, int off, bool kc, int rs) -> bf16x8 {
         if (kc) {
@@ -1160,70 +1173,78 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_kernel(GemmArgs g) {
             return __builtin_bit_cast(bf16x8, v);
         }
     };
-    // six LDS-DMA instructions per wave and stage: quarter `wave` of the three A and the three B plane images.  Inline asm on
-    // purpose: behind the builtin form hipcc waits vmcnt(0) before the next ds_read (it cannot tell the two stage buffers
-    // apart), which would drain the DMA it has just issued; an asm load is outside its bookkeeping and is waited for by the
-    // explicit s_waitcnt in the loop.  M0 (the LDS destination base) is saved and restored inside each statement.
-    const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) char*)ldsb) + 1024u * (unsigned)wave;
-#define EKAID_DMA16(RS, LDSADDR, VOFF, SOFF, IMM)                                                                           \
+    const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) char*)ldsb);
+#define EKAID_DMA16(RS, LDSADDR, VOFF, SOFF)                                                                                \
     do {                                                                                                                     \
         unsigned keep_;                                                                                                      \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen offset:" #IMM " lds\n\ts_mov_b32 m0, %0" \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0" \
                      : "=&s"(keep_) : "s"(LDSADDR), "v"(VOFF), "s"(RS), "s"(SOFF) : "memory");                               \
     } while (0)
-    auto issue = [&](unsigned stage_off) {
-        const unsigned d = lds_base + stage_off;
-        EKAID_DMA16(rsrcA, d + 0u * PLANE, voA, soA, 0);
-        EKAID_DMA16(rsrcA, d + 1u * PLANE, voA, soA, 16);
-        EKAID_DMA16(rsrcA, d + 2u * PLANE, voA, soA, 32);
-        EKAID_DMA16(rsrcB, d + 3u * PLANE, voB, soB, 0);
-        EKAID_DMA16(rsrcB, d + 4u * PLANE, voB, soB, 16);
-        EKAID_DMA16(rsrcB, d + 5u * PLANE, voB, soB, 32);
+    // NDMA LDS-DMA instructions per wave and stage.  M0 (the LDS destination base) is saved and restored inside each
+    // statement; the plane rides in the scalar offset (an instruction immediate would also move the LDS address).
+    auto issue = [&](unsigned slot_off) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                EKAID_DMA16(rsrcA, lds_base + slot_off + (unsigned)(p * PLANE + 1024 * (wave + 4 * q)), voA[q], soA + (unsigned)p * psA);
+                EKAID_DMA16(rsrcB, lds_base + slot_off + (unsigned)((3 + p) * PLANE + 1024 * (wave + 4 * q)), voB[q], soB + (unsigned)p * psB);
+            }
         soA += kstepA;
         soB += kstepB;
     };
     auto compute = [&](const char* buf) {
         const char* const cA = buf;
         const char* const cB = buf + 3 * PLANE;
-        bf16x8 fa[TM][3], fb[TN][3];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int c = 0; c < NCH; ++c) {
+            bf16x8 fa[TM][3], fb[TN][3];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) fa[i][p] = frag(cA + p * PLANE, fA[i], A_KC, A_RS);
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+                for (int p = 0; p < 3; ++p) fa[i][p] = frag(cA + p * PLANE, fA[i][c], A_KC, A_RS);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) fb[j][p] = frag(cB + p * PLANE, fB[j], B_KC, B_RS);
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+                for (int p = 0; p < 3; ++p) fb[j][p] = frag(cB + p * PLANE, fB[j][c], B_KC, B_RS);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {      // smallest terms first
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
-            }
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {      // smallest terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
     };
     const int nst = (kend - kbeg) / KS;
     if (nst > 0) {
-        issue(0u);
+#pragma unroll
+        for (int s = 0; s < NBUF - 1; ++s)
+            if (s < nst) issue((unsigned)(s * STAGE));
+        unsigned cur = 0u, nxt = (unsigned)((NBUF - 1) * STAGE);      // slot of stage s / of stage s + NBUF - 1
         for (int s = 0; s < nst; ++s) {
-            // my DMA of stage s has landed -> barrier -> everybody's has, and everybody is done reading the other buffer
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            const unsigned cur = (s & 1) ? (unsigned)STAGE : 0u;
-            if (s + 1 < nst) issue((unsigned)STAGE - cur);
+            // retire my DMA of stage s: everything issued after it (the NBUF-2 younger stages) may stay in flight
+            if (NBUF == 3 && s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NDMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();       // everybody's stage s has landed, and everybody is done reading slot `nxt`
+            if (s + NBUF - 1 < nst) issue(nxt);
             compute(ldsb + cur);
+            nxt = cur;
+            cur = (cur + (unsigned)STAGE == (unsigned)(NBUF * STAGE)) ? 0u : cur + (unsigned)STAGE;
         }
     }
 #undef EKAID_DMA16
     write_tiles<TM, TN>(g, acc, m0, n0, wm, wn, r, h, z);
 }
 
-// f32 -> P8 planes (see above).  One thread per group of 8 elements: two 16-byte loads, three 16-byte stores.
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, long long ngroups, long long n, u32x4* __restrict__ out) {
+// f32 -> three bf16 planes (plane-major, see above).  One thread per group of 8 elements: two 16-byte loads, one 16-byte
+// store per plane (consecutive lanes -> consecutive 16 bytes in every plane).
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, long long ngroups, long long n,
+                                                           u32x4* __restrict__ out, long long plane_stride16) {
     for (long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += (long long)gridDim.x * blockDim.x) {
         f32x4 v0, v1;
         const long long e = gi * 8;
@@ -1237,31 +1258,55 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
         u32x2 H0, M0, L0, H1, M1, L1;
         split4(v0, H0, M0, L0);
         split4(v1, H1, M1, L1);
-        u32x4* o = out + gi * 3;
-        o[0] = u32x4{H0[0], H0[1], H1[0], H1[1]};
-        o[1] = u32x4{M0[0], M0[1], M1[0], M1[1]};
-        o[2] = u32x4{L0[0], L0[1], L1[0], L1[1]};
+        out[gi] = u32x4{H0[0], H0[1], H1[0], H1[1]};
+        out[gi + plane_stride16] = u32x4{M0[0], M0[1], M1[0], M1[1]};
+        out[gi + 2 * plane_stride16] = u32x4{L0[0], L0[1], L1[0], L1[1]};
     }
+}
+
+static int planes_variant() {          // tuning aid: EKAID_PLANES_VARIANT = 0 (KS 16, 2 slots, 3 wg/CU) | 1 (16, 3, 2) | 2 (32, 3, 1) | 3 (32, 2, 1)
+    static const char* v = getenv("EKAID_PLANES_VARIANT");
+    return v ? atoi(v) : 2;
+}
+
+template <bool A_KC, bool B_KC, int KS, int NBUF, int OCC>
+static int launch_planes(const GemmArgs& a, unsigned long long sa, unsigned long long sb, dim3 grid, hipStream_t st) {
+    constexpr size_t lds = (size_t)NBUF * 6 * 128 * KS * 2;
+    auto kern = gemm_planes_kernel<A_KC, B_KC, KS, NBUF, OCC>;
+    if (lds > 64 * 1024) {
+        constexpr int slot = 32 + (A_KC ? 1 : 0) + (B_KC ? 2 : 0) + 4 * (KS == 32 ? 1 : 0) + 8 * (NBUF - 2);
+        if (func_attr_once(slot)) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                (void)hipGetLastError();
+                set_error("gemm_planes: cannot raise the dynamic LDS limit to %zu bytes", lds);
+                return EKAID_ERR_LAUNCH;
+            }
+        }
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, sa, sb);
+    return EKAID_OK;
 }
 
 }  // namespace ekaid
 using namespace ekaid;
 
-extern "C" int ekaid_split_planes(const float* x, long long n, void* planes, void* stream) {
+extern "C" int ekaid_split_planes(const float* x, long long n, void* planes, long long plane_stride_bytes, void* stream) {
     if (n <= 0) return EKAID_OK;
-    if (!x || !planes || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(planes) & 15)) {
-        set_error("ekaid_split_planes: null or unaligned pointer (16-byte alignment required)");
+    const long long ngroups = (n + 7) / 8;
+    if (!x || !planes || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(planes) & 15) ||
+        (plane_stride_bytes & 15) || plane_stride_bytes < 16 * ngroups) {
+        set_error("ekaid_split_planes: null / unaligned pointer, or plane stride %lld not a multiple of 16 >= %lld", plane_stride_bytes, 16 * ngroups);
         return EKAID_ERR_ARG;
     }
-    const long long ngroups = (n + 7) / 8;
     long long blocks = (ngroups + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ngroups, n, (u32x4*)planes);
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ngroups, n, (u32x4*)planes,
+                       plane_stride_bytes / 16);
     return check_launch("split_planes");
 }
 
-extern "C" int ekaid_gemm_planes(const ekaid_gemm_t* d, const void* A_planes, const void* B_planes, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
+extern "C" int ekaid_gemm_planes(const ekaid_gemm_t* d, const void* A_planes, long long a_plane_stride, const void* B_planes,
+                                 long long b_plane_stride, void* workspace, size_t workspace_bytes, void* stream) {
     if (!d || !A_planes || !B_planes || !d->C) { set_error("ekaid_gemm_planes: null pointer"); return EKAID_ERR_ARG; }
     if (d->transA && d->transB) { set_error("ekaid_gemm_planes: transA && transB unsupported"); return EKAID_ERR_UNSUPPORTED; }
     if (d->M <= 0 || d->N <= 0) return EKAID_OK;
@@ -1270,11 +1315,12 @@ extern "C" int ekaid_gemm_planes(const ekaid_gemm_t* d, const void* A_planes, co
     const long long spanB = bkc ? ((long long)(d->N - 1) * d->ldb + d->K) : ((long long)(d->K - 1) * d->ldb + d->N);
     int TMN, splitk, tm, tn;
     plan(d, TMN, splitk, tm, tn);
-    if (d->batch1 * d->batch2 != 1 || TMN != 2 || d->K < 16 || (d->K & 15) || (d->lda & 7) || (d->ldb & 7) ||
-        6 * (spanA + 8) >= (1ll << 32) || 6 * (spanB + 8) >= (1ll << 32) ||
+    if (d->batch1 * d->batch2 != 1 || TMN != 2 || d->K < 32 || (d->K & 31) || (d->lda & 7) || (d->ldb & 7) ||
+        a_plane_stride < 2 * spanA || b_plane_stride < 2 * spanB || (a_plane_stride & 15) || (b_plane_stride & 15) ||
+        2 * a_plane_stride + 2 * spanA >= (1ll << 32) || 2 * b_plane_stride + 2 * spanB >= (1ll << 32) ||
         (reinterpret_cast<uintptr_t>(A_planes) & 15) || (reinterpret_cast<uintptr_t>(B_planes) & 15)) {
-        set_error("ekaid_gemm_planes: shape outside the pre-split kernel's envelope (one batch, M >= 512, N >= 128, K %% 16 == 0, "
-                  "leading dimensions %% 8 == 0): M=%d N=%d K=%d lda=%d ldb=%d", d->M, d->N, d->K, d->lda, d->ldb);
+        set_error("ekaid_gemm_planes: shape outside the pre-split kernel's envelope (one batch, M >= 512, N >= 128, K %% 32 == 0, "
+                  "leading dimensions %% 8 == 0, planes < 4 GiB apart): M=%d N=%d K=%d lda=%d ldb=%d", d->M, d->N, d->K, d->lda, d->ldb);
         return EKAID_ERR_UNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -1299,11 +1345,18 @@ extern "C" int ekaid_gemm_planes(const ekaid_gemm_t* d, const void* A_planes, co
         if (a.splitk <= 1) { a.splitk = 1; a.ws = nullptr; a.k_per_split = cdiv(d->K, BK_BIG) * BK_BIG; }
     }
     dim3 grid(a.tiles_m * a.tiles_n, 1, a.splitk > 1 ? a.splitk : 1);
-    constexpr size_t lds = 2 * 6 * 4096;
-    if (akc && bkc) hipLaunchKernelGGL((gemm_planes_kernel<true, true>), grid, dim3(256), lds, st, a);
-    else if (akc && !bkc) hipLaunchKernelGGL((gemm_planes_kernel<true, false>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((gemm_planes_kernel<false, false>), grid, dim3(256), lds, st, a);
-    int rc = check_launch("gemm_planes_kernel");
+    const unsigned long long sa = (unsigned long long)a_plane_stride, sb = (unsigned long long)b_plane_stride;
+    int rc;
+#define EKAID_PL(AK, BK) (planes_variant() == 0 ? launch_planes<AK, BK, 16, 2, 3>(a, sa, sb, grid, st) \
+                          : planes_variant() == 1 ? launch_planes<AK, BK, 16, 3, 2>(a, sa, sb, grid, st) \
+                          : planes_variant() == 3 ? launch_planes<AK, BK, 32, 2, 1>(a, sa, sb, grid, st) \
+                          : launch_planes<AK, BK, 32, 3, 1>(a, sa, sb, grid, st))
+    if (akc && bkc) rc = EKAID_PL(true, true);
+    else if (akc && !bkc) rc = EKAID_PL(true, false);
+    else rc = EKAID_PL(false, false);
+#undef EKAID_PL
+    if (rc) return rc;
+    rc = check_launch("gemm_planes_kernel");
     if (rc) return rc;
     if (a.splitk > 1) {
         const long long total = (long long)d->M * d->N;

@@ -108,11 +108,13 @@ class GradBuckets:
         from . import ops
         if not ops.USE_PLANES:
             return
+        stride = 2 * self.total
         if getattr(self, 'planes', None) is None:
-            self.planes = torch.empty(6 * self.total, dtype=torch.uint8, device=self.pflat.device)
-        hip.check(hip.lib().ekaid_split_planes(hip.ptr(self.pflat), self.total, hip.ptr(self.planes), hip.stream()), 'split_planes')
+            self.planes = torch.empty(3 * stride, dtype=torch.uint8, device=self.pflat.device)
+        hip.check(hip.lib().ekaid_split_planes(hip.ptr(self.pflat), self.total, hip.ptr(self.planes), stride, hip.stream()),
+                  'split_planes')
         for p, o in zip(self.live, self.offsets):
-            ops.register_weight_planes(p, self.planes[6 * o:6 * (o + (p.numel() + 7) // 8 * 8)], self.pflat)
+            ops.register_weight_planes(p, ops.Planes(self.planes, stride, 2 * o), self.pflat)
 
     def comm_active(self):
         return self.world > 1 or self.force_comm

@@ -147,7 +147,8 @@ class TrainStep:
         torch.cuda.synchronize(dev)
         ops.set_seed_state(seed_state)          # the capture draws the same site seeds as the first warm-up step
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self._pool):
+        # thread_local: the RCCL watchdog thread of torch.distributed queries events while this thread captures
+        with torch.cuda.graph(g, pool=self._pool, capture_error_mode='thread_local'):
             loss, sp_loss = self._body(static, T, sden)
         if self._pool is None:
             self._pool = g.pool()

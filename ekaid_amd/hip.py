@@ -53,8 +53,8 @@ SIGNATURES = {
     'ekaid_set_gemm_mode': [I],
     'ekaid_get_gemm_mode': [],
     'ekaid_gemm_f32': [POINTER(GemmDesc), P, c_size_t, P],
-    'ekaid_gemm_planes': [POINTER(GemmDesc), P, P, P, c_size_t, P],
-    'ekaid_split_planes': [P, L, P, P],
+    'ekaid_gemm_planes': [POINTER(GemmDesc), P, L, P, L, P, c_size_t, P],
+    'ekaid_split_planes': [P, L, P, L, P],
     'ekaid_wn_scale_fwd': [P, P, L, P, P, P],
     'ekaid_wn_scale_bwd': [P, P, P, P, L, P, I, P, P],
     'ekaid_scale_dot': [P, P, P, L, P, P],

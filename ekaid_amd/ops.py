@@ -83,14 +83,27 @@ USE_PLANES = os.environ.get('EKAID_GEMM_PLANES', '1') not in ('0', 'off', 'false
 _weight_planes = {}          # data_ptr of a parameter -> (planes view, owner flat buffer, its version when refreshed)
 
 
+class Planes:
+    """Three bf16 planes of an f32 buffer, plane-major: ``buf`` (uint8) holds hi | mid | lo, ``stride`` bytes apart;
+    ``base`` = byte offset of the buffer's element 0 inside plane 0 (non-zero for views into a larger plane buffer)."""
+    __slots__ = ('buf', 'stride', 'base')
+
+    def __init__(self, buf, stride, base=0):
+        self.buf, self.stride, self.base = buf, stride, base
+
+    def ptr(self, elem_off=0):
+        return self.buf.data_ptr() + self.base + 2 * elem_off
+
+
 def split_planes(t):
-    """float32 tensor (contiguous) -> its three bf16 planes in P8 storage: uint8 tensor of 6 bytes per element."""
+    """float32 tensor (contiguous) -> its three bf16 planes (``Planes``)."""
     require_cuda(t)
     t = _c(t)
     n = t.numel()
-    out = torch.empty(6 * ((n + 7) // 8 * 8), dtype=torch.uint8, device=t.device)
-    check(hip.lib().ekaid_split_planes(ptr(t), n, ptr(out), stream()), 'split_planes')
-    return out
+    stride = 2 * ((n + 7) // 8 * 8)
+    out = torch.empty(3 * stride, dtype=torch.uint8, device=t.device)
+    check(hip.lib().ekaid_split_planes(ptr(t), n, ptr(out), stride, stream()), 'split_planes')
+    return Planes(out, stride)
 
 
 def planes_of(t):
@@ -107,8 +120,8 @@ def planes_of(t):
     return pl
 
 
-def register_weight_planes(param, planes_view, owner):
-    _weight_planes[param.data_ptr()] = (planes_view, owner, owner._version)
+def register_weight_planes(param, planes, owner):
+    _weight_planes[param.data_ptr()] = (planes, owner, owner._version)
 
 
 def weight_planes(W):
@@ -122,7 +135,7 @@ def weight_planes(W):
 
 def planes_ok(M, N, K, lda, ldb, batch=(1, 1), a_off=0, b_off=0):
     """Shapes the pre-split kernel takes (mirrors the check in ekaid_gemm_planes)."""
-    return (USE_PLANES and batch == (1, 1) and M >= 512 and N >= 128 and K >= 16 and K % 16 == 0 and lda % 8 == 0 and
+    return (USE_PLANES and batch == (1, 1) and M >= 512 and N >= 128 and K >= 32 and K % 32 == 0 and lda % 8 == 0 and
             ldb % 8 == 0 and a_off % 8 == 0 and b_off % 8 == 0 and get_gemm_mode() == GEMM_BF16_SPLIT)
 
 
@@ -131,7 +144,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=N
          batch=(1, 1), strides=(0, 0, 0, 0, 0, 0), a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_seed=0,
          A_planes=None, B_planes=None):
     """C = act(alpha * op(A) op(B) [+C] [+bias] [+R]) on raw device buffers (element offsets a_off..).
-    ``A_planes`` / ``B_planes``: P8 planes of the WHOLE buffers A / B (``split_planes``); when both are given and the
+    ``A_planes`` / ``B_planes``: ``Planes`` of the WHOLE buffers A / B (``split_planes``); when both are given and the
     shape is inside the pre-split kernel's envelope the product runs on them (no conversion in the K loop)."""
     d = GemmDesc()
     d.A = A.data_ptr() + 4 * a_off
@@ -162,8 +175,8 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=N
         e0.record()
     done = False
     if A_planes is not None and B_planes is not None and planes_ok(M, N, K, lda, ldb, batch, a_off, b_off):
-        rc = L.ekaid_gemm_planes(ctypes.byref(d), A_planes.data_ptr() + 6 * a_off, B_planes.data_ptr() + 6 * b_off, ptr(ws), need,
-                                 stream())
+        rc = L.ekaid_gemm_planes(ctypes.byref(d), A_planes.ptr(a_off), A_planes.stride, B_planes.ptr(b_off), B_planes.stride,
+                                 ptr(ws), need, stream())
         if rc != hip.ERR_UNSUPPORTED:
             check(rc, 'ekaid_gemm_planes')
             done = True

@@ -86,21 +86,22 @@ typedef struct ekaid_gemm {
 size_t ekaid_gemm_workspace_bytes(const ekaid_gemm_t* g);
 int ekaid_gemm_f32(const ekaid_gemm_t* g, void* workspace, size_t workspace_bytes, void* stream);
 
-/* The same contraction on PRE-SPLIT operands (EKAID_GEMM_BF16_SPLIT arithmetic, bit-identical products): the three bf16
- * planes of an operand are produced once, where the tensor is produced, instead of inside every K loop that reads it.
- * Plane storage "P8": for a flat f32 array x[0..n) every group of 8 consecutive elements becomes 48 bytes
- *     [ hi(x[8g..8g+7]) : 8 x bf16 | mid(...) : 8 x bf16 | lo(...) : 8 x bf16 ],   hi + mid + lo == x exactly;
- * the layout does not depend on the matrix shape, so planes of a buffer serve every row-major view of it whose leading
- * dimension and offsets are multiples of 8 elements.
- *   ekaid_split_planes: x (n floats, 16-byte aligned) -> planes (6 * ceil8(n) bytes, 16-byte aligned).
- *   ekaid_gemm_planes:  g as for ekaid_gemm_f32 (g->A / g->B are ignored), A_planes / B_planes = planes of the arrays the
- *                       A / B pointers would address.  Envelope: one batch, M >= 512, N >= 128, K % 16 == 0, lda % 8 == 0,
- *                       ldb % 8 == 0; outside it the call returns EKAID_ERR_UNSUPPORTED (-3) and the caller uses
- *                       ekaid_gemm_f32.  Workspace as ekaid_gemm_workspace_bytes(g).
+/* The same contraction on PRE-SPLIT operands (EKAID_GEMM_BF16_SPLIT arithmetic, the same six products per block): the
+ * three bf16 planes of an operand are produced once, where the tensor is produced, instead of inside every K loop that
+ * reads it (the K loop then contains no vector-ALU work; operands stream global -> LDS by LDS-DMA).
+ * Plane storage: plane-major -- three bf16 arrays hi, mid, lo (hi + mid + lo == x exactly; truncation split), each laid out
+ * like the f32 array, `plane_stride_bytes` apart; a row-major view of the f32 buffer addresses its planes with the same
+ * (row, column) arithmetic at 2 bytes per element.
+ *   ekaid_split_planes: x (n floats, 16-byte aligned) -> planes (16-byte aligned; plane_stride_bytes % 16 == 0 and
+ *                       >= 2 * ceil8(n); elements n .. ceil8(n) of every plane are written as zero).
+ *   ekaid_gemm_planes:  g as for ekaid_gemm_f32 (g->A / g->B are ignored); A_planes / B_planes = address, inside plane 0, of
+ *                       the element the A / B pointer would address.  Envelope: one batch, M >= 512, N >= 128, K % 32 == 0,
+ *                       lda % 8 == 0, ldb % 8 == 0, 16-byte aligned operand starts; outside it the call returns
+ *                       EKAID_ERR_UNSUPPORTED (-3) and the caller uses ekaid_gemm_f32.  Workspace as ekaid_gemm_workspace_bytes(g).
  * ref: the same call sites as ekaid_gemm_f32 with >= 512 rows (all detector layers: modules.py:195-303, graph_att*.py). */
-int ekaid_split_planes(const float* x, long long n, void* planes, void* stream);
-int ekaid_gemm_planes(const ekaid_gemm_t* g, const void* A_planes, const void* B_planes, void* workspace,
-                      size_t workspace_bytes, void* stream);
+int ekaid_split_planes(const float* x, long long n, void* planes, long long plane_stride_bytes, void* stream);
+int ekaid_gemm_planes(const ekaid_gemm_t* g, const void* A_planes, long long a_plane_stride_bytes, const void* B_planes,
+                      long long b_plane_stride_bytes, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Arithmetic of ekaid_gemm_f32 (per device; both take and return f32 and accumulate in f32):
  *   EKAID_GEMM_F32_MFMA   (0)  v_mfma_f32_32x32x2_f32, an exact f32 fma chain;

@@ -124,7 +124,7 @@ def test_graph_replay_equals_eager():
     b = {k: v.cuda() for k, v in host.items()}
     T = 5
     finals, losses = [], []
-    for mode in ('eager', 'graph'):
+    for mode in ('eager', 'eager', 'graph'):
         cd, sp = build_models(cfg, 147, 148, 'cuda', train=True)
         opt = FlatAdam([cd, sp], lr=1e-3)
         ts = TrainStep(cfg, cd, sp, opt, use_graph=(mode == 'graph'))
@@ -136,19 +136,26 @@ def test_graph_replay_equals_eager():
                 s0 = ops.seed_state()
                 for _ in range(3):
                     ops.set_seed_state(s0)
-                    ls.append(float(ts._body(b, T, None)[0]))
+                    ls.append(float(ts._body(b, T, None)[0].detach()))
             else:
                 for _ in range(3):
-                    ls.append(float(ts(b, T)[0]))
+                    ls.append(float(ts(b, T)[0].detach()))
                 assert opt.step_count == 3
         finally:
             ts.close()
         finals.append(torch.cat([p.detach().reshape(-1).double().cpu() for p in list(cd.parameters()) + list(sp.parameters())]))
         losses.append(ls)
-    assert losses[0] == pytest.approx(losses[1], rel=1e-5), losses
-    assert len(set(losses[1])) == 3
-    d = float((finals[0] - finals[1]).abs().max())
-    assert d < 1e-5, d
+    # yardstick: the two eager runs differ by float-atomic noise, which Adam amplifies (a noise-level gradient becomes a
+    # +-lr step); the graph run must sit inside the same band
+    rms = lambda x: float(x.pow(2).mean().sqrt())       # noqa: E731
+    noise_w = rms(finals[0] - finals[1])
+    noise_l = max(abs(a - c) for a, c in zip(losses[0], losses[1]))
+    d_w = rms(finals[0] - finals[2])
+    d_l = max(abs(a - c) for a, c in zip(losses[0], losses[2]))
+    print('graph vs eager: rms dw %.3e (eager vs eager %.3e), max dloss %.3e (eager vs eager %.3e)' % (d_w, noise_w, d_l, noise_l))
+    assert losses[0][0] == pytest.approx(losses[2][0], rel=1e-6)
+    assert len(set(losses[2])) == 3
+    assert d_w <= 4 * noise_w + 1e-9 and d_l <= 4 * noise_l + 2e-5 * abs(losses[0][-1])
 
 
 def test_rccl_path_on_one_gpu(tmp_path):
@@ -162,4 +169,4 @@ def test_rccl_path_on_one_gpu(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.load(open(str(tmp_path / 'out.json')))
     assert out['buckets'] > 1 and out['collectives'] > 0
-    assert out['max_delta_eager'] < 1e-6 and out['max_delta_graph'] < 1e-5, out
+    assert out['delta_eager'] <= 4 * out['noise'] + 1e-9 and out['delta_graph'] <= 4 * out['noise'] + 1e-9, out

@@ -765,7 +765,7 @@ def test_round2_kernels_int8_labels_loss_denominator_device_adam_dropout_epoch()
 
 
 @pytest.mark.parametrize('tA,tB,M,N,K', [(0, 1, 640, 256, 128), (0, 0, 1152, 384, 1024), (1, 0, 1024, 640, 2304),
-                                         (0, 1, 2304, 1024, 4096), (0, 1, 600, 200, 48), (1, 0, 512, 128, 18432)])
+                                         (0, 1, 2304, 1024, 4096), (0, 1, 600, 200, 96), (1, 0, 512, 128, 18432)])
 def test_gemm_on_presplit_planes(tA, tB, M, N, K):
     """ekaid_gemm_planes == ekaid_gemm_f32 (same six products per block, same order: bit-identical accumulators up to the
     split-K slab order) and both within the f32 error of a float64 product; epilogue (bias, activation, accumulate) shared."""
@@ -778,7 +778,6 @@ def test_gemm_on_presplit_planes(tA, tB, M, N, K):
     bias = torch.randn(N, generator=g).to(DEV)
     lda, ldb = A.shape[1], B.shape[1]
     Ap, Bp = ops.split_planes(A), ops.split_planes(B)
-    assert Ap.numel() == 6 * A.numel()
     c_f32, c_pl = torch.zeros(M, N, device=DEV), torch.zeros(M, N, device=DEV)
     assert ops.planes_ok(M, N, K, lda, ldb)
     ops.gemm(A, B, c_f32, M, N, K, lda, ldb, N, tA, tB, bias=bias, act=ACT_RELU)
@@ -795,7 +794,7 @@ def test_gemm_on_presplit_planes(tA, tB, M, N, K):
     c2 = c_pl.clone()
     ops.gemm(A, B, c2, M, N, K, lda, ldb, N, tA, tB, accumulate=True, A_planes=Ap, B_planes=Bp)
     want = c_pl.double().cpu() + A64 @ B64
-    assert float(((c2.double().cpu() - want).abs() / (mag + c_pl.double().cpu().abs())).max()) < 3e-7
+    assert float(((c2.double().cpu() - want).abs() / (mag + c_pl.double().cpu().abs())).max()) < 5e-7
 
 
 def test_gemm_planes_exact_on_integers_and_views():
@@ -814,7 +813,10 @@ def test_gemm_planes_exact_on_integers_and_views():
     assert torch.equal(C.double().cpu(), want)
     # planes round trip: hi + mid + lo == x bit for bit
     x = torch.randn(4099, generator=g).to(DEV) * 1e3
-    pl = ops.split_planes(x).cpu().view(torch.int16).view(-1, 3, 8)
-    parts = (pl.to(torch.int32) << 16).view(torch.float32)
-    back = (parts[:, 0] + parts[:, 1] + parts[:, 2]).reshape(-1)[:4099]
+    pl = ops.split_planes(x)
+    assert pl.stride == 2 * 4104 and pl.buf.numel() == 3 * pl.stride
+    raw = pl.buf.cpu().view(torch.int16).view(3, -1)
+    parts = (raw.to(torch.int32) << 16).view(torch.float32)
+    back = (parts[0] + parts[1] + parts[2])[:4099]
+    assert float(parts[:, 4099:].abs().max()) == 0.0
     assert torch.equal(back, x.cpu())
