@@ -79,7 +79,10 @@ def _rows2d(t):
 # --------------------------------------------------------------------------- #
 # pre-split operands ("planes", include/ekaid_hip.h: ekaid_split_planes / ekaid_gemm_planes)
 # --------------------------------------------------------------------------- #
-USE_PLANES = os.environ.get('EKAID_GEMM_PLANES', '1') not in ('0', 'off', 'false')
+# Opt-in (EKAID_GEMM_PLANES=1): on MI355X the pre-split kernel is bit-identical to the in-kernel split but not faster
+# end to end (profiles/r02_planes_gemm_microbench.txt: +18 % on the m-contiguous wgrad shapes, -20 % on the k-contiguous
+# forward shapes, and every activation / gradient costs one extra split pass), so the layers do not use it by default.
+USE_PLANES = os.environ.get('EKAID_GEMM_PLANES', '0') not in ('0', 'off', 'false', '')
 _weight_planes = {}          # data_ptr of a parameter -> (planes view, owner flat buffer, its version when refreshed)
 
 
@@ -135,7 +138,7 @@ def weight_planes(W):
 
 def planes_ok(M, N, K, lda, ldb, batch=(1, 1), a_off=0, b_off=0):
     """Shapes the pre-split kernel takes (mirrors the check in ekaid_gemm_planes)."""
-    return (USE_PLANES and batch == (1, 1) and M >= 512 and N >= 128 and K >= 32 and K % 32 == 0 and lda % 8 == 0 and
+    return (batch == (1, 1) and M >= 512 and N >= 128 and K >= 32 and K % 32 == 0 and lda % 8 == 0 and
             ldb % 8 == 0 and a_off % 8 == 0 and b_off % 8 == 0 and get_gemm_mode() == GEMM_BF16_SPLIT)
 
 
@@ -266,7 +269,7 @@ class LinearFn(Function):
                 xps.append(None)
             else:
                 xp = None
-                if planes_ok(M, N, K, ld, Ktot, b_off=off) and x.is_contiguous():
+                if USE_PLANES and planes_ok(M, N, K, ld, Ktot, b_off=off) and x.is_contiguous():
                     # cache on the caller's tensor object when the 2-D view is the same memory (one split serves every
                     # layer that reads this activation)
                     src = xs[i] if (isinstance(xs[i], torch.Tensor) and xs[i].data_ptr() == x.data_ptr() and xs[i].is_contiguous()
@@ -368,7 +371,7 @@ class LinearRowStackFn(Function):
                 xps.append(None)
             else:
                 xp = None
-                if planes_ok(M, N, K, ld, K) and x.is_contiguous():
+                if USE_PLANES and planes_ok(M, N, K, ld, K) and x.is_contiguous():
                     xp = planes_of(x)
                     Wp = weight_planes(W) if Wp is None else Wp
                 xps.append(xp)
