@@ -84,3 +84,67 @@ def test_bucketed_allreduce_matches_single_process(bucket_mb, overlap):
     # gather semantics
     assert gath0 == gath1 == [[0., 1., 2.], [3., 4., 5.], [10., 11., 12.], [13., 14., 15.]]
     assert ga0 == [[0., 2., 4.], [6., 8., 10.]] and ga1 == [[12., 14., 16.], [18., 20., 22.]]
+
+
+def _ragged_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ekaid_amd.dp import GradBuckets, loss_denominator
+    torch.manual_seed(5)
+    V, T = 7, 6
+    model = nn.Linear(4, V)
+    x = torch.randn(4, T, 4)
+    target = torch.randint(0, V, (4, T))
+    mask = torch.zeros(4, T)
+    for b, n in enumerate((6, 2, 3, 1)):         # ragged answers: rank 0 holds 8 target tokens, rank 1 holds 4
+        mask[b, :n] = 1
+    sl = slice(rank * 2, rank * 2 + 2)
+    gb = GradBuckets(list(model.parameters()), bucket_mb=1e-5)
+    gb.zero_grad()
+    logp = torch.log_softmax(model(x[sl]), -1)
+    num = -(logp.gather(2, target[sl].unsqueeze(2)).squeeze(2) * mask[sl]).sum()
+    denom = loss_denominator(mask[sl].sum())      # (global mask sum) / world, one tiny all-reduce
+    (num / denom).backward()
+    gb.finish()                                   # SUM over ranks; the optimizer applies 1/world
+    naive = -(logp.detach().gather(2, target[sl].unsqueeze(2)).squeeze(2) * mask[sl]).sum() / mask[sl].sum()
+    q.put((rank, (gb.gflat / world).tolist(), gb.live_names(model.named_parameters()), float(denom), float(num.detach() / denom),
+           float(naive)))
+    dist.destroy_process_group()
+
+
+def test_ragged_masks_reproduce_the_global_batch_loss():
+    """Ranks holding answers of different lengths: dividing each rank's numerator by (global mask sum / world) makes the
+    averaged gradient equal to the single-process gradient of the reference loss over the global batch
+    (utils/utils.py:213-214); plain per-rank mean losses would not."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 50
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    (_, g0, names, d0, l0, n0), (_, g1, _, d1, l1, n1) = res
+    assert g0 == g1 and d0 == d1 == 6.0           # (8 + 4) / 2
+    torch.manual_seed(5)
+    V, T = 7, 6
+    model = nn.Linear(4, V)
+    x = torch.randn(4, T, 4)
+    target = torch.randint(0, V, (4, T))
+    mask = torch.zeros(4, T)
+    for b, n in enumerate((6, 2, 3, 1)):
+        mask[b, :n] = 1
+    logp = torch.log_softmax(model(x), -1)
+    loss = -(logp.gather(2, target.unsqueeze(2)).squeeze(2) * mask).sum() / mask.sum()
+    loss.backward()
+    want = {n: p.grad for n, p in model.named_parameters()}
+    flat = torch.tensor(g0)
+    off = 0
+    for n in names:
+        k = want[n].numel()
+        assert torch.allclose(flat[off:off + k], want[n].reshape(-1), atol=1e-6), n
+        off += (k + 7) // 8 * 8
+    assert (l0 + l1) / 2 == pytest.approx(float(loss), rel=1e-6)
+    assert abs((n0 + n1) / 2 - float(loss)) > 1e-3, 'the naive average of per-rank means must differ (else the test is vacuous)'

@@ -1,7 +1,8 @@
 """Data-parallel step on the GPU box: two processes share cuda:0 and talk over gloo (the box has one GPU, so the
 RCCL transport itself is exercised only by the driver's multi-GPU runs; everything above the transport --
 live-set discovery, flat views, bucket hooks, fused Adam with grad_scale, the global-batch Q-C gather -- is the
-same code).  With global question-attention semantics, 2 ranks x B=2 must reproduce 1 process x B=4."""
+same code).  With global question-attention semantics and the global loss denominator, 2 ranks x B=2 holding answers
+of DIFFERENT lengths (different decode-step counts per rank) must reproduce 1 process x B=4."""
 import json
 import os
 import sys
@@ -24,20 +25,29 @@ def _run(rank, world, port, out_path):
     if world > 1:
         dist.init_process_group('gloo', rank=rank, world_size=world)
     from common import SMALL, small_models
-    from ekaid_amd.dp import FlatAdam, enable_global_question_attention
+    from ekaid_amd.dp import FlatAdam, enable_global_question_attention, loss_denominator
+    from ekaid_amd.engine import forward_loss
+    from ekaid_amd.models.dynamic_speaker_change_pos import DynamicSpeaker
     from ekaid_amd.synthetic import make_batch, slice_batch
-    from test_hip_model import hip_step
     cfg, cd, sp = small_models('all', device='cuda')
     if world > 1:
         enable_global_question_attention(cd)
     full = make_batch(**dict(SMALL, B=4))
+    # ragged answers: samples 0/1 (rank 0) keep 3 and 1 answer tokens, samples 2/3 (rank 1) keep 2 and 1
+    for b, n in enumerate((4, 2, 3, 2)):
+        full['labels'][b, n:] = 0
+        full['masks'][b] = 0
+        full['masks'][b, :n + 1] = 1
     per = 4 // world
     batch = slice_batch(full, rank * per, (rank + 1) * per)
+    dev_batch = {k: v.cuda() for k, v in batch.items()}
+    T = DynamicSpeaker.count_steps(batch['labels'], cfg.model.speaker.seq_length)       # differs between the ranks
+    denom = loss_denominator(batch['masks'][:, 1:].sum().cuda()) if world > 1 else None
     opt = FlatAdam([cd, sp], lr=1e-3, bucket_mb=0.5)
     losses = []
     for _ in range(3):
         opt.zero_grad()
-        loss = hip_step(cfg, cd, sp, batch, 'mode2', 'all')[0]
+        loss = forward_loss(cfg, cd, sp, dev_batch, T, 'all', 'mode2', denom)[0]
         loss.backward()
         opt.step()
         losses.append(float(loss.detach()))
