@@ -53,6 +53,13 @@ class GradBuckets:
         if b is None:
             raise RuntimeError('a parameter outside the live set discovered on the first backward received a '
                                'gradient; rebuild GradBuckets (call reset())')
+        o = self._offset_of[id(p)]
+        if p.grad.data_ptr() != self._gbase + 4 * o:
+            # the gradient was produced outside its flat slot (a node that does not know about slots, a gradient shared
+            # by two parameters, a cloned gradient): move it in before the bucket can be reduced
+            view = self.gflat[o:o + p.numel()].view(p.shape)
+            view.copy_(p.grad)
+            p.grad = view
         self._pending[b] -= 1
         if self.overlap and self.comm_active():
             # strictly in bucket order (bucket b only once 0..b-1 are out): every rank issues the same sequence of
@@ -75,6 +82,8 @@ class GradBuckets:
         self.pflat = torch.zeros(total, device=dev, dtype=dt)
         self.gflat = torch.zeros(total, device=dev, dtype=dt)
         self.live, self.offsets = live, offs
+        self._offset_of = {id(p): o for p, o in zip(live, offs)}
+        self._gbase = self.gflat.data_ptr()
         with torch.no_grad():
             for p, o in zip(live, offs):
                 n = p.numel()
@@ -99,6 +108,10 @@ class GradBuckets:
         self._reset_pending()
         self._check_layout_agreement()
         self.refresh_planes()
+        if self.gflat.is_cuda:
+            from . import ops
+            for p, o in zip(self.live, self.offsets):         # backward kernels write straight into the flat buffer (ops.grad_out)
+                ops.register_grad_slot(p, self.gflat, o)
 
     def refresh_planes(self):
         """bf16 planes of the whole flat parameter buffer (ekaid_split_planes) for the pre-split GEMM kernel: one pass
@@ -145,8 +158,16 @@ class GradBuckets:
     def zero_grad(self):
         if self.built:
             self.gflat.zero_()
-            for p, o in zip(self.live, self.offsets):     # autograd then accumulates in place into the views
-                p.grad = self.gflat[o:o + p.numel()].view(p.shape)
+            if self.gflat.is_cuda:
+                # gradients are WRITTEN into their flat slots by the backward kernels and adopted by autograd as p.grad
+                # (ops.grad_out); a parameter that receives none this step keeps the zeros of its slot
+                from . import ops
+                ops.clear_grad_claims()
+                for p in self.live:
+                    p.grad = None
+            else:
+                for p, o in zip(self.live, self.offsets):     # autograd accumulates in place into the views
+                    p.grad = self.gflat[o:o + p.numel()].view(p.shape)
             self._reset_pending()
         else:
             for p in self.params:

@@ -77,6 +77,49 @@ def _rows2d(t):
 # raw GEMM
 # --------------------------------------------------------------------------- #
 # --------------------------------------------------------------------------- #
+# gradient slots: backward kernels write weight gradients straight into the optimizer's flat gradient buffer
+# --------------------------------------------------------------------------- #
+# With ``p.grad`` pre-pointed at a zeroed flat view, autograd ADDS every incoming weight gradient into it: one ATen add per
+# parameter and step (~100 launches).  Instead ``FlatAdam.zero_grad`` leaves ``p.grad = None`` and the backward nodes ask
+# ``grad_out(W)`` for their output buffer: a fresh alias of the parameter's slice of the flat buffer, which autograd's
+# AccumulateGrad then adopts as ``p.grad`` without copying (it steals a gradient nobody else references).  A second
+# contribution to the same parameter in the same step (the weight-norm direction term) is accumulated by its kernel into
+# the claimed slot and reported to autograd as "no gradient".  Anything that still arrives outside its slot is copied into
+# it by the optimizer's post-accumulate hook (ekaid_amd/dp.py), so the flat layout is always complete.
+_grad_slots = {}             # parameter data_ptr -> (parameter, flat gradient buffer, offset, numel, shape)
+_grad_claimed = set()
+
+
+def register_grad_slot(param, gflat, offset):
+    _grad_slots[param.data_ptr()] = (param, gflat, offset, param.numel(), tuple(param.shape))
+
+
+def clear_grad_claims():
+    _grad_claimed.clear()
+
+
+def grad_out(W, zero=False):
+    """Output buffer for the gradient of weight ``W`` (same shape): its flat-buffer slot when available (already zero: the
+    optimizer clears the flat buffer every step), else a fresh tensor."""
+    key = W.data_ptr()
+    ent = _grad_slots.get(key)
+    if ent is not None and ent[0].grad is None and key not in _grad_claimed and tuple(W.shape) == ent[4]:
+        _grad_claimed.add(key)
+        return ent[1][ent[2]:ent[2] + ent[3]].view(ent[4])
+    return torch.zeros_like(W) if zero else torch.empty_like(W)
+
+
+def grad_claimed_slot(W):
+    """The slot of ``W`` if an earlier backward node of this step already wrote its gradient there (then a further
+    contribution is accumulated in place and returned to autograd as None), else None."""
+    key = W.data_ptr()
+    ent = _grad_slots.get(key)
+    if ent is not None and key in _grad_claimed and tuple(W.shape) == ent[4]:
+        return ent[1][ent[2]:ent[2] + ent[3]].view(ent[4])
+    return None
+
+
+# --------------------------------------------------------------------------- #
 # pre-split operands ("planes", include/ekaid_hip.h: ekaid_split_planes / ekaid_gemm_planes)
 # --------------------------------------------------------------------------- #
 # Opt-in (EKAID_GEMM_PLANES=1): on MI355X the pre-split kernel is bit-identical to the in-kernel split but not faster
@@ -283,6 +326,7 @@ class LinearFn(Function):
         ctx.xps = xps
         ctx.act = act
         ctx.has_b = b is not None
+        ctx.bias_ref = b.detach() if b is not None else None       # (an alias: its data_ptr finds the gradient slot)
         ctx.has_scale = scale is not None
         ctx.lead = [x.shape[:-1] for x in xs]
         ctx.save_for_backward(W, scale, y if act != ACT_NONE else None, *xs2)
@@ -304,7 +348,7 @@ class LinearFn(Function):
         need = ctx.needs_input_grad
         db = None
         if ctx.has_b and need[1]:
-            db = torch.empty(N, device=W.device, dtype=torch.float32)
+            db = grad_out(ctx.bias_ref) if ctx.bias_ref is not None else torch.empty(N, device=W.device, dtype=torch.float32)
             check(L.ekaid_colsum(ptr(dz), M, N, N, ptr(db), stream()), 'colsum')
         # the gradient dz feeds up to two products per input (dgrad as the k-contiguous A, wgrad as the m-contiguous A):
         # split it once
@@ -328,7 +372,7 @@ class LinearFn(Function):
             off += K
         dW = dscale = None
         if need[0] or (ctx.has_scale and need[2]):
-            dW = torch.empty(N, Ktot, device=W.device, dtype=torch.float32)
+            dW = grad_out(W)
             off = 0
             for x, ld, xp in zip(xs2, ctx.lds, ctx.xps):
                 K = x.shape[1]
@@ -379,6 +423,7 @@ class LinearRowStackFn(Function):
             r0 += M
         ctx.xps = xps
         ctx.save_for_backward(W, *xs2)
+        ctx.bias_ref = b.detach() if b is not None else None
         ctx.lds, ctx.Ms, ctx.has_b = lds, Ms, b is not None
         ctx.lead = [x.shape[:-1] for x in xs]
         return y
@@ -392,11 +437,11 @@ class LinearRowStackFn(Function):
         need = ctx.needs_input_grad
         db = None
         if ctx.has_b and need[1]:
-            db = torch.empty(N, device=W.device, dtype=torch.float32)
+            db = grad_out(ctx.bias_ref)
             check(hip.lib().ekaid_colsum(ptr(dy), Mtot, N, N, ptr(db), stream()), 'colsum')
         dW = None
         if need[0]:
-            dW = torch.empty(N, K, device=W.device, dtype=torch.float32)
+            dW = grad_out(W)
             r0 = 0
             dyp = split_planes(dy) if any(xp is not None for xp in ctx.xps) else None
             for i, (x, ld, M) in enumerate(zip(xs2, ctx.lds, ctx.Ms)):
@@ -437,11 +482,12 @@ class WNScaleFn(Function):
     @staticmethod
     def backward(ctx, dscale):
         v, g, norm = ctx.saved_tensors
-        dv = torch.empty_like(v)
-        dg = torch.empty((), device=v.device, dtype=torch.float32)
-        check(hip.lib().ekaid_wn_scale_bwd(ptr(v), ptr(g), ptr(norm), ptr(_c(dscale)), v.numel(), ptr(dv), 0,
+        dg = grad_out(g)
+        slot = grad_claimed_slot(v)          # the layer's wgrad (LinearFn.backward, run just before) already sits there
+        dv = slot if slot is not None else torch.empty_like(v)
+        check(hip.lib().ekaid_wn_scale_bwd(ptr(v), ptr(g), ptr(norm), ptr(_c(dscale)), v.numel(), ptr(dv), int(slot is not None),
                                            ptr(dg), stream()), 'wn_scale_bwd')
-        return dv, dg.view(g.shape)
+        return (None if slot is not None else dv), dg.view(g.shape)
 
 
 def wn_linear(xs, v, g, b=None, act=ACT_NONE, drops=None):
@@ -745,7 +791,7 @@ class EmbeddingFn(Function):
         off = 0
         for i, t in enumerate(tables):
             if ctx.needs_input_grad[3 + i]:
-                dt = torch.zeros_like(t)
+                dt = grad_out(t, zero=True)
                 check(hip.lib().ekaid_embedding_bwd(ptr(tok), tok.numel(), ptr(t), ptr(d), t.shape[1], ctx.width, off,
                                                     int(ctx.relu), ctx.pad, ptr(dt), stream()), 'embedding_bwd')
                 grads.append(dt)
@@ -862,13 +908,13 @@ class GRUSeqFn(Function):
             if t > 0:       # dh_{t-1} = z*d (written by the kernel) + dgh_t . W_hh
                 gemm(dgh, w_hh, dh, B, H, 3 * H, 3 * H, H, H, 0, 0, accumulate=True, a_off=t * B * 3 * H)
         # weight gradients batched over time: K = T*B rows (previous states are the contiguous slice hall[0:T])
-        dw_hh = torch.empty_like(w_hh)
+        dw_hh = grad_out(w_hh)
         gemm(dgh, hall, dw_hh, 3 * H, H, T * B, 3 * H, H, H, 1, 0)
         db_hh = torch.empty(3 * H, device=dev, dtype=torch.float32)
         check(L.ekaid_colsum(ptr(dgh), T * B, 3 * H, 3 * H, ptr(db_hh), stream()), 'colsum')
         db_ih = torch.empty(3 * H, device=dev, dtype=torch.float32)
         check(L.ekaid_colsum(ptr(dgi), B * T, 3 * H, 3 * H, ptr(db_ih), stream()), 'colsum')
-        dw_ih = torch.empty_like(w_ih)
+        dw_ih = grad_out(w_ih)
         gemm(dgi, x, dw_ih, 3 * H, E, B * T, 3 * H, E, E, 1, 0)
         dx = None
         if ctx.needs_input_grad[0]:

@@ -189,7 +189,7 @@ class SpeakerSeqFn(Function):
         # ---- head (time-batched)
         dlogits = torch.empty(T, B, V, **f32)
         check(L.ekaid_softmax_bwd(ptr(logp), ptr(dlogp), ptr(dlogits), TB, V, 1, stream()), 'softmax_bwd')
-        d_w_lo = torch.empty_like(w_lo)
+        d_w_lo = ops.grad_out(w_lo)
         _tn(dlogits, V, HO, R, d_w_lo, 0, R, V, R, TB)
         d_b_lo = torch.empty(V, **f32)
         _colsum(dlogits, TB, V, d_b_lo)
@@ -259,14 +259,14 @@ class SpeakerSeqFn(Function):
             dh_a, dh_a_prev = dh_a_prev, dh_a
 
         # ---- time-batched weight gradients (K = T*B) and input gradients; DCAT column blocks with ld = NW
-        d_wih_a = torch.empty_like(wih_a)
+        d_wih_a = ops.grad_out(wih_a)
         _tn(DCAT, NW, ED, E, d_wih_a, 0, E + R, 4 * R, E, TB)
         _tn(DCAT, NW, HL, R, d_wih_a, E, E + R, 4 * R, R, TB)
-        d_whh_a = torch.empty_like(whh_a)
+        d_whh_a = ops.grad_out(whh_a)
         _tn(DCAT, NW, HA, R, d_whh_a, 0, R, 4 * R, R, TB)
         d_b_a = torch.empty(4 * R, **f32)
         check(L.ekaid_colsum(ptr(DCAT), TB, 4 * R, NW, ptr(d_b_a), stream()), 'colsum')
-        d_w_fc = torch.empty_like(w_fc)
+        d_w_fc = ops.grad_out(w_fc)
         _tn(DZFC, 3, HA, R, d_w_fc, 0, R, 3, R, TB, xoff=B * R)
         d_b_fc = torch.empty(3, **f32)
         _colsum(DZFC, TB, 3, d_b_fc)
@@ -274,24 +274,24 @@ class SpeakerSeqFn(Function):
         _tn(DCAT, NW, HL, R, d_w_p1, 0, R, R, R, TB, doff=oP1)
         d_b_p1 = torch.empty(R, **f32)
         check(L.ekaid_colsum(DCAT.data_ptr() + 4 * oP1, TB, R, NW, ptr(d_b_p1), stream()), 'colsum')
-        d_w_wp = torch.empty_like(w_wp)
+        d_w_wp = ops.grad_out(w_wp)
         _tn(DWP, NP, VP, R, d_w_wp, 0, R, NP, R, TB)
         d_b_wp = torch.empty(NP, **f32)
         _colsum(DWP, TB, NP, d_b_wp)
-        d_w_p2 = torch.empty_like(w_p2)
+        d_w_p2 = ops.grad_out(w_p2)
         _tn(DPA, R + A, PW, NP, d_w_p2, 0, NP, R, NP, TB)
         d_b_p2 = torch.empty(R, **f32)
         check(L.ekaid_colsum(ptr(DPA), TB, R, R + A, ptr(d_b_p2), stream()), 'colsum')
-        d_w_g1 = torch.empty_like(w_g1)
+        d_w_g1 = ops.grad_out(w_g1)
         _tn(DCAT, NW, HL, R, d_w_g1, 0, G1, G1, R, TB, doff=oG1)
         _tn(DCAT, NW, PA, R + A, d_w_g1, R, G1, G1, R + A, TB, doff=oG1)
         d_b_g1 = torch.empty(G1, **f32)
         check(L.ekaid_colsum(DCAT.data_ptr() + 4 * oG1, TB, G1, NW, ptr(d_b_g1), stream()), 'colsum')
-        d_w_g2 = torch.empty_like(w_g2)
+        d_w_g2 = ops.grad_out(w_g2)
         _tn(DZ2, A, HLW, NW, d_w_g2, 0, G1, A, G1, TB, xoff=oG1)                                  # input = dropout(relu(gate1x)) block
         d_b_g2 = torch.empty(A, **f32)
         _colsum(DZ2, TB, A, d_b_g2)
-        d_wih_l = torch.empty_like(wih_l)
+        d_wih_l = ops.grad_out(wih_l)
         _tn(DCAT, NW, Xd, We, d_wih_l, 0, We + A, 4 * R, We, TB, doff=oGL)
         _tn(DCAT, NW, GA, A, d_wih_l, We, We + A, 4 * R, A, TB, doff=oGL)
         d_whh_l = torch.empty(4 * R, R, **f32)
@@ -307,7 +307,7 @@ class SpeakerSeqFn(Function):
         check(L.ekaid_colsum(ptr(dED), T, B * E, B * E, ptr(d_epre), stream()), 'colsum')
         d_ez = torch.empty(B, E, **f32)
         check(L.ekaid_act_bwd(ptr(d_epre), ptr(embed_pre), ptr(d_ez), B * E, ACT_RELU, stream()), 'act_bwd')
-        d_w_e = torch.empty_like(w_e)
+        d_w_e = ops.grad_out(w_e)
         _tn(d_ez, E, bef, A, d_w_e, 0, 3 * A, E, A, B)
         _tn(d_ez, E, diff, A, d_w_e, A, 3 * A, E, A, B)
         _tn(d_ez, E, aft, A, d_w_e, 2 * A, 3 * A, E, A, B)
@@ -320,7 +320,7 @@ class SpeakerSeqFn(Function):
         dX = torch.empty(T, B, We, **f32)
         _nn(DCAT, oGL, NW, wih_l, 0, We + A, dX, 0, We, TB, We, 4 * R)
         _drop(dX, dX, TB * We, p, seeds['xt'])
-        d_emb = torch.zeros_like(emb)
+        d_emb = ops.grad_out(emb, zero=True)
         check(L.ekaid_embedding_bwd(tok_tb.data_ptr(), TB, ptr(emb), ptr(dX), We, We, 0, 1, -1, ptr(d_emb), stream()),
               'embedding_bwd')
         grads = (d_emb, d_w_e, d_b_e, d_wih_a, d_whh_a, d_b_a, d_b_a, d_w_fc, d_b_fc, d_w_p1, d_b_p1, d_w_wp, d_b_wp,
