@@ -53,9 +53,11 @@ struct Epi {
     unsigned long long drop_seed;
     const unsigned long long* drop_epoch;   // device word folded into drop_seed (ekaid_set_dropout_epoch_ptr) or NULL
     int n_cols;
+    int m_base;                 // row offset of this launch inside the logical output (hybrid tiling: second part)
 };
 
 __device__ __forceinline__ float epilogue(float acc, float cold, int m, int n, const Epi& e, float alpha) {
+    m += e.m_base;
     float v = acc * alpha;
     if (e.beta) v += cold;
     if (e.bias) v += e.bias[n];
@@ -1006,7 +1008,7 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     a.sC1 = d->strideC1; a.sC2 = d->strideC2; a.nb2 = d->batch2;
     a.e.alpha = d->alpha; a.e.alpha_dev = d->alpha_dev; a.e.beta = d->accumulate; a.e.bias = d->bias;
     a.e.R = d->R; a.e.ldr = d->ldr; a.e.rdiv = d->rdiv < 1 ? 1 : d->rdiv; a.e.rowmask = d->rowmask; a.e.act = d->act;
-    a.e.drop_p = d->drop_p; a.e.drop_inv = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f; a.e.drop_seed = d->drop_seed; a.e.drop_epoch = dropout_epoch_ptr(); a.e.n_cols = d->N;
+    a.e.drop_p = d->drop_p; a.e.drop_inv = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f; a.e.drop_seed = d->drop_seed; a.e.drop_epoch = dropout_epoch_ptr(); a.e.n_cols = d->N; a.e.m_base = 0;
     int TMN;
     plan(d, TMN, a.splitk, a.tiles_m, a.tiles_n);
     if (d->K == 0) a.splitk = 1;
@@ -1026,6 +1028,30 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     const int batch = d->batch1 * d->batch2;
     const bool akc = !d->transA, bkc = d->transB != 0;
     int rc;
+    // Hybrid tiling against the tail (experiment, off unless EKAID_GEMM_HYBRID=1): the 128x128 kernel runs 3 workgroups per CU
+    // = 768 at a time and the 18432x1024 outputs of the detector are 1152 tiles = 1.5 waves; here the rows of the whole
+    // waves keep 128x128 tiles and the remaining tile-rows are launched as 128x64 tiles.  Measured SLOWER (224 -> 232-245 us
+    // on 18432x1024x1024: two launches each pay their own ramp, and the 128x64 kernel moves more bytes per MFMA).
+    static const char* hyb_env = getenv("EKAID_GEMM_HYBRID");
+    const bool hyb_on = hyb_env && hyb_env[0] == '1';
+    if (hyb_on && gemm_mode() == 1 && TMN == 2 && a.splitk == 1 && batch == 1 && !d->transA && (d->N % 64) == 0) {
+        const int slots = 768;
+        const int T = a.tiles_m * a.tiles_n;
+        const int full_rows = ((T / slots) * slots) / a.tiles_n;            // tile-rows covered by whole waves
+        const int rem_tiles = (a.tiles_m - full_rows) * a.tiles_n;
+        if (full_rows > 0 && rem_tiles > 0 && rem_tiles * 10 <= slots * 6) {
+            GemmArgs a1 = a, a2 = a;
+            const int rows1 = full_rows * 128;
+            a1.M = rows1; a1.tiles_m = full_rows;
+            a2.M = d->M - rows1; a2.A = a.A + (long long)rows1 * a.lda; a2.C = a.C + (long long)rows1 * a.ldc;
+            a2.e.m_base = rows1; a2.tiles_m = cdiv(a2.M, 128); a2.tiles_n = cdiv(d->N, 64);
+            int rc2;
+            if (bkc) { rc2 = launch_split<true, true, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG>(a1, 1, st); if (!rc2) rc2 = launch_split<true, true, 2, 1, 32, 1, false>(a2, 1, st); }
+            else { rc2 = launch_split<true, false, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG>(a1, 1, st); if (!rc2) rc2 = launch_split<true, false, 2, 1, 32, 1, false>(a2, 1, st); }
+            if (rc2) return rc2;
+            return check_launch("gemm_split_kernel (hybrid tiling)");
+        }
+    }
     if (gemm_mode() == 1 && TMN >= 1 && TMN <= 4) {
 #define EKAID_LAUNCH_SPLIT(AK, BKC) (TMN == 2 ? launch_split<AK, BKC, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG>(a, batch, st) \
                                      : TMN == 1 ? launch_split<AK, BKC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL, false>(a, batch, st) \
@@ -1087,7 +1113,7 @@ namespace ekaid {
 // barrier that opens stage s (everybody has then finished reading the slot it overwrites).
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
-template <bool A_KC, bool B_KC, int KS, int NBUF, int OCC>
+template <bool A_KC, bool B_KC, int KS, int NBUF, int OCC, bool REGSTAGE = false>
 __global__ __launch_bounds__(256, OCC) void gemm_planes_kernel(GemmArgs g, unsigned long long strideA, unsigned long long strideB) {
     constexpr int TM = 2, TN = 2, BM = 128, BN = 128;
     constexpr int NCH = KS / 16;                      // 16-k MFMA chunks per stage
@@ -1221,7 +1247,53 @@ __global__ __launch_bounds__(256, OCC) void gemm_planes_kernel(GemmArgs g, unsig
         }
     };
     const int nst = (kend - kbeg) / KS;
-    if (nst > 0) {
+    if constexpr (REGSTAGE) {
+        // Register-staged alternative (same LDS images, same source offsets): 16-byte buffer loads into VGPRs two stages
+        // ahead, ds_write_b128 of stage s+1 into the other slot while stage s is multiplied -- no LDS-DMA, no vector ALU.
+        static_assert(NBUF == 2 && NI == 1, "register staging: 2 slots, 16-deep stages");
+        const __amdgpu_buffer_rsrc_t bA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)rsrcA[2], 0x00020000);
+        const __amdgpu_buffer_rsrc_t bB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, (int)rsrcB[2], 0x00020000);
+        u32x4 ra[2][3], rb[2][3];
+        auto gload = [&](auto set_tag) {
+            constexpr int S = decltype(set_tag)::value;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                ra[S][p] = __builtin_amdgcn_raw_buffer_load_b128(bA, voA[0], soA + (unsigned)p * psA, 0);
+                rb[S][p] = __builtin_amdgcn_raw_buffer_load_b128(bB, voB[0], soB + (unsigned)p * psB, 0);
+            }
+            soA += kstepA;
+            soB += kstepB;
+        };
+        auto lstore = [&](auto set_tag, char* slot) {
+            constexpr int S = decltype(set_tag)::value;
+            char* const d = slot + 1024 * wave + 16 * lane;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                *reinterpret_cast<u32x4*>(d + p * PLANE) = ra[S][p];
+                *reinterpret_cast<u32x4*>(d + (3 + p) * PLANE) = rb[S][p];
+            }
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        if (nst > 0) {          // loads beyond the last stage read past the K range (clamped by the descriptor or unused)
+            gload(S0{});
+            gload(S1{});
+            lstore(S0{}, ldsb);
+            gload(S0{});
+            __syncthreads();
+            for (int s0 = 0; s0 < nst; s0 += 2) {
+                compute(ldsb);                                   // stage s0 from slot 0
+                if (s0 + 1 < nst) lstore(S1{}, ldsb + STAGE);    // stage s0+1 -> slot 1
+                gload(S1{});
+                __syncthreads();
+                if (s0 + 1 >= nst) break;
+                compute(ldsb + STAGE);                           // stage s0+1 from slot 1
+                if (s0 + 2 < nst) lstore(S0{}, ldsb);            // stage s0+2 -> slot 0
+                gload(S0{});
+                __syncthreads();
+            }
+        }
+    } else if (nst > 0) {
 #pragma unroll
         for (int s = 0; s < NBUF - 1; ++s)
             if (s < nst) issue((unsigned)(s * STAGE));
@@ -1264,15 +1336,15 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     }
 }
 
-static int planes_variant() {          // tuning aid: EKAID_PLANES_VARIANT = 0 (KS 16, 2 slots, 3 wg/CU) | 1 (16, 3, 2) | 2 (32, 3, 1) | 3 (32, 2, 1)
+static int planes_variant() {          // tuning aid: EKAID_PLANES_VARIANT = 0 (KS 16, 2 slots, 3 wg/CU) | 1 (16, 3, 2) | 2 (32, 3, 1) | 3 (32, 2, 1) | 4 (0 with register staging)
     static const char* v = getenv("EKAID_PLANES_VARIANT");
     return v ? atoi(v) : 2;
 }
 
-template <bool A_KC, bool B_KC, int KS, int NBUF, int OCC>
+template <bool A_KC, bool B_KC, int KS, int NBUF, int OCC, bool REGSTAGE = false>
 static int launch_planes(const GemmArgs& a, unsigned long long sa, unsigned long long sb, dim3 grid, hipStream_t st) {
     constexpr size_t lds = (size_t)NBUF * 6 * 128 * KS * 2;
-    auto kern = gemm_planes_kernel<A_KC, B_KC, KS, NBUF, OCC>;
+    auto kern = gemm_planes_kernel<A_KC, B_KC, KS, NBUF, OCC, REGSTAGE>;
     if (lds > 64 * 1024) {
         constexpr int slot = 32 + (A_KC ? 1 : 0) + (B_KC ? 2 : 0) + 4 * (KS == 32 ? 1 : 0) + 8 * (NBUF - 2);
         if (func_attr_once(slot)) {
@@ -1331,7 +1403,7 @@ extern "C" int ekaid_gemm_planes(const ekaid_gemm_t* d, const void* A_planes, lo
     a.e.alpha = d->alpha; a.e.alpha_dev = d->alpha_dev; a.e.beta = d->accumulate; a.e.bias = d->bias;
     a.e.R = d->R; a.e.ldr = d->ldr; a.e.rdiv = d->rdiv < 1 ? 1 : d->rdiv; a.e.rowmask = d->rowmask; a.e.act = d->act;
     a.e.drop_p = d->drop_p; a.e.drop_inv = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f; a.e.drop_seed = d->drop_seed;
-    a.e.drop_epoch = dropout_epoch_ptr(); a.e.n_cols = d->N;
+    a.e.drop_epoch = dropout_epoch_ptr(); a.e.n_cols = d->N; a.e.m_base = 0;
     a.splitk = splitk; a.tiles_m = tm; a.tiles_n = tn; a.ws = nullptr;
     a.k_per_split = cdiv(cdiv(d->K, BK_BIG), a.splitk) * BK_BIG;
     if (a.splitk > 1) {
@@ -1350,6 +1422,7 @@ extern "C" int ekaid_gemm_planes(const ekaid_gemm_t* d, const void* A_planes, lo
 #define EKAID_PL(AK, BK) (planes_variant() == 0 ? launch_planes<AK, BK, 16, 2, 3>(a, sa, sb, grid, st) \
                           : planes_variant() == 1 ? launch_planes<AK, BK, 16, 3, 2>(a, sa, sb, grid, st) \
                           : planes_variant() == 3 ? launch_planes<AK, BK, 32, 2, 1>(a, sa, sb, grid, st) \
+                          : planes_variant() == 4 ? launch_planes<AK, BK, 16, 2, 2, true>(a, sa, sb, grid, st) \
                           : launch_planes<AK, BK, 32, 3, 1>(a, sa, sb, grid, st))
     if (akc && bkc) rc = EKAID_PL(true, true);
     else if (akc && !bkc) rc = EKAID_PL(true, false);
