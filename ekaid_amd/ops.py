@@ -1113,6 +1113,20 @@ class GatAttentionFn(Function):
         L = hip.lib()
         dev = q.device
         doutT = _c(doutT)
+        if dP_ext is None and GAT_FUSED_BWD:
+            # everything between d outT and (dq, dk, dS) in one kernel per slice (csrc/gat.hip: gat_fused_bwd_kernel)
+            dq = torch.empty(R, N, A, device=dev, dtype=torch.float32)
+            dk = torch.empty(R, M, A, device=dev, dtype=torch.float32)
+            dS = torch.empty(R, N, A, device=dev, dtype=torch.float32)
+            dlbias = torch.zeros(R, N, N, device=dev, dtype=torch.float32) if M < N else \
+                torch.empty(R, N, N, device=dev, dtype=torch.float32)
+            dgeo = torch.empty_like(geo) if ctx.has_geo else None
+            rc = L.ekaid_gat_fused_bwd(ptr(doutT), ptr(S), ptr(P), ptr(q), ptr(k), ptr(cond), ptr(geo), R, N, M, A, H, direction,
+                                       ptr(dq), ptr(dk), ptr(dS), ptr(dlbias), ptr(dgeo), stream())
+            if rc != hip.ERR_UNSUPPORTED:
+                check(rc, 'gat_fused_bwd')
+                return dq, dk, dS, None, dlbias, dgeo, None, None, None
+        doutT = _c(doutT)
         # dP = doutT . S[:M]^T   (R, N*H, M)
         dP = torch.empty(R, N, H, M, device=dev, dtype=torch.float32)
         gemm(doutT, S, dP, N * H, M, A, A, A, M, 0, 1, batch=(R, 1), strides=(N * H * A, 0, N * A, 0, N * H * M, 0))
@@ -1135,6 +1149,9 @@ class GatAttentionFn(Function):
         gemm(daff, q, dk, M, dh, N, H * M, A, A, 1, 0, alpha=sc, batch=(R, H),
              strides=(N * H * M, M, N * A, dh, M * A, dh))
         return dq, dk, dS, None, dlbias, dgeo, None, None, None
+
+
+GAT_FUSED_BWD = os.environ.get('EKAID_GAT_FUSED_BWD', '1') not in ('0', 'off', 'false')     # A/B aid: '0' = composed backward
 
 
 def gat_attention(q, k, S, cond, lbias, geo, H, direction, impl='fused'):

@@ -160,6 +160,12 @@ int ekaid_expand_rows_bwd(const float* dout, const float* mask, long long rows, 
 int ekaid_gat_fused_fwd(const float* q, const float* k, const float* S, const float* cond, const float* lbias,
                         const float* geo, int R, int N, int M, int A, int H, int dir, float* P, float* outT,
                         void* stream);
+/* Fused backward of the same core: from d outT [R][N][H*A] (and the saved P) to dq [R][N][A], dk [R][M][A], dS [R][N][A]
+ * (rows >= M zero), dlbias [R][N][N] (original orientation; may be NULL) and dgeo [R][N][M][H] (NULL without geometry), one
+ * workgroup per slice, nothing but those tensors touches HBM.  Returns EKAID_ERR_UNSUPPORTED outside N <= 64, (A/H) % 32 == 0. */
+int ekaid_gat_fused_bwd(const float* doutT, const float* S, const float* P, const float* q, const float* k, const float* cond,
+                        const float* geo, int R, int N, int M, int A, int H, int dir, float* dq, float* dk, float* dS,
+                        float* dlbias, float* dgeo, void* stream);
 int ekaid_masked_softmax_fwd(const float* aff, const float* cond, const float* lbias, const float* geo, int R,
                              int N, int M, int H, int dir, float* P, void* stream);
 int ekaid_masked_softmax_bwd(const float* P, const float* dP, const float* cond, const float* geo, int R, int N,

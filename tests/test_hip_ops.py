@@ -531,7 +531,8 @@ def _gat_reference(q, k, S, cond, lbias, geo, H, direction):
     return out, P
 
 
-@pytest.mark.parametrize('N,M,A,H', [(8, 8, 64, 4), (36, 36, 128, 4), (52, 52, 64, 4), (9, 7, 32, 2), (36, 36, 1024, 4)])
+@pytest.mark.parametrize('N,M,A,H', [(8, 8, 64, 4), (36, 36, 128, 4), (52, 52, 64, 4), (9, 7, 32, 2), (36, 36, 1024, 4),
+                                     (52, 52, 1024, 4), (36, 30, 256, 4), (64, 64, 128, 4), (13, 13, 64, 2), (40, 33, 192, 3)])
 @pytest.mark.parametrize('direction', [0, 1])
 @pytest.mark.parametrize('with_geo', [False, True])
 def test_gat_attention_fused_and_composed(N, M, A, H, direction, with_geo):
