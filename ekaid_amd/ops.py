@@ -1098,6 +1098,7 @@ class GatAttentionFn(Function):
                                              stream()), 'masked_softmax_fwd')
             gemm(P, S, outT, N * H, A, M, M, A, A, 0, 0, batch=(R, 1), strides=(N * H * M, 0, N * A, 0, N * H * A, 0))
         ctx.cfg = (H, direction)
+        ctx.set_materialize_grads(False)         # an unused output (the returned softmax) arrives as None, not as zeros
         ctx.save_for_backward(q, k, S, cond, geo, P)
         ctx.has_geo = geo is not None
         return outT, P
@@ -1112,6 +1113,8 @@ class GatAttentionFn(Function):
         sc = 1.0 / math.sqrt(float(dh))
         L = hip.lib()
         dev = q.device
+        if doutT is None:
+            doutT = torch.zeros(R, N, H * A, device=dev, dtype=torch.float32)
         doutT = _c(doutT)
         if dP_ext is None and GAT_FUSED_BWD:
             # everything between d outT and (dq, dk, dS) in one kernel per slice (csrc/gat.hip: gat_fused_bwd_kernel)
@@ -1151,7 +1154,10 @@ class GatAttentionFn(Function):
         return dq, dk, dS, None, dlbias, dgeo, None, None, None
 
 
-GAT_FUSED_BWD = os.environ.get('EKAID_GAT_FUSED_BWD', '1') not in ('0', 'off', 'false')     # A/B aid: '0' = composed backward
+# Opt-in: the one-kernel-per-slice backward (csrc/gat.hip: gat_fused_bwd_kernel, plain f32 FMA) is correct but measured
+# SLOWER than the composed form (four batched MFMA GEMMs + softmax backward): 819 vs 414 us at R=512, N=36, A=1024
+# (tools/gat_bench.py); it stays available for shapes where the batched GEMMs do worse.
+GAT_FUSED_BWD = os.environ.get('EKAID_GAT_FUSED_BWD', '0') not in ('0', 'off', 'false', '')
 
 
 def gat_attention(q, k, S, cond, lbias, geo, H, direction, impl='fused'):

@@ -549,15 +549,20 @@ def test_gat_attention_fused_and_composed(N, M, A, H, direction, with_geo):
     out_r, P_r = _gat_reference(cpu[0], cpu[1], cpu[2], cond.double(), cpu[3], cpu[4], H, direction)
     assert torch.allclose(P_r[0, 2], torch.full_like(P_r[0, 2], 1.0 / M))
     gr = _grads([out_r], [t for t in cpu if t is not None])
-    for impl in ('fused', 'gemm'):
+    for impl, fused_bwd in (('fused', False), ('gemm', False), ('fused', True)):
         gpu = [t.to(DEV).requires_grad_(True) if t is not None else None for t in (q, k, S, lbias, geo)]
         out, P = ops.gat_attention(gpu[0], gpu[1], gpu[2], cond.to(DEV), gpu[3], gpu[4], H, direction, impl)
         check(P, P_r, 5e-6, 'P ' + impl)
         check(out, out_r, 5e-6, 'outT ' + impl)
         ins_g = [t for t in gpu if t is not None]
-        gg = _grads([out], ins_g)
+        was = ops.GAT_FUSED_BWD
+        ops.GAT_FUSED_BWD = fused_bwd              # composed backward (default) and the one-kernel backward
+        try:
+            gg = _grads([out], ins_g)
+        finally:
+            ops.GAT_FUSED_BWD = was
         for n, a, r in zip(('dq', 'dk', 'dS', 'dlbias', 'dgeo'), gg, gr):
-            check(a, r.float(), 5e-5, '%s %s' % (n, impl))
+            check(a, r.float(), 5e-5, '%s %s%s' % (n, impl, ' fused-bwd' if fused_bwd else ''))
 
 
 # --------------------------------------------------------------------------- fused decoder-step chains (speaker.hip)
