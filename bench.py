@@ -251,6 +251,8 @@ def main():
     step(b, T)
     host_issue_ms = (time.perf_counter() - th) * 1e3
     torch.cuda.synchronize()
+    if use_graph:
+        step.close()        # drop the captured graphs (their static loss pins autograd nodes to the capture stream)
     th = time.perf_counter()
     eager(b, T)
     host_issue_eager_ms = (time.perf_counter() - th) * 1e3
@@ -365,7 +367,6 @@ def main():
         if extra is not None:
             out['extra'] = extra
         if world == 1 and not args.no_cpu_baseline:
-            step.close()
             out['cpu_baseline'] = cpu_baseline(cfg, cd, sp, args.cpu_batch, args.graph)
         print(json.dumps(out))
     if world > 1:
