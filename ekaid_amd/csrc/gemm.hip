@@ -984,40 +984,10 @@ extern "C" int ekaid_set_gemm_mode(int mode) {
 }
 extern "C" int ekaid_get_gemm_mode(void) { return gemm_mode(); }
 
-// Tail plan of the 128x128 kernel (3 workgroups per CU = 768 slots): when the grid ends in a short last wave, the rows of the
-// whole waves are launched as they are and the remaining tile-rows are split along K so that they fill one more wave
-// (slabs + the reduce kernel, as for small grids).  Returns the number of leading rows (0 = no tail handling) and the split.
-static int gemm_tail_mode() {      // EKAID_GEMM_HYBRID: 0 off | 1 tail as 128x64 tiles (experiment) | 2 tail split along K
-    static const char* e = getenv("EKAID_GEMM_HYBRID");
-    return e ? atoi(e) : 2;
-}
-static int tail_plan(const ekaid_gemm_t* d, int TMN, int splitk, int tiles_m, int tiles_n, int& tail_split) {
-    tail_split = 1;
-    if (gemm_mode() != 1 || TMN != 2 || splitk != 1 || d->batch1 * d->batch2 != 1 || d->transA || gemm_tail_mode() == 0) return 0;
-    const int slots = 768;
-    const int T = tiles_m * tiles_n;
-    const int full_rows = ((T / slots) * slots) / tiles_n;
-    const int rem_tiles = (tiles_m - full_rows) * tiles_n;
-    if (full_rows <= 0 || rem_tiles <= 0 || rem_tiles * 10 > slots * 6) return 0;
-    if (gemm_tail_mode() == 2) {
-        int s = slots / rem_tiles;
-        const int ksteps = cdiv(d->K, BK_BIG);
-        if (s > ksteps / 8) s = ksteps / 8;           // at least 8 K-steps (256 k) per slice
-        if (s < 2) return 0;
-        tail_split = s;
-    } else if (d->N % 64) {
-        return 0;
-    }
-    return full_rows * 128;
-}
-
 extern "C" size_t ekaid_gemm_workspace_bytes(const ekaid_gemm_t* d) {
     if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
     int TMN, splitk, tm, tn;
     plan(d, TMN, splitk, tm, tn);
-    int ts;
-    const int rows1 = tail_plan(d, TMN, splitk, tm, tn, ts);
-    if (rows1 > 0 && ts > 1) return (size_t)ts * (d->M - rows1) * d->N * sizeof(float);
     return splitk > 1 ? (size_t)splitk * d->M * d->N * sizeof(float) : 0;
 }
 
@@ -1058,47 +1028,10 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     const int batch = d->batch1 * d->batch2;
     const bool akc = !d->transA, bkc = d->transB != 0;
     int rc;
-    // Tail handling (tail_plan above).  Mode 2 (default): the tail rows run the SAME pipelined 128x128 kernel, split along K
-    // into one more full wave, + the reduce kernel.  Mode 1 (experiment): the tail rows as 128x64 tiles of the non-pipelined
-    // kernel -- measured slower (224 -> 232-245 us on 18432x1024x1024).
-    {
-        int ts;
-        const int rows1 = tail_plan(d, TMN, a.splitk, a.tiles_m, a.tiles_n, ts);
-        if (rows1 > 0) {
-            GemmArgs a1 = a, a2 = a;
-            a1.M = rows1; a1.tiles_m = rows1 / 128;
-            a2.M = d->M - rows1; a2.A = a.A + (long long)rows1 * a.lda; a2.C = a.C + (long long)rows1 * a.ldc;
-            a2.e.m_base = rows1; a2.tiles_m = cdiv(a2.M, 128);
-            int rc2;
-            if (ts > 1) {
-                const size_t need = (size_t)ts * a2.M * d->N * sizeof(float);
-                if (!workspace || workspace_bytes < need) { set_error("ekaid_gemm_f32: workspace too small (%zu < %zu)", workspace_bytes, need); return EKAID_ERR_ARG; }
-                a2.ws = (float*)workspace;
-                a2.k_per_split = cdiv(cdiv(d->K, BK_BIG), ts) * BK_BIG;
-                a2.splitk = cdiv(d->K, a2.k_per_split);
-                if (bkc) { rc2 = launch_split<true, true, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG>(a1, 1, st); if (!rc2) rc2 = launch_split<true, true, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG>(a2, 1, st); }
-                else { rc2 = launch_split<true, false, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG>(a1, 1, st); if (!rc2) rc2 = launch_split<true, false, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG>(a2, 1, st); }
-                if (rc2) return rc2;
-                rc2 = check_launch("gemm_split_kernel (tail split)");
-                if (rc2) return rc2;
-                const bool vec_ok = (d->N % 4 == 0) && (d->ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(a2.C) & 15) == 0);
-                if (vec_ok) {
-                    const int n4 = d->N / 4;
-                    hipLaunchKernelGGL(splitk_reduce_vec_kernel<4>, dim3(cdiv((long long)a2.M * n4, 256)), dim3(256), 0, st, a2.ws, a2.C, a2.M, n4, d->ldc, a2.splitk, a2.e);
-                } else {
-                    int blocks = cdiv((long long)a2.M * d->N, 256);
-                    if (blocks > 2048) blocks = 2048;
-                    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a2.ws, a2.C, a2.M, d->N, d->ldc, a2.splitk, a2.e);
-                }
-                return check_launch("splitk_reduce_kernel (tail)");
-            }
-            a2.tiles_n = cdiv(d->N, 64);
-            if (bkc) { rc2 = launch_split<true, true, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG>(a1, 1, st); if (!rc2) rc2 = launch_split<true, true, 2, 1, 32, 1, false>(a2, 1, st); }
-            else { rc2 = launch_split<true, false, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG>(a1, 1, st); if (!rc2) rc2 = launch_split<true, false, 2, 1, 32, 1, false>(a2, 1, st); }
-            if (rc2) return rc2;
-            return check_launch("gemm_split_kernel (hybrid tiling)");
-        }
-    }
+    // (Two ways of repairing the short last wave of the 18432x1024 outputs -- 1152 tiles on 768 resident workgroups -- were
+    // measured and removed: the tail rows as 128x64 tiles, 224 -> 232-245 us, and the tail rows split along K into one more
+    // full wave, 222 -> 231 us.  With 1.5 workgroups per CU instead of 3 each one runs almost twice as fast: the kernel is
+    // bound by what a CU can sustain, not by the tail.  profiles/r02_planes_gemm_microbench.txt)
     if (gemm_mode() == 1 && TMN >= 1 && TMN <= 4) {
 #define EKAID_LAUNCH_SPLIT(AK, BKC) (TMN == 2 ? launch_split<AK, BKC, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG>(a, batch, st) \
                                      : TMN == 1 ? launch_split<AK, BKC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL, false>(a, batch, st) \

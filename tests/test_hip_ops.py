@@ -831,41 +831,3 @@ def test_gemm_planes_exact_on_integers_and_views():
     back = (parts[0] + parts[1] + parts[2])[:4099]
     assert float(parts[:, 4099:].abs().max()) == 0.0
     assert torch.equal(back, x.cpu())
-
-
-@pytest.mark.parametrize('mode', ['nt', 'nn'])
-def test_gemm_tail_rows_split_along_k(mode):
-    """A 128x128-tile grid that ends in a short last wave (800 tiles on 768 slots): the rows of the whole waves run as they
-    are, the remaining tile-rows are split along K (slabs + reduce).  The full epilogue (bias, residual with row divisor and
-    row mask, activation, dropout mask indexed by the GLOBAL row, accumulate) must be oblivious to the row split."""
-    from ekaid_amd import ops
-    from ekaid_amd.hip import ACT_RELU
-    M, N, K = 12800, 1024, 512
-    g = torch.Generator().manual_seed(11)
-    A = torch.randn(M, K, generator=g)
-    B = torch.randn(K, N, generator=g)
-    bias = torch.randn(N, generator=g)
-    R = torch.randn(M // 4, N, generator=g)
-    rowmask = (torch.rand(M, generator=g) > 0.3).float()
-    if mode == 'nt':
-        a, b, tb, ldb = A, B.t().contiguous(), 1, K
-    else:
-        a, b, tb, ldb = A, B, 0, N
-    a, b = a.to(DEV), b.to(DEV)
-    want = torch.relu(A.double() @ B.double() + bias.double() + rowmask.double()[:, None] * R.double().repeat_interleave(4, 0))
-    C = torch.full((M, N), float('nan'), device=DEV)
-    ops.gemm(a, b, C, M, N, K, K, ldb, N, 0, tb, bias=bias.to(DEV), R=R.to(DEV), ldr=N, rdiv=4, rowmask=rowmask.to(DEV), act=ACT_RELU)
-    check(C, want, 3e-6, 'tail-split gemm with epilogue ' + mode)
-    # dropout in the epilogue: the mask of row m must not depend on how the rows were launched (compare with ekaid_dropout
-    # of the plain product, whose mask index is the flat output index m * N + n)
-    C2, plain, dropped = (torch.empty(M, N, device=DEV) for _ in range(3))
-    ops.gemm(a, b, C2, M, N, K, K, ldb, N, 0, tb, drop_p=0.5, drop_seed=4242)
-    ops.gemm(a, b, plain, M, N, K, K, ldb, N, 0, tb)
-    from ekaid_amd import hip
-    hip.check(hip.lib().ekaid_dropout(hip.ptr(plain), hip.ptr(dropped), plain.numel(), 0.5, 4242, hip.stream()), 'dropout')
-    assert torch.equal(C2 != 0, dropped != 0)
-    check(C2, dropped, 3e-6, 'tail-split gemm with fused dropout ' + mode)
-    # accumulate
-    C3 = plain.clone()
-    ops.gemm(a, b, C3, M, N, K, K, ldb, N, 0, tb, accumulate=True)
-    check(C3, 2 * (A.double() @ B.double()), 3e-6, 'tail-split gemm accumulate ' + mode)
