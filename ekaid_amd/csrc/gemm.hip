@@ -53,11 +53,9 @@ struct Epi {
     unsigned long long drop_seed;
     const unsigned long long* drop_epoch;   // device word folded into drop_seed (ekaid_set_dropout_epoch_ptr) or NULL
     int n_cols;
-    int m_base;                 // row offset of this launch inside the logical output (hybrid tiling: second part)
 };
 
 __device__ __forceinline__ float epilogue(float acc, float cold, int m, int n, const Epi& e, float alpha) {
-    m += e.m_base;
     float v = acc * alpha;
     if (e.beta) v += cold;
     if (e.bias) v += e.bias[n];
@@ -1008,7 +1006,7 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     a.sC1 = d->strideC1; a.sC2 = d->strideC2; a.nb2 = d->batch2;
     a.e.alpha = d->alpha; a.e.alpha_dev = d->alpha_dev; a.e.beta = d->accumulate; a.e.bias = d->bias;
     a.e.R = d->R; a.e.ldr = d->ldr; a.e.rdiv = d->rdiv < 1 ? 1 : d->rdiv; a.e.rowmask = d->rowmask; a.e.act = d->act;
-    a.e.drop_p = d->drop_p; a.e.drop_inv = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f; a.e.drop_seed = d->drop_seed; a.e.drop_epoch = dropout_epoch_ptr(); a.e.n_cols = d->N; a.e.m_base = 0;
+    a.e.drop_p = d->drop_p; a.e.drop_inv = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f; a.e.drop_seed = d->drop_seed; a.e.drop_epoch = dropout_epoch_ptr(); a.e.n_cols = d->N;
     int TMN;
     plan(d, TMN, a.splitk, a.tiles_m, a.tiles_n);
     if (d->K == 0) a.splitk = 1;
@@ -1028,6 +1026,10 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     const int batch = d->batch1 * d->batch2;
     const bool akc = !d->transA, bkc = d->transB != 0;
     int rc;
+    // (Split-K with the reduction done by the last workgroup of each tile -- arrival counter, device-scope slab accesses --
+    // instead of the second kernel was measured and removed: bit-identical, but 0.97-2.9x the time of GEMM + reduce kernel on
+    // the recurrent shapes (the reduce kernel uses every CU, the last arriver is one workgroup per tile), and 5x with
+    // __threadfence() per workgroup.  profiles/r02_splitk_in_kernel_reduce.txt)
     // (Two ways of repairing the short last wave of the 18432x1024 outputs -- 1152 tiles on 768 resident workgroups -- were
     // measured and removed: the tail rows as 128x64 tiles, 224 -> 232-245 us, and the tail rows split along K into one more
     // full wave, 222 -> 231 us.  With 1.5 workgroups per CU instead of 3 each one runs almost twice as fast: the kernel is
@@ -1316,7 +1318,8 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     }
 }
 
-static int planes_variant() {          // tuning aid: EKAID_PLANES_VARIANT = 0 (KS 16, 2 slots, 3 wg/CU) | 1 (16, 3, 2) | 2 (32, 3, 1) | 3 (32, 2, 1) | 4 (0 with register staging)
+static int planes_variant() {          // tuning aid: EKAID_PLANES_VARIANT = 0 (KS 16, 2 slots, 3 wg/CU) | 2 (32, 3 slots, 1 wg/CU; default).
+                                       // (16,3,2), (32,2,1) and a register-staged form of 0 were measured too: profiles/r02_planes_gemm_microbench.txt
     static const char* v = getenv("EKAID_PLANES_VARIANT");
     return v ? atoi(v) : 2;
 }
@@ -1383,7 +1386,7 @@ extern "C" int ekaid_gemm_planes(const ekaid_gemm_t* d, const void* A_planes, lo
     a.e.alpha = d->alpha; a.e.alpha_dev = d->alpha_dev; a.e.beta = d->accumulate; a.e.bias = d->bias;
     a.e.R = d->R; a.e.ldr = d->ldr; a.e.rdiv = d->rdiv < 1 ? 1 : d->rdiv; a.e.rowmask = d->rowmask; a.e.act = d->act;
     a.e.drop_p = d->drop_p; a.e.drop_inv = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f; a.e.drop_seed = d->drop_seed;
-    a.e.drop_epoch = dropout_epoch_ptr(); a.e.n_cols = d->N; a.e.m_base = 0;
+    a.e.drop_epoch = dropout_epoch_ptr(); a.e.n_cols = d->N;
     a.splitk = splitk; a.tiles_m = tm; a.tiles_n = tn; a.ws = nullptr;
     a.k_per_split = cdiv(cdiv(d->K, BK_BIG), a.splitk) * BK_BIG;
     if (a.splitk > 1) {
@@ -1400,9 +1403,6 @@ extern "C" int ekaid_gemm_planes(const ekaid_gemm_t* d, const void* A_planes, lo
     const unsigned long long sa = (unsigned long long)a_plane_stride, sb = (unsigned long long)b_plane_stride;
     int rc;
 #define EKAID_PL(AK, BK) (planes_variant() == 0 ? launch_planes<AK, BK, 16, 2, 3>(a, sa, sb, grid, st) \
-                          : planes_variant() == 1 ? launch_planes<AK, BK, 16, 3, 2>(a, sa, sb, grid, st) \
-                          : planes_variant() == 3 ? launch_planes<AK, BK, 32, 2, 1>(a, sa, sb, grid, st) \
-                          : planes_variant() == 4 ? launch_planes<AK, BK, 16, 2, 2, true>(a, sa, sb, grid, st) \
                           : launch_planes<AK, BK, 32, 3, 1>(a, sa, sb, grid, st))
     if (akc && bkc) rc = EKAID_PL(true, true);
     else if (akc && !bkc) rc = EKAID_PL(true, false);
