@@ -122,6 +122,35 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* x, float* y, 
                                                       DropSeed seed) {
     GS_LOOP(i, n) y[i] = x[i] * dropout_scale(seed, (uint64_t)i, p, inv_keep);
 }
+// T independent masks over the same index range: step t uses seed + t; x advances by x_step elements per step (0: every
+// step reads the same input -- the decoder's per-step dropout of one embedding)
+__global__ __launch_bounds__(256) void dropout_steps_kernel(const float* x, float* y, long long n, int steps, long long x_step,
+                                                            float p, float inv_keep, DropSeed seed) {
+    const long long total = n * steps;
+    GS_LOOP(j, total) {
+        const int t = (int)(j / n);
+        const long long i = j - (long long)t * n;
+        y[j] = x[t * x_step + i] * dropout_scale(DropSeed{seed.s + (uint64_t)t, seed.ep}, (uint64_t)i, p, inv_keep);
+    }
+}
+struct SumArgs { const float* x[8]; int k; };
+__global__ __launch_bounds__(256) void sum_n_kernel(SumArgs a, float* out, long long n4) {
+    GS_LOOP(i, n4) {
+        f32x4 s = reinterpret_cast<const f32x4*>(a.x[0])[i];
+#pragma unroll
+        for (int j = 1; j < 8; ++j)
+            if (j < a.k) s += reinterpret_cast<const f32x4*>(a.x[j])[i];
+        reinterpret_cast<f32x4*>(out)[i] = s;
+    }
+}
+__global__ __launch_bounds__(256) void sum_n_tail_kernel(SumArgs a, float* out, long long from, long long n) {
+    GS_LOOP(i0, n - from) {
+        const long long i = from + i0;
+        float s = a.x[0][i];
+        for (int j = 1; j < a.k; ++j) s += a.x[j][i];
+        out[i] = s;
+    }
+}
 __global__ __launch_bounds__(256) void axpby_kernel(const float* x, const float* y, float* out, long long n, float a, float b) {
     GS_LOOP(i, n) out[i] = y ? a * x[i] + b * y[i] : a * x[i];
 }
@@ -559,6 +588,37 @@ extern "C" int ekaid_colsum(const float* x, int M, int N, int ldx, float* out, v
     (void)hipMemsetAsync(out, 0, sizeof(float) * N, ST);
     hipLaunchKernelGGL((colsum_kernel<true>), dim3(colblks, nparts), dim3(256), 0, ST, x, M, N, ldx, out, rows_per_blk);
     return check_launch("colsum");
+}
+extern "C" int ekaid_colsum_acc(const float* x, int M, int N, int ldx, float* out, void* stream) {
+    if (N <= 0 || M <= 0) return EKAID_OK;
+    const int colblks = cdiv(N, 256);
+    int rows_per_blk = (int)(((long long)M * colblks + 1023) / 1024);
+    rows_per_blk = rows_per_blk < 8 ? 8 : rows_per_blk;
+    hipLaunchKernelGGL((colsum_kernel<true>), dim3(colblks, cdiv(M, rows_per_blk)), dim3(256), 0, ST, x, M, N, ldx, out, rows_per_blk);
+    return check_launch("colsum_acc");
+}
+extern "C" int ekaid_sum_n(const float* const* xs, int k, float* out, long long n, void* stream) {
+    if (k < 1 || k > 8 || !xs) { set_error("sum_n: 1 <= k <= 8 addends (got %d)", k); return EKAID_ERR_ARG; }
+    if (n <= 0) return EKAID_OK;
+    SumArgs a;
+    bool vec = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    for (int j = 0; j < 8; ++j) {
+        a.x[j] = j < k ? xs[j] : nullptr;
+        if (j < k && !xs[j]) { set_error("sum_n: null addend %d", j); return EKAID_ERR_ARG; }
+        if (j < k && (reinterpret_cast<uintptr_t>(xs[j]) & 15)) vec = false;
+    }
+    a.k = k;
+    const long long n4 = vec ? n / 4 : 0;
+    if (n4) hipLaunchKernelGGL(sum_n_kernel, grid1d(n4), dim3(256), 0, ST, a, out, n4);
+    if (4 * n4 < n) hipLaunchKernelGGL(sum_n_tail_kernel, grid1d(n - 4 * n4), dim3(256), 0, ST, a, out, 4 * n4, n);
+    return check_launch("sum_n");
+}
+extern "C" int ekaid_dropout_steps(const float* x, float* y, long long n, int steps, long long x_step, float p, uint64_t seed,
+                                   void* stream) {
+    if (p < 0.f || p >= 1.f) { set_error("dropout_steps: p=%f out of range", p); return EKAID_ERR_ARG; }
+    if (n <= 0 || steps <= 0) return EKAID_OK;
+    hipLaunchKernelGGL(dropout_steps_kernel, grid1d(n * steps), dim3(256), 0, ST, x, y, n, steps, x_step, p, INVK(p), DS(seed));
+    return check_launch("dropout_steps");
 }
 extern "C" int ekaid_act_bwd(const float* dy, const float* y, float* dz, long long n, int act, void* stream) {
     hipLaunchKernelGGL(act_bwd_kernel, grid1d(n), dim3(256), 0, ST, dy, y, dz, n, act);

@@ -34,7 +34,15 @@ def forward_loss(cfg, cd, sp, b, T, graph='all', setting='mode2', denom=None, ma
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             marks.append((name, e))
-    adj = [process_matrix(b[k], cfg, N, dev, type=ty) for k, ty in ADJ_KEYS]
+    # the one-hot adjacency of the main and the reference image land in the two halves of one buffer: the detector stacks
+    # them along the batch axis (ops.stack2) without a copy
+    Bsz = b['input_1'].shape[0]
+    adj = []
+    for (kd, ty), (kq, _) in ((ADJ_KEYS[0], ADJ_KEYS[1]), (ADJ_KEYS[2], ADJ_KEYS[3])):
+        L = cfg.model.change_detector.spa_label_num if ty == 'spatial' else cfg.model.change_detector.sem_label_num
+        pair = torch.empty(2 * Bsz, N, N, L, device=dev, dtype=torch.float32)
+        adj.append(process_matrix(b[kd], cfg, N, dev, type=ty, out=pair[:Bsz]))
+        adj.append(process_matrix(b[kq], cfg, N, dev, type=ty, out=pair[Bsz:]))
     mark('adjacency')
     outs = cd(b['input_1'], b['input_2'], adj[0], adj[1], adj[2], adj[3], b['d_bb'], b['q_bb'], b['question'],
               setting=setting, graph=graph)

@@ -59,6 +59,9 @@ SIGNATURES = {
     'ekaid_wn_scale_bwd': [P, P, P, P, L, P, I, P, P],
     'ekaid_scale_dot': [P, P, P, L, P, P],
     'ekaid_colsum': [P, I, I, I, P, P],
+    'ekaid_colsum_acc': [P, I, I, I, P, P],
+    'ekaid_sum_n': [P, I, P, L, P],
+    'ekaid_dropout_steps': [P, P, L, I, L, F, U64, P],
     'ekaid_act_bwd': [P, P, P, L, I, P],
     'ekaid_dropout': [P, P, L, F, U64, P],
     'ekaid_axpby': [P, P, P, L, F, F, P],

@@ -46,8 +46,9 @@ class GraphSelfAttentionLayer(nn.Module):
         """
         R, N, A = roi_feat.shape
         M = self.nongt_dim if self.nongt_dim < N else N
-        key_feat = roi_feat if M == N else roi_feat[:, :M].contiguous()
-        q_data = self.query(roi_feat).view(R, N, A)
+        feat_q, feat_k, feat_s = ops.fanout(roi_feat, 3)          # three readers: query, key, aggregated values
+        key_feat = feat_k if M == N else feat_k[:, :M].contiguous()
+        q_data = self.query(feat_q).view(R, N, A)
         k_data = self.key(key_feat).view(R, M, A)
         geo = None
         if position_embedding is not None and self.pos_emb_dim > 0:
@@ -58,7 +59,7 @@ class GraphSelfAttentionLayer(nn.Module):
             geo = fc.main[1](pe2, ACT_RELU).view(R, N, M, self.fc_dim)
         if adj_matrix is None:
             raise ValueError('GraphSelfAttentionLayer: adj_matrix=None is not on the EKAID path')
-        out_t, aff_softmax = ops.gat_attention(q_data, k_data, roi_feat, adj_matrix, label_biases_att, geo,
+        out_t, aff_softmax = ops.gat_attention(q_data, k_data, feat_s, adj_matrix, label_biases_att, geo,
                                                self.num_heads, direction, self.attention_impl)
         output = self.linear_out_2(out_t.view(R * N, self.fc_dim * A)).view(R, N, self.dim[2])
         return output, aff_softmax

@@ -152,17 +152,19 @@ class ChangeDetector(nn.Module):
         q = self.encode_question(question)
 
         if setting == 'mode2':
+            n_enc = {'all': 3, 'i+s': 2}.get(graph, 1)
+            qs = list(ops.fanout(q, n_enc))                  # the question vector feeds every encoder
             if graph == 'semantic' or graph == 'all':
-                x, _ = self.semantic_relation.forward(x, torch.cat((d_sem_adj_matrix, q_sem_adj_matrix), 0), q)
+                x, _ = self.semantic_relation.forward(x, ops.stack2(d_sem_adj_matrix, q_sem_adj_matrix), qs.pop())
             if graph == 'spatial' or graph == 'all' or graph == 'i+s':
-                x, _ = self.spatial_relation.forward(x, torch.cat((d_adj_matrix, q_adj_matrix), 0), q)
+                x, _ = self.spatial_relation.forward(x, ops.stack2(d_adj_matrix, q_adj_matrix), qs.pop())
             if graph == 'implicit' or graph == 'all' or graph == 'i+s':
-                pos = self.position_emb(torch.cat((d_bb, q_bb), 0))
-                x, _ = self.imp_relation.forward(x, pos, q)
+                pos = self.position_emb(ops.stack2(d_bb, q_bb))
+                x, _ = self.imp_relation.forward(x, pos, qs.pop())
             if graph == 'all':
                 # Q-A: input_bef1/2/3 are one tensor -> cs*x + cp*x + (1-cs-cp)*x   (modules.py:234-235)
                 cs, cp = self.coef_sem, self.coef_spa
-                x = ops.AxpbyFn.apply(ops.AxpbyFn.apply(x, x, cs, cp), x, 1.0, 1 - cs - cp)
+                x = ops.self_mix3(x, cs, cp, 1 - cs - cp)
             elif graph == 'i+s':
                 x = ops.scale(ops.add(x, x), 0.5)
         elif setting == 'mode0':
@@ -172,26 +174,31 @@ class ChangeDetector(nn.Module):
             raise ValueError("setting %r references a non-existent graph_relation in the reference "
                              "(modules.py:214,257,263) and is not supported" % (setting,))
 
-        x = x.reshape(2 * B, N, A)
-        bef, aft = x[:B], x[B:]
-        diff = ops.sub(aft, bef)                                            # (B, N, A)
-        c1d = self.context1(diff)                                           # shared by both images: computed once
-        g1d = self.gate1(diff)
-        c2 = self.context2(x)                                               # (2B, N, A), bias in the epilogue
-        g2 = self.gate2(x)
+        # every tensor with several readers goes through ops.fanout / ops.halves: its gradient is then ONE n-ary sum
+        # instead of autograd's zero-fill + copy per slice and pairwise adds
+        x = x.reshape(2 * B, N, A).contiguous()
+        x_c, x_g, x_h = ops.fanout(x, 3)
+        bef_d, bef_e, bef_p, aft_d, aft_e, aft_p = ops.halves(x_h, 3)       # bef = x[:B], aft = x[B:], three readers each
+        diff = ops.sub(aft_d, bef_d)                                        # (B, N, A)
+        diff_c, diff_g, diff_b, diff_a = ops.fanout(diff, 4)
+        c1d = self.context1(diff_c)                                         # shared by both images: computed once
+        g1d = self.gate1(diff_g)
+        c2 = self.context2(x_c)                                             # (2B, N, A), bias in the epilogue
+        g2 = self.gate2(x_g)
         gated = ops.gate_fuse(c2, g2, c1d, g1d, self.dropout.p, self.training).view(2 * B, N, A)
+        gated_b, gated_a = ops.halves(gated)
 
         emb_lin, emb_drop = self.embed[0], self.embed[1]
 
-        def region_attention(feat, gated_feat):
-            e = emb_lin((feat, diff, gated_feat), ACT_RELU)                 # relu(dropout(x)) == dropout(relu(x))
+        def region_attention(feat, diff_, gated_feat):
+            e = emb_lin((feat, diff_, gated_feat), ACT_RELU)                # relu(dropout(x)) == dropout(relu(x))
             e = ops.dropout(e, emb_drop.p, self.training)
             return self.att(e, ACT_SIGMOID).view(B, N)
 
-        att_b = region_attention(bef, gated[:B])
-        att_a = region_attention(aft, gated[B:])
-        attended_1 = ops.weighted_pool(att_b, bef)
-        attended_2 = ops.weighted_pool(att_a, aft)
+        att_b = region_attention(bef_e, diff_b, gated_b)
+        att_a = region_attention(aft_e, diff_a, gated_a)
+        attended_1 = ops.weighted_pool(att_b, bef_p)
+        attended_2 = ops.weighted_pool(att_a, aft_p)
         input_attended = ops.sub(attended_2, attended_1)
         pred = self.fc1(input_attended)
         return pred, att_b.view(B, 1, N), att_a.view(B, 1, N), attended_1, attended_2, input_attended

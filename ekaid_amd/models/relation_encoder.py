@@ -50,10 +50,9 @@ class ImplicitRelationEncoder(nn.Module):
         affs = []
         for _ in range(self.num_steps):
             fc = self.implicit_relation.self_weights
-            v_cat_q = q_expand_v_cat(q, imp_v, True, fc.input_dropout(), fc.training)
-            imp_v, aff = self.implicit_relation.forward(
-                v_cat_q, imp_adj_mat, position_embedding,
-                residual=imp_v if self.residual_connection else None)
+            v_in, v_res = ops.fanout(imp_v, 2) if self.residual_connection else (imp_v, None)
+            v_cat_q = q_expand_v_cat(q, v_in, True, fc.input_dropout(), fc.training)
+            imp_v, aff = self.implicit_relation.forward(v_cat_q, imp_adj_mat, position_embedding, residual=v_res)
             affs.append(aff)
         return imp_v, affs[0]
 
@@ -78,7 +77,7 @@ class ExplicitRelationEncoder(nn.Module):
         aff = None
         for _ in range(self.num_steps):
             fc = self.explicit_relation.self_weights
-            v_cat_q = q_expand_v_cat(q, exp_v, True, fc.input_dropout(), fc.training)
-            exp_v, aff = self.explicit_relation.forward(
-                v_cat_q, exp_adj_matrix, residual=exp_v if self.residual_connection else None)
+            v_in, v_res = ops.fanout(exp_v, 2) if self.residual_connection else (exp_v, None)
+            v_cat_q = q_expand_v_cat(q, v_in, True, fc.input_dropout(), fc.training)
+            exp_v, aff = self.explicit_relation.forward(v_cat_q, exp_adj_matrix, residual=v_res)
         return exp_v, aff

@@ -109,6 +109,27 @@ def grad_out(W, zero=False):
     return torch.zeros_like(W) if zero else torch.empty_like(W)
 
 
+def bias_grad(b, x, rows, cols, ld, x_off=0):
+    """Gradient of bias ``b`` = column sums of x[rows, cols] (leading dim ``ld``, element offset ``x_off``), accumulated
+    straight into the bias' zeroed slot of the flat gradient buffer (no zero-fill launch, no copy afterwards); a second
+    contribution of a shared bias is accumulated onto the first.  Returns what the backward node hands to autograd."""
+    slot = grad_claimed_slot(b)
+    out = slot if slot is not None else grad_out(b, zero=True)
+    check(hip.lib().ekaid_colsum_acc(x.data_ptr() + 4 * x_off, rows, cols, ld, ptr(out), stream()), 'colsum_acc')
+    return None if slot is not None else out
+
+
+def zeros_pool(device, *shapes):
+    """Several zero-initialised f32 tensors from ONE allocation and ONE fill launch."""
+    sizes = [int(math.prod(sh)) for sh in shapes]
+    offs, tot = [], 0
+    for n in sizes:
+        offs.append(tot)
+        tot += (n + 3) & ~3                        # keep every tensor 16-byte aligned
+    flat = torch.zeros(tot, device=device, dtype=torch.float32)
+    return [flat[o:o + n].view(sh) for o, n, sh in zip(offs, sizes, shapes)]
+
+
 def grad_claimed_slot(W):
     """The slot of ``W`` if an earlier backward node of this step already wrote its gradient there (then a further
     contribution is accumulated in place and returned to autograd as None), else None."""
@@ -348,8 +369,7 @@ class LinearFn(Function):
         need = ctx.needs_input_grad
         db = None
         if ctx.has_b and need[1]:
-            db = grad_out(ctx.bias_ref) if ctx.bias_ref is not None else torch.empty(N, device=W.device, dtype=torch.float32)
-            check(L.ekaid_colsum(ptr(dz), M, N, N, ptr(db), stream()), 'colsum')
+            db = bias_grad(ctx.bias_ref, dz, M, N, N)
         # the gradient dz feeds up to two products per input (dgrad as the k-contiguous A, wgrad as the m-contiguous A):
         # split it once
         dzp = Wp = None
@@ -437,8 +457,7 @@ class LinearRowStackFn(Function):
         need = ctx.needs_input_grad
         db = None
         if ctx.has_b and need[1]:
-            db = grad_out(ctx.bias_ref)
-            check(hip.lib().ekaid_colsum(ptr(dy), Mtot, N, N, ptr(db), stream()), 'colsum')
+            db = bias_grad(ctx.bias_ref, dy, Mtot, N, N)
         dW = None
         if need[0]:
             dW = grad_out(W)
@@ -539,12 +558,138 @@ class AxpbyFn(Function):
         L = hip.lib()
         dx = dy = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(d)
-            check(L.ekaid_axpby(ptr(d), None, ptr(dx), d.numel(), ctx.a, 0.0, stream()), 'axpby')
+            if ctx.a == 1.0:
+                dx = d                          # the incoming gradient itself (nothing downstream writes into gradients)
+            else:
+                dx = torch.empty_like(d)
+                check(L.ekaid_axpby(ptr(d), None, ptr(dx), d.numel(), ctx.a, 0.0, stream()), 'axpby')
         if ctx.needs_input_grad[1]:
-            dy = torch.empty_like(d)
-            check(L.ekaid_axpby(ptr(d), None, ptr(dy), d.numel(), ctx.b, 0.0, stream()), 'axpby')
+            if ctx.b == 1.0:
+                dy = d
+            else:
+                dy = torch.empty_like(d)
+                check(L.ekaid_axpby(ptr(d), None, ptr(dy), d.numel(), ctx.b, 0.0, stream()), 'axpby')
         return dx, dy, None, None
+
+
+class SelfMix3Fn(Function):
+    """a*x + b*x + c*x evaluated in that order (quirk Q-A: the reference's three "parallel" encoder outputs are one tensor,
+    modules.py:234-235): two launches forward, two backward, no fan-out adds."""
+
+    @staticmethod
+    def forward(ctx, x, a, b, c):
+        require_cuda(x)
+        x = _c(x)
+        L = hip.lib()
+        t = torch.empty_like(x)
+        check(L.ekaid_axpby(ptr(x), ptr(x), ptr(t), x.numel(), a, b, stream()), 'axpby')
+        out = torch.empty_like(x)
+        check(L.ekaid_axpby(ptr(t), ptr(x), ptr(out), x.numel(), 1.0, c, stream()), 'axpby')
+        ctx.abc = (a, b, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        a, b, c = ctx.abc
+        d = _c(d)
+        L = hip.lib()
+        t = torch.empty_like(d)
+        check(L.ekaid_axpby(ptr(d), ptr(d), ptr(t), d.numel(), a, b, stream()), 'axpby')
+        dx = torch.empty_like(d)
+        check(L.ekaid_axpby(ptr(t), ptr(d), ptr(dx), d.numel(), 1.0, c, stream()), 'axpby')
+        return dx, None, None, None
+
+
+def self_mix3(x, a, b, c):
+    return SelfMix3Fn.apply(x, float(a), float(b), float(c))
+
+
+# --------------------------------------------------------------------------- #
+# tensors with several consumers: one n-ary sum instead of autograd's pairwise adds
+# --------------------------------------------------------------------------- #
+def _sum_into(grads, out):
+    """out = sum of the non-None ``grads`` (each the shape of ``out``); zero when there are none."""
+    gs = [_c(g) for g in grads if g is not None]
+    if not gs:
+        out.zero_()
+        return
+    for i in range(0, len(gs), 7):                  # 8 addends per launch; later launches add onto ``out``
+        part = ([out] if i else []) + gs[i:i + 7]
+        arr = (ctypes.c_void_p * len(part))(*[g.data_ptr() for g in part])
+        check(hip.lib().ekaid_sum_n(arr, len(part), ptr(out), out.numel(), stream()), 'sum_n')
+
+
+class FanoutFn(Function):
+    """x -> n aliases of x, one per consumer.  Backward: the n incoming gradients are summed by ONE kernel (autograd would
+    accumulate them pairwise: n-1 ATen adds, each re-reading the running sum).  ref: every tensor of the path with more
+    than one reader, e.g. the encoder output feeding context2 / gate2 / attention / pooling (modules.py:266-303)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view(x.shape) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        out = torch.empty(gs[0].shape, device=gs[0].device, dtype=gs[0].dtype)
+        _sum_into(gs, out)
+        return out, None
+
+
+def fanout(x, n):
+    if n <= 1 or not x.requires_grad:
+        return (x,) * n
+    return FanoutFn.apply(x, n)
+
+
+class HalvesFn(Function):
+    """x (2B, ...) -> n aliases of x[:B] followed by n aliases of x[B:] (the two images of a pair, stacked along the leading
+    axis).  Backward: the gradients of each half are summed straight into their half of one buffer (autograd's slice
+    backward would zero-fill a full-size tensor per use, copy the half in and add the results pairwise)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        ctx.shape = tuple(x.shape)
+        h = x.shape[0] // 2
+        return tuple(x[:h] for _ in range(n)) + tuple(x[h:] for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n = len(grads) // 2
+        if all(g is None for g in grads):
+            return None, None
+        ref = next(g for g in grads if g is not None)
+        out = torch.empty(ctx.shape, device=ref.device, dtype=ref.dtype)
+        h = ctx.shape[0] // 2
+        _sum_into(grads[:n], out[:h])
+        _sum_into(grads[n:], out[h:])
+        return out, None
+
+
+def stack2(a, b):
+    """cat((a, b), 0) -- as a VIEW when ``b`` directly follows ``a`` in one allocation (engine.forward_loss expands both
+    images' adjacency into the halves of one buffer), else a copy."""
+    if (a.shape == b.shape and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous() and a.device == b.device
+            and not a.requires_grad and not b.requires_grad
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and a.data_ptr() + a.numel() * a.element_size() == b.data_ptr()):
+        return torch.as_strided(a, (2 * a.shape[0],) + tuple(a.shape[1:]), a.stride())
+    return torch.cat((a, b), 0)
+
+
+def halves(x, n=1):
+    """(first-half aliases..., second-half aliases...) of a tensor stacked along axis 0; see HalvesFn."""
+    assert x.shape[0] % 2 == 0 and x.is_contiguous()
+    if not x.requires_grad:
+        h = x.shape[0] // 2
+        return (x[:h],) * n + (x[h:],) * n
+    return HalvesFn.apply(x, n)
 
 
 def sub(x, y):
@@ -887,11 +1032,13 @@ class GRUSeqFn(Function):
                                        hall.data_ptr() + 4 * (t + 1) * B * H, H, save.data_ptr() + 4 * t * B * 4 * H,
                                        stream()), 'gru_cell_fwd')
         ctx.save_for_backward(x, w_ih, w_hh, hall, save)
+        ctx.b_refs = (b_ih.detach(), b_hh.detach())          # (aliases: their data_ptr finds the gradient slots)
         return hall[1:].transpose(0, 1)          # (B, T, H) view of the time-major buffer
 
     @staticmethod
     def backward(ctx, dout):
         x, w_ih, w_hh, hall, save = ctx.saved_tensors
+        b_ih, b_hh = ctx.b_refs
         B, T, E = x.shape
         H = w_hh.shape[1]
         dev = x.device
@@ -910,10 +1057,8 @@ class GRUSeqFn(Function):
         # weight gradients batched over time: K = T*B rows (previous states are the contiguous slice hall[0:T])
         dw_hh = grad_out(w_hh)
         gemm(dgh, hall, dw_hh, 3 * H, H, T * B, 3 * H, H, H, 1, 0)
-        db_hh = torch.empty(3 * H, device=dev, dtype=torch.float32)
-        check(L.ekaid_colsum(ptr(dgh), T * B, 3 * H, 3 * H, ptr(db_hh), stream()), 'colsum')
-        db_ih = torch.empty(3 * H, device=dev, dtype=torch.float32)
-        check(L.ekaid_colsum(ptr(dgi), B * T, 3 * H, 3 * H, ptr(db_ih), stream()), 'colsum')
+        db_hh = bias_grad(b_hh, dgh, T * B, 3 * H, 3 * H)
+        db_ih = bias_grad(b_ih, dgi, B * T, 3 * H, 3 * H)
         dw_ih = grad_out(w_ih)
         gemm(dgi, x, dw_ih, 3 * H, E, B * T, 3 * H, E, E, 1, 0)
         dx = None

@@ -45,10 +45,6 @@ def _tn(D, ldd, X, ldx, G, goff, ldg, Nout, Kin, rows, doff=0, xoff=0):
     gemm(D, X, G, Nout, Kin, rows, ldd, ldx, ldg, 1, 0, a_off=doff, b_off=xoff, c_off=goff)
 
 
-def _colsum(x, rows, cols, out):
-    check(hip.lib().ekaid_colsum(ptr(x), rows, cols, cols, ptr(out), stream()), 'colsum')
-
-
 def _drop(x, y, n, p, seed, xoff=0, yoff=0):
     check(hip.lib().ekaid_dropout(x.data_ptr() + 4 * xoff, y.data_ptr() + 4 * yoff, n, p, seed, stream()), 'dropout')
 
@@ -90,9 +86,8 @@ class SpeakerSeqFn(Function):
         _nt(bef, 0, A, w_e, 0, 3 * A, embed_pre, 0, E, B, E, A)
         _nt(diff, 0, A, w_e, A, 3 * A, embed_pre, 0, E, B, E, A, acc=True)
         _nt(aft, 0, A, w_e, 2 * A, 3 * A, embed_pre, 0, E, B, E, A, bias=b_e, acc=True, act=ACT_RELU)
-        ED = torch.empty(T, B, E, **f32)
-        for t in range(T):                        # dropout mask differs per step (step index folded into the seed)
-            _drop(embed_pre, ED, B * E, p, seeds['ed'] + t, 0, t * B * E)
+        ED = torch.empty(T, B, E, **f32)             # dropout mask differs per step (step index folded into the seed)
+        check(L.ekaid_dropout_steps(ptr(embed_pre), ptr(ED), B * E, T, 0, p, seeds['ed'], stream()), 'dropout_steps')
         Xr = torch.empty(T, B, We, **f32)
         check(L.ekaid_embedding_fwd(tok_tb.data_ptr(), TB, ptr(emb), We, ptr(Xr), We, 0, 1, stream()), 'embedding_fwd')
         Xd = torch.empty_like(Xr)
@@ -104,10 +99,8 @@ class SpeakerSeqFn(Function):
         # row-concatenated weights applied to h_lang_{t-1} (a copy, no arithmetic)
         Wcat = torch.cat([wih_a[:, E:], w_p1, w_g1[:, :R], whh_l], 0).contiguous()          # (NW, R)
 
-        HA = torch.zeros(T + 1, B, R, **f32)      # h of the module-attention LSTM, HA[0] = 0
-        CA = torch.zeros(T + 1, B, R, **f32)
-        HL = torch.zeros(T + 1, B, R, **f32)      # h of the language LSTM
-        CL = torch.zeros(T + 1, B, R, **f32)
+        # HA / HL: h of the module-attention / language LSTM, CA / CL their cells; row 0 = the zero initial state
+        HA, CA, HL, CL = ops.zeros_pool(dev, (T + 1, B, R), (T + 1, B, R), (T + 1, B, R), (T + 1, B, R))
         SA = torch.empty(T, B, 4 * R, **f32)      # gate activations (i,f,g,o)
         SL = torch.empty(T, B, 4 * R, **f32)
         HLW = torch.empty(T, B, NW, **f32)        # see class docstring; the G1 block ends up holding dropout(relu(gate1x))
@@ -165,6 +158,9 @@ class SpeakerSeqFn(Function):
         check(L.ekaid_softmax_fwd(ptr(DP), ptr(logpos), TB, NP, 1, stream()), 'softmax_fwd')
 
         ctx.dims = (T, B, A, E, R, We, V, G1)
+        # aliases of the bias parameters: their data_ptr finds the gradient slots (ops.bias_grad)
+        ctx.biases = tuple(t.detach() for t in (b_e, bih_a, bhh_a, b_fc, b_p1, b_wp, b_p2, b_g1, b_g2, bih_l, bhh_l, b_lo))
+        ctx.wrefs = (w_p1.detach(), whh_l.detach())   # (read through Wcat in the backward pass; needed for their slots only)
         ctx.pp = (p, p5, seeds, seeds_t)
         ctx.save_for_backward(bef, aft, diff, tok_tb, embed_pre, ED, Xd, HA, CA, HL, CL, SA, SL, MW, VP, PW, PA, AT,
                               HLW, GT, GA, HO, logp, logpos, emb, w_e, wih_a, whh_a, w_fc, w_wp, w_p2, w_g1, w_g2,
@@ -181,6 +177,8 @@ class SpeakerSeqFn(Function):
         NW = 9 * R + G1
         oP1, oG1, oGL = 4 * R, 5 * R, 5 * R + G1
         p, p5, seeds, seeds_t = ctx.pp
+        b_e, bih_a, bhh_a, b_fc, b_p1, b_wp, b_p2, b_g1, b_g2, bih_l, bhh_l, b_lo = ctx.biases
+        w_p1, whh_l = ctx.wrefs
         dev = bef.device
         L = hip.lib()
         f32 = dict(device=dev, dtype=torch.float32)
@@ -191,13 +189,15 @@ class SpeakerSeqFn(Function):
         check(L.ekaid_softmax_bwd(ptr(logp), ptr(dlogp), ptr(dlogits), TB, V, 1, stream()), 'softmax_bwd')
         d_w_lo = ops.grad_out(w_lo)
         _tn(dlogits, V, HO, R, d_w_lo, 0, R, V, R, TB)
-        d_b_lo = torch.empty(V, **f32)
-        _colsum(dlogits, TB, V, d_b_lo)
+        d_b_lo = ops.bias_grad(b_lo, dlogits, TB, V, V)
         dHO = torch.empty(T, B, R, **f32)
         _nn(dlogits, 0, V, w_lo, 0, R, dHO, 0, R, TB, R, V)
         dHLo = torch.empty(T, B, R, **f32)        # gradient reaching h_lang_t through the output dropout
         _drop(dHO, dHLo, TB * R, p, seeds['out'])
-        dDPl = torch.zeros(T, B, NP, **f32)       # gradient reaching dpos through log_softmax(output_pos)
+        # dDPl: gradient reaching dpos through log_softmax(output_pos); d_bef/d_diff/d_aft and the four carries
+        # (gradient w.r.t. h_lang_t / c_lang_t / h_att_t / c_att_t) start at zero: one allocation, one fill
+        dDPl, d_bef, d_diff, d_aft, dh_l, dc_l, dh_a, dc_a = ops.zeros_pool(
+            dev, (T, B, NP), (B, A), (B, A), (B, A), (B, R), (B, R), (B, R), (B, R))
         if dlogpos is not None:
             check(L.ekaid_softmax_bwd(ptr(logpos), ptr(dlogpos.contiguous()), ptr(dDPl), TB, NP, 1, stream()), 'softmax_bwd')
 
@@ -206,13 +206,6 @@ class SpeakerSeqFn(Function):
         DWP = torch.empty(T, B, NP, **f32)
         DPA = torch.empty(T, B, R + A, **f32)     # [d pos_feat | d att_feat (gate-MLP path)] per step, one dgrad GEMM
         DZ2 = torch.empty(T, B, A, **f32)
-        d_bef = torch.zeros(B, A, **f32)
-        d_diff = torch.zeros(B, A, **f32)
-        d_aft = torch.zeros(B, A, **f32)
-        dh_l = torch.zeros(B, R, **f32)           # carries: gradient w.r.t. h_lang_t / c_lang_t / h_att_t / c_att_t
-        dc_l = torch.zeros(B, R, **f32)
-        dh_a = torch.zeros(B, R, **f32)
-        dc_a = torch.zeros(B, R, **f32)
         dh_l_prev = torch.empty(B, R, **f32)
         dh_a_prev = torch.empty(B, R, **f32)
         dc_tmp = torch.empty(B, R, **f32)
@@ -264,45 +257,38 @@ class SpeakerSeqFn(Function):
         _tn(DCAT, NW, HL, R, d_wih_a, E, E + R, 4 * R, R, TB)
         d_whh_a = ops.grad_out(whh_a)
         _tn(DCAT, NW, HA, R, d_whh_a, 0, R, 4 * R, R, TB)
-        d_b_a = torch.empty(4 * R, **f32)
-        check(L.ekaid_colsum(ptr(DCAT), TB, 4 * R, NW, ptr(d_b_a), stream()), 'colsum')
+        d_bih_a = ops.bias_grad(bih_a, DCAT, TB, 4 * R, NW)          # bias_ih and bias_hh receive the same gradient
+        d_bhh_a = ops.bias_grad(bhh_a, DCAT, TB, 4 * R, NW)
         d_w_fc = ops.grad_out(w_fc)
         _tn(DZFC, 3, HA, R, d_w_fc, 0, R, 3, R, TB, xoff=B * R)
-        d_b_fc = torch.empty(3, **f32)
-        _colsum(DZFC, TB, 3, d_b_fc)
-        d_w_p1 = torch.empty(R, R, **f32)
+        d_b_fc = ops.bias_grad(b_fc, DZFC, TB, 3, 3)
+        d_w_p1 = ops.grad_out(w_p1)
         _tn(DCAT, NW, HL, R, d_w_p1, 0, R, R, R, TB, doff=oP1)
-        d_b_p1 = torch.empty(R, **f32)
-        check(L.ekaid_colsum(DCAT.data_ptr() + 4 * oP1, TB, R, NW, ptr(d_b_p1), stream()), 'colsum')
+        d_b_p1 = ops.bias_grad(b_p1, DCAT, TB, R, NW, oP1)
         d_w_wp = ops.grad_out(w_wp)
         _tn(DWP, NP, VP, R, d_w_wp, 0, R, NP, R, TB)
-        d_b_wp = torch.empty(NP, **f32)
-        _colsum(DWP, TB, NP, d_b_wp)
+        d_b_wp = ops.bias_grad(b_wp, DWP, TB, NP, NP)
         d_w_p2 = ops.grad_out(w_p2)
         _tn(DPA, R + A, PW, NP, d_w_p2, 0, NP, R, NP, TB)
-        d_b_p2 = torch.empty(R, **f32)
-        check(L.ekaid_colsum(ptr(DPA), TB, R, R + A, ptr(d_b_p2), stream()), 'colsum')
+        d_b_p2 = ops.bias_grad(b_p2, DPA, TB, R, R + A)
         d_w_g1 = ops.grad_out(w_g1)
         _tn(DCAT, NW, HL, R, d_w_g1, 0, G1, G1, R, TB, doff=oG1)
         _tn(DCAT, NW, PA, R + A, d_w_g1, R, G1, G1, R + A, TB, doff=oG1)
-        d_b_g1 = torch.empty(G1, **f32)
-        check(L.ekaid_colsum(DCAT.data_ptr() + 4 * oG1, TB, G1, NW, ptr(d_b_g1), stream()), 'colsum')
+        d_b_g1 = ops.bias_grad(b_g1, DCAT, TB, G1, NW, oG1)
         d_w_g2 = ops.grad_out(w_g2)
         _tn(DZ2, A, HLW, NW, d_w_g2, 0, G1, A, G1, TB, xoff=oG1)                                  # input = dropout(relu(gate1x)) block
-        d_b_g2 = torch.empty(A, **f32)
-        _colsum(DZ2, TB, A, d_b_g2)
+        d_b_g2 = ops.bias_grad(b_g2, DZ2, TB, A, A)
         d_wih_l = ops.grad_out(wih_l)
         _tn(DCAT, NW, Xd, We, d_wih_l, 0, We + A, 4 * R, We, TB, doff=oGL)
         _tn(DCAT, NW, GA, A, d_wih_l, We, We + A, 4 * R, A, TB, doff=oGL)
-        d_whh_l = torch.empty(4 * R, R, **f32)
+        d_whh_l = ops.grad_out(whh_l)
         _tn(DCAT, NW, HL, R, d_whh_l, 0, R, 4 * R, R, TB, doff=oGL)
-        d_b_l = torch.empty(4 * R, **f32)
-        check(L.ekaid_colsum(DCAT.data_ptr() + 4 * oGL, TB, 4 * R, NW, ptr(d_b_l), stream()), 'colsum')
+        d_bih_l = ops.bias_grad(bih_l, DCAT, TB, 4 * R, NW, oGL)
+        d_bhh_l = ops.bias_grad(bhh_l, DCAT, TB, 4 * R, NW, oGL)
         # embed path: dED = DGA . W_ih_att[:, :E]; per-step dropout backward; sum over t; relu; Linear(3A -> E)
         dED = torch.empty(T, B, E, **f32)
         _nn(DCAT, 0, NW, wih_a, 0, E + R, dED, 0, E, TB, E, 4 * R)
-        for t in range(T):
-            _drop(dED, dED, B * E, p, seeds['ed'] + t, t * B * E, t * B * E)
+        check(L.ekaid_dropout_steps(ptr(dED), ptr(dED), B * E, T, B * E, p, seeds['ed'], stream()), 'dropout_steps')
         d_epre = torch.empty(B, E, **f32)
         check(L.ekaid_colsum(ptr(dED), T, B * E, B * E, ptr(d_epre), stream()), 'colsum')
         d_ez = torch.empty(B, E, **f32)
@@ -311,8 +297,7 @@ class SpeakerSeqFn(Function):
         _tn(d_ez, E, bef, A, d_w_e, 0, 3 * A, E, A, B)
         _tn(d_ez, E, diff, A, d_w_e, A, 3 * A, E, A, B)
         _tn(d_ez, E, aft, A, d_w_e, 2 * A, 3 * A, E, A, B)
-        d_b_e = torch.empty(E, **f32)
-        _colsum(d_ez, B, E, d_b_e)
+        d_b_e = ops.bias_grad(b_e, d_ez, B, E, E)
         _nn(d_ez, 0, E, w_e, 0, 3 * A, d_bef, 0, A, B, A, E, acc=True)
         _nn(d_ez, 0, E, w_e, A, 3 * A, d_diff, 0, A, B, A, E, acc=True)
         _nn(d_ez, 0, E, w_e, 2 * A, 3 * A, d_aft, 0, A, B, A, E, acc=True)
@@ -323,8 +308,8 @@ class SpeakerSeqFn(Function):
         d_emb = ops.grad_out(emb, zero=True)
         check(L.ekaid_embedding_bwd(tok_tb.data_ptr(), TB, ptr(emb), ptr(dX), We, We, 0, 1, -1, ptr(d_emb), stream()),
               'embedding_bwd')
-        grads = (d_emb, d_w_e, d_b_e, d_wih_a, d_whh_a, d_b_a, d_b_a, d_w_fc, d_b_fc, d_w_p1, d_b_p1, d_w_wp, d_b_wp,
-                 d_w_p2, d_b_p2, d_w_g1, d_b_g1, d_w_g2, d_b_g2, d_wih_l, d_whh_l, d_b_l, d_b_l, d_w_lo, d_b_lo)
+        grads = (d_emb, d_w_e, d_b_e, d_wih_a, d_whh_a, d_bih_a, d_bhh_a, d_w_fc, d_b_fc, d_w_p1, d_b_p1, d_w_wp, d_b_wp,
+                 d_w_p2, d_b_p2, d_w_g1, d_b_g1, d_w_g2, d_b_g2, d_wih_l, d_whh_l, d_bih_l, d_bhh_l, d_w_lo, d_b_lo)
         return (d_bef, d_aft, d_diff, None, None, None, None) + grads
 
 

@@ -12,7 +12,8 @@ def torch_broadcast_adj_matrix(adj_matrix, label_num=11, device=None):
     return process_matrix_labels(adj_matrix, adj_matrix.shape[1], label_num, device)
 
 
-def process_matrix_labels(adj_matrix, num_objects, label_num, device=None):
+def process_matrix_labels(adj_matrix, num_objects, label_num, device=None, out=None):
+    """``out``: optional (B, num_objects, num_objects, label_num) f32 destination (a half of a pair buffer)."""
     device = torch.device(device) if device is not None else adj_matrix.device
     adj = adj_matrix.to(device)
     if adj.dtype not in (torch.float64, torch.int64, torch.int8):
@@ -22,21 +23,23 @@ def process_matrix_labels(adj_matrix, num_objects, label_num, device=None):
     hip.require_cuda(adj)
     B, S = adj.shape[0], adj.shape[1]
     assert adj.shape[2] == S
-    out = torch.empty(B, num_objects, num_objects, label_num, device=device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(B, num_objects, num_objects, label_num, device=device, dtype=torch.float32)
+    assert out.shape == (B, num_objects, num_objects, label_num) and out.is_contiguous() and out.dtype == torch.float32
     check(hip.lib().ekaid_process_matrix(adj.data_ptr(), label_type, B, S, num_objects, label_num,
                                          ptr(out), stream()), 'process_matrix')
     return out
 
 
-def process_matrix(adj_matrix, cfg, num_objects, device, type):
-    """Same signature as the reference (mimic_utils.py:141-149)."""
+def process_matrix(adj_matrix, cfg, num_objects, device, type, out=None):
+    """Same signature as the reference (mimic_utils.py:141-149) + an optional destination."""
     if type == 'spatial':
         label_num = cfg.model.change_detector.spa_label_num
     elif type == 'semantic':
         label_num = cfg.model.change_detector.sem_label_num
     else:
         raise ValueError('process_matrix: unknown type %r' % (type,))
-    return process_matrix_labels(adj_matrix, num_objects, label_num, device)
+    return process_matrix_labels(adj_matrix, num_objects, label_num, device, out)
 
 
 def torch_extract_position_embedding_from_boxes(bbox, nongt_dim=36, feat_dim=64, wave_length=1000, device=None):

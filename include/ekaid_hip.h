@@ -129,6 +129,16 @@ int ekaid_scale_dot(float* G, const float* w, const float* scale_dev, long long 
 
 /* column sum of an [M][N] matrix (bias gradient), out[N] */
 int ekaid_colsum(const float* x, int M, int N, int ldx, float* out, void* stream);
+/* out[N] += column sums (no zero-fill: the bias gradient accumulated straight into its zeroed slot of the flat gradient
+ * buffer, or on top of an earlier contribution of a shared bias) */
+int ekaid_colsum_acc(const float* x, int M, int N, int ldx, float* out, void* stream);
+/* out = xs[0] + ... + xs[k-1] (1 <= k <= 8 device arrays of n floats, xs itself is a HOST array; out may alias xs[0]):
+ * the gradient of a tensor with several consumers in one pass (ref: autograd's pairwise accumulation of fan-out gradients,
+ * e.g. the encoder output feeding context/gate/attention/pooling, modules.py:266-303) */
+int ekaid_sum_n(const float* const* xs, int k, float* out, long long n, void* stream);
+/* `steps` dropout masks in one launch: y[t][i] = x[t * x_step + i] * keep(seed + t, i) / (1 - p), i < n  (x_step = 0: one
+ * input under a fresh mask per decoding step, dynamic_speaker_change_pos.py:101; x_step = n: its backward) */
+int ekaid_dropout_steps(const float* x, float* y, long long n, int steps, long long x_step, float p, uint64_t seed, void* stream);
 /* dz = dy * act'(y) with the derivative written through the activation output y */
 int ekaid_act_bwd(const float* dy, const float* y, float* dz, long long n, int act, void* stream);
 /* y = x * keep(seed, i) / (1 - p)      (also its own backward)   ref: every nn.Dropout on the path */

@@ -831,3 +831,85 @@ def test_gemm_planes_exact_on_integers_and_views():
     back = (parts[0] + parts[1] + parts[2])[:4099]
     assert float(parts[:, 4099:].abs().max()) == 0.0
     assert torch.equal(back, x.cpu())
+
+
+def test_fanout_sums_bias_slots_and_batched_step_dropout():
+    """Launch-diet entry points: n-ary gradient sum (ops.fanout / ops.halves), bias gradients accumulated into a zeroed
+    slot (ekaid_colsum_acc), T dropout masks in one launch (ekaid_dropout_steps), Q-A mix, stacked adjacency view."""
+    import ctypes
+    from ekaid_amd import hip, ops
+    from ekaid_amd.hip import check as hcheck, ptr, stream
+    L = hip.lib()
+    # ekaid_sum_n: 1..8 addends, vector path + unaligned tail + unaligned base
+    for n in (1, 5, 1024, 4099):
+        for k in (1, 2, 3, 8):
+            xs = [rnd(n + 1, seed=100 + j).to(DEV) for j in range(k)]
+            for shift in (0, 1):
+                part = [x[shift:shift + n] for x in xs]
+                out = torch.empty(n, device=DEV)
+                arr = (ctypes.c_void_p * k)(*[p.data_ptr() for p in part])
+                hcheck(L.ekaid_sum_n(arr, k, ptr(out), n, stream()), 'sum_n')
+                want = part[0].clone()
+                for p in part[1:]:
+                    want = want + p                      # same left-to-right order: bit-identical
+                assert torch.equal(out, want)
+    assert L.ekaid_sum_n(None, 9, None, 4, None) != 0
+    # fanout / halves: gradients equal autograd's own accumulation over plain slices
+    x = rnd(6, 5, 8, seed=1).to(DEV).requires_grad_(True)
+    w = [rnd(6, 5, 8, seed=10 + i).to(DEV) for i in range(3)]
+    wh = [rnd(3, 5, 8, seed=20 + i).to(DEV) for i in range(4)]
+    a, b, c = ops.fanout(x, 3)
+    b0, b1, a0, a1 = ops.halves(c, 2)
+    y = (a * w[0]).sum() + (b * w[1]).sum() + (b0 * wh[0]).sum() + (b1 * wh[1]).sum() + (a0 * wh[2]).sum() + (a1 * wh[3]).sum()
+    g, = torch.autograd.grad(y, x)
+    want = w[0] + w[1] + torch.cat((wh[0] + wh[1], wh[2] + wh[3]), 0)
+    check(g, want, 1e-6, 'fanout/halves gradient')
+    # unused branches arrive as None
+    x2 = rnd(4, 3, seed=2).to(DEV).requires_grad_(True)
+    u, v, _unused = ops.fanout(x2, 3)
+    h0, h1 = ops.halves(v)
+    g2, = torch.autograd.grad((u * 2).sum() + (h1 * 3).sum(), x2)
+    want2 = torch.full((4, 3), 2.0)
+    want2[2:] += 3.0
+    assert torch.equal(g2.cpu(), want2)
+    # mix3 == a*x + b*x + c*x, value and gradient
+    x3 = rnd(1000, seed=3).to(DEV).requires_grad_(True)
+    y3 = ops.self_mix3(x3, 0.3, 0.5, 1 - 0.3 - 0.5)
+    check(y3, 0.3 * x3.detach().cpu() + 0.5 * x3.detach().cpu() + 0.2 * x3.detach().cpu(), 1e-6, 'mix3')
+    g3, = torch.autograd.grad(y3.sum(), x3)
+    check(g3, torch.ones(1000), 1e-6, 'mix3 gradient')
+    # colsum_acc accumulates on top of what is there (a zeroed slot, or an earlier contribution of a shared bias)
+    m = rnd(300, 70, seed=4).to(DEV)
+    out = torch.full((70,), 1.5, device=DEV)
+    hcheck(L.ekaid_colsum_acc(ptr(m), 300, 70, 70, ptr(out), stream()), 'colsum_acc')
+    check(out, 1.5 + m.double().sum(0).cpu(), 2e-6, 'colsum_acc')
+    sub = torch.zeros(20, device=DEV)
+    hcheck(L.ekaid_colsum_acc(m.data_ptr() + 4 * 10, 300, 20, 70, ptr(sub), stream()), 'colsum_acc')
+    check(sub, m[:, 10:30].double().sum(0).cpu(), 2e-6, 'colsum_acc column block')
+    # dropout_steps == one ekaid_dropout per step with seed + t (shared input, and per-step input in place)
+    T, n, seed, p = 5, 777, 4242, 0.3
+    src = rnd(n, seed=5).to(DEV)
+    many = torch.empty(T, n, device=DEV)
+    hcheck(L.ekaid_dropout_steps(ptr(src), ptr(many), n, T, 0, p, seed, stream()), 'dropout_steps')
+    one = torch.empty(T, n, device=DEV)
+    for t in range(T):
+        hcheck(L.ekaid_dropout(ptr(src), one.data_ptr() + 4 * t * n, n, p, seed + t, stream()), 'dropout')
+    assert torch.equal(many, one)
+    assert 0.2 < float((many == 0).float().mean()) < 0.4 and not torch.equal(many[0], many[1])
+    grads = rnd(T, n, seed=6).to(DEV)
+    inplace = grads.clone()
+    hcheck(L.ekaid_dropout_steps(ptr(inplace), ptr(inplace), n, T, n, p, seed, stream()), 'dropout_steps')
+    want_g = torch.empty(T, n, device=DEV)
+    for t in range(T):
+        hcheck(L.ekaid_dropout(grads.data_ptr() + 4 * t * n, want_g.data_ptr() + 4 * t * n, n, p, seed + t, stream()), 'dropout')
+    assert torch.equal(inplace, want_g)
+    # stack2: a view when the halves are adjacent in one buffer, a copy otherwise
+    pair = torch.arange(24, device=DEV, dtype=torch.float32).view(4, 3, 2)
+    v2 = ops.stack2(pair[:2], pair[2:])
+    assert v2.data_ptr() == pair.data_ptr() and torch.equal(v2, pair)
+    cpy = ops.stack2(pair[2:], pair[:2])
+    assert cpy.data_ptr() != pair.data_ptr() and torch.equal(cpy, torch.cat((pair[2:], pair[:2]), 0))
+    # zeros_pool: aligned, zero, disjoint
+    z = ops.zeros_pool(DEV, (3, 5), (7,), (2, 2))
+    assert [tuple(t.shape) for t in z] == [(3, 5), (7,), (2, 2)] and all(float(t.abs().sum()) == 0 for t in z)
+    assert all(t.data_ptr() % 16 == 0 for t in z)
