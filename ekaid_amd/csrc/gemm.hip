@@ -416,7 +416,11 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// four f32 -> three planes of four bf16 (truncation split; h + m + l == v exactly for finite v)
+// four f32 -> three planes of four bf16 (truncation split; h + m + l == v exactly for finite v).
+// (A round-to-nearest split on v_cvt_pk_bf16_f32 + v_pk_add_f32 is 18 instead of 22 vector instructions per four words and
+// equally exact, but the 64-bit register pairs of the packed subtracts push the 128x128 kernel over its 168-VGPR budget
+// (62-179 spilled registers in the k-contiguous variants: 2.5x slower) and, applied only where it fits, measured no
+// faster: 182 vs 187 TF on the wgrad form.)
 __device__ __forceinline__ void split4(const f32x4& v, u32x2& H, u32x2& M, u32x2& L) {
 #if EKAID_SPLIT_ABLATE == 2              // timing-only: no split arithmetic (three copies of the raw words)
     H[0] = __float_as_uint(v[0]); H[1] = __float_as_uint(v[1]); M[0] = __float_as_uint(v[2]); M[1] = __float_as_uint(v[3]); L = H;
@@ -938,12 +942,15 @@ static int launch_split(const GemmArgs& a, int batch, hipStream_t st) {
 // arithmetic of the MFMA kernels: 0 = v_mfma_f32_32x32x2_f32, 1 = exact 3-way bf16 split (6 x v_mfma_f32_32x32x16_bf16);
 // kept in the per-device state (api.hip: gemm_mode / set_gemm_mode)
 
-static int plan_splitk(int tiles, int K, int batch, long long MN, int BK) {
+static int plan_splitk(int tiles, int K, int batch, long long MN, int BK, bool big_tiles) {
     if (batch > 1) return 1;
     static const char* tgt = getenv("EKAID_GEMM_SPLIT_TARGET");   // tuning aid
     const int target = tgt ? atoi(tgt) : 768;     // ~3 workgroups per CU (the register budget admits 3 per SIMD)
     if (tiles * 4 >= target * 3) return 1;
-    if (tiles >= 256 && gemm_mode() == 1) return 1;    // one workgroup per CU already: a 2-way split + reduce kernel measured no faster (256x6656x512: 23 vs 24 us)
+    // 64x64 tiles, one workgroup per CU already: a 2-way split + reduce kernel measured no faster (256x6656x512: 23 vs 24 us).
+    // (128x128 tiles are different: 256 tiles leave two of the three workgroup slots of every CU empty for the whole K
+    // range -- wgrad 1024x4096x18432: 156-162 TF unsplit, 199 TF as 3 x 256 workgroups + reduce)
+    if (tiles >= 256 && gemm_mode() == 1 && !big_tiles) return 1;
     int s = (target + tiles - 1) / tiles;
     const int ksteps = cdiv(K, BK);
     static const char* mk = getenv("EKAID_GEMM_MIN_KSTEPS");     // tuning aid
@@ -969,7 +976,7 @@ static void plan(const ekaid_gemm_t* d, int& TMN, int& splitk, int& tiles_m, int
     const int bn = TMN == 3 ? 64 : (TMN == 4 ? 128 : 64 * TMN);
     tiles_m = cdiv(d->M, bm);
     tiles_n = cdiv(d->N, bn);
-    splitk = plan_splitk(tiles_m * tiles_n, d->K, batch, (long long)d->M * d->N, TMN >= 2 ? BK_BIG : (gemm_mode() == 1 && TMN == 1 ? EKAID_SPLIT_KB_SMALL : BK_SMALL));
+    splitk = plan_splitk(tiles_m * tiles_n, d->K, batch, (long long)d->M * d->N, TMN >= 2 ? BK_BIG : (gemm_mode() == 1 && TMN == 1 ? EKAID_SPLIT_KB_SMALL : BK_SMALL), TMN == 2);
 }
 
 }  // namespace ekaid
