@@ -12,3 +12,5 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_A
   i=$((i+1))
   timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/g$i -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra "$@" > $out/g$i.log 2>&1
 done
+# keep the summaries only: the per-launch traces are tens of MB and gpurun copies back at most 64 MiB
+rm -f $out/trace/*kernel_trace.csv
