@@ -69,12 +69,14 @@ def build(cfg, n_words, vocab):
     return cd, sp
 
 
-def ref_step(cfg, cd, sp, batch, setting, graph):
+def ref_step(cfg, cd, sp, batch, setting, graph, adj_dtype=None):
     """Replay of train_mimic.py:209-247 in eval-with-grad mode."""
     dev = torch.device('cpu')
     N = batch['input_1'].shape[1]
     adj = [ref_mu.process_matrix(batch[k], cfg, N, dev, type=t) for k, t in
            (('d_adj', 'spatial'), ('q_adj', 'spatial'), ('d_sem', 'semantic'), ('q_sem', 'semantic'))]
+    if adj_dtype is not None:
+        adj = [a.to(adj_dtype) for a in adj]       # (one-hot 0/1 values: exact in any float type)
     outs = cd(batch['input_1'], batch['input_2'], adj[0], adj[1], adj[2], adj[3],
               batch['d_bb'], batch['q_bb'], batch['question'], setting=setting, graph=graph)
     pred, att_b, att_a, f_bef, f_aft, f_diff = outs
@@ -251,6 +253,31 @@ def gen_f4():
          argmax=logp[:, :16].argmax(-1), grad_names=np.array(names), grad_rows=rows)
 
 
+def gen_f4_ref64():
+    """F4 again with the REFERENCE modules themselves in float64 (module.double(), float64 inputs): the gradient truth the
+    GPU test measures both float32 paths against -- and a pin of the oracle's float64 run (tests/test_oracle_golden.py)."""
+    import json
+    torch.set_default_dtype(torch.float64)       # tensors the reference creates inside forward (zeros, ones, arange) follow
+    real_float = torch.Tensor.float               # the reference hard-casts two inputs with .float() (graph_att.py:74,
+    torch.Tensor.float = lambda self, *a, **k: self.double()      # graph_att_layer.py:115): widen those casts for this run
+    try:
+        cfg = bench_cfg(D=2048, seq_length=90)
+        cd, sp = build(cfg, 147, 148)
+        cd.double()
+        sp.double()
+        batch = make_batch(B=2, N=36, D=2048, Lq=20, T=16, seq_length=90, V=148)
+        batch = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in batch.items()}
+        loss, sp_loss, outs, logp, logpos, _ = ref_step(cfg, cd, sp, batch, 'mode2', 'all', adj_dtype=torch.float64)
+        assert loss.dtype == torch.float64 and logp.dtype == torch.float64
+        loss.backward()
+        assert all(p.grad is None or p.grad.dtype == torch.float64 for p in list(cd.parameters()) + list(sp.parameters()))
+        names, rows = summarize(named_grads(cd, sp))
+        save('f4_full_ref64', loss=loss, logp=logp[:, :16], grad_names=np.array(names), grad_rows=rows)
+    finally:
+        torch.Tensor.float = real_float
+        torch.set_default_dtype(torch.float32)
+
+
 def gen_keys():
     """state_dict key -> shape of the reference modules (the drop-in contract)."""
     import json
@@ -273,3 +300,4 @@ if __name__ == '__main__':
     gen_f3()
     gen_mode0()
     gen_f4()
+    gen_f4_ref64()

@@ -206,3 +206,25 @@ def test_f4_full_width_spot_check():
                          select=lambda k: not k.endswith('weight_g'))
     assert_summary_close(g['grad_names'], g['grad_rows'], named, 1e-2, 'grads[full, weight_g]',
                          select=lambda k: k.endswith('weight_g'))
+
+
+def test_f4_float64_oracle_agrees_with_float64_reference():
+    """The gradient truth of the full-width check.  f4_full_ref64 = the REFERENCE modules run in float64
+    (tests/golden/make_golden.py: gen_f4_ref64, .float() casts widened), f4_full_f64 = the oracle run in float64
+    (tests/golden/make_f64_truth.py).  They agree three decades below the reference's own float32 error (1e-3 .. 5e-2 on
+    these gradients; the residue is the position-embedding wave-length table, which the float64 reference run builds in
+    float64 and the pipeline -- and the oracle -- in float32), so either bounds the float32 paths; the GPU test uses the
+    reference's."""
+    import json
+    r, o, g32 = load_golden('f4_full_ref64'), load_golden('f4_full_f64'), load_golden('f4_full')
+    assert abs(float(r['loss']) - float(o['loss'])) <= 1e-8 * abs(float(r['loss']))
+    assert np.abs(r['logp'] - o['logp']).max() <= 1e-6
+    names = json.loads(str(o['grad_names']))
+    assert names == json.loads(str(r['grad_names'])) == json.loads(str(g32['grad_names']))
+    R, O, G = r['grad_rows'], o['grad_rows'], g32['grad_rows']
+    floor = 1e-6 * float(np.median(R[:, 0]))
+    live = R[:, 0] > floor                      # (gradients that are mathematically zero -- e.g. the key bias under a softmax -- are noise)
+    rel = np.abs(R[:, 0] - O[:, 0]) / R[:, 0].clip(1e-300)
+    assert live.sum() >= 70 and rel[live].max() <= 5e-5, (np.array(names)[live][np.argsort(-rel[live])[:3]], rel[live].max())
+    ref32 = np.abs(G[:, 0] - R[:, 0]) / R[:, 0].clip(1e-300)
+    assert np.median(ref32[live]) > 20 * np.median(rel[live])        # the float32 reference is far noisier than the gap between the truths
