@@ -13,6 +13,7 @@
 // The kernel is HBM-bound: algorithmic bytes per slice = 3*N*A*4 (q,k,S) + N*H*A*4 (outT) + N*H*M*4 (P).
 #include "common.h"
 #include "../../include/ekaid_hip.h"
+#include <cstdlib>
 
 namespace ekaid {
 
@@ -50,14 +51,20 @@ __global__ __launch_bounds__(256) void gat_fused_fwd_kernel(const float* __restr
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long r = blockIdx.x;
+    // query-node split (gridDim.y parts per slice, used when there are fewer slices than CUs): this workgroup owns nodes
+    // [n_lo, n_lo + NL) -- their affinities, softmax rows and output rows; keys and values are read whole by every part
+    const int n_per = (N + gridDim.y - 1) / gridDim.y;
+    const int n_lo = blockIdx.y * n_per;
+    const int NL = min(N - n_lo, n_per);
+    if (NL <= 0) return;
     const int dh = A / H;
     const float scale = 1.0f / sqrtf((float)dh);
-    const float* qr = q + r * N * A;
+    const float* qr = q + (r * N + n_lo) * A;
     const float* kr = k + r * M * A;           // keys exist for the first M (= nongt) nodes only
     const float* Sr = S + r * N * A;
 
     // ---------------- phase 1: scaled affinities into LDS
-    const int n2 = (N + 1) >> 1, m2 = (M + 1) >> 1, tiles = n2 * m2;
+    const int n2 = (NL + 1) >> 1, m2 = (M + 1) >> 1, tiles = n2 * m2;
     float acc[4][4];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
@@ -66,7 +73,7 @@ __global__ __launch_bounds__(256) void gat_fused_fwd_kernel(const float* __restr
 
     const int dc4 = DC >> 2;
     for (int c0 = 0; c0 < A; c0 += DC) {
-        for (int i = tid; i < N * dc4; i += 256) {
+        for (int i = tid; i < NL * dc4; i += 256) {
             const int row = i / dc4, c4 = i % dc4;
             *reinterpret_cast<f32x4*>(&qs[row * LDC + 4 * c4]) =
                 *reinterpret_cast<const f32x4*>(&qr[(long long)row * A + c0 + 4 * c4]);
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(256) void gat_fused_fwd_kernel(const float* __restr
             const int t = tid + p * 256;
             if (t < tiles) {
                 const int na = 2 * (t / m2), ma = 2 * (t % m2);
-                const int nb = min(na + 1, N - 1), mb = min(ma + 1, M - 1);
+                const int nb = min(na + 1, NL - 1), mb = min(ma + 1, M - 1);
                 const float* qa = qs + na * LDC; const float* qb = qs + nb * LDC;
                 const float* ka = ks + ma * LDC; const float* kb = ks + mb * LDC;
                 for (int d = 0; d < DC; d += 4) {
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(256) void gat_fused_fwd_kernel(const float* __restr
                     const int na = 2 * (t / m2), ma = 2 * (t % m2);
                     aff_s[(na * H + hd) * MP + ma] = acc[p][0] * scale;
                     if (ma + 1 < M) aff_s[(na * H + hd) * MP + ma + 1] = acc[p][1] * scale;
-                    if (na + 1 < N) {
+                    if (na + 1 < NL) {
                         aff_s[((na + 1) * H + hd) * MP + ma] = acc[p][2] * scale;
                         if (ma + 1 < M) aff_s[((na + 1) * H + hd) * MP + ma + 1] = acc[p][3] * scale;
                     }
@@ -123,8 +130,8 @@ __global__ __launch_bounds__(256) void gat_fused_fwd_kernel(const float* __restr
 
     // ---------------- phase 2: edge softmax, one (n,h) row per wave pass, neighbour m on lane m
     const long long ebase = r * N * N;
-    for (int row = wave; row < N * H; row += 4) {
-        const int n = row / H, hd = row % H;
+    for (int row = wave; row < NL * H; row += 4) {
+        const int n = n_lo + row / H, hd = row % H;
         const bool active = lane < M;
         float x = 0.f;
         if (active) {
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256) void gat_fused_fwd_kernel(const float* __restr
                 for (int e = 0; e < VEC; ++e) s[m][e] = 0.f;
             }
         }
-        for (int row = 0; row < N * H; ++row) {
+        for (int row = 0; row < NL * H; ++row) {
             float o[VEC];
 #pragma unroll
             for (int e = 0; e < VEC; ++e) o[e] = 0.f;
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(256) void gat_fused_fwd_kernel(const float* __restr
                         for (int e = 0; e < VEC; ++e) o[e] = fmaf(pw[j], s[m4 + j][e], o[e]);
                 }
             }
-            float* op = outT + ((r * N * H + row) * (long long)A) + cb;
+            float* op = outT + (((r * N + n_lo) * H + row) * (long long)A) + cb;
             if (VEC == 4) {
                 f32x4 v = {o[0], o[1], o[2], o[3]};
                 *reinterpret_cast<f32x4*>(op) = v;
@@ -514,7 +521,11 @@ static int launch_fused(const float* q, const float* k, const float* S, const fl
             }
         }
     }
-    hipLaunchKernelGGL(kern, dim3(R), dim3(256), lds, st, q, k, S, cond, lbias, geo, N, M, A, H, dir, DC, P, outT);
+    // fewer slices than ~1.5 per CU (the strong-scaling batches): split the query nodes of a slice over up to 4 workgroups
+    static const char* force = getenv("EKAID_GAT_PARTS");       // tuning aid
+    int parts = force ? atoi(force) : (R >= 384 ? 1 : (R >= 192 ? 2 : 4));
+    parts = parts < 1 ? 1 : (parts > N ? N : parts);
+    hipLaunchKernelGGL(kern, dim3(R, parts), dim3(256), lds, st, q, k, S, cond, lbias, geo, N, M, A, H, dir, DC, P, outT);
     return check_launch("gat_fused_fwd");
 }
 

@@ -565,6 +565,25 @@ def test_gat_attention_fused_and_composed(N, M, A, H, direction, with_geo):
             check(a, r.float(), 5e-5, '%s %s%s' % (n, impl, ' fused-bwd' if fused_bwd else ''))
 
 
+@pytest.mark.parametrize('R', [1, 5, 200, 400])
+@pytest.mark.parametrize('N,M,A,H', [(9, 7, 64, 2), (36, 36, 128, 4), (3, 3, 32, 1)])
+def test_gat_fused_forward_query_node_split(R, N, M, A, H):
+    """The fused forward splits the query nodes of a slice over 4 / 2 / 1 workgroups depending on the number of slices
+    (R < 192 / < 384 / more): every split equals the composition of batched GEMMs + stand-alone softmax, for node counts
+    that do not divide evenly (9 = 3+3+3+0, 3 = 1+1+1+0) and with both edge orientations."""
+    from ekaid_amd import ops
+    sc = 1.0 / math.sqrt(A / H) ** 0.5
+    q, k, S = rnd(R, N, A, seed=157, scale=sc).to(DEV), rnd(R, M, A, seed=158, scale=sc).to(DEV), rnd(R, N, A, seed=159).to(DEV)
+    cond = (torch.rand(R, N, N) > 0.4).float().to(DEV)
+    lbias = rnd(R, N, N, seed=160, scale=0.3).to(DEV)
+    geo = torch.relu(rnd(R, N, M, H, seed=161)).to(DEV)
+    for direction in (0, 1):
+        out_f, P_f = ops.gat_attention(q, k, S, cond, lbias, geo, H, direction, 'fused')
+        out_g, P_g = ops.gat_attention(q, k, S, cond, lbias, geo, H, direction, 'gemm')
+        check(P_f, P_g.cpu(), 5e-6, 'P split R=%d' % R)
+        check(out_f, out_g.cpu(), 5e-6, 'outT split R=%d' % R)
+
+
 # --------------------------------------------------------------------------- fused decoder-step chains (speaker.hip)
 def _stream():
     from ekaid_amd import hip
