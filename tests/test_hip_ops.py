@@ -532,7 +532,8 @@ def _gat_reference(q, k, S, cond, lbias, geo, H, direction):
 
 
 @pytest.mark.parametrize('N,M,A,H', [(8, 8, 64, 4), (36, 36, 128, 4), (52, 52, 64, 4), (9, 7, 32, 2), (36, 36, 1024, 4),
-                                     (52, 52, 1024, 4), (36, 30, 256, 4), (64, 64, 128, 4), (13, 13, 64, 2), (40, 33, 192, 3)])
+                                     (52, 52, 1024, 4), (36, 30, 256, 4), (64, 64, 128, 4), (13, 13, 64, 2), (40, 33, 192, 3),
+                                     (10, 10, 48, 2), (36, 36, 40, 2)])     # (the last two: width not a multiple of 32 -> vector-ALU aggregation)
 @pytest.mark.parametrize('direction', [0, 1])
 @pytest.mark.parametrize('with_geo', [False, True])
 def test_gat_attention_fused_and_composed(N, M, A, H, direction, with_geo):
