@@ -32,6 +32,7 @@ struct DeviceState {
     std::atomic<int> ready{0};
     std::atomic<int> gemm_mode{-1};
     std::atomic<const unsigned long long*> epoch{nullptr};
+    std::atomic<double*> scratch{nullptr};        // two-stage reduction partials (pointwise.hip), device memory of THIS device
     std::atomic<bool> attr[ATTR_SLOTS];
 };
 static DeviceState g_dev[MAX_DEVICES];
@@ -59,6 +60,17 @@ int gemm_mode() {
 }
 int set_gemm_mode(int mode) { device_state().gemm_mode.store(mode); return EKAID_OK; }
 const unsigned long long* dropout_epoch_ptr() { return device_state().epoch.load(std::memory_order_relaxed); }
+double* device_scratch(size_t bytes) {
+    // allocated once per device (first use, or ekaid_init), on the calling thread's current device; a second thread racing
+    // here frees its own allocation and adopts the winner's
+    DeviceState& s = device_state();
+    double* p = s.scratch.load();
+    if (p) return p;
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    double* expected = nullptr;
+    if (!s.scratch.compare_exchange_strong(expected, p)) { (void)hipFree(p); p = expected; }
+    return p;
+}
 bool func_attr_once(int slot) {
     if (slot < 0 || slot >= ATTR_SLOTS) return true;
     bool expected = false;
@@ -77,7 +89,9 @@ extern "C" int ekaid_init(int device_id) {
         return EKAID_ERR_ARG;
     }
     (void)ekaid::device_state();
+    const bool ok = ekaid::device_scratch(2 * 2048 * sizeof(double)) != nullptr;      // (size: pointwise.hip RED_SLOT)
     (void)hipSetDevice(cur);
+    if (!ok) { ekaid::set_error("ekaid_init: cannot allocate the reduction scratch on device %d", device_id); return EKAID_ERR_LAUNCH; }
     return EKAID_OK;
 }
 extern "C" int ekaid_set_dropout_epoch_ptr(const unsigned long long* epoch_dev) {

@@ -532,17 +532,12 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* p, const float* g,
 }
 
 // scratch for the two-stage weight-norm reductions: per-workgroup partials of sumsq / dot (two slots of 2048 doubles),
-// summed in a fixed order by the finish kernels (deterministic, no atomics, no zero-fill).  One buffer per process
-// (= per device), used by stream-ordered calls on one stream; allocated at first use (outside any graph capture:
-// ekaid_amd.hip warms it up).
+// summed in a fixed order by the finish kernels (deterministic, no atomics, no zero-fill).  One buffer per DEVICE (part
+// of the per-device state, api.hip), shared by the stream-ordered calls of one stream: ekaid_wn_scale_fwd and
+// ekaid_scale_dot must not run concurrently on two streams of the same device.  Allocated by ekaid_init / at first use
+// (outside any graph capture: ekaid_amd.hip warms it up).
 constexpr int RED_SLOT = 2048;
-static double* reduction_scratch() {
-    static double* buf = nullptr;
-    if (!buf) {
-        if (hipMalloc(&buf, 2 * RED_SLOT * sizeof(double)) != hipSuccess) return nullptr;
-    }
-    return buf;
-}
+static double* reduction_scratch() { return device_scratch(2 * RED_SLOT * sizeof(double)); }
 
 }  // namespace ekaid
 
