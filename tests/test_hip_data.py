@@ -76,6 +76,29 @@ def test_entry_scripts_run_on_a_dataset_without_synthetic(data_dir, tmp_path):
     assert res['n'] == n_test == len(rows) and set(rows[0]) == {'caption', 'image_id'}
 
 
+def test_real_data_loop_replayed_from_hip_graphs(data_dir, tmp_path):
+    """train_mimic.py --hip_graph on the HDF5 files: ragged answers give batches with different numbers of decode steps,
+    each captured once (one hipGraph per shape, one shared memory pool) and replayed afterwards.  The replayed run draws
+    its dropout masks from (frozen site seeds, device epoch word) instead of the advancing host seed stream, so it is a
+    different -- equally valid -- sample of the same training process: it must travel as far as an eager run and end at a
+    comparable loss, not at the same weights (mask-for-mask equality is test_graph_replay_equals_eager)."""
+    import train_mimic
+    common = ['--data_dir', data_dir, '--max_iter', '8', '--batch_size', '8', '--snapshot_interval', '100', '--quiet',
+              '--eval_batches', '1', '--seed', '5']
+    w0 = _weights(train_mimic.main(common[:2] + ['--max_iter', '0'] + common[4:] + ['--exp_dir', str(tmp_path / 'w0')]))
+    e1 = train_mimic.main(common + ['--exp_dir', str(tmp_path / 'e1')])
+    g = train_mimic.main(common + ['--exp_dir', str(tmp_path / 'g'), '--hip_graph'])
+    assert g['iteration'] == 8 and np.isfinite(g['last']['total_loss'])
+    assert g['graphs_captured'] >= 2 and e1['graphs_captured'] == 0          # several decode lengths among the 8 batches
+    we1, wg = _weights(e1), _weights(g)
+    rms = lambda x: float(x.pow(2).mean().sqrt())      # noqa: E731
+    travelled_e, travelled_g = rms(we1 - w0), rms(wg - w0)
+    print('real-data loop: rms weight travel eager %.3e, replayed %.3e; apart %.3e; last loss %.4f vs %.4f; %d graphs'
+          % (travelled_e, travelled_g, rms(we1 - wg), e1['last']['total_loss'], g['last']['total_loss'], g['graphs_captured']))
+    assert 0.5 * travelled_e <= travelled_g <= 2.0 * travelled_e and rms(we1 - wg) <= 1.5 * travelled_e
+    assert abs(g['last']['total_loss'] - e1['last']['total_loss']) <= 0.25 * abs(e1['last']['total_loss'])
+
+
 def _weights(out):
     return torch.cat([p.detach().reshape(-1).double().cpu() for m in (out['change_detector'], out['speaker'])
                       for p in m.parameters()])

@@ -303,7 +303,8 @@ def main(argv=None):
     if own_pg:
         dist.destroy_process_group()
     return {'iteration': t, 'epoch': epoch, 'lr': optimizer.lr, 'last': last, 'snapshot_dir': snapshot_dir,
-            'change_detector': change_detector, 'speaker': speaker, 'optimizer': optimizer}
+            'change_detector': change_detector, 'speaker': speaker, 'optimizer': optimizer,
+            'graphs_captured': len(step._graphs)}
 
 
 if __name__ == '__main__':
