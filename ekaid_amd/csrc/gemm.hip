@@ -852,6 +852,109 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? EKAID_SPLIT_OCC_BIG : (TM * TN
     write_tiles<TM, TN>(g, acc, m0, n0, wm, wn, r, h, z);
 }
 
+// ---- tall-skinny wgrad: C[M][N] = A^T . B with M * N <= 256 outputs and a very long contraction (the label-bias and
+// pair-geometry layers: 1 x 11 and 4 x 64 outputs over K = R * N * N = 663 552 rows at B = 256).  As a tiled GEMM this is one
+// 64x64 tile cut into ~770 K slabs with scalar operand loads (M, N not multiples of 4): 113-146 us for 30-180 MB.  Here:
+// thread (row lane rl, output o) of a workgroup walks its K chunk with stride RL = 256 / NO (NO = outputs rounded up to a
+// power of two), so a wave reads RL consecutive rows of both operands (contiguous memory); lanes are combined through LDS,
+// workgroup partials by a fixed-order finish kernel (deterministic, no atomics).
+__global__ __launch_bounds__(256) void tn_skinny_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                        int M, int N, int K, int rows_per_wg, int NO, float* __restrict__ partial) {
+    __shared__ float sm[256];
+    const int tid = threadIdx.x;
+    const int o = tid & (NO - 1), rl = tid / NO, RL = 256 / NO;
+    const int MN = M * N;
+    const int m = o < MN ? o / N : 0, n = o < MN ? o % N : 0;
+    const int k0 = blockIdx.x * rows_per_wg, k1 = min(K, k0 + rows_per_wg);
+    const float* ap = A + (long long)(k0 + rl) * lda + m;
+    const float* bp = B + (long long)(k0 + rl) * ldb + n;
+    const long long sa = (long long)RL * lda, sb = (long long)RL * ldb;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = k0 + rl;
+    for (; k + 3 * RL < k1; k += 4 * RL) {          // four independent row pairs in flight
+        const float a0 = ap[0], a1 = ap[sa], a2 = ap[2 * sa], a3 = ap[3 * sa];
+        const float b0 = bp[0], b1 = bp[sb], b2 = bp[2 * sb], b3 = bp[3 * sb];
+        s0 = fmaf(a0, b0, s0); s1 = fmaf(a1, b1, s1); s2 = fmaf(a2, b2, s2); s3 = fmaf(a3, b3, s3);
+        ap += 4 * sa; bp += 4 * sb;
+    }
+    for (; k < k1; k += RL) { s0 = fmaf(ap[0], bp[0], s0); ap += sa; bp += sb; }
+    sm[tid] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (tid < NO) {
+        float s = 0.f;
+        for (int q = 0; q < RL; ++q) s += sm[q * NO + tid];
+        if (tid < MN) partial[(long long)blockIdx.x * MN + tid] = s;
+    }
+}
+// M <= 4 with a wide N: thread (row lane, n) keeps all M outputs of column n -- every B word is loaded once per workgroup
+// (the one-output-per-thread mapping above makes the M waves of a workgroup fetch the same B row)
+template <int MT>
+__global__ __launch_bounds__(256) void tn_skinny_cols_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                             int M, int N, int K, int rows_per_wg, int NO, float* __restrict__ partial) {
+    __shared__ float sm[MT][256];
+    const int tid = threadIdx.x;
+    const int n = tid & (NO - 1), rl = tid / NO, RL = 256 / NO;
+    const int nc = n < N ? n : 0;
+    const int k0 = blockIdx.x * rows_per_wg, k1 = min(K, k0 + rows_per_wg);
+    const float* ap = A + (long long)(k0 + rl) * lda;
+    const float* bp = B + (long long)(k0 + rl) * ldb + nc;
+    const long long sa = (long long)RL * lda, sb = (long long)RL * ldb;
+    float s[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) s[m][0] = s[m][1] = 0.f;
+    int k = k0 + rl;
+    for (; k + 3 * RL < k1; k += 4 * RL) {
+        float b[4], a[4][MT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            b[u] = bp[u * sb];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[u][m] = m < M ? ap[u * sa + m] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) s[m][u & 1] = fmaf(a[u][m], b[u], s[m][u & 1]);
+        ap += 4 * sa; bp += 4 * sb;
+    }
+    for (; k < k1; k += RL) {
+        const float b0 = bp[0];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) s[m][0] = fmaf(m < M ? ap[m] : 0.f, b0, s[m][0]);
+        ap += sa; bp += sb;
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) sm[m][tid] = s[m][0] + s[m][1];
+    __syncthreads();
+    if (tid < NO && tid < N) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (m < M) {
+                float t = 0.f;
+                for (int q = 0; q < RL; ++q) t += sm[m][q * NO + tid];
+                partial[(long long)blockIdx.x * M * N + m * N + tid] = t;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void tn_skinny_finish_kernel(const float* __restrict__ partial, int G, int MN, int N, float* C, int ldc,
+                                                               float alpha, int accumulate) {
+    __shared__ float sm[256];
+    const int o = blockIdx.x, tid = threadIdx.x;
+    float s = 0.f;
+    for (int gidx = tid; gidx < G; gidx += 256) s += partial[(long long)gidx * MN + o];
+    sm[tid] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) sm[tid] += sm[tid + w];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float* cp = C + (long long)(o / N) * ldc + o % N;
+        *cp = alpha * sm[0] + (accumulate ? *cp : 0.f);
+    }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, float* C, int M, int N, int ldc,
                                                             int splitk, Epi e) {
     const long long total = (long long)M * N;
@@ -979,6 +1082,25 @@ static void plan(const ekaid_gemm_t* d, int& TMN, int& splitk, int& tiles_m, int
     splitk = plan_splitk(tiles_m * tiles_n, d->K, batch, (long long)d->M * d->N, TMN >= 2 ? BK_BIG : (gemm_mode() == 1 && TMN == 1 ? EKAID_SPLIT_KB_SMALL : BK_SMALL), TMN == 2);
 }
 
+// shapes of tn_skinny_kernel: (workgroups, outputs rounded up to a power of two), or false
+static bool skinny_tn(const ekaid_gemm_t* d, int& G, int& NO) {
+    const char* e = getenv("EKAID_GEMM_SKINNY");         // tuning aid / A-B tests: 0 = tiled kernels only
+    if (e && e[0] == '0') return false;
+    const long long MN = (long long)d->M * d->N;
+    if (!d->transA || d->transB || d->batch1 * d->batch2 != 1 || MN > 256 || d->K < 8192 || d->bias || d->R || d->act != 0 ||
+        d->drop_p > 0.f || d->alpha_dev)
+        return false;
+    NO = 16;
+    if (d->M <= 4 && d->N >= 32) {               // tn_skinny_cols_kernel: NO = columns rounded up
+        while (NO < d->N) NO <<= 1;
+    } else {
+        while (NO < MN) NO <<= 1;
+    }
+    G = d->K / ((NO >= 128 || (d->M <= 4 && d->N >= 32)) ? 128 : 512);     // few row lanes per workgroup: shorter chunks, more workgroups
+    G = G > 4096 ? 4096 : (G < 1 ? 1 : G);
+    return true;
+}
+
 }  // namespace ekaid
 
 using namespace ekaid;
@@ -992,6 +1114,10 @@ extern "C" int ekaid_get_gemm_mode(void) { return gemm_mode(); }
 extern "C" size_t ekaid_gemm_workspace_bytes(const ekaid_gemm_t* d) {
     if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
     int TMN, splitk, tm, tn;
+    {
+        int G, NO;
+        if (skinny_tn(d, G, NO)) return (size_t)G * d->M * d->N * sizeof(float);
+    }
     plan(d, TMN, splitk, tm, tn);
     return splitk > 1 ? (size_t)splitk * d->M * d->N * sizeof(float) : 0;
 }
@@ -1006,6 +1132,26 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     if (d->rdiv < 1 && d->R) { set_error("ekaid_gemm_f32: rdiv must be >= 1"); return EKAID_ERR_ARG; }
     if (d->M == 0 || d->N == 0) return EKAID_OK;
     hipStream_t st = (hipStream_t)stream;
+    {
+        int G, NO;
+        if (skinny_tn(d, G, NO)) {
+            const size_t need = (size_t)G * d->M * d->N * sizeof(float);
+            if (!workspace || workspace_bytes < need) {
+                set_error("ekaid_gemm_f32: workspace too small (%zu < %zu)", workspace_bytes, need);
+                return EKAID_ERR_ARG;
+            }
+            const int rows_per_wg = cdiv(d->K, G);
+            if (d->M <= 4 && d->N >= 32)
+                hipLaunchKernelGGL(tn_skinny_cols_kernel<4>, dim3(cdiv(d->K, rows_per_wg)), dim3(256), 0, st, d->A, d->lda, d->B, d->ldb,
+                                   d->M, d->N, d->K, rows_per_wg, NO, (float*)workspace);
+            else
+                hipLaunchKernelGGL(tn_skinny_kernel, dim3(cdiv(d->K, rows_per_wg)), dim3(256), 0, st, d->A, d->lda, d->B, d->ldb, d->M, d->N,
+                                   d->K, rows_per_wg, NO, (float*)workspace);
+            hipLaunchKernelGGL(tn_skinny_finish_kernel, dim3(d->M * d->N), dim3(256), 0, st, (const float*)workspace,
+                               cdiv(d->K, rows_per_wg), d->M * d->N, d->N, d->C, d->ldc, d->alpha, d->accumulate);
+            return check_launch("tn_skinny_kernel");
+        }
+    }
     GemmArgs a;
     a.A = d->A; a.B = d->B; a.C = d->C;
     a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;

@@ -235,6 +235,30 @@ def test_gemm_splitk_path_is_exercised():
     check(C, A.double() @ W.double().t() + rnd(64, seed=12).double(), 4e-6, 'split-K + bias')
 
 
+@pytest.mark.parametrize('M,N,K', [(1, 11, 70001), (4, 64, 100000), (3, 5, 8192), (16, 16, 9000), (1, 1, 33000), (2, 128, 20000)])
+def test_gemm_tall_skinny_weight_gradient(M, N, K, gemm_arith):
+    """C[M][N] = A^T . B with at most 256 outputs and a very long contraction (label-bias / pair-geometry weight gradients,
+    graph_att.py:92, graph_att_layer.py:121): dedicated reduction kernels, deterministic, with alpha and accumulate."""
+    from ekaid_amd import ops
+    A, B = rnd(K, M, seed=41).to(DEV), rnd(K, N, seed=42).to(DEV)
+    C0 = rnd(M, N, seed=43).to(DEV)
+    want = A.double().t() @ B.double()
+    C = torch.empty(M, N, device=DEV)
+    ops.gemm(A, B, C, M, N, K, M, N, N, 1, 0)
+    check(C, want.cpu(), 3e-6, 'tall-skinny wgrad')
+    C2 = torch.empty(M, N, device=DEV)
+    ops.gemm(A, B, C2, M, N, K, M, N, N, 1, 0)
+    assert torch.equal(C, C2)                                   # fixed summation order
+    Cacc = C0.clone()
+    ops.gemm(A, B, Cacc, M, N, K, M, N, N, 1, 0, alpha=0.5, accumulate=True)
+    check(Cacc, (0.5 * want + C0.double()).cpu(), 3e-6, 'tall-skinny wgrad, alpha + accumulate')
+    # a column block of wider operands (leading dimensions larger than the extents)
+    Aw, Bw = rnd(K, M + 3, seed=44).to(DEV), rnd(K, N + 5, seed=45).to(DEV)
+    Cs = torch.empty(M, N, device=DEV)
+    ops.gemm(Aw, Bw, Cs, M, N, K, M + 3, N + 5, N, 1, 0, a_off=2, b_off=1)
+    check(Cs, (Aw[:, 2:2 + M].double().t() @ Bw[:, 1:1 + N].double()).cpu(), 3e-6, 'tall-skinny wgrad on views')
+
+
 def test_gemm_rejects_bad_args():
     from ekaid_amd import hip, ops
     A = torch.zeros(4, 4, device=DEV)
