@@ -71,11 +71,19 @@ class TrainStep:
         self.marks = None
 
     def close(self):
-        """Drop the captured graphs and detach the dropout epoch word from the library."""
+        """Drop the captured graphs and detach the dropout epoch word from the library.  Must run before the object goes
+        away: the library would otherwise keep folding a freed device word into every dropout seed of later (eager) runs."""
         self._graphs = {}
         if self._epoch is not None:
             hip.check(hip.lib().ekaid_set_dropout_epoch_ptr(None), 'set_dropout_epoch_ptr')
             self._epoch = None
+
+    def __del__(self):
+        try:
+            if getattr(self, '_epoch', None) is not None:
+                hip.lib().ekaid_set_dropout_epoch_ptr(None)
+        except Exception:       # noqa: BLE001  (interpreter shutdown)
+            pass
 
     # ------------------------------------------------------------------ eager
     def _eager(self, b, T, denom):

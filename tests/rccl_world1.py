@@ -53,13 +53,15 @@ def main(out_path):
         w = torch.cat([p.detach().reshape(-1).double() for p in list(cd.parameters()) + list(sp.parameters())])
         return w, len(opt.buckets)
     rms = lambda x: float(x.pow(2).mean().sqrt())       # noqa: E731
+    cd0, sp0 = build_models(cfg, 147, 148, 'cuda', train=True)
+    w0 = torch.cat([p.detach().reshape(-1).double() for p in list(cd0.parameters()) + list(sp0.parameters())])
     base, _ = run(False, False, 'captured')
     base2, _ = run(False, False, 'captured')            # yardstick: run-to-run float-atomic noise (amplified by Adam)
     eager, nb = run(True, False, 'captured')            # hook-driven async all-reduce per bucket + wait + Adam
     n_eager = calls['n']
     graph, _ = run(True, True, 'captured')              # the same inside the captured graph
     graph2, _ = run(True, True, 'eager')                # graph for forward/backward, collectives + Adam after the replay
-    json.dump({'buckets': nb, 'collectives': n_eager, 'noise': rms(base - base2), 'delta_eager': rms(base - eager),
+    json.dump({'buckets': nb, 'collectives': n_eager, 'noise': rms(base - base2), 'travel': rms(base - w0), 'delta_eager': rms(base - eager),
                'delta_graph': max(rms(base - graph), rms(base - graph2))}, open(out_path, 'w'))
     dist.destroy_process_group()
 

@@ -97,6 +97,9 @@ def test_real_data_loop_replayed_from_hip_graphs(data_dir, tmp_path):
           % (travelled_e, travelled_g, rms(we1 - wg), e1['last']['total_loss'], g['last']['total_loss'], g['graphs_captured']))
     assert 0.5 * travelled_e <= travelled_g <= 2.0 * travelled_e and rms(we1 - wg) <= 1.5 * travelled_e
     assert abs(g['last']['total_loss'] - e1['last']['total_loss']) <= 0.25 * abs(e1['last']['total_loss'])
+    # the replayed run detaches its dropout epoch word when it ends: an eager run afterwards draws the masks of the first one
+    e2 = train_mimic.main(common + ['--exp_dir', str(tmp_path / 'e2')])
+    assert rms(_weights(e2) - we1) <= 0.2 * travelled_e, 'an eager run after a --hip_graph run does not reproduce the earlier eager run'
 
 
 def _weights(out):
@@ -128,8 +131,11 @@ def test_resumed_run_continues_the_uninterrupted_run(tmp_path, stop):
     rms = lambda x: float(x.pow(2).mean().sqrt())      # noqa: E731
     print('resume at %d: max |dw| resumed vs straight %.3e (two straight runs: %.3e; travelled after the snapshot %.3e); '
           'rms %.3e vs %.3e' % (stop, drift, noise, moved, rms(wa - wb), rms(wa - wa2)))
-    assert drift <= 4.0 * noise + 1e-9 and rms(wa - wb) <= 4.0 * rms(wa - wa2) + 1e-12
-    assert rms(wa - wb) < 0.05 * rms(wa - _weights(b1))
+    # band: 4 x the noise of two straight runs (one sample of a noisy quantity) + 2 % of the distance travelled after the
+    # snapshot (a lost moment / epoch / seed moves the weights by tens of percent of it)
+    travel = rms(wa - _weights(b1))
+    assert drift <= 4.0 * noise + 0.02 * moved + 1e-9 and rms(wa - wb) <= 4.0 * rms(wa - wa2) + 0.02 * travel + 1e-12
+    assert rms(wa - wb) < 0.05 * travel
     assert a['last']['total_loss'] == pytest.approx(b2['last']['total_loss'], rel=1e-4)
 
 
@@ -178,7 +184,10 @@ def test_graph_replay_equals_eager():
     print('graph vs eager: rms dw %.3e (eager vs eager %.3e), max dloss %.3e (eager vs eager %.3e)' % (d_w, noise_w, d_l, noise_l))
     assert losses[0][0] == pytest.approx(losses[2][0], rel=1e-6)
     assert len(set(losses[2])) == 3
-    assert d_w <= 4 * noise_w + 1e-9 and d_l <= 4 * noise_l + 2e-5 * abs(losses[0][-1])
+    cd0, sp0 = build_models(cfg, 147, 148, 'cuda', train=True)
+    w0 = torch.cat([p.detach().reshape(-1).double().cpu() for p in list(cd0.parameters()) + list(sp0.parameters())])
+    travel = rms(finals[0] - w0)
+    assert d_w <= 4 * noise_w + 0.02 * travel + 1e-9 and d_l <= 4 * noise_l + 2e-5 * abs(losses[0][-1])
 
 
 def test_rccl_path_on_one_gpu(tmp_path):
@@ -201,4 +210,9 @@ def test_rccl_path_on_one_gpu(tmp_path):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     out = json.load(open(str(tmp_path / 'out.json')))
     assert out['buckets'] > 1 and out['collectives'] > 0
-    assert out['delta_eager'] <= 4 * out['noise'] + 1e-9 and out['delta_graph'] <= 4 * out['noise'] + 1e-9, out
+    # band: 4 x the run-to-run noise of two collective-free runs + 15 % of the distance the weights travelled.  The noise
+    # is heavy-tailed (float atomics reorder sums; Adam turns a noise-level gradient -- parameters whose true gradient is
+    # zero -- into a +-lr step: measured 1.5e-5 ... 3.7e-4 between identical runs, deltas 6e-5 ... 3.8e-4, travel 1.5e-3);
+    # a corrupted or mis-scaled reduction moves the weights by ~100 % of the travel
+    band = 4 * out['noise'] + 0.15 * out['travel'] + 1e-9
+    assert out['delta_eager'] <= band and out['delta_graph'] <= band, out

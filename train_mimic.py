@@ -300,11 +300,13 @@ def main(argv=None):
         i0 = 0
         epoch += 1
     torch.cuda.synchronize()
+    graphs_captured = len(step._graphs)
+    step.close()            # drop the captured graphs and detach the dropout epoch word from the library (it dies with this run)
     if own_pg:
         dist.destroy_process_group()
     return {'iteration': t, 'epoch': epoch, 'lr': optimizer.lr, 'last': last, 'snapshot_dir': snapshot_dir,
             'change_detector': change_detector, 'speaker': speaker, 'optimizer': optimizer,
-            'graphs_captured': len(step._graphs)}
+            'graphs_captured': graphs_captured}
 
 
 if __name__ == '__main__':
