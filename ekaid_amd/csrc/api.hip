@@ -89,7 +89,7 @@ extern "C" int ekaid_init(int device_id) {
         return EKAID_ERR_ARG;
     }
     (void)ekaid::device_state();
-    const bool ok = ekaid::device_scratch(2 * 2048 * sizeof(double)) != nullptr;      // (size: pointwise.hip RED_SLOT)
+    const bool ok = ekaid::device_scratch(ekaid::EKAID_SCRATCH_BYTES) != nullptr;
     (void)hipSetDevice(cur);
     if (!ok) { ekaid::set_error("ekaid_init: cannot allocate the reduction scratch on device %d", device_id); return EKAID_ERR_LAUNCH; }
     return EKAID_OK;

@@ -22,6 +22,7 @@ DeviceState& device_state();                       // of the calling thread's cu
 int gemm_mode();                                   // 0 = f32 MFMA, 1 = exact bf16 split (per device)
 int set_gemm_mode(int mode);
 const unsigned long long* dropout_epoch_ptr();     // device word folded into every dropout seed, or NULL
+constexpr size_t EKAID_SCRATCH_BYTES = 2 * 2048 * sizeof(double) + (size_t(1) << 20);    // reduction slots + column-sum partials (pointwise.hip)
 double* device_scratch(size_t bytes);              // per-device reduction scratch (allocated at first use / by ekaid_init), or NULL
 bool func_attr_once(int slot);                     // true exactly once per (device, slot): "raise the LDS limit" bookkeeping
 

@@ -75,7 +75,10 @@ __global__ __launch_bounds__(256) void scale_finish_kernel(float* G, const float
 // ------------------------------------------------------------------ reductions
 // column sums of [M][N]: one thread per column (coalesced rows), four independent accumulators so four row loads are
 // in flight per lane; the grid is cut along rows so that ~1024 workgroups stream concurrently; partial sums by atomics
-template <bool ATOMIC>
+// PART = false: one row block, plain store.  PART = true: row block y writes its partial sums to partial[y][N]; colsum_finish_kernel
+// adds the partials in block order (fixed order: the result does not depend on scheduling -- float atomics made two runs of
+// the same step differ in the last bits of every bias gradient, which Adam amplifies into visibly different weights).
+template <bool PART>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* x, int M, int N, int ldx, float* out, int rows_per_blk) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
@@ -89,8 +92,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* x, int M, int 
         p += 4 * (long long)ldx;
     }
     for (; r < r1; ++r) { s0 += p[0]; p += ldx; }
-    if (ATOMIC) atomicAdd(out + n, (s0 + s1) + (s2 + s3));
+    if (PART) out[(long long)blockIdx.y * N + n] = (s0 + s1) + (s2 + s3);
     else out[n] = (s0 + s1) + (s2 + s3);
+}
+// 64 columns x 4 partial lanes per workgroup: lane q adds partials q, q+4, ... (eight loads in flight), the four lane sums are
+// combined in lane order
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, int nparts, int N, float* out, int accumulate) {
+    __shared__ float sm[4][64];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    float s0 = 0.f, s1 = 0.f;
+    if (n < N) {
+        int p = q;
+        for (; p + 28 < nparts; p += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(long long)(p + 4 * u) * N + n];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { if (u & 1) s1 += v[u]; else s0 += v[u]; }
+        }
+        for (; p < nparts; p += 4) s0 += partial[(long long)p * N + n];
+    }
+    sm[q][c] = s0 + s1;
+    __syncthreads();
+    if (q == 0 && n < N) {
+        const float v = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+        out[n] = accumulate ? out[n] + v : v;
+    }
 }
 __global__ __launch_bounds__(256) void rowsum_short_kernel(const float* x, long long rows, int cols, float* out, int as_mask) {
     GS_LOOP(r, rows) {                          // short rows (one-hot label channels): one thread per row
@@ -306,18 +334,65 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* tok, 
         out[t * ld_out + col_off + e] = v;
     }
 }
-__global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* tok, long long ntok, const float* table,
-                                                            const float* dout, int E, int ld_out, int col_off, int relu,
-                                                            long long padding_idx, float* dtable) {
-    const long long n = ntok * E;
+// dtable[id] += sum over the positions t with tok[t] == id, in position order.  One WAVE per (table row, 64 columns): the
+// wave reads 64 token ids at a time (next chunk's load in flight), ballots the matches and walks the set bits in order --
+// no LDS, no barrier, no float atomics; lane = column.
+__global__ __launch_bounds__(64) void embedding_bwd_kernel(const int64_t* tok, long long ntok, const float* table,
+                                                           const float* dout, int E, int ld_out, int col_off, int relu,
+                                                           long long padding_idx, float* dtable) {
+    constexpr int U = 16;                            // 16 x 64 token ids per round: sixteen independent loads per lane
+    const int64_t id = blockIdx.x;
+    if (id == padding_idx) return;
+    const int lane = threadIdx.x;
+    const int e = blockIdx.y * 64 + lane;
+    const bool col = e < E;
+    const bool live = col && (!relu || table[id * E + e] > 0.f);
+    const float* dcol = dout + col_off + (col ? e : 0);
+    float acc = 0.f;
+    for (long long sbase = 0; sbase < ntok; sbase += 64 * U) {
+        bool hit[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long t = sbase + 64 * u + lane;
+            hit[u] = t < ntok && tok[t] == id;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            unsigned long long m = __ballot(hit[u]);                 // uniform over the wave
+            const float* rowbase = dcol + (sbase + 64 * u) * ld_out;
+            while (m) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                        // up to four row loads in flight, added in position order
+                    if (m) {
+                        const int bpos = __builtin_ctzll(m);
+                        m &= m - 1;
+                        v[q] = rowbase[(long long)bpos * ld_out];
+                    }
+                }
+                acc += v[0]; acc += v[1]; acc += v[2]; acc += v[3];
+            }
+        }
+    }
+    if (live && acc != 0.f) dtable[id * E + e] += acc;
+}
+
+// one-hot rows of the token ids (padding rows all zero): the A operand of  dtable = OneHot^T . dout  (a deterministic
+// split-K GEMM whose cost does not depend on how skewed the id distribution is -- padding / '<start>' ids hit thousands of
+// positions, which a per-row scan serialises)
+__global__ __launch_bounds__(256) void onehot_kernel(const int64_t* tok, long long ntok, int V, long long padding_idx, float* out) {
+    const long long n = ntok * V;
     GS_LOOP(i, n) {
-        const long long t = i / E;
-        const int e = (int)(i % E);
+        const long long t = i / V;
+        const int v = (int)(i % V);
         const int64_t id = tok[t];
-        if (id == padding_idx) continue;
-        float d = dout[t * ld_out + col_off + e];
-        if (relu && !(table[id * E + e] > 0.f)) d = 0.f;
-        atomicAdd(dtable + id * E + e, d);
+        out[i] = (id == v && id != padding_idx) ? 1.f : 0.f;
+    }
+}
+// dtable += raw * (relu ? table > 0 : 1)
+__global__ __launch_bounds__(256) void masked_add_kernel(const float* raw, const float* table, int relu, float* dtable, long long n) {
+    GS_LOOP(i, n) {
+        if (!relu || table[i] > 0.f) dtable[i] += raw[i];
     }
 }
 
@@ -389,20 +464,38 @@ __global__ __launch_bounds__(256) void mix3_bwd_kernel(const float* w, const flo
 }
 
 // ------------------------------------------------------------------ masked NLL
-__global__ __launch_bounds__(256) void nll_fwd_kernel(const float* logp, const int64_t* target, int ld_t, const float* mask,
-                                                      int ld_m, int B, int T, int V, float* sums) {
+// one workgroup (B * T <= a few ten thousand terms): strided partial sums, fixed-order tree -- deterministic; the division by
+// the (optionally external) denominator is folded in
+__global__ __launch_bounds__(1024) void nll_fwd_kernel(const float* logp, const int64_t* target, int ld_t, const float* mask,
+                                                       int ld_m, int B, int T, int V, const float* denom, float* sums, float* loss) {
+    __shared__ float ss[1024], sm[1024];
     float s = 0.f, ms = 0.f;
     const long long n = (long long)B * T;
-    GS_LOOP(i, n) {
-        const long long b = i / T;
-        const int t = (int)(i % T);
-        const float mk = mask[b * ld_m + t];
-        const int64_t tg = target[b * ld_t + t];
-        s -= logp[(b * T + t) * V + tg] * mk;
-        ms += mk;
+    for (long long i0 = threadIdx.x; i0 < n; i0 += 4 * 1024) {          // four independent gathers in flight per thread
+        float lp[4], mk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long i = i0 + u * 1024;
+            const bool ok = i < n;
+            const long long b = ok ? i / T : 0;
+            const int t = ok ? (int)(i % T) : 0;
+            mk[u] = ok ? mask[b * ld_m + t] : 0.f;
+            lp[u] = logp[(b * T + t) * V + target[b * ld_t + t]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s -= lp[u] * mk[u]; ms += mk[u]; }
     }
-    s = wave_sum(s); ms = wave_sum(ms);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(sums, s); atomicAdd(sums + 1, ms); }
+    ss[threadIdx.x] = s; sm[threadIdx.x] = ms;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) { ss[threadIdx.x] += ss[threadIdx.x + w]; sm[threadIdx.x] += sm[threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sums[0] = ss[0];
+        sums[1] = denom ? denom[0] : sm[0];
+        loss[0] = sums[0] / sums[1];
+    }
 }
 __global__ __launch_bounds__(256) void nll_bwd_kernel(const int64_t* target, int ld_t, const float* mask, int ld_m,
                                                       const float* sums, const float* gscale, int B, int T, int V, float* dlogp) {
@@ -419,10 +512,6 @@ __global__ __launch_bounds__(256) void nll_bwd_kernel(const int64_t* target, int
 
 // denom (optional): replaces the local sum of the mask -- the global-batch mask sum / world size under data parallelism,
 // so that the average of the per-rank losses is the reference's loss over the global batch (utils/utils.py:213-214)
-__global__ void nll_finish_kernel(float* sums, const float* denom, float* loss) {
-    if (denom) sums[1] = denom[0];
-    loss[0] = sums[0] / sums[1];
-}
 __global__ __launch_bounds__(256) void total_loss_kernel(const float* sl, const float* a, const float* b, long long n, float coef,
                                                          float* out) {
     float s = 0.f;
@@ -532,12 +621,14 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* p, const float* g,
 }
 
 // scratch for the two-stage weight-norm reductions: per-workgroup partials of sumsq / dot (two slots of 2048 doubles),
-// summed in a fixed order by the finish kernels (deterministic, no atomics, no zero-fill).  One buffer per DEVICE (part
-// of the per-device state, api.hip), shared by the stream-ordered calls of one stream: ekaid_wn_scale_fwd and
-// ekaid_scale_dot must not run concurrently on two streams of the same device.  Allocated by ekaid_init / at first use
+// summed in a fixed order by the finish kernels (deterministic, no atomics, no zero-fill), followed by the row-block
+// partials of the column sums.  One buffer per DEVICE (part of the per-device state, api.hip), shared by the stream-ordered
+// calls of one stream: ekaid_wn_scale_fwd, ekaid_scale_dot and ekaid_colsum(_acc) must not run concurrently on two streams
+// of the same device.  Allocated by ekaid_init / at first use
 // (outside any graph capture: ekaid_amd.hip warms it up).
 constexpr int RED_SLOT = 2048;
-static double* reduction_scratch() { return device_scratch(2 * RED_SLOT * sizeof(double)); }
+constexpr long long COLSUM_PART_FLOATS = 1 << 18;       // column-sum partials [row blocks][N] behind the two reduction slots (1 MiB)
+static double* reduction_scratch() { return device_scratch(EKAID_SCRATCH_BYTES); }
 
 }  // namespace ekaid
 
@@ -567,31 +658,28 @@ extern "C" int ekaid_scale_dot(float* G, const float* w, const float* scale_dev,
                        dot_out);
     return check_launch("scale_dot");
 }
-extern "C" int ekaid_colsum(const float* x, int M, int N, int ldx, float* out, void* stream) {
+// column sums: one row block -> plain store; several -> per-block partials in the per-device scratch + fixed-order finish
+static int colsum_impl(const float* x, int M, int N, int ldx, float* out, int accumulate, hipStream_t st) {
     if (N <= 0) return EKAID_OK;
-    if (M <= 0) { (void)hipMemsetAsync(out, 0, sizeof(float) * N, ST); return EKAID_OK; }
+    if (M <= 0) { if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * N, st); return EKAID_OK; }
     const int colblks = cdiv(N, 256);
-    int rows_per_blk = (int)(((long long)M * colblks + 1023) / 1024);
-    rows_per_blk = rows_per_blk < 8 ? 8 : rows_per_blk;
-    const int nparts = cdiv(M, rows_per_blk);
-    if (nparts == 1) {                      // one row block: plain stores, no zero-fill
-        hipLaunchKernelGGL((colsum_kernel<false>), dim3(colblks, 1), dim3(256), 0, ST, x, M, N, ldx, out, rows_per_blk);
+    int rows_per_blk = (int)(((long long)M * colblks + 511) / 512);          // ~512 workgroups stream the matrix
+    rows_per_blk = rows_per_blk < 16 ? 16 : rows_per_blk;
+    int nparts = cdiv(M, rows_per_blk);
+    while ((long long)nparts * N > COLSUM_PART_FLOATS) { rows_per_blk *= 2; nparts = cdiv(M, rows_per_blk); }     // (very wide N)
+    if (nparts == 1 && !accumulate) {
+        hipLaunchKernelGGL((colsum_kernel<false>), dim3(colblks, 1), dim3(256), 0, st, x, M, N, ldx, out, rows_per_blk);
         return check_launch("colsum");
     }
-    // several row blocks: float atomics into a zeroed output (a two-stage fixed-order sum was measured 5 % slower end
-    // to end: its finish kernel is a chain of dependent partial loads on a handful of workgroups)
-    (void)hipMemsetAsync(out, 0, sizeof(float) * N, ST);
-    hipLaunchKernelGGL((colsum_kernel<true>), dim3(colblks, nparts), dim3(256), 0, ST, x, M, N, ldx, out, rows_per_blk);
+    double* scr = reduction_scratch();
+    if (!scr) { set_error("colsum: scratch alloc failed"); return EKAID_ERR_LAUNCH; }
+    float* partial = reinterpret_cast<float*>(scr + 2 * RED_SLOT);
+    hipLaunchKernelGGL((colsum_kernel<true>), dim3(colblks, nparts), dim3(256), 0, st, x, M, N, ldx, partial, rows_per_blk);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(N, 64)), dim3(256), 0, st, (const float*)partial, nparts, N, out, accumulate);
     return check_launch("colsum");
 }
-extern "C" int ekaid_colsum_acc(const float* x, int M, int N, int ldx, float* out, void* stream) {
-    if (N <= 0 || M <= 0) return EKAID_OK;
-    const int colblks = cdiv(N, 256);
-    int rows_per_blk = (int)(((long long)M * colblks + 1023) / 1024);
-    rows_per_blk = rows_per_blk < 8 ? 8 : rows_per_blk;
-    hipLaunchKernelGGL((colsum_kernel<true>), dim3(colblks, cdiv(M, rows_per_blk)), dim3(256), 0, ST, x, M, N, ldx, out, rows_per_blk);
-    return check_launch("colsum_acc");
-}
+extern "C" int ekaid_colsum(const float* x, int M, int N, int ldx, float* out, void* stream) { return colsum_impl(x, M, N, ldx, out, 0, ST); }
+extern "C" int ekaid_colsum_acc(const float* x, int M, int N, int ldx, float* out, void* stream) { return colsum_impl(x, M, N, ldx, out, 1, ST); }
 extern "C" int ekaid_sum_n(const float* const* xs, int k, float* out, long long n, void* stream) {
     if (k < 1 || k > 8 || !xs) { set_error("sum_n: 1 <= k <= 8 addends (got %d)", k); return EKAID_ERR_ARG; }
     if (n <= 0) return EKAID_OK;
@@ -694,11 +782,22 @@ extern "C" int ekaid_embedding_fwd(const int64_t* tok, long long ntok, const flo
     hipLaunchKernelGGL(embedding_fwd_kernel, grid1d(ntok * E), dim3(256), 0, ST, tok, ntok, table, E, out, ld_out, col_off, relu);
     return check_launch("embedding_fwd");
 }
-extern "C" int ekaid_embedding_bwd(const int64_t* tok, long long ntok, const float* table, const float* dout, int E, int ld_out,
-                                   int col_off, int relu, long long padding_idx, float* dtable, void* stream) {
-    hipLaunchKernelGGL(embedding_bwd_kernel, grid1d(ntok * E), dim3(256), 0, ST, tok, ntok, table, dout, E, ld_out, col_off, relu,
-                       padding_idx, dtable);
+extern "C" int ekaid_embedding_bwd(const int64_t* tok, long long ntok, const float* table, int vocab, const float* dout, int E,
+                                   int ld_out, int col_off, int relu, long long padding_idx, float* dtable, void* stream) {
+    if (vocab <= 0 || ntok <= 0 || E <= 0) return EKAID_OK;
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(vocab, cdiv(E, 64)), dim3(64), 0, ST, tok, ntok, table, dout, E, ld_out, col_off,
+                       relu, padding_idx, dtable);
     return check_launch("embedding_bwd");
+}
+extern "C" int ekaid_onehot(const int64_t* tok, long long ntok, int vocab, long long padding_idx, float* out, void* stream) {
+    if (ntok <= 0 || vocab <= 0) return EKAID_OK;
+    hipLaunchKernelGGL(onehot_kernel, grid1d(ntok * vocab), dim3(256), 0, ST, tok, ntok, vocab, padding_idx, out);
+    return check_launch("onehot");
+}
+extern "C" int ekaid_masked_add(const float* raw, const float* table, int relu, float* dtable, long long n, void* stream) {
+    if (n <= 0) return EKAID_OK;
+    hipLaunchKernelGGL(masked_add_kernel, grid1d(n), dim3(256), 0, ST, raw, table, relu, dtable, n);
+    return check_launch("masked_add");
 }
 extern "C" int ekaid_softmax_fwd(const float* x, float* y, long long rows, int cols, int log_mode, void* stream) {
     hipLaunchKernelGGL(softmax_fwd_kernel, grid1d(rows * 64), dim3(256), 0, ST, x, y, rows, cols, log_mode);
@@ -719,8 +818,7 @@ extern "C" int ekaid_mix3_bwd(const float* w, const float* a, const float* b, co
 }
 extern "C" int ekaid_nll_fwd(const float* logp, const int64_t* target, int ld_target, const float* mask, int ld_mask, int B, int T,
                              int V, const float* denom_dev, float* sums, float* loss_out, void* stream) {
-    hipLaunchKernelGGL(nll_fwd_kernel, grid1d((long long)B * T), dim3(256), 0, ST, logp, target, ld_target, mask, ld_mask, B, T, V, sums);
-    hipLaunchKernelGGL(nll_finish_kernel, dim3(1), dim3(1), 0, ST, sums, denom_dev, loss_out);
+    hipLaunchKernelGGL(nll_fwd_kernel, dim3(1), dim3(1024), 0, ST, logp, target, ld_target, mask, ld_mask, B, T, V, denom_dev, sums, loss_out);
     return check_launch("nll_fwd");
 }
 extern "C" int ekaid_total_loss_fwd(const float* speaker_loss, const float* att_bef, const float* att_aft, long long n, float coef,

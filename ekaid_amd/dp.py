@@ -17,8 +17,16 @@ buckets overlaps the rest of backward.  xGMI is point-to-point (7 links x ~153 G
 223 MB of gradients need ~0.4-2.6 ms per step, far below the backward time, so a few large buckets
 (default 32 MB) are preferred over many small ones.  The 1/world_size averaging is folded into the
 Adam kernel (``grad_scale``).
+
+Difference from ``torch.optim.Adam`` (documented, not emulated): the live set is fixed at the first backward and updated as
+ONE flat range under one global step counter.  A live parameter that receives no gradient in some later step keeps the
+zeros of its slot: its moments decay and it still moves by ``lr * m_hat / (sqrt(v_hat) + eps)``, where torch (gradients set
+to None) would skip it and keep a per-parameter step count.  On this path every live parameter fires in every step (fixed
+graph / setting per run; ragged answers only change the number of decode steps, not which weights are used), which
+``FlatAdam.step`` can assert with ``EKAID_DP_ASSERT_ALL_FIRED=1`` (tests run with it).
 """
 import hashlib
+import os
 
 import torch
 import torch.distributed as dist
@@ -245,6 +253,13 @@ class FlatAdam(GradBuckets):
             self._step_dev.fill_(int(value))
 
     def step(self):
+        if self.built and os.environ.get('EKAID_DP_ASSERT_ALL_FIRED') == '1':
+            fired = [n - q for (_, _, n), q in zip(self.buckets, self._pending)]
+            # (after a hipGraph replay no hook has run: nothing to check; after an eager backward every live parameter must
+            # have delivered its gradient -- the module docstring explains why that matters for Adam)
+            if any(fired) and any(self._pending):
+                raise RuntimeError('FlatAdam.step: %d live parameters received no gradient in this step'
+                                   % sum(self._pending))
         self.finish()
         self.apply_update()
 

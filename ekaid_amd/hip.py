@@ -83,7 +83,9 @@ SIGNATURES = {
     'ekaid_qatt_weights_fwd': [P, I, I, P, P, P],
     'ekaid_qatt_weights_bwd': [P, P, I, I, P, P],
     'ekaid_embedding_fwd': [P, L, P, I, P, I, I, I, P],
-    'ekaid_embedding_bwd': [P, L, P, P, I, I, I, I, L, P, P],
+    'ekaid_embedding_bwd': [P, L, P, I, P, I, I, I, I, L, P, P],
+    'ekaid_onehot': [P, L, I, L, P, P],
+    'ekaid_masked_add': [P, P, I, P, L, P],
     'ekaid_gru_cell_fwd': [P, I, P, I, P, I, I, I, P, I, P, P],
     'ekaid_gru_cell_bwd': [P, I, P, P, P, I, I, I, P, I, P, P, P],
     'ekaid_lstm_cell_fwd': [P, P, I, P, I, I, P, P, P, P],

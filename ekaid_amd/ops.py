@@ -907,6 +907,21 @@ class QAttWeightsFn(Function):
         return da
 
 
+def embedding_grad(tok, table, dout, ld_out, col_off, relu, padding_idx, dtable):
+    """dtable (V, E) += gradient of ``act(table[tok])`` given dout (ntok rows, leading dim ld_out, columns col_off..+E):
+    OneHot(tok)^T . dout as a split-K GEMM with a fixed-order reduction -- deterministic, and its cost does not depend on how
+    many positions share an id (padding and '<start>' ids hit thousands).  ref: autograd of nn.Embedding (+ ReLU),
+    language_model.py:48-53, dynamic_speaker_change_pos.py:153-156."""
+    V, E = table.shape
+    ntok = tok.numel()
+    L = hip.lib()
+    onehot = torch.empty(ntok, V, device=table.device, dtype=torch.float32)
+    check(L.ekaid_onehot(ptr(tok), ntok, V, int(padding_idx), ptr(onehot), stream()), 'onehot')
+    raw = torch.empty(V, E, device=table.device, dtype=torch.float32)
+    gemm(onehot, dout, raw, V, E, ntok, V, ld_out, E, 1, 0, b_off=col_off)
+    check(L.ekaid_masked_add(ptr(raw), ptr(table), int(relu), ptr(dtable), V * E, stream()), 'masked_add')
+
+
 class EmbeddingFn(Function):
     """One or two lookup tables written side by side (+ optional ReLU).
     ref: language_model.py:48-53, dynamic_speaker_change_pos.py:153-156."""
@@ -937,8 +952,7 @@ class EmbeddingFn(Function):
         for i, t in enumerate(tables):
             if ctx.needs_input_grad[3 + i]:
                 dt = grad_out(t, zero=True)
-                check(hip.lib().ekaid_embedding_bwd(ptr(tok), tok.numel(), ptr(t), ptr(d), t.shape[1], ctx.width, off,
-                                                    int(ctx.relu), ctx.pad, ptr(dt), stream()), 'embedding_bwd')
+                embedding_grad(tok, t, d, ctx.width, off, ctx.relu, ctx.pad, dt)
                 grads.append(dt)
             else:
                 grads.append(None)
@@ -1109,7 +1123,7 @@ class LMLossFn(Function):
         B, T, V = logp.shape
         assert target.stride(1) == 1 and mask.stride(1) == 1 and target.dtype == torch.int64
         assert target.shape[1] >= T and mask.shape[1] >= T and mask.dtype == torch.float32
-        sums = torch.zeros(2, device=logp.device, dtype=torch.float32)
+        sums = torch.empty(2, device=logp.device, dtype=torch.float32)       # written by the kernel
         loss = torch.empty((), device=logp.device, dtype=torch.float32)
         check(hip.lib().ekaid_nll_fwd(ptr(logp), target.data_ptr(), target.stride(0), mask.data_ptr(), mask.stride(0),
                                       B, T, V, ptr(denom), ptr(sums), ptr(loss), stream()), 'nll_fwd')

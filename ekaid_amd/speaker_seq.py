@@ -306,8 +306,7 @@ class SpeakerSeqFn(Function):
         _nn(DCAT, oGL, NW, wih_l, 0, We + A, dX, 0, We, TB, We, 4 * R)
         _drop(dX, dX, TB * We, p, seeds['xt'])
         d_emb = ops.grad_out(emb, zero=True)
-        check(L.ekaid_embedding_bwd(tok_tb.data_ptr(), TB, ptr(emb), ptr(dX), We, We, 0, 1, -1, ptr(d_emb), stream()),
-              'embedding_bwd')
+        ops.embedding_grad(tok_tb, emb, dX, We, 0, True, -1, d_emb)
         grads = (d_emb, d_w_e, d_b_e, d_wih_a, d_whh_a, d_bih_a, d_bhh_a, d_w_fc, d_b_fc, d_w_p1, d_b_p1, d_w_wp, d_b_wp,
                  d_w_p2, d_b_p2, d_w_g1, d_b_g1, d_w_g2, d_b_g2, d_wih_l, d_whh_l, d_bih_l, d_bhh_l, d_w_lo, d_b_lo)
         return (d_bef, d_aft, d_diff, None, None, None, None) + grads

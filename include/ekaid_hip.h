@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EKAID_ABI_VERSION 2
+#define EKAID_ABI_VERSION 3
 
 int ekaid_version(void);
 const char* ekaid_last_error(void);        /* thread-local */
@@ -127,10 +127,10 @@ int ekaid_wn_scale_bwd(const float* v, const float* g, const float* norm, const 
                        float* dv, int accumulate_dv, float* dg, void* stream);
 int ekaid_scale_dot(float* G, const float* w, const float* scale_dev, long long n, float* dot_out, void* stream);
 
-/* column sum of an [M][N] matrix (bias gradient), out[N] */
+/* column sum of an [M][N] matrix (bias gradient), out[N]; row-block partials summed in a fixed order (deterministic) */
 int ekaid_colsum(const float* x, int M, int N, int ldx, float* out, void* stream);
-/* out[N] += column sums (no zero-fill: the bias gradient accumulated straight into its zeroed slot of the flat gradient
- * buffer, or on top of an earlier contribution of a shared bias) */
+/* out[N] += column sums (the bias gradient accumulated straight into its zeroed slot of the flat gradient buffer, or on
+ * top of an earlier contribution of a shared bias); same fixed-order partial sums */
 int ekaid_colsum_acc(const float* x, int M, int N, int ldx, float* out, void* stream);
 /* out = xs[0] + ... + xs[k-1] (1 <= k <= 8 device arrays of n floats, xs itself is a HOST array; out may alias xs[0]):
  * the gradient of a tensor with several consumers in one pass (ref: autograd's pairwise accumulation of fan-out gradients,
@@ -216,7 +216,14 @@ int ekaid_qatt_weights_bwd(const float* S, const float* dweight, int B, int L, f
  *      (rows equal to padding_idx receive no gradient) */
 int ekaid_embedding_fwd(const int64_t* tok, long long ntok, const float* table, int E, float* out, int ld_out,
                         int col_off, int relu, void* stream);
-int ekaid_embedding_bwd(const int64_t* tok, long long ntok, const float* table, const float* dout, int E, int ld_out,
+/* bwd takes the number of table rows: one wave per (row, 64 columns) adds the matching positions in position order
+ * (deterministic, no float atomics; serial in the number of positions per row -- fine for evenly used ids).  The layers use
+ * the GEMM form instead, whose cost does not depend on the id distribution (padding / start ids hit thousands of
+ * positions):  onehot [ntok][vocab] (ekaid_onehot, padding rows zero);  raw [vocab][E] = onehot^T . dout (ekaid_gemm_f32,
+ * transA = 1: split-K with a fixed-order reduction);  dtable += raw * (table > 0 if relu) (ekaid_masked_add). */
+int ekaid_onehot(const int64_t* tok, long long ntok, int vocab, long long padding_idx, float* out, void* stream);
+int ekaid_masked_add(const float* raw, const float* table, int relu, float* dtable, long long n, void* stream);
+int ekaid_embedding_bwd(const int64_t* tok, long long ntok, const float* table, int vocab, const float* dout, int E, int ld_out,
                         int col_off, int relu, long long padding_idx, float* dtable, void* stream);
 
 /* GRU / LSTM cell point-wise parts (the gate GEMMs go through ekaid_gemm_f32).
@@ -281,7 +288,7 @@ int ekaid_mix3_bwd(const float* w, const float* a, const float* b, const float* 
                    float* dw, float* da, float* db, float* dc, int accumulate /* 1: da/db/dc += */, void* stream);
 
 /* masked NLL of teacher-forced log-probs.   ref: utils/utils.py:208-216
- * sums[0] = -sum logp[b][t][target[b][t]] * mask[b][t], sums[1] = sum mask  (t < T); caller zero-fills sums;
+ * sums[0] = -sum logp[b][t][target[b][t]] * mask[b][t], sums[1] = sum mask  (t < T), both written by the call (fixed-order sums);
  * loss_out[0] = sums[0] / sums[1].  denom_dev (optional device scalar): overrides sums[1] -- under data parallelism
  * the caller passes (mask sum of the GLOBAL batch) / world_size, so that averaging the ranks' gradients reproduces the
  * loss of the global batch when the ranks hold answers of different lengths.

@@ -9,5 +9,8 @@ for p in (ROOT, os.path.join(ROOT, 'tests')):
         sys.path.insert(0, p)
 
 
+os.environ.setdefault('EKAID_DP_ASSERT_ALL_FIRED', '1')      # FlatAdam.step checks that every live parameter delivered a gradient
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')

@@ -505,3 +505,27 @@ def test_resume_with_optimizer_state_continues_the_run():
     _, err_no_state = resume(False)
     print('resume without optimizer state: %.3e (must exceed %.1e)' % (err_no_state, 0.1 * lr))
     assert err_no_state >= 0.1 * lr, 'control: dropping the optimizer state should be visible (%.2e rms)' % err_no_state
+
+
+def test_training_step_is_bit_reproducible():
+    """No float atomics on the path (column sums, embedding gradient and the loss sum add in a fixed order; split-K, weight
+    norm and the tall-skinny reductions always did): the same three training steps from the same seeds give bit-identical
+    weights, run after run -- the precondition for 'resumed == uninterrupted' and 'graph replay == eager' to be exact."""
+    from ekaid_amd import ops
+    from ekaid_amd.dp import FlatAdam
+    from ekaid_amd.engine import TrainStep
+    cfg = bench_cfg(D=256, seq_length=12)
+    host = make_batch(B=4, N=12, D=256, Lq=8, T=5, seq_length=12, V=148, seed=5)
+    b = to_device(host, DEV)
+    finals, losses = [], []
+    for _ in range(3):
+        cd, sp = build_models(cfg, 147, 148, DEV, train=True)
+        opt = FlatAdam([cd, sp], lr=1e-3)
+        ts = TrainStep(cfg, cd, sp, opt)
+        ops.manual_seed(4242)
+        ls = [float(ts(b, 5)[0].detach()) for _ in range(3)]
+        ts.close()
+        finals.append(opt.pflat.detach().clone())
+        losses.append(ls)
+    assert losses[0] == losses[1] == losses[2], losses
+    assert torch.equal(finals[0], finals[1]) and torch.equal(finals[0], finals[2])
