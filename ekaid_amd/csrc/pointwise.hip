@@ -559,8 +559,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* x, cons
             const float xh = (xp[c] - mean) * rstd;
             const float g = dp[c] * gamma[c];
             s1 += g; s2 += g * xh;
-            atomicAdd(dgamma + c, dp[c] * xh);
-            atomicAdd(dbeta + c, dp[c]);
         }
         s1 = wave_sum(s1) / cols; s2 = wave_sum(s2) / cols;
         for (int c = lane; c < cols; c += 64) {
@@ -568,6 +566,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* x, cons
             dx[r * cols + c] = rstd * (dp[c] * gamma[c] - s1 - xh * s2);
         }
     }
+}
+
+// dgamma[c] = sum_r dy[r][c] * xhat[r][c], dbeta[c] = sum_r dy[r][c]: row-block partials (thread = column) for the fixed-order
+// finish of the column sums (no float atomics)
+__global__ __launch_bounds__(256) void layernorm_param_partial_kernel(const float* x, const float* save, const float* dy, long long rows,
+                                                                      int cols, int rows_per_blk, float* pg, float* pb) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const long long r0 = (long long)blockIdx.y * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
+    float g = 0.f, b = 0.f;
+    for (long long r = r0; r < r1; ++r) {
+        const float d = dy[r * cols + c];
+        g += d * (x[r * cols + c] - save[r * 2]) * save[r * 2 + 1];
+        b += d;
+    }
+    pg[(long long)blockIdx.y * cols + c] = g;
+    pb[(long long)blockIdx.y * cols + c] = b;
 }
 
 // ------------------------------------------------------------------ label matrix -> one-hot adjacency
@@ -843,9 +858,20 @@ extern "C" int ekaid_layernorm_fwd(const float* x, const float* gamma, const flo
 }
 extern "C" int ekaid_layernorm_bwd(const float* x, const float* gamma, const float* save, const float* dy, long long rows, int cols,
                                    float* dx, float* dgamma, float* dbeta, void* stream) {
-    (void)hipMemsetAsync(dgamma, 0, sizeof(float) * cols, ST);
-    (void)hipMemsetAsync(dbeta, 0, sizeof(float) * cols, ST);
     hipLaunchKernelGGL(layernorm_bwd_kernel, grid1d(rows * 64), dim3(256), 0, ST, x, gamma, save, dy, rows, cols, dx, dgamma, dbeta);
+    double* scr = reduction_scratch();
+    if (!scr) { set_error("layernorm_bwd: scratch alloc failed"); return EKAID_ERR_LAUNCH; }
+    float* pg = reinterpret_cast<float*>(scr + 2 * RED_SLOT);
+    const int colblks = cdiv(cols, 256);
+    int nparts = (int)(rows < 128 ? rows : 128);
+    while (nparts > 1 && 2ll * nparts * cols > COLSUM_PART_FLOATS) nparts >>= 1;
+    if (2ll * nparts * cols > COLSUM_PART_FLOATS) { set_error("layernorm_bwd: %d columns exceed the reduction scratch", cols); return EKAID_ERR_UNSUPPORTED; }
+    const int rows_per_blk = cdiv(rows, nparts);
+    nparts = cdiv(rows, rows_per_blk);
+    float* pb = pg + (long long)nparts * cols;
+    hipLaunchKernelGGL(layernorm_param_partial_kernel, dim3(colblks, nparts), dim3(256), 0, ST, x, save, dy, rows, cols, rows_per_blk, pg, pb);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, ST, (const float*)pg, nparts, cols, dgamma, 0);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, ST, (const float*)pb, nparts, cols, dbeta, 0);
     return check_launch("layernorm_bwd");
 }
 extern "C" int ekaid_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
