@@ -1073,6 +1073,13 @@ static void plan(const ekaid_gemm_t* d, int& TMN, int& splitk, int& tiles_m, int
     // 4-5 workgroups per CU and quantise better than 128x128 (measured 94 -> 104 TF NT, 114 -> 122 TF NN at N = 1024)
     // (f32 MFMA kernel only: the bf16-split kernel runs 3 workgroups of 128x128 per CU and is faster with them)
     if (TMN == 2 && batch == 1 && d->M >= 4096 && d->N <= 2048 && gemm_mode() == 0) TMN = 3;
+    // bf16-split arithmetic, tall outputs with ONE 128-wide column tile or a 128-deep contraction (the 128-unit attention
+    // layers, M = 9216): 72 tiles of 128x128 cannot fill the chip; measured 35.0 -> 28.5 us (nt 9216x128x1024 as 128x64
+    // tiles) and 35.1 -> 28.7 us (nn 9216x1024x128 as 64x64 tiles)
+    if (TMN == 2 && batch == 1 && gemm_mode() == 1 && d->M >= 4096 && !d->transA) {
+        if (d->transB && d->N <= 128) TMN = 3;
+        else if (!d->transB && d->K <= 128) TMN = 1;
+    }
     static const char* force = getenv("EKAID_GEMM_TILE");         // tuning aid: "1" (64x64), "2" (128x128), "3" (128x64), "4" (64x128)
     if (force && force[0] >= '1' && force[0] <= '4' && (force[0] < '3' || TMN == 2)) TMN = force[0] - '0';
     const int bm = TMN == 4 ? 64 : (TMN == 3 ? 128 : 64 * TMN);
