@@ -98,9 +98,8 @@ def physical_cores():
 def cpu_baseline(cfg, cd, sp, batch_size, graph, budget_s=25.0):
     """Oracle on the host cores, bounded sample: full train step (forward + backward + torch.optim.Adam) and eval
     forward at ``batch_size``; then log-prob parity of the very same weights / inputs through the HIP path."""
-    sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    from common import oracle_params
     from ekaid_amd.engine import forward_loss
+    from ekaid_amd.formula_init import state_copy as oracle_params
     from ekaid_amd.synthetic import make_batch
     from oracle import ekaid_oracle as O
     cores = physical_cores()
@@ -185,9 +184,8 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    from common import build_models
     from ekaid_amd import hip, ops
+    from ekaid_amd.formula_init import build_models
     from ekaid_amd.config import bench_cfg
     from ekaid_amd.dp import FlatAdam, enable_global_question_attention
     from ekaid_amd.engine import TrainStep, forward_loss

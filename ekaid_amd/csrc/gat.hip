@@ -252,215 +252,6 @@ __global__ __launch_bounds__(256) void masked_softmax_bwd_kernel(const float* P,
         if (active && dlbias) dlbias[eidx] = dlb;
     }
 }
-
-// ---------------- fused backward of the attention core (ref: autograd of graph_att_layer.py:105-172)
-// One workgroup per R-slice; everything between the incoming gradient of outT and the gradients of q, k, S stays on chip:
-//   A. stream doutT [N*H][A] and S [M][A] through LDS in DC-wide column chunks:
-//        dP[nh][m]  += sum_c doutT[nh][c] * S[m][c]        (4x8 register blocks per thread, accumulated over the chunks)
-//        dS[m][c]    = sum_nh P[nh][m] * doutT[nh][c]      (complete per chunk: written straight to HBM)
-//   B. edge-softmax backward per (n, h) row, neighbour m on lane m: daff = mask * P * (dP - <P, dP>); dlbias = sum_h of it
-//      (written in the ORIGINAL orientation), dgeo = daff / geo where the geometry term was above its floor;
-//   C. per head, q / k column chunks through LDS:   dq[n][c] = sc * sum_m daff[n,h,m] k[m][c],   dk[m][c] = sc * sum_n daff[n,h,m] q[n][c].
-// Replaces four batched tiny-GEMM launches (M, N or K = 36: 16-50 TF) + the stand-alone softmax backward and their
-// (R, N, H, M) round trips.  Algorithmic bytes per slice: read doutT N*H*A*4 + S, q, k 3*N*A*4 + P; write dq, dk, dS 3*N*A*4.
-template <int DC>
-__global__ __launch_bounds__(256) void gat_fused_bwd_kernel(const float* __restrict__ doutT, const float* __restrict__ S,
-                                                            const float* __restrict__ P, const float* __restrict__ q,
-                                                            const float* __restrict__ k, const float* __restrict__ cond,
-                                                            const float* __restrict__ geo, int N, int M, int A, int H, int dir,
-                                                            float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dS,
-                                                            float* __restrict__ dlbias, float* __restrict__ dgeo) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int LD = DC + 4;
-    constexpr int CQ = DC / 4;                 // column quads per chunk
-    constexpr int RG = 256 / CQ;               // row groups of the (row, column-quad) thread map
-    const int NH = N * H;
-    const int MP = (M + 3) & ~3;
-    float* Ps = smem;                          // [NH][MP]   P, later daff (in place)
-    float* dts = Ps + NH * MP;                 // [NH][LD]   doutT chunk   | phase B: dP [NH][MP] | phase C: q chunk [N][LD]
-    float* ss = dts + NH * LD;                 // [N][LD]    S chunk (M rows used) | phase C: k chunk
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long r = blockIdx.x;
-    const int dh = A / H;
-    const float sc = 1.0f / sqrtf((float)dh);
-    const float* dor = doutT + r * NH * A;
-    const float* Sr = S + r * N * A;
-    const float* Pr = P + r * NH * M;
-
-    for (int i = tid; i < NH * MP; i += 256) {
-        const int row = i / MP, m = i % MP;
-        Ps[i] = m < M ? Pr[(long long)row * M + m] : 0.f;
-    }
-    // ---- phase A
-    const int nb_m = (M + 7) >> 3, nblk = ((NH + 3) >> 2) * nb_m;          // 4 x 8 blocks of dP
-    float accP[2][4][8];
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) accP[ps][i][j] = 0.f;
-    const int cq = tid % CQ, rg = tid / CQ;
-    for (int c0 = 0; c0 < A; c0 += DC) {
-        for (int i = tid; i < NH * CQ; i += 256) {
-            const int row = i / CQ, c4 = i % CQ;
-            *reinterpret_cast<f32x4*>(&dts[row * LD + 4 * c4]) = *reinterpret_cast<const f32x4*>(&dor[(long long)row * A + c0 + 4 * c4]);
-        }
-        for (int i = tid; i < M * CQ; i += 256) {
-            const int row = i / CQ, c4 = i % CQ;
-            *reinterpret_cast<f32x4*>(&ss[row * LD + 4 * c4]) = *reinterpret_cast<const f32x4*>(&Sr[(long long)row * A + c0 + 4 * c4]);
-        }
-        __syncthreads();
-        // dP partial sums
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            const int b = tid + ps * 256;
-            if (b < nblk) {
-                const int nh0 = 4 * (b / nb_m), m0 = 8 * (b % nb_m);
-                const float* dr[4];
-                const float* sr[8];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) dr[i] = dts + min(nh0 + i, NH - 1) * LD;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) sr[j] = ss + min(m0 + j, M - 1) * LD;
-#pragma unroll 2
-                for (int c = 0; c < DC; c += 4) {
-                    f32x4 dv[4], sv[8];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) dv[i] = *reinterpret_cast<const f32x4*>(dr[i] + c);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) sv[j] = *reinterpret_cast<const f32x4*>(sr[j] + c);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) accP[ps][i][j] = fmaf(dv[i][e], sv[j][e], accP[ps][i][j]);
-                }
-            }
-        }
-        // dS chunk: thread (cq, rg) owns columns 4cq..4cq+3 of rows rg, rg+RG, ...
-        {
-            f32x4 o[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int nh = 0; nh < NH; ++nh) {
-                const f32x4 d = *reinterpret_cast<const f32x4*>(&dts[nh * LD + 4 * cq]);
-                const float* prow = Ps + nh * MP;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int m = rg + RG * j;
-                    if (RG * j < 64 && m < M) {
-                        const float pv = prow[m];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[j][e] = fmaf(pv, d[e], o[j][e]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = rg + RG * j;
-                if (RG * j < 64 && m < M) *reinterpret_cast<f32x4*>(&dS[(r * N + m) * (long long)A + c0 + 4 * cq]) = o[j];
-            }
-        }
-        __syncthreads();
-    }
-    // rows of dS beyond the keys (M < N) receive no gradient
-    for (long long i = tid; i < (long long)(N - M) * (A / 4); i += 256)
-        *reinterpret_cast<f32x4*>(&dS[(r * N + M) * (long long)A + 4 * i]) = f32x4{0.f, 0.f, 0.f, 0.f};
-    // ---- phase B: dP to LDS, edge-softmax backward in place (Ps: P -> daff)
-    float* dPs = dts;
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-        const int b = tid + ps * 256;
-        if (b < nblk) {
-            const int nh0 = 4 * (b / nb_m), m0 = 8 * (b % nb_m);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (nh0 + i < NH && m0 + j < M) dPs[(nh0 + i) * MP + m0 + j] = accP[ps][i][j];
-        }
-    }
-    __syncthreads();
-    for (int n = wave; n < N; n += 4) {
-        const bool active = lane < M;
-        const long long eidx = dir ? r * N * N + (long long)lane * N + n : r * N * N + (long long)n * N + lane;
-        const float c = active ? cond[eidx] : 0.f;
-        float dlb = 0.f;
-        for (int hd = 0; hd < H; ++hd) {
-            const int row = n * H + hd;
-            const float p = active ? Ps[row * MP + lane] : 0.f;
-            const float dp = active ? dPs[row * MP + lane] : 0.f;
-            const float dot = wave_sum(p * dp);
-            const float dx = p * (dp - dot);
-            dlb += dx;
-            if (active) {
-                Ps[row * MP + lane] = c > 0.f ? dx : 0.f;
-                if (dgeo) {
-                    const long long gidx = ((r * N + n) * M + lane) * H + hd;
-                    const float gv = geo[gidx];
-                    dgeo[gidx] = (c > 0.f && gv > GEO_EPS) ? dx / gv : 0.f;
-                }
-            }
-        }
-        if (active && dlbias) dlbias[eidx] = dlb;
-    }
-    __syncthreads();
-    // ---- phase C: dq, dk per head and column chunk
-    float* qs = dts;
-    float* ks = ss;
-    const float* qr = q + r * N * A;
-    const float* kr = k + r * M * A;
-    for (int c0 = 0; c0 < A; c0 += DC) {
-        const int hd = c0 / dh;                       // DC divides dh: a chunk never straddles two heads
-        for (int i = tid; i < N * CQ; i += 256) {
-            const int row = i / CQ, c4 = i % CQ;
-            *reinterpret_cast<f32x4*>(&qs[row * LD + 4 * c4]) = *reinterpret_cast<const f32x4*>(&qr[(long long)row * A + c0 + 4 * c4]);
-        }
-        for (int i = tid; i < M * CQ; i += 256) {
-            const int row = i / CQ, c4 = i % CQ;
-            *reinterpret_cast<f32x4*>(&ks[row * LD + 4 * c4]) = *reinterpret_cast<const f32x4*>(&kr[(long long)row * A + c0 + 4 * c4]);
-        }
-        __syncthreads();
-        f32x4 oq[4], ok[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { oq[j] = f32x4{0.f, 0.f, 0.f, 0.f}; ok[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        for (int m = 0; m < M; ++m) {                 // dq[n] += daff[n,h,m] * k[m]
-            const f32x4 kv = *reinterpret_cast<const f32x4*>(&ks[m * LD + 4 * cq]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = rg + RG * j;
-                if (RG * j < 64 && n < N) {
-                    const float a = Ps[(n * H + hd) * MP + m];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) oq[j][e] = fmaf(a, kv[e], oq[j][e]);
-                }
-            }
-        }
-        for (int n = 0; n < N; ++n) {                 // dk[m] += daff[n,h,m] * q[n]
-            const f32x4 qv = *reinterpret_cast<const f32x4*>(&qs[n * LD + 4 * cq]);
-            const float* arow = Ps + (n * H + hd) * MP;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = rg + RG * j;
-                if (RG * j < 64 && m < M) {
-                    const float a = arow[m];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ok[j][e] = fmaf(a, qv[e], ok[j][e]);
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = rg + RG * j;
-            if (RG * j < 64 && row < N) *reinterpret_cast<f32x4*>(&dq[(r * N + row) * (long long)A + c0 + 4 * cq]) = oq[j] * sc;
-            if (RG * j < 64 && row < M) *reinterpret_cast<f32x4*>(&dk[(r * M + row) * (long long)A + c0 + 4 * cq]) = ok[j] * sc;
-        }
-        __syncthreads();
-    }
-}
-
 // ---------------- pair geometry: float64 math exactly as the reference, rounded to f32 once at the end
 // ref: utils/mimic_utils.py:152-208.  out[r][i][j][c*(fd/4) + s*(fd/8) + t], c = component (dx,dy,dw,dh),
 // s = 0 sin / 1 cos, t = frequency index; dim_mat[t] = 1000^(8t/fd) is the reference's float32 table, built on the host
@@ -545,46 +336,6 @@ extern "C" int ekaid_gat_fused_fwd(const float* q, const float* k, const float* 
     if (lds > 150 * 1024) { set_error("gat_fused_fwd: LDS need %zu too large", lds); return EKAID_ERR_UNSUPPORTED; }
     if (M <= 40) return launch_fused<4, 40>(q, k, S, cond, lbias, geo, R, N, M, A, H, dir, DC, lds, P, outT, ST);
     return launch_fused<2, 64>(q, k, S, cond, lbias, geo, R, N, M, A, H, dir, DC, lds, P, outT, ST);
-}
-
-template <int DC>
-static int launch_fused_bwd(const float* doutT, const float* S, const float* P, const float* q, const float* k, const float* cond,
-                            const float* geo, int R, int N, int M, int A, int H, int dir, size_t lds, float* dq, float* dk, float* dS,
-                            float* dlbias, float* dgeo, hipStream_t st) {
-    auto kern = gat_fused_bwd_kernel<DC>;
-    if (lds > 64 * 1024) {
-        if (func_attr_once(DC == 64 ? 50 : 51)) {
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-                (void)hipGetLastError();
-                set_error("gat_fused_bwd: cannot raise dynamic LDS limit to %zu bytes", lds);
-                return EKAID_ERR_UNSUPPORTED;
-            }
-        }
-    }
-    hipLaunchKernelGGL(kern, dim3(R), dim3(256), lds, st, doutT, S, P, q, k, cond, geo, N, M, A, H, dir, dq, dk, dS, dlbias, dgeo);
-    return check_launch("gat_fused_bwd");
-}
-
-extern "C" int ekaid_gat_fused_bwd(const float* doutT, const float* S, const float* P, const float* q, const float* k,
-                                   const float* cond, const float* geo, int R, int N, int M, int A, int H, int dir, float* dq,
-                                   float* dk, float* dS, float* dlbias, float* dgeo, void* stream) {
-    if (R <= 0) return EKAID_OK;
-    const int dh = H > 0 ? A / H : 0;
-    if (N < 1 || N > 64 || M < 1 || M > N || H < 1 || A % H || (dh % 32) || ((long long)N * H + 3) / 4 * ((M + 7) / 8) > 512) {
-        set_error("gat_fused_bwd: unsupported shape N=%d M=%d A=%d H=%d", N, M, A, H);
-        return EKAID_ERR_UNSUPPORTED;
-    }
-    const int MP = (M + 3) & ~3;
-    auto need = [&](int DC) { return sizeof(float) * ((size_t)N * H * MP + (size_t)(N * H + N) * (DC + 4)); };
-    // phase B parks dP [N*H][MP] in the doutT-chunk region: it must be at least that large
-    const bool ok64 = (dh % 64) == 0 && need(64) <= 150 * 1024 && (size_t)(64 + 4) >= (size_t)MP;
-    const bool ok32 = need(32) <= 150 * 1024 && (size_t)(32 + 4) >= (size_t)MP;
-    if (ok64 && (need(64) <= 78 * 1024 || !ok32))
-        return launch_fused_bwd<64>(doutT, S, P, q, k, cond, geo, R, N, M, A, H, dir, need(64), dq, dk, dS, dlbias, dgeo, ST);
-    if (ok32) return launch_fused_bwd<32>(doutT, S, P, q, k, cond, geo, R, N, M, A, H, dir, need(32), dq, dk, dS, dlbias, dgeo, ST);
-    if (ok64) return launch_fused_bwd<64>(doutT, S, P, q, k, cond, geo, R, N, M, A, H, dir, need(64), dq, dk, dS, dlbias, dgeo, ST);
-    set_error("gat_fused_bwd: LDS need too large for N=%d M=%d H=%d", N, M, H);
-    return EKAID_ERR_UNSUPPORTED;
 }
 
 static dim3 wave_grid(long long waves) {

@@ -1232,357 +1232,3 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     return rc;
 }
 
-namespace ekaid {
-
-// ------------------------------------------------------------------------------------------------------------------
-// The same 6-product arithmetic on PRE-SPLIT operands ("planes"): the three bf16 planes of an f32 tensor are produced
-// once, where the tensor is produced (ekaid_split_planes; for the weights once per optimizer step), instead of inside
-// every K loop that reads it.  In gemm_split_kernel the split costs 5.2 vector-ALU instructions per MFMA and the shared
-// vector-issue port is ~90 % subscribed (profiles/r01_pmc_gemm_split_nn_18432x1024x1024.json: MFMA busy 52 %); here the
-// K loop has no vector ALU work at all.
-//
-// Plane storage: PLANE-MAJOR -- three bf16 arrays (hi, mid, lo; hi + mid + lo == x exactly, truncation split) laid out
-// exactly like the f32 array, `plane_stride` bytes apart.  Any row-major view of the f32 buffer addresses its planes with
-// the same (row, column) arithmetic, 2 bytes per element.
-//
-// Staging: buffer_load_dwordx4 ... lds (LDS-DMA: no VGPRs, no ds_write).  One wave instruction fills 1 KiB of LDS, lane L
-// the 16 bytes at +16 L (= 8 consecutive k of a k-contiguous operand, or 8 consecutive rows of an m/n-contiguous one); the
-// XOR swizzles of the LDS images (kc_store_off / mc_store_off above) are applied on the per-lane SOURCE offset, because
-// the LDS side of an LDS-DMA is lane-linear.  K advance and plane selection ride in the scalar offset.  The loads are
-// issued from inline asm: behind the builtin form hipcc waits vmcnt(0) before the next ds_read (it cannot tell the ring
-// slots apart) and would drain the DMA it has just issued; asm loads are outside its bookkeeping and are retired by the
-// counted s_waitcnt in the loop.  NBUF ring slots of one KS-deep stage each; stage s+NBUF-1 is issued right after the
-// barrier that opens stage s (everybody has then finished reading the slot it overwrites).
-typedef __attribute__((address_space(3))) void* lds_void_ptr;
-
-template <bool A_KC, bool B_KC, int KS, int NBUF, int OCC, bool REGSTAGE = false>
-__global__ __launch_bounds__(256, OCC) void gemm_planes_kernel(GemmArgs g, unsigned long long strideA, unsigned long long strideB) {
-    constexpr int TM = 2, TN = 2, BM = 128, BN = 128;
-    constexpr int NCH = KS / 16;                      // 16-k MFMA chunks per stage
-    constexpr int PLANE = 128 * KS * 2;               // bytes of one plane image of one operand per stage
-    constexpr int STAGE = 6 * PLANE;
-    constexpr int NI = PLANE / 4096;                  // LDS-DMA instructions per wave and plane image (1 KiB each, 4 waves)
-    constexpr int NDMA = 6 * NI;                      // per wave and stage
-    constexpr int A_RS = A_KC ? 2 * KS : 2 * BM, B_RS = B_KC ? 2 * KS : 2 * BN;
-    static_assert(KS == 16 || KS == 32, "stage depth");
-    static_assert(NBUF == 2 || NBUF == 3, "ring slots");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    char* const ldsb = reinterpret_cast<char*>(lds);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    const int nwg = g.tiles_m * g.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
-    }
-    const int m0 = (bid / g.tiles_n) * BM, n0 = (bid % g.tiles_n) * BN;
-    const int z = blockIdx.z;
-    int kbeg = 0, kend = g.K;
-    if (g.splitk > 1) {
-        kbeg = z * g.k_per_split;
-        kend = min(g.K, kbeg + g.k_per_split);
-    }
-    // raw buffer descriptors {base lo, base hi (stride 0), num_records in bytes, flags}, covering all three planes
-    const long long spanA = A_KC ? ((long long)(g.M - 1) * g.lda + g.K) : ((long long)(g.K - 1) * g.lda + g.M);
-    const long long spanB = B_KC ? ((long long)(g.N - 1) * g.ldb + g.K) : ((long long)(g.K - 1) * g.ldb + g.N);
-    const unsigned long long pa = reinterpret_cast<unsigned long long>(g.A), pb = reinterpret_cast<unsigned long long>(g.B);
-    const u32x4 rsrcA = {(unsigned)pa, (unsigned)(pa >> 32) & 0xFFFFu, (unsigned)(2 * strideA + 2 * (unsigned long long)spanA), 0x00020000u};
-    const u32x4 rsrcB = {(unsigned)pb, (unsigned)(pb >> 32) & 0xFFFFu, (unsigned)(2 * strideB + 2 * (unsigned long long)spanB), 0x00020000u};
-    // this lane's 16-byte units: instruction q of a plane image covers units [64 (wave + 4 q), +64) of the image
-    unsigned voA[NI], voB[NI];
-#pragma unroll
-    for (int q = 0; q < NI; ++q) {
-        const int u = 64 * (wave + 4 * q) + lane;
-        // k-contiguous image [128 rows][KS/8 slots]: physical slot -> logical slot through the row's key
-        const int rowk = u / (KS / 8), sl = (u % (KS / 8)) ^ kc_key<KS>(rowk);
-        // m-contiguous image [KS k-rows][16 units of 8 rows]: 64-byte chunks XOR-ed with k & 3
-        const int km = u >> 4, c = u & 15, col = 32 * ((c >> 2) ^ (km & 3)) + 8 * (c & 3);
-        voA[q] = A_KC ? 2u * ((unsigned)(m0 + rowk) * (unsigned)g.lda + 8u * sl) : 2u * ((unsigned)km * (unsigned)g.lda + (unsigned)(m0 + col));
-        voB[q] = B_KC ? 2u * ((unsigned)(n0 + rowk) * (unsigned)g.ldb + 8u * sl) : 2u * ((unsigned)km * (unsigned)g.ldb + (unsigned)(n0 + col));
-    }
-    const unsigned kstepA = A_KC ? 2u * KS : 2u * KS * (unsigned)g.lda;      // soffset advance per stage, bytes
-    const unsigned kstepB = B_KC ? 2u * KS : 2u * KS * (unsigned)g.ldb;
-    unsigned soA = (A_KC ? 2u : 2u * (unsigned)g.lda) * (unsigned)kbeg, soB = (B_KC ? 2u : 2u * (unsigned)g.ldb) * (unsigned)kbeg;
-    const unsigned psA = (unsigned)strideA, psB = (unsigned)strideB;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
-
-    const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
-    int fA[TM][NCH], fB[TN][NCH];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int c = 0; c < NCH; ++c)
-            fA[i][c] = A_KC ? kc_read_off<KS>(wm + 32 * i + r, 2 * c + h) : mc_read_off<BM>(16 * c + 8 * h + tq, wm + 32 * i, tg, tp);
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int c = 0; c < NCH; ++c)
-            fB[j][c] = B_KC ? kc_read_off<KS>(wn + 32 * j + r, 2 * c + h) : mc_read_off<BN>(16 * c + 8 * h + tq, wn + 32 * j, tg, tp);
-    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
-    auto frag = [&](const char* plane, int off, bool kc, int rs) -> bf16x8 {
-        if (kc) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(plane + off);
-            return __builtin_bit_cast(bf16x8, v);
-        } else {
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(plane + off));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(plane + off + 4 * rs));
-            const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            return __builtin_bit_cast(bf16x8, v);
-        }
-    };
-    const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) char*)ldsb);
-#define EKAID_DMA16(RS, LDSADDR, VOFF, SOFF)                                                                                \
-    do {                                                                                                                     \
-        unsigned keep_;                                                                                                      \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0" \
-                     : "=&s"(keep_) : "s"(LDSADDR), "v"(VOFF), "s"(RS), "s"(SOFF) : "memory");                               \
-    } while (0)
-    // NDMA LDS-DMA instructions per wave and stage.  M0 (the LDS destination base) is saved and restored inside each
-    // statement; the plane rides in the scalar offset (an instruction immediate would also move the LDS address).
-    auto issue = [&](unsigned slot_off) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int q = 0; q < NI; ++q) {
-                EKAID_DMA16(rsrcA, lds_base + slot_off + (unsigned)(p * PLANE + 1024 * (wave + 4 * q)), voA[q], soA + (unsigned)p * psA);
-                EKAID_DMA16(rsrcB, lds_base + slot_off + (unsigned)((3 + p) * PLANE + 1024 * (wave + 4 * q)), voB[q], soB + (unsigned)p * psB);
-            }
-        soA += kstepA;
-        soB += kstepB;
-    };
-    auto compute = [&](const char* buf) {
-        const char* const cA = buf;
-        const char* const cB = buf + 3 * PLANE;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            bf16x8 fa[TM][3], fb[TN][3];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) fa[i][p] = frag(cA + p * PLANE, fA[i][c], A_KC, A_RS);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) fb[j][p] = frag(cB + p * PLANE, fB[j][c], B_KC, B_RS);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {      // smallest terms first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
-                }
-        }
-    };
-    const int nst = (kend - kbeg) / KS;
-    if constexpr (REGSTAGE) {
-        // Register-staged alternative (same LDS images, same source offsets): 16-byte buffer loads into VGPRs two stages
-        // ahead, ds_write_b128 of stage s+1 into the other slot while stage s is multiplied -- no LDS-DMA, no vector ALU.
-        static_assert(NBUF == 2 && NI == 1, "register staging: 2 slots, 16-deep stages");
-        const __amdgpu_buffer_rsrc_t bA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)rsrcA[2], 0x00020000);
-        const __amdgpu_buffer_rsrc_t bB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, (int)rsrcB[2], 0x00020000);
-        u32x4 ra[2][3], rb[2][3];
-        auto gload = [&](auto set_tag) {
-            constexpr int S = decltype(set_tag)::value;
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                ra[S][p] = __builtin_amdgcn_raw_buffer_load_b128(bA, voA[0], soA + (unsigned)p * psA, 0);
-                rb[S][p] = __builtin_amdgcn_raw_buffer_load_b128(bB, voB[0], soB + (unsigned)p * psB, 0);
-            }
-            soA += kstepA;
-            soB += kstepB;
-        };
-        auto lstore = [&](auto set_tag, char* slot) {
-            constexpr int S = decltype(set_tag)::value;
-            char* const d = slot + 1024 * wave + 16 * lane;
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                *reinterpret_cast<u32x4*>(d + p * PLANE) = ra[S][p];
-                *reinterpret_cast<u32x4*>(d + (3 + p) * PLANE) = rb[S][p];
-            }
-        };
-        using S0 = std::integral_constant<int, 0>;
-        using S1 = std::integral_constant<int, 1>;
-        if (nst > 0) {          // loads beyond the last stage read past the K range (clamped by the descriptor or unused)
-            gload(S0{});
-            gload(S1{});
-            lstore(S0{}, ldsb);
-            gload(S0{});
-            __syncthreads();
-            for (int s0 = 0; s0 < nst; s0 += 2) {
-                compute(ldsb);                                   // stage s0 from slot 0
-                if (s0 + 1 < nst) lstore(S1{}, ldsb + STAGE);    // stage s0+1 -> slot 1
-                gload(S1{});
-                __syncthreads();
-                if (s0 + 1 >= nst) break;
-                compute(ldsb + STAGE);                           // stage s0+1 from slot 1
-                if (s0 + 2 < nst) lstore(S0{}, ldsb);            // stage s0+2 -> slot 0
-                gload(S0{});
-                __syncthreads();
-            }
-        }
-    } else if (nst > 0) {
-#pragma unroll
-        for (int s = 0; s < NBUF - 1; ++s)
-            if (s < nst) issue((unsigned)(s * STAGE));
-        unsigned cur = 0u, nxt = (unsigned)((NBUF - 1) * STAGE);      // slot of stage s / of stage s + NBUF - 1
-        for (int s = 0; s < nst; ++s) {
-            // retire my DMA of stage s: everything issued after it (the NBUF-2 younger stages) may stay in flight
-            if (NBUF == 3 && s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NDMA) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();       // everybody's stage s has landed, and everybody is done reading slot `nxt`
-            if (s + NBUF - 1 < nst) issue(nxt);
-            compute(ldsb + cur);
-            nxt = cur;
-            cur = (cur + (unsigned)STAGE == (unsigned)(NBUF * STAGE)) ? 0u : cur + (unsigned)STAGE;
-        }
-    }
-#undef EKAID_DMA16
-    write_tiles<TM, TN>(g, acc, m0, n0, wm, wn, r, h, z);
-}
-
-// f32 -> three bf16 planes (plane-major, see above).  One thread per group of 8 elements: two 16-byte loads, one 16-byte
-// store per plane (consecutive lanes -> consecutive 16 bytes in every plane).
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, long long ngroups, long long n,
-                                                           u32x4* __restrict__ out, long long plane_stride16) {
-    for (long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += (long long)gridDim.x * blockDim.x) {
-        f32x4 v0, v1;
-        const long long e = gi * 8;
-        if (e + 8 <= n) {
-            v0 = *reinterpret_cast<const f32x4*>(x + e);
-            v1 = *reinterpret_cast<const f32x4*>(x + e + 4);
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { v0[c] = e + c < n ? x[e + c] : 0.f; v1[c] = e + 4 + c < n ? x[e + 4 + c] : 0.f; }
-        }
-        u32x2 H0, M0, L0, H1, M1, L1;
-        split4(v0, H0, M0, L0);
-        split4(v1, H1, M1, L1);
-        out[gi] = u32x4{H0[0], H0[1], H1[0], H1[1]};
-        out[gi + plane_stride16] = u32x4{M0[0], M0[1], M1[0], M1[1]};
-        out[gi + 2 * plane_stride16] = u32x4{L0[0], L0[1], L1[0], L1[1]};
-    }
-}
-
-static int planes_variant() {          // tuning aid: EKAID_PLANES_VARIANT = 0 (KS 16, 2 slots, 3 wg/CU) | 2 (32, 3 slots, 1 wg/CU; default).
-                                       // (16,3,2), (32,2,1) and a register-staged form of 0 were measured too: profiles/r02_planes_gemm_microbench.txt
-    static const char* v = getenv("EKAID_PLANES_VARIANT");
-    return v ? atoi(v) : 2;
-}
-
-template <bool A_KC, bool B_KC, int KS, int NBUF, int OCC, bool REGSTAGE = false>
-static int launch_planes(const GemmArgs& a, unsigned long long sa, unsigned long long sb, dim3 grid, hipStream_t st) {
-    constexpr size_t lds = (size_t)NBUF * 6 * 128 * KS * 2;
-    auto kern = gemm_planes_kernel<A_KC, B_KC, KS, NBUF, OCC, REGSTAGE>;
-    if (lds > 64 * 1024) {
-        constexpr int slot = 32 + (A_KC ? 1 : 0) + (B_KC ? 2 : 0) + 4 * (KS == 32 ? 1 : 0) + 8 * (NBUF - 2);
-        if (func_attr_once(slot)) {
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-                (void)hipGetLastError();
-                set_error("gemm_planes: cannot raise the dynamic LDS limit to %zu bytes", lds);
-                return EKAID_ERR_LAUNCH;
-            }
-        }
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, sa, sb);
-    return EKAID_OK;
-}
-
-}  // namespace ekaid
-using namespace ekaid;
-
-extern "C" int ekaid_split_planes(const float* x, long long n, void* planes, long long plane_stride_bytes, void* stream) {
-    if (n <= 0) return EKAID_OK;
-    const long long ngroups = (n + 7) / 8;
-    if (!x || !planes || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(planes) & 15) ||
-        (plane_stride_bytes & 15) || plane_stride_bytes < 16 * ngroups) {
-        set_error("ekaid_split_planes: null / unaligned pointer, or plane stride %lld not a multiple of 16 >= %lld", plane_stride_bytes, 16 * ngroups);
-        return EKAID_ERR_ARG;
-    }
-    long long blocks = (ngroups + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ngroups, n, (u32x4*)planes,
-                       plane_stride_bytes / 16);
-    return check_launch("split_planes");
-}
-
-extern "C" int ekaid_gemm_planes(const ekaid_gemm_t* d, const void* A_planes, long long a_plane_stride, const void* B_planes,
-                                 long long b_plane_stride, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!d || !A_planes || !B_planes || !d->C) { set_error("ekaid_gemm_planes: null pointer"); return EKAID_ERR_ARG; }
-    if (d->transA && d->transB) { set_error("ekaid_gemm_planes: transA && transB unsupported"); return EKAID_ERR_UNSUPPORTED; }
-    if (d->M <= 0 || d->N <= 0) return EKAID_OK;
-    const bool akc = !d->transA, bkc = d->transB != 0;
-    const long long spanA = akc ? ((long long)(d->M - 1) * d->lda + d->K) : ((long long)(d->K - 1) * d->lda + d->M);
-    const long long spanB = bkc ? ((long long)(d->N - 1) * d->ldb + d->K) : ((long long)(d->K - 1) * d->ldb + d->N);
-    int TMN, splitk, tm, tn;
-    plan(d, TMN, splitk, tm, tn);
-    if (d->batch1 * d->batch2 != 1 || TMN != 2 || d->K < 32 || (d->K & 31) || (d->lda & 7) || (d->ldb & 7) ||
-        a_plane_stride < 2 * spanA || b_plane_stride < 2 * spanB || (a_plane_stride & 15) || (b_plane_stride & 15) ||
-        2 * a_plane_stride + 2 * spanA >= (1ll << 32) || 2 * b_plane_stride + 2 * spanB >= (1ll << 32) ||
-        (reinterpret_cast<uintptr_t>(A_planes) & 15) || (reinterpret_cast<uintptr_t>(B_planes) & 15)) {
-        set_error("ekaid_gemm_planes: shape outside the pre-split kernel's envelope (one batch, M >= 512, N >= 128, K %% 32 == 0, "
-                  "leading dimensions %% 8 == 0, planes < 4 GiB apart): M=%d N=%d K=%d lda=%d ldb=%d", d->M, d->N, d->K, d->lda, d->ldb);
-        return EKAID_ERR_UNSUPPORTED;
-    }
-    hipStream_t st = (hipStream_t)stream;
-    GemmArgs a;
-    a.A = (const float*)A_planes; a.B = (const float*)B_planes; a.C = d->C;
-    a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
-    a.sA1 = a.sA2 = a.sB1 = a.sB2 = a.sC1 = a.sC2 = 0; a.nb2 = 1;
-    a.e.alpha = d->alpha; a.e.alpha_dev = d->alpha_dev; a.e.beta = d->accumulate; a.e.bias = d->bias;
-    a.e.R = d->R; a.e.ldr = d->ldr; a.e.rdiv = d->rdiv < 1 ? 1 : d->rdiv; a.e.rowmask = d->rowmask; a.e.act = d->act;
-    a.e.drop_p = d->drop_p; a.e.drop_inv = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f; a.e.drop_seed = d->drop_seed;
-    a.e.drop_epoch = dropout_epoch_ptr(); a.e.n_cols = d->N;
-    a.splitk = splitk; a.tiles_m = tm; a.tiles_n = tn; a.ws = nullptr;
-    a.k_per_split = cdiv(cdiv(d->K, BK_BIG), a.splitk) * BK_BIG;
-    if (a.splitk > 1) {
-        const size_t need = (size_t)a.splitk * d->M * d->N * sizeof(float);
-        if (!workspace || workspace_bytes < need) {
-            set_error("ekaid_gemm_planes: workspace too small (%zu < %zu)", workspace_bytes, need);
-            return EKAID_ERR_ARG;
-        }
-        a.ws = (float*)workspace;
-        a.splitk = cdiv(d->K, a.k_per_split);
-        if (a.splitk <= 1) { a.splitk = 1; a.ws = nullptr; a.k_per_split = cdiv(d->K, BK_BIG) * BK_BIG; }
-    }
-    dim3 grid(a.tiles_m * a.tiles_n, 1, a.splitk > 1 ? a.splitk : 1);
-    const unsigned long long sa = (unsigned long long)a_plane_stride, sb = (unsigned long long)b_plane_stride;
-    int rc;
-#define EKAID_PL(AK, BK) (planes_variant() == 0 ? launch_planes<AK, BK, 16, 2, 3>(a, sa, sb, grid, st) \
-                          : launch_planes<AK, BK, 32, 3, 1>(a, sa, sb, grid, st))
-    if (akc && bkc) rc = EKAID_PL(true, true);
-    else if (akc && !bkc) rc = EKAID_PL(true, false);
-    else rc = EKAID_PL(false, false);
-#undef EKAID_PL
-    if (rc) return rc;
-    rc = check_launch("gemm_planes_kernel");
-    if (rc) return rc;
-    if (a.splitk > 1) {
-        const long long total = (long long)d->M * d->N;
-        const bool vec_ok = (d->N % 4 == 0) && (d->ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->C) & 15) == 0) && total / 4 < (1ll << 30);
-        if (vec_ok) {
-            const int n4 = d->N / 4;
-            hipLaunchKernelGGL(splitk_reduce_vec_kernel<4>, dim3(cdiv((long long)d->M * n4, 256)), dim3(256), 0, st, a.ws, d->C, d->M, n4, d->ldc, a.splitk, a.e);
-        } else {
-            int blocks = cdiv(total, 256);
-            if (blocks > 2048) blocks = 2048;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.ws, d->C, d->M, d->N, d->ldc, a.splitk, a.e);
-        }
-        rc = check_launch("splitk_reduce_kernel");
-    }
-    return rc;
-}

@@ -681,7 +681,17 @@ static int colsum_impl(const float* x, int M, int N, int ldx, float* out, int ac
     int rows_per_blk = (int)(((long long)M * colblks + 511) / 512);          // ~512 workgroups stream the matrix
     rows_per_blk = rows_per_blk < 16 ? 16 : rows_per_blk;
     int nparts = cdiv(M, rows_per_blk);
-    while ((long long)nparts * N > COLSUM_PART_FLOATS) { rows_per_blk *= 2; nparts = cdiv(M, rows_per_blk); }     // (very wide N)
+    if (N > COLSUM_PART_FLOATS) {          // wider than the partial-sum scratch: column chunks, each a call of its own
+        for (int c0 = 0; c0 < N; c0 += (int)COLSUM_PART_FLOATS) {
+            const int rc = colsum_impl(x + c0, M, (int)(N - c0 < COLSUM_PART_FLOATS ? N - c0 : COLSUM_PART_FLOATS), ldx, out + c0, accumulate, st);
+            if (rc) return rc;
+        }
+        return EKAID_OK;
+    }
+    while (nparts > 1 && (long long)nparts * N > COLSUM_PART_FLOATS) {      // (very wide N: fewer, longer row blocks)
+        rows_per_blk = rows_per_blk > M / 2 ? M : rows_per_blk * 2;
+        nparts = cdiv(M, rows_per_blk);
+    }
     if (nparts == 1 && !accumulate) {
         hipLaunchKernelGGL((colsum_kernel<false>), dim3(colblks, 1), dim3(256), 0, st, x, M, N, ldx, out, rows_per_blk);
         return check_launch("colsum");

@@ -44,6 +44,8 @@ class GradBuckets:
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.overlap = overlap
         self.force_comm = False       # issue the collectives even at world size 1 (exercises the RCCL path on one GPU)
+        self.comm_suspended = False   # True: no collectives at all (warm-up iterations of a hipGraph capture, engine.py)
+        self.launch_log = None        # list -> (bucket, C-ABI calls issued so far) per all-reduce launch (tests, bench)
         self.built = False
         self.order = []             # parameters in first-backward completion order
         self._seen = set()
@@ -85,7 +87,7 @@ class GradBuckets:
         offs, total = [], 0
         for n in sizes:
             offs.append(total)
-            total += (n + 7) // 8 * 8                    # every tensor starts on an 8-element group (16-byte aligned; P8 planes)
+            total += (n + 7) // 8 * 8                    # every tensor starts on an 8-element group (32-byte aligned)
         self.total = total
         self.pflat = torch.zeros(total, device=dev, dtype=dt)
         self.gflat = torch.zeros(total, device=dev, dtype=dt)
@@ -115,30 +117,13 @@ class GradBuckets:
         self.built = True
         self._reset_pending()
         self._check_layout_agreement()
-        self.refresh_planes()
         if self.gflat.is_cuda:
             from . import ops
             for p, o in zip(self.live, self.offsets):         # backward kernels write straight into the flat buffer (ops.grad_out)
                 ops.register_grad_slot(p, self.gflat, o)
 
-    def refresh_planes(self):
-        """bf16 planes of the whole flat parameter buffer (ekaid_split_planes) for the pre-split GEMM kernel: one pass
-        over the weights per update instead of one split inside every K loop that reads them."""
-        if not self.pflat.is_cuda:
-            return
-        from . import ops
-        if not ops.USE_PLANES:
-            return
-        stride = 2 * self.total
-        if getattr(self, 'planes', None) is None:
-            self.planes = torch.empty(3 * stride, dtype=torch.uint8, device=self.pflat.device)
-        hip.check(hip.lib().ekaid_split_planes(hip.ptr(self.pflat), self.total, hip.ptr(self.planes), stride, hip.stream()),
-                  'split_planes')
-        for p, o in zip(self.live, self.offsets):
-            ops.register_weight_planes(p, ops.Planes(self.planes, stride, 2 * o), self.pflat)
-
     def comm_active(self):
-        return self.world > 1 or self.force_comm
+        return (self.world > 1 or self.force_comm) and not self.comm_suspended
 
     def _check_layout_agreement(self):
         """Buckets are reduced by raw offset: all ranks must have derived the SAME flat layout (same live set, same
@@ -187,6 +172,8 @@ class GradBuckets:
         s, e, _ = self.buckets[b]
         self._launched[b] = True
         self._next = max(self._next, b + 1)
+        if self.launch_log is not None:
+            self.launch_log.append((b, hip.calls_issued()))
         self.handles.append(dist.all_reduce(self.gflat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
@@ -275,7 +262,6 @@ class FlatAdam(GradBuckets):
         hip.check(hip.lib().ekaid_adam_step_dev(hip.ptr(self.pflat), hip.ptr(self.gflat), hip.ptr(self.m), hip.ptr(self.v),
                                                 self.total, hip.ptr(hyper), hip.ptr(step), hip.ptr(derived), hip.stream()),
                   'adam_step_dev')
-        self.refresh_planes()
 
     # ------------------------------------------------------------------ checkpointing (SURVEY f-4)
     def state_dict(self, named_parameters=None):

@@ -154,11 +154,18 @@ class TrainStep:
         snap_step, snap_epoch = self.opt.step_count, self._epoch.clone()
         seed_state = ops.seed_state()
         s.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(s):
-            for _ in range(self.warmup):        # sizes every workspace, raises kernel attributes, warms the allocator
-                self._body(static, T, sden)
-                if self.comm == 'eager' and self.opt.comm_active():
-                    self.opt.step()
+        # The warm-up iterations run WITHOUT collectives (local Adam on local gradients; everything is restored below): with
+        # ragged answers the ranks meet a new (shape, decode steps) key at different iterations, so a rank that captures
+        # must not issue all-reduces its peers (which already hold that key and just replay) would not match.
+        self.opt.comm_suspended = True
+        try:
+            with torch.cuda.stream(s):
+                for _ in range(self.warmup):    # sizes every workspace, raises kernel attributes, warms the allocator
+                    self._body(static, T, sden)
+                    if self.comm == 'eager' and self.opt.comm_active():
+                        self.opt.step()
+        finally:
+            self.opt.comm_suspended = False
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
         ops.set_seed_state(seed_state)          # the capture draws the same site seeds as the first warm-up step
@@ -169,7 +176,6 @@ class TrainStep:
         if self._pool is None:
             self._pool = g.pool()
         self.opt.pflat.copy_(snap_p)
-        self.opt.refresh_planes()
         if snap_m is not None:
             self.opt.m.copy_(snap_m)
             self.opt.v.copy_(snap_v)

@@ -88,3 +88,35 @@ def formula_init_(module, prefix):
         t = sd[k[len(prefix):]]
         t.copy_(torch.from_numpy(arr).to(t.device))
     return module
+
+
+def build_models(cfg, n_words, vocab, device='cpu', train=False):
+    """The two product modules (``ChangeDetector``, ``DynamicSpeaker``) with the closed-form weights of this file: what the
+    benchmark, the smoke test and the parity tests construct (identical on every rank, no checkpoint needed)."""
+    import contextlib
+    import io
+    import warnings
+    from .models.dynamic_speaker_change_pos import DynamicSpeaker
+    from .models.modules import ChangeDetector
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        with contextlib.redirect_stdout(io.StringIO()):
+            cd = ChangeDetector(cfg, {str(i): i for i in range(n_words)})
+            sp = DynamicSpeaker(cfg, vocab)
+    formula_init_(cd, 'cd.')
+    formula_init_(sp, 'sp.')
+    cd.train(train)
+    sp.train(train)
+    return cd.to(device), sp.to(device)
+
+
+def state_copy(module, requires_grad=False):
+    """CPU copy of a module's ``state_dict`` (optionally as autograd leaves): the weights handed to a functional
+    restatement of the path for comparison."""
+    P = {}
+    for k, v in module.state_dict().items():
+        t = v.detach().cpu().clone()
+        if requires_grad and t.dtype.is_floating_point:
+            t.requires_grad_(True)
+        P[k] = t
+    return P

@@ -53,8 +53,6 @@ SIGNATURES = {
     'ekaid_set_gemm_mode': [I],
     'ekaid_get_gemm_mode': [],
     'ekaid_gemm_f32': [POINTER(GemmDesc), P, c_size_t, P],
-    'ekaid_gemm_planes': [POINTER(GemmDesc), P, L, P, L, P, c_size_t, P],
-    'ekaid_split_planes': [P, L, P, L, P],
     'ekaid_wn_scale_fwd': [P, P, L, P, P, P],
     'ekaid_wn_scale_bwd': [P, P, P, P, L, P, I, P, P],
     'ekaid_scale_dot': [P, P, P, L, P, P],
@@ -70,7 +68,6 @@ SIGNATURES = {
     'ekaid_expand_rows_fwd': [P, P, L, I, I, I, P, F, U64, P],
     'ekaid_expand_rows_bwd': [P, P, L, I, I, I, P, F, U64, P],
     'ekaid_gat_fused_fwd': [P, P, P, P, P, P, I, I, I, I, I, I, P, P, P],
-    'ekaid_gat_fused_bwd': [P, P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P],
     'ekaid_masked_softmax_fwd': [P, P, P, P, I, I, I, I, I, P, P],
     'ekaid_masked_softmax_bwd': [P, P, P, P, I, I, I, I, I, P, P, P, P],
     'ekaid_geom_embed': [P, P, I, I, I, I, P, P],
@@ -147,7 +144,19 @@ def last_error():
     return msg.decode() if msg else ''
 
 
+_calls = 0
+
+
+def calls_issued():
+    """C-ABI calls checked so far in this process (every kernel-launching call goes through ``check``): a host-side clock
+    for "was X enqueued before Y" assertions (tests/test_hip_dp.py: the first gradient bucket's all-reduce vs the last
+    backward kernel)."""
+    return _calls
+
+
 def check(rc, what=''):
+    global _calls
+    _calls += 1
     if rc != 0:
         raise EkaidError('%s failed (rc=%d): %s' % (what or 'ekaid call', rc, last_error()))
 

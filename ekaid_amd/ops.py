@@ -140,79 +140,10 @@ def grad_claimed_slot(W):
     return None
 
 
-# --------------------------------------------------------------------------- #
-# pre-split operands ("planes", include/ekaid_hip.h: ekaid_split_planes / ekaid_gemm_planes)
-# --------------------------------------------------------------------------- #
-# Opt-in (EKAID_GEMM_PLANES=1): on MI355X the pre-split kernel is bit-identical to the in-kernel split but not faster
-# end to end (profiles/r02_planes_gemm_microbench.txt: +18 % on the m-contiguous wgrad shapes, -20 % on the k-contiguous
-# forward shapes, and every activation / gradient costs one extra split pass), so the layers do not use it by default.
-USE_PLANES = os.environ.get('EKAID_GEMM_PLANES', '0') not in ('0', 'off', 'false', '')
-_weight_planes = {}          # data_ptr of a parameter -> (planes view, owner flat buffer, its version when refreshed)
-
-
-class Planes:
-    """Three bf16 planes of an f32 buffer, plane-major: ``buf`` (uint8) holds hi | mid | lo, ``stride`` bytes apart;
-    ``base`` = byte offset of the buffer's element 0 inside plane 0 (non-zero for views into a larger plane buffer)."""
-    __slots__ = ('buf', 'stride', 'base')
-
-    def __init__(self, buf, stride, base=0):
-        self.buf, self.stride, self.base = buf, stride, base
-
-    def ptr(self, elem_off=0):
-        return self.buf.data_ptr() + self.base + 2 * elem_off
-
-
-def split_planes(t):
-    """float32 tensor (contiguous) -> its three bf16 planes (``Planes``)."""
-    require_cuda(t)
-    t = _c(t)
-    n = t.numel()
-    stride = 2 * ((n + 7) // 8 * 8)
-    out = torch.empty(3 * stride, dtype=torch.uint8, device=t.device)
-    check(hip.lib().ekaid_split_planes(ptr(t), n, ptr(out), stride, stream()), 'split_planes')
-    return Planes(out, stride)
-
-
-def planes_of(t):
-    """Planes of a tensor that is not written again after its creation (activations, inputs, eval-mode weights): cached
-    on the tensor object and dropped with it; torch-visible in-place writes invalidate the cache through ``_version``."""
-    ent = getattr(t, '_ekaid_planes', None)
-    if ent is not None and ent[0] == t._version and ent[1] == t.data_ptr():
-        return ent[2]
-    pl = split_planes(t)
-    try:
-        t._ekaid_planes = (t._version, t.data_ptr(), pl)
-    except Exception:       # noqa: BLE001  (a tensor type that refuses attributes: just do not cache)
-        pass
-    return pl
-
-
-def register_weight_planes(param, planes, owner):
-    _weight_planes[param.data_ptr()] = (planes, owner, owner._version)
-
-
-def weight_planes(W):
-    """Planes of a weight: the slice of the optimizer's flat plane buffer (refreshed by every update, ekaid_amd/dp.py)
-    when the parameter lives there and has not been overwritten since, otherwise split on demand."""
-    ent = _weight_planes.get(W.data_ptr())
-    if ent is not None and ent[1]._version == ent[2]:
-        return ent[0]
-    return planes_of(W)
-
-
-def planes_ok(M, N, K, lda, ldb, batch=(1, 1), a_off=0, b_off=0):
-    """Shapes the pre-split kernel takes (mirrors the check in ekaid_gemm_planes)."""
-    return (batch == (1, 1) and M >= 512 and N >= 128 and K >= 32 and K % 32 == 0 and lda % 8 == 0 and
-            ldb % 8 == 0 and a_off % 8 == 0 and b_off % 8 == 0 and get_gemm_mode() == GEMM_BF16_SPLIT)
-
-
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=None,
          accumulate=False, bias=None, R=None, ldr=0, rdiv=1, rowmask=None, act=ACT_NONE,
-         batch=(1, 1), strides=(0, 0, 0, 0, 0, 0), a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_seed=0,
-         A_planes=None, B_planes=None):
-    """C = act(alpha * op(A) op(B) [+C] [+bias] [+R]) on raw device buffers (element offsets a_off..).
-    ``A_planes`` / ``B_planes``: ``Planes`` of the WHOLE buffers A / B (``split_planes``); when both are given and the
-    shape is inside the pre-split kernel's envelope the product runs on them (no conversion in the K loop)."""
+         batch=(1, 1), strides=(0, 0, 0, 0, 0, 0), a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_seed=0):
+    """C = act(alpha * op(A) op(B) [+C] [+bias] [+R]) on raw device buffers (element offsets a_off..)."""
     d = GemmDesc()
     d.A = A.data_ptr() + 4 * a_off
     d.B = B.data_ptr() + 4 * b_off
@@ -240,15 +171,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=N
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    done = False
-    if A_planes is not None and B_planes is not None and planes_ok(M, N, K, lda, ldb, batch, a_off, b_off):
-        rc = L.ekaid_gemm_planes(ctypes.byref(d), A_planes.ptr(a_off), A_planes.stride, B_planes.ptr(b_off), B_planes.stride,
-                                 ptr(ws), need, stream())
-        if rc != hip.ERR_UNSUPPORTED:
-            check(rc, 'ekaid_gemm_planes')
-            done = True
-    if not done:
-        check(L.ekaid_gemm_f32(ctypes.byref(d), ptr(ws), need, stream()), 'ekaid_gemm_f32')
+    check(L.ekaid_gemm_f32(ctypes.byref(d), ptr(ws), need, stream()), 'ekaid_gemm_f32')
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
@@ -322,29 +245,16 @@ class LinearFn(Function):
         y = torch.empty(M, N, device=W.device, dtype=torch.float32)
         Wt = weight_transposed(W) if _use_transposed(M) else None
         off = 0
-        xps = []
-        Wp = None
         for i, (x, ld) in enumerate(zip(xs2, lds)):
             last = i == len(xs2) - 1
             K = x.shape[1]
             if Wt is not None:      # B = W^T [K][N]: n-contiguous staging (512-byte row segments), the faster variant
                 gemm(x, Wt, y, M, N, K, ld, N, N, 0, 0, alpha_dev=scale, accumulate=i > 0,
                      bias=b if last else None, act=act if last else ACT_NONE, b_off=off * N)
-                xps.append(None)
             else:
-                xp = None
-                if USE_PLANES and planes_ok(M, N, K, ld, Ktot, b_off=off) and x.is_contiguous():
-                    # cache on the caller's tensor object when the 2-D view is the same memory (one split serves every
-                    # layer that reads this activation)
-                    src = xs[i] if (isinstance(xs[i], torch.Tensor) and xs[i].data_ptr() == x.data_ptr() and xs[i].is_contiguous()
-                                    and xs[i].numel() == x.numel()) else x
-                    xp = planes_of(src)
-                    Wp = weight_planes(W) if Wp is None else Wp
-                xps.append(xp)
                 gemm(x, W, y, M, N, K, ld, Ktot, N, 0, 1, alpha_dev=scale, accumulate=i > 0,
-                     bias=b if last else None, act=act if last else ACT_NONE, b_off=off, A_planes=xp, B_planes=Wp)
+                     bias=b if last else None, act=act if last else ACT_NONE, b_off=off)
             off += K
-        ctx.xps = xps
         ctx.act = act
         ctx.has_b = b is not None
         ctx.bias_ref = b.detach() if b is not None else None       # (an alias: its data_ptr finds the gradient slot)
@@ -370,12 +280,6 @@ class LinearFn(Function):
         db = None
         if ctx.has_b and need[1]:
             db = bias_grad(ctx.bias_ref, dz, M, N, N)
-        # the gradient dz feeds up to two products per input (dgrad as the k-contiguous A, wgrad as the m-contiguous A):
-        # split it once
-        dzp = Wp = None
-        if any(xp is not None for xp in ctx.xps):
-            dzp = split_planes(dz)
-            Wp = weight_planes(W)
         dxs = []
         off = 0
         for i, x in enumerate(xs2):
@@ -384,8 +288,7 @@ class LinearFn(Function):
                 dx = torch.empty(M, K, device=W.device, dtype=torch.float32)
                 pd = ctx.drops[i] if ctx.drops is not None else 0.0
                 gemm(dz, W, dx, M, K, N, N, Ktot, K, 0, 0, alpha_dev=scale, b_off=off,
-                     drop_p=float(pd), drop_seed=ctx.seeds[i],          # input-dropout backward in the epilogue
-                     A_planes=dzp, B_planes=Wp if dzp is not None else None)
+                     drop_p=float(pd), drop_seed=ctx.seeds[i])          # input-dropout backward in the epilogue
                 dxs.append(dx.view(*ctx.lead[i], K))
             else:
                 dxs.append(None)
@@ -394,9 +297,9 @@ class LinearFn(Function):
         if need[0] or (ctx.has_scale and need[2]):
             dW = grad_out(W)
             off = 0
-            for x, ld, xp in zip(xs2, ctx.lds, ctx.xps):
+            for x, ld in zip(xs2, ctx.lds):
                 K = x.shape[1]
-                gemm(dz, x, dW, N, K, M, N, ld, Ktot, 1, 0, c_off=off, A_planes=dzp if xp is not None else None, B_planes=xp)
+                gemm(dz, x, dW, N, K, M, N, ld, Ktot, 1, 0, c_off=off)
                 off += K
             if ctx.has_scale:
                 dscale = torch.empty((), device=W.device, dtype=torch.float32)
@@ -427,21 +330,12 @@ class LinearRowStackFn(Function):
         y = torch.empty(sum(Ms), N, device=W.device, dtype=torch.float32)
         r0 = 0
         Wt = weight_transposed(W) if _use_transposed(sum(Ms)) else None
-        xps = []
-        Wp = None
         for x, ld, M in zip(xs2, lds, Ms):
             if Wt is not None:
                 gemm(x, Wt, y, M, N, K, ld, N, N, 0, 0, bias=b, c_off=r0 * N)
-                xps.append(None)
             else:
-                xp = None
-                if USE_PLANES and planes_ok(M, N, K, ld, K) and x.is_contiguous():
-                    xp = planes_of(x)
-                    Wp = weight_planes(W) if Wp is None else Wp
-                xps.append(xp)
-                gemm(x, W, y, M, N, K, ld, K, N, 0, 1, bias=b, c_off=r0 * N, A_planes=xp, B_planes=Wp)
+                gemm(x, W, y, M, N, K, ld, K, N, 0, 1, bias=b, c_off=r0 * N)
             r0 += M
-        ctx.xps = xps
         ctx.save_for_backward(W, *xs2)
         ctx.bias_ref = b.detach() if b is not None else None
         ctx.lds, ctx.Ms, ctx.has_b = lds, Ms, b is not None
@@ -462,10 +356,8 @@ class LinearRowStackFn(Function):
         if need[0]:
             dW = grad_out(W)
             r0 = 0
-            dyp = split_planes(dy) if any(xp is not None for xp in ctx.xps) else None
             for i, (x, ld, M) in enumerate(zip(xs2, ctx.lds, ctx.Ms)):
-                gemm(dy, x, dW, N, K, M, N, ld, K, 1, 0, accumulate=i > 0, a_off=r0 * N,
-                     A_planes=dyp if ctx.xps[i] is not None else None, B_planes=ctx.xps[i])
+                gemm(dy, x, dW, N, K, M, N, ld, K, 1, 0, accumulate=i > 0, a_off=r0 * N)
                 r0 += M
         dxs = []
         r0 = 0
@@ -1275,19 +1167,6 @@ class GatAttentionFn(Function):
         if doutT is None:
             doutT = torch.zeros(R, N, H * A, device=dev, dtype=torch.float32)
         doutT = _c(doutT)
-        if dP_ext is None and GAT_FUSED_BWD:
-            # everything between d outT and (dq, dk, dS) in one kernel per slice (csrc/gat.hip: gat_fused_bwd_kernel)
-            dq = torch.empty(R, N, A, device=dev, dtype=torch.float32)
-            dk = torch.empty(R, M, A, device=dev, dtype=torch.float32)
-            dS = torch.empty(R, N, A, device=dev, dtype=torch.float32)
-            dlbias = torch.zeros(R, N, N, device=dev, dtype=torch.float32) if M < N else \
-                torch.empty(R, N, N, device=dev, dtype=torch.float32)
-            dgeo = torch.empty_like(geo) if ctx.has_geo else None
-            rc = L.ekaid_gat_fused_bwd(ptr(doutT), ptr(S), ptr(P), ptr(q), ptr(k), ptr(cond), ptr(geo), R, N, M, A, H, direction,
-                                       ptr(dq), ptr(dk), ptr(dS), ptr(dlbias), ptr(dgeo), stream())
-            if rc != hip.ERR_UNSUPPORTED:
-                check(rc, 'gat_fused_bwd')
-                return dq, dk, dS, None, dlbias, dgeo, None, None, None
         doutT = _c(doutT)
         # dP = doutT . S[:M]^T   (R, N*H, M)
         dP = torch.empty(R, N, H, M, device=dev, dtype=torch.float32)
@@ -1311,12 +1190,6 @@ class GatAttentionFn(Function):
         gemm(daff, q, dk, M, dh, N, H * M, A, A, 1, 0, alpha=sc, batch=(R, H),
              strides=(N * H * M, M, N * A, dh, M * A, dh))
         return dq, dk, dS, None, dlbias, dgeo, None, None, None
-
-
-# Opt-in: the one-kernel-per-slice backward (csrc/gat.hip: gat_fused_bwd_kernel, plain f32 FMA) is correct but measured
-# SLOWER than the composed form (four batched MFMA GEMMs + softmax backward): 819 vs 414 us at R=512, N=36, A=1024
-# (tools/gat_bench.py); it stays available for shapes where the batched GEMMs do worse.
-GAT_FUSED_BWD = os.environ.get('EKAID_GAT_FUSED_BWD', '0') not in ('0', 'off', 'false', '')
 
 
 def gat_attention(q, k, S, cond, lbias, geo, H, direction, impl='fused'):

@@ -86,30 +86,15 @@ typedef struct ekaid_gemm {
 size_t ekaid_gemm_workspace_bytes(const ekaid_gemm_t* g);
 int ekaid_gemm_f32(const ekaid_gemm_t* g, void* workspace, size_t workspace_bytes, void* stream);
 
-/* The same contraction on PRE-SPLIT operands (EKAID_GEMM_BF16_SPLIT arithmetic, the same six products per block): the
- * three bf16 planes of an operand are produced once, where the tensor is produced, instead of inside every K loop that
- * reads it (the K loop then contains no vector-ALU work; operands stream global -> LDS by LDS-DMA).
- * Plane storage: plane-major -- three bf16 arrays hi, mid, lo (hi + mid + lo == x exactly; truncation split), each laid out
- * like the f32 array, `plane_stride_bytes` apart; a row-major view of the f32 buffer addresses its planes with the same
- * (row, column) arithmetic at 2 bytes per element.
- *   ekaid_split_planes: x (n floats, 16-byte aligned) -> planes (16-byte aligned; plane_stride_bytes % 16 == 0 and
- *                       >= 2 * ceil8(n); elements n .. ceil8(n) of every plane are written as zero).
- *   ekaid_gemm_planes:  g as for ekaid_gemm_f32 (g->A / g->B are ignored); A_planes / B_planes = address, inside plane 0, of
- *                       the element the A / B pointer would address.  Envelope: one batch, M >= 512, N >= 128, K % 32 == 0,
- *                       lda % 8 == 0, ldb % 8 == 0, 16-byte aligned operand starts; outside it the call returns
- *                       EKAID_ERR_UNSUPPORTED (-3) and the caller uses ekaid_gemm_f32.  Workspace as ekaid_gemm_workspace_bytes(g).
- * ref: the same call sites as ekaid_gemm_f32 with >= 512 rows (all detector layers: modules.py:195-303, graph_att*.py). */
-int ekaid_split_planes(const float* x, long long n, void* planes, long long plane_stride_bytes, void* stream);
-int ekaid_gemm_planes(const ekaid_gemm_t* g, const void* A_planes, long long a_plane_stride_bytes, const void* B_planes,
-                      long long b_plane_stride_bytes, void* workspace, size_t workspace_bytes, void* stream);
-
 /* Arithmetic of ekaid_gemm_f32 (per device; both take and return f32 and accumulate in f32):
  *   EKAID_GEMM_F32_MFMA   (0)  v_mfma_f32_32x32x2_f32, an exact f32 fma chain;
  *   EKAID_GEMM_BF16_SPLIT (1)  every f32 operand element is split EXACTLY into three bf16 values (8+8+8 significant
  *                              bits) and the six products above 2^-24 relative are formed on v_mfma_f32_32x32x16_bf16
  *                              with f32 accumulation: f32-level accuracy (dropped terms < 2^-23 |a.b| per product) at
  *                              2.67x the matrix rate.  Default; the environment variable EKAID_GEMM_MODE=f32 selects 0.
- * Inputs must be finite in mode 1 (an Inf operand gives NaN where mode 0 gives Inf). */
+ * Inputs must be finite in mode 1: an Inf operand gives NaN where mode 0 gives Inf (Inf - Inf in the split).  Unreachable on
+ * this path -- every GEMM operand is a finite activation, weight or gradient; a non-finite one is already a failed run, and
+ * EKAID_CHECK_FINITE=1 (ekaid_amd/ops.py) asserts exactly that per module output. */
 #define EKAID_GEMM_F32_MFMA 0
 #define EKAID_GEMM_BF16_SPLIT 1
 int ekaid_set_gemm_mode(int mode);
@@ -170,12 +155,6 @@ int ekaid_expand_rows_bwd(const float* dout, const float* mask, long long rows, 
 int ekaid_gat_fused_fwd(const float* q, const float* k, const float* S, const float* cond, const float* lbias,
                         const float* geo, int R, int N, int M, int A, int H, int dir, float* P, float* outT,
                         void* stream);
-/* Fused backward of the same core: from d outT [R][N][H*A] (and the saved P) to dq [R][N][A], dk [R][M][A], dS [R][N][A]
- * (rows >= M zero), dlbias [R][N][N] (original orientation; may be NULL) and dgeo [R][N][M][H] (NULL without geometry), one
- * workgroup per slice, nothing but those tensors touches HBM.  Returns EKAID_ERR_UNSUPPORTED outside N <= 64, (A/H) % 32 == 0. */
-int ekaid_gat_fused_bwd(const float* doutT, const float* S, const float* P, const float* q, const float* k, const float* cond,
-                        const float* geo, int R, int N, int M, int A, int H, int dir, float* dq, float* dk, float* dS,
-                        float* dlbias, float* dgeo, void* stream);
 int ekaid_masked_softmax_fwd(const float* aff, const float* cond, const float* lbias, const float* geo, int R,
                              int N, int M, int H, int dir, float* P, void* stream);
 int ekaid_masked_softmax_bwd(const float* P, const float* dP, const float* cond, const float* geo, int R, int N,

@@ -574,20 +574,15 @@ def test_gat_attention_fused_and_composed(N, M, A, H, direction, with_geo):
     out_r, P_r = _gat_reference(cpu[0], cpu[1], cpu[2], cond.double(), cpu[3], cpu[4], H, direction)
     assert torch.allclose(P_r[0, 2], torch.full_like(P_r[0, 2], 1.0 / M))
     gr = _grads([out_r], [t for t in cpu if t is not None])
-    for impl, fused_bwd in (('fused', False), ('gemm', False), ('fused', True)):
+    for impl in ('fused', 'gemm'):
         gpu = [t.to(DEV).requires_grad_(True) if t is not None else None for t in (q, k, S, lbias, geo)]
         out, P = ops.gat_attention(gpu[0], gpu[1], gpu[2], cond.to(DEV), gpu[3], gpu[4], H, direction, impl)
         check(P, P_r, 5e-6, 'P ' + impl)
         check(out, out_r, 5e-6, 'outT ' + impl)
         ins_g = [t for t in gpu if t is not None]
-        was = ops.GAT_FUSED_BWD
-        ops.GAT_FUSED_BWD = fused_bwd              # composed backward (default) and the one-kernel backward
-        try:
-            gg = _grads([out], ins_g)
-        finally:
-            ops.GAT_FUSED_BWD = was
+        gg = _grads([out], ins_g)
         for n, a, r in zip(('dq', 'dk', 'dS', 'dlbias', 'dgeo'), gg, gr):
-            check(a, r.float(), 5e-5, '%s %s%s' % (n, impl, ' fused-bwd' if fused_bwd else ''))
+            check(a, r.float(), 5e-5, '%s %s' % (n, impl))
 
 
 @pytest.mark.parametrize('R', [1, 5, 200, 400])
@@ -812,69 +807,6 @@ def test_round2_kernels_int8_labels_loss_denominator_device_adam_dropout_epoch()
     assert torch.equal(y2, y3) and not torch.equal(y1, y2)
     assert abs(float((y2 != 0).float().mean()) - 0.5) < 0.02 and abs(float(((y1 != 0) & (y2 != 0)).float().mean()) - 0.25) < 0.02
     assert not torch.equal(c1 != 0, c2 != 0)
-
-
-@pytest.mark.parametrize('tA,tB,M,N,K', [(0, 1, 640, 256, 128), (0, 0, 1152, 384, 1024), (1, 0, 1024, 640, 2304),
-                                         (0, 1, 2304, 1024, 4096), (0, 1, 600, 200, 96), (1, 0, 512, 128, 18432)])
-def test_gemm_on_presplit_planes(tA, tB, M, N, K):
-    """ekaid_gemm_planes == ekaid_gemm_f32 (same six products per block, same order: bit-identical accumulators up to the
-    split-K slab order) and both within the f32 error of a float64 product; epilogue (bias, activation, accumulate) shared."""
-    from ekaid_amd import ops
-    from ekaid_amd.hip import ACT_RELU
-    g = torch.Generator().manual_seed(M + N + K)
-    scale_r = torch.exp(torch.randn(M if not tA else K, 1, generator=g))          # rows with a 3-decade dynamic range
-    A = (torch.randn(*((M, K) if not tA else (K, M)), generator=g) * scale_r).to(DEV)
-    B = torch.randn(*((N, K) if tB else (K, N)), generator=g).to(DEV)
-    bias = torch.randn(N, generator=g).to(DEV)
-    lda, ldb = A.shape[1], B.shape[1]
-    Ap, Bp = ops.split_planes(A), ops.split_planes(B)
-    c_f32, c_pl = torch.zeros(M, N, device=DEV), torch.zeros(M, N, device=DEV)
-    assert ops.planes_ok(M, N, K, lda, ldb)
-    ops.gemm(A, B, c_f32, M, N, K, lda, ldb, N, tA, tB, bias=bias, act=ACT_RELU)
-    ops.gemm(A, B, c_pl, M, N, K, lda, ldb, N, tA, tB, bias=bias, act=ACT_RELU, A_planes=Ap, B_planes=Bp)
-    A64 = (A.double().cpu().t() if tA else A.double().cpu())
-    B64 = (B.double().cpu().t() if tB else B.double().cpu())
-    ref = torch.relu(A64 @ B64 + bias.double().cpu())
-    mag = A64.abs() @ B64.abs() + bias.double().cpu().abs()
-    e_pl = float(((c_pl.double().cpu() - ref).abs() / mag).max())
-    e_f32 = float(((c_f32.double().cpu() - ref).abs() / mag).max())
-    assert e_pl <= max(1.5 * e_f32, 2e-7), (e_pl, e_f32)
-    assert float((c_pl - c_f32).abs().max()) <= 4e-6 * float(mag.max()), 'the two staging paths compute the same products'
-    # accumulate into C
-    c2 = c_pl.clone()
-    ops.gemm(A, B, c2, M, N, K, lda, ldb, N, tA, tB, accumulate=True, A_planes=Ap, B_planes=Bp)
-    want = c_pl.double().cpu() + A64 @ B64
-    assert float(((c2.double().cpu() - want).abs() / (mag + c_pl.double().cpu().abs())).max()) < 5e-7
-
-
-def test_gemm_planes_exact_on_integers_and_views():
-    """Integer-valued operands that need all three planes reproduce the exact integer product (lane maps of the LDS-DMA
-    staging, swizzles and fragment reads), also through column-offset views of wider buffers (offsets % 8 == 0)."""
-    from ekaid_amd import ops
-    g = torch.Generator().manual_seed(3)
-    M, N, K, off = 1024, 256, 64, 16
-    Awide = torch.randint(-2000000, 2000000, (M, K + 2 * off), generator=g).float().to(DEV)      # 21 significant bits
-    # B selects (with a sign and a small integer factor) ONE k per output column: every output is a single exact product
-    Bw = torch.zeros(N, K + off)
-    sel = torch.randint(0, K, (N,), generator=g)
-    fac = torch.randint(1, 4, (N,), generator=g).float() * (torch.randint(0, 2, (N,), generator=g).float() * 2 - 1)
-    Bw[torch.arange(N), off + sel] = fac
-    Bwide = Bw.to(DEV)
-    Ap, Bp = ops.split_planes(Awide), ops.split_planes(Bwide)
-    C = torch.empty(M, N, device=DEV)
-    ops.gemm(Awide, Bwide, C, M, N, K, K + 2 * off, K + off, N, 0, 1, a_off=off, b_off=off, A_planes=Ap, B_planes=Bp)
-    want = Awide[:, off:off + K].double().cpu() @ Bwide[:, off:off + K].double().cpu().t()
-    assert float(want.abs().max()) < 2 ** 24
-    assert torch.equal(C.double().cpu(), want)
-    # planes round trip: hi + mid + lo == x bit for bit
-    x = torch.randn(4099, generator=g).to(DEV) * 1e3
-    pl = ops.split_planes(x)
-    assert pl.stride == 2 * 4104 and pl.buf.numel() == 3 * pl.stride
-    raw = pl.buf.cpu().view(torch.int16).view(3, -1)
-    parts = (raw.to(torch.int32) << 16).view(torch.float32)
-    back = (parts[0] + parts[1] + parts[2])[:4099]
-    assert float(parts[:, 4099:].abs().max()) == 0.0
-    assert torch.equal(back, x.cpu())
 
 
 def test_fanout_sums_bias_slots_and_batched_step_dropout():

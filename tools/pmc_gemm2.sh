@@ -1,5 +1,5 @@
 #!/bin/bash
-# Detailed PMC passes over one GEMM shape (tuning aid).  usage: tools/pmc_gemm2.sh <outdir> <nt|nn|tn> M N K [planes]
+# Detailed PMC passes over one GEMM shape (tuning aid).  usage: tools/pmc_gemm2.sh <outdir> <nt|nn|tn> M N K
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p $out

@@ -269,7 +269,11 @@ def main(argv=None):
                                   'speaker_state': speaker.state_dict(), 'model_cfg': cfg,
                                   'optimizer_state': optimizer.state_dict(named()), 'iteration': t,
                                   'epoch': epoch + 1 if end_of_epoch else epoch, 'iter_in_epoch': 0 if end_of_epoch else i,
-                                  'epoch_rng_state': None if end_of_epoch else rng_at_epoch_start,
+                                  # mid-epoch: the state the epoch's sampler drew its permutation from; on an epoch
+                                  # boundary: the state NOW, from which the next epoch's sampler will draw (nothing between
+                                  # here and the next epoch start consumes torch's generator: evaluation runs without dropout
+                                  # over a sequential sampler)
+                                  'epoch_rng_state': torch.get_rng_state() if end_of_epoch else rng_at_epoch_start,
                                   'dropout_seed_counter': ops.seed_state()[1], 'best': best}
                     save_checkpoint(checkpoint, os.path.join(snapshot_dir, 'checkpoint_%d.pt' % t))
                 say('Running eval at iter %d' % t)
