@@ -78,6 +78,7 @@ struct GemmArgs {
     int splitk;
     float* ws;            // slabs [splitk][M][N] when splitk > 1
     int tiles_m, tiles_n;
+    int slab_mode;        // 1: raw partial products go to ws even when splitk == 1 (ekaid_gemm_slabs: the consumer reduces)
     Epi e;
 };
 
@@ -168,7 +169,7 @@ __device__ __forceinline__ void loader_mask(const TileLoader<NV>& L, f32x4* r, i
 template <int TM, int TN>
 __device__ __forceinline__ void write_tiles(const GemmArgs& g, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int r, int h, int z) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    const bool slab = g.splitk > 1;
+    const bool slab = g.splitk > 1 || g.slab_mode;
     float* C;
     int ldc;
     if (slab) {
@@ -472,7 +473,7 @@ __device__ __forceinline__ int mc_read_off(int k, int row0, int tg, int tp) {   
 // PF = K-steps of global loads kept in flight (1: the next step's loads hide under this step's MFMAs -- enough for the
 // large tiles; 2: for the 64x64 tile, whose 12 MFMAs per 32-deep step are far shorter than a load round trip)
 template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE>
-__global__ __launch_bounds__(256, (TM * TN >= 4 ? EKAID_SPLIT_OCC_BIG : (TM * TN == 2 ? 2 : EKAID_SPLIT_OCC_SMALL))) void gemm_split_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int block_x, const int z) {
     static_assert(!PIPE || (KB == 32 && PF == 1), "the pipelined loop shares the 32-deep LDS footprint");
     constexpr int BM = 64 * TM, BN = 64 * TN;
     static_assert(KB == 32 || KB == 64 || KB == 128, "K-step");
@@ -495,14 +496,13 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? EKAID_SPLIT_OCC_BIG : (TM * TN
     const int wm = (wave >> 1) * (32 * TM), wn = (wave & 1) * (32 * TN);
 
     const int nwg = g.tiles_m * g.tiles_n;
-    int bid = blockIdx.x;
+    int bid = block_x;
     {
         const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
     }
     const int m0 = (bid / g.tiles_n) * BM, n0 = (bid % g.tiles_n) * BN;
 
-    const int z = blockIdx.z;
     const float* A = g.A; const float* B = g.B;
     int kbeg = 0, kend = g.K;
     if (g.splitk > 1) {
@@ -852,6 +852,24 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? EKAID_SPLIT_OCC_BIG : (TM * TN
     write_tiles<TM, TN>(g, acc, m0, n0, wm, wn, r, h, z);
 }
 
+template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE>
+__global__ __launch_bounds__(256, (TM * TN >= 4 ? EKAID_SPLIT_OCC_BIG : (TM * TN == 2 ? 2 : EKAID_SPLIT_OCC_SMALL))) void gemm_split_kernel(GemmArgs g) {
+    gemm_split_body<A_KC, B_KC, TM, TN, KB, PF, PIPE>(g, blockIdx.x, blockIdx.z);
+}
+
+// TWO independent products of the same operand layout in one launch (64x64 tiles): workgroups [0, tiles of g0) work on g0,
+// the rest on g1; grid.z = the larger of the two K splits, a workgroup beyond its own problem's split count leaves at once.
+// For the recurrent steps, where two small GEMMs of one step have no dependence on each other (ekaid_gemm_slabs2).
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, EKAID_SPLIT_OCC_SMALL) void gemm_split_pair_kernel(GemmArgs g0, GemmArgs g1) {
+    const int n0 = g0.tiles_m * g0.tiles_n;
+    if ((int)blockIdx.x < n0) {
+        if ((int)blockIdx.z < g0.splitk) gemm_split_body<A_KC, B_KC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL, false>(g0, blockIdx.x, blockIdx.z);
+    } else {
+        if ((int)blockIdx.z < g1.splitk) gemm_split_body<A_KC, B_KC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL, false>(g1, blockIdx.x - n0, blockIdx.z);
+    }
+}
+
 // ---- tall-skinny wgrad: C[M][N] = A^T . B with M * N <= 256 outputs and a very long contraction (the label-bias and
 // pair-geometry layers: 1 x 11 and 4 x 64 outputs over K = R * N * N = 663 552 rows at B = 256).  As a tiled GEMM this is one
 // 64x64 tile cut into ~770 K slabs with scalar operand loads (M, N not multiples of 4): 113-146 us for 30-180 MB.  Here:
@@ -1108,6 +1126,77 @@ static bool skinny_tn(const ekaid_gemm_t* d, int& G, int& NO) {
     return true;
 }
 
+
+// planner + the K range of one slab (empty trailing slabs dropped): what every entry point launches
+static void plan_full(const ekaid_gemm_t* d, int& TMN, int& splitk, int& k_per_split, int& tiles_m, int& tiles_n) {
+    plan(d, TMN, splitk, tiles_m, tiles_n);
+    if (d->K == 0) splitk = 1;
+    const int BK = (TMN == 3 || TMN == 4 ? BK_HALF : (TMN >= 2 ? BK_BIG : (gemm_mode() == 1 && TMN == 1 ? EKAID_SPLIT_KB_SMALL : BK_SMALL)));
+    k_per_split = cdiv(cdiv(d->K, BK), splitk) * BK;
+    if (splitk > 1) {
+        splitk = cdiv(d->K, k_per_split);
+        if (splitk <= 1) { splitk = 1; k_per_split = cdiv(d->K, BK) * BK; }
+    }
+}
+
+// GemmArgs of one product: tiling + K split from the planner, slab workspace checked.  slab_mode: raw partial products into
+// `workspace` as [splitk][M][N] even when the planner does not split (ekaid_gemm_slabs).
+static int fill_args(const ekaid_gemm_t* d, GemmArgs& a, int& TMN, void* workspace, size_t workspace_bytes, int slab_mode) {
+    a.A = d->A; a.B = d->B; a.C = d->C;
+    a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
+    a.sA1 = d->strideA1; a.sA2 = d->strideA2; a.sB1 = d->strideB1; a.sB2 = d->strideB2;
+    a.sC1 = d->strideC1; a.sC2 = d->strideC2; a.nb2 = d->batch2;
+    a.e.alpha = d->alpha; a.e.alpha_dev = d->alpha_dev; a.e.beta = d->accumulate; a.e.bias = d->bias;
+    a.e.R = d->R; a.e.ldr = d->ldr; a.e.rdiv = d->rdiv < 1 ? 1 : d->rdiv; a.e.rowmask = d->rowmask; a.e.act = d->act;
+    a.e.drop_p = d->drop_p; a.e.drop_inv = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f; a.e.drop_seed = d->drop_seed; a.e.drop_epoch = dropout_epoch_ptr(); a.e.n_cols = d->N;
+    a.slab_mode = slab_mode;
+    plan_full(d, TMN, a.splitk, a.k_per_split, a.tiles_m, a.tiles_n);
+    a.ws = nullptr;
+    if (a.splitk > 1 || slab_mode) {
+        const size_t need = (size_t)a.splitk * d->M * d->N * sizeof(float);
+        if (!workspace || workspace_bytes < need) {
+            set_error("ekaid_gemm: workspace too small (%zu < %zu)", workspace_bytes, need);
+            return EKAID_ERR_ARG;
+        }
+        a.ws = (float*)workspace;
+    }
+    return EKAID_OK;
+}
+
+
+// the product kernel of one planned GEMM (arithmetic per device state, tile shape TMN from the planner)
+static int launch_product(const GemmArgs& a, int TMN, bool akc, bool bkc, int batch, hipStream_t st) {
+    int rc;
+    if (gemm_mode() == 1 && TMN >= 1 && TMN <= 4) {
+#define EKAID_LAUNCH_SPLIT(AK, BKC) (TMN == 2 ? launch_split<AK, BKC, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG>(a, batch, st) \
+                                     : TMN == 1 ? launch_split<AK, BKC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL, false>(a, batch, st) \
+                                     : TMN == 3 ? launch_split<AK, BKC, 2, 1, 32, 1, false>(a, batch, st) : launch_split<AK, BKC, 1, 2, 32, 1, false>(a, batch, st))
+        if (akc && bkc) rc = EKAID_LAUNCH_SPLIT(true, true);
+        else if (akc && !bkc) rc = EKAID_LAUNCH_SPLIT(true, false);
+        else rc = EKAID_LAUNCH_SPLIT(false, false);
+#undef EKAID_LAUNCH_SPLIT
+    } else {
+#define EKAID_LAUNCH(AK, BKC) (TMN == 2 ? launch<AK, BKC, 2, 2, BK_BIG>(a, batch, st) : TMN == 1 ? launch<AK, BKC, 1, 1, BK_SMALL>(a, batch, st) \
+                               : TMN == 3 ? launch<AK, BKC, 2, 1, BK_HALF>(a, batch, st) : launch<AK, BKC, 1, 2, BK_HALF>(a, batch, st))
+        if (akc && bkc) rc = EKAID_LAUNCH(true, true);
+        else if (akc && !bkc) rc = EKAID_LAUNCH(true, false);
+        else rc = EKAID_LAUNCH(false, false);
+#undef EKAID_LAUNCH
+    }
+    if (rc) return rc;
+    return check_launch("gemm kernel");
+}
+
+template <bool AK, bool BKC>
+static int launch_pair(const GemmArgs& a0, const GemmArgs& a1, hipStream_t st) {
+    constexpr int KB = EKAID_SPLIT_KB_SMALL;
+    constexpr size_t lds = 3 * 2 * KB * (64 + 64);
+    static_assert(lds <= 64 * 1024, "pair kernel: 64x64 tiles fit the default dynamic LDS limit");
+    const int sk = a0.splitk > a1.splitk ? a0.splitk : a1.splitk;
+    dim3 grid(a0.tiles_m * a0.tiles_n + a1.tiles_m * a1.tiles_n, 1, sk);
+    hipLaunchKernelGGL((gemm_split_pair_kernel<AK, BKC>), grid, dim3(256), lds, st, a0, a1);
+    return check_launch("gemm_split_pair_kernel");
+}
 }  // namespace ekaid
 
 using namespace ekaid;
@@ -1160,32 +1249,13 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
         }
     }
     GemmArgs a;
-    a.A = d->A; a.B = d->B; a.C = d->C;
-    a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
-    a.sA1 = d->strideA1; a.sA2 = d->strideA2; a.sB1 = d->strideB1; a.sB2 = d->strideB2;
-    a.sC1 = d->strideC1; a.sC2 = d->strideC2; a.nb2 = d->batch2;
-    a.e.alpha = d->alpha; a.e.alpha_dev = d->alpha_dev; a.e.beta = d->accumulate; a.e.bias = d->bias;
-    a.e.R = d->R; a.e.ldr = d->ldr; a.e.rdiv = d->rdiv < 1 ? 1 : d->rdiv; a.e.rowmask = d->rowmask; a.e.act = d->act;
-    a.e.drop_p = d->drop_p; a.e.drop_inv = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f; a.e.drop_seed = d->drop_seed; a.e.drop_epoch = dropout_epoch_ptr(); a.e.n_cols = d->N;
     int TMN;
-    plan(d, TMN, a.splitk, a.tiles_m, a.tiles_n);
-    if (d->K == 0) a.splitk = 1;
-    a.ws = nullptr;
-    const int BK = (TMN == 3 || TMN == 4 ? BK_HALF : (TMN >= 2 ? BK_BIG : (gemm_mode() == 1 && TMN == 1 ? EKAID_SPLIT_KB_SMALL : BK_SMALL)));
-    a.k_per_split = cdiv(cdiv(d->K, BK), a.splitk) * BK;
-    if (a.splitk > 1) {
-        const size_t need = (size_t)a.splitk * d->M * d->N * sizeof(float);
-        if (!workspace || workspace_bytes < need) {
-            set_error("ekaid_gemm_f32: workspace too small (%zu < %zu)", workspace_bytes, need);
-            return EKAID_ERR_ARG;
-        }
-        a.ws = (float*)workspace;
-        a.splitk = cdiv(d->K, a.k_per_split);      // drop empty trailing splits
-        if (a.splitk <= 1) { a.splitk = 1; a.ws = nullptr; a.k_per_split = cdiv(d->K, BK) * BK; }
+    {
+        const int rc0 = fill_args(d, a, TMN, workspace, workspace_bytes, 0);
+        if (rc0) return rc0;
     }
     const int batch = d->batch1 * d->batch2;
     const bool akc = !d->transA, bkc = d->transB != 0;
-    int rc;
     // (Split-K with the reduction done by the last workgroup of each tile -- arrival counter, device-scope slab accesses --
     // instead of the second kernel was measured and removed: bit-identical, but 0.97-2.9x the time of GEMM + reduce kernel on
     // the recurrent shapes (the reduce kernel uses every CU, the last arriver is one workgroup per tile), and 5x with
@@ -1194,24 +1264,7 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     // measured and removed: the tail rows as 128x64 tiles, 224 -> 232-245 us, and the tail rows split along K into one more
     // full wave, 222 -> 231 us.  With 1.5 workgroups per CU instead of 3 each one runs almost twice as fast: the kernel is
     // bound by what a CU can sustain, not by the tail.  profiles/r02_planes_gemm_microbench.txt)
-    if (gemm_mode() == 1 && TMN >= 1 && TMN <= 4) {
-#define EKAID_LAUNCH_SPLIT(AK, BKC) (TMN == 2 ? launch_split<AK, BKC, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG>(a, batch, st) \
-                                     : TMN == 1 ? launch_split<AK, BKC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL, false>(a, batch, st) \
-                                     : TMN == 3 ? launch_split<AK, BKC, 2, 1, 32, 1, false>(a, batch, st) : launch_split<AK, BKC, 1, 2, 32, 1, false>(a, batch, st))
-        if (akc && bkc) rc = EKAID_LAUNCH_SPLIT(true, true);
-        else if (akc && !bkc) rc = EKAID_LAUNCH_SPLIT(true, false);
-        else rc = EKAID_LAUNCH_SPLIT(false, false);
-#undef EKAID_LAUNCH_SPLIT
-    } else {
-#define EKAID_LAUNCH(AK, BKC) (TMN == 2 ? launch<AK, BKC, 2, 2, BK_BIG>(a, batch, st) : TMN == 1 ? launch<AK, BKC, 1, 1, BK_SMALL>(a, batch, st) \
-                               : TMN == 3 ? launch<AK, BKC, 2, 1, BK_HALF>(a, batch, st) : launch<AK, BKC, 1, 2, BK_HALF>(a, batch, st))
-    if (akc && bkc) rc = EKAID_LAUNCH(true, true);
-    else if (akc && !bkc) rc = EKAID_LAUNCH(true, false);
-    else rc = EKAID_LAUNCH(false, false);
-#undef EKAID_LAUNCH
-    }
-    if (rc) return rc;
-    rc = check_launch("gemm_mfma_kernel");
+    int rc = launch_product(a, TMN, akc, bkc, batch, st);
     if (rc) return rc;
     if (a.splitk > 1) {
         const long long total = (long long)d->M * d->N;
@@ -1232,3 +1285,48 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     return rc;
 }
 
+
+// ---- raw partial products for consumers that finish the reduction themselves (include/ekaid_hip.h: ekaid_gemm_slabs)
+static int slabs_check(const ekaid_gemm_t* d, const char* who) {
+    if (!d || !d->A || !d->B) { set_error("%s: null pointer", who); return EKAID_ERR_ARG; }
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0) { set_error("%s: bad dims M=%d N=%d K=%d", who, d->M, d->N, d->K); return EKAID_ERR_ARG; }
+    if (d->batch1 != 1 || d->batch2 != 1 || (d->transA && d->transB)) { set_error("%s: one batch, not both operands transposed", who); return EKAID_ERR_UNSUPPORTED; }
+    return EKAID_OK;
+}
+extern "C" int ekaid_gemm_slab_count(const ekaid_gemm_t* d) {
+    if (slabs_check(d, "ekaid_gemm_slab_count")) return EKAID_ERR_ARG;
+    int TMN, splitk, kps, tm, tn;
+    plan_full(d, TMN, splitk, kps, tm, tn);
+    return splitk;
+}
+extern "C" int ekaid_gemm_slabs(const ekaid_gemm_t* d, float* slabs, size_t slab_bytes, void* stream) {
+    int rc = slabs_check(d, "ekaid_gemm_slabs");
+    if (rc) return rc;
+    GemmArgs a;
+    int TMN;
+    rc = fill_args(d, a, TMN, slabs, slab_bytes, 1);
+    if (rc) return rc;
+    return launch_product(a, TMN, !d->transA, d->transB != 0, 1, (hipStream_t)stream);
+}
+extern "C" int ekaid_gemm_slabs2(const ekaid_gemm_t* d0, float* slabs0, size_t slab_bytes0, const ekaid_gemm_t* d1, float* slabs1,
+                                 size_t slab_bytes1, void* stream) {
+    int rc = slabs_check(d0, "ekaid_gemm_slabs2");
+    if (!rc) rc = slabs_check(d1, "ekaid_gemm_slabs2");
+    if (rc) return rc;
+    GemmArgs a0, a1;
+    int T0, T1;
+    rc = fill_args(d0, a0, T0, slabs0, slab_bytes0, 1);
+    if (!rc) rc = fill_args(d1, a1, T1, slabs1, slab_bytes1, 1);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const bool same = (d0->transA != 0) == (d1->transA != 0) && (d0->transB != 0) == (d1->transB != 0);
+    if (gemm_mode() != 1 || T0 != 1 || T1 != 1 || !same) {        // outside the pair kernel's envelope: two launches, same results
+        rc = launch_product(a0, T0, !d0->transA, d0->transB != 0, 1, st);
+        if (rc) return rc;
+        return launch_product(a1, T1, !d1->transA, d1->transB != 0, 1, st);
+    }
+    const bool akc = !d0->transA, bkc = d0->transB != 0;
+    if (akc && bkc) return launch_pair<true, true>(a0, a1, st);
+    if (akc && !bkc) return launch_pair<true, false>(a0, a1, st);
+    return launch_pair<false, false>(a0, a1, st);
+}

@@ -40,6 +40,36 @@ class GemmDesc(Structure):
     ]
 
 
+class Slabs(Structure):
+    """ekaid_slabs_t: element (row, col) of slab s = p[s * stride + row * ld + col]."""
+    _fields_ = [('p', c_void_p), ('n', c_int), ('stride', c_longlong), ('ld', c_int)]
+
+
+class SpkStepAFwd(Structure):
+    """ekaid_spk_step_a_fwd_t (include/ekaid_hip.h)."""
+    _fields_ = [('B', c_int), ('R', c_int), ('A', c_int), ('P', c_int),
+                ('gxa', c_void_p), ('gates_src', Slabs * 3), ('n_gates_src', c_int), ('b_hh', c_void_p), ('c_prev', c_void_p),
+                ('h_out', c_void_p), ('c_out', c_void_p), ('gate_save', c_void_p),
+                ('w_fc', c_void_p), ('b_fc', c_void_p), ('bef', c_void_p), ('diff', c_void_p), ('aft', c_void_p),
+                ('mw', c_void_p), ('att', c_void_p), ('att2', c_void_p), ('ld2', c_int),
+                ('pos_src', Slabs), ('b_p1', c_void_p), ('w_wp', c_void_p), ('b_wp', c_void_p), ('w_p2', c_void_p),
+                ('b_p2', c_void_p), ('p_v', c_float), ('seed_v', c_uint64), ('p_d', c_float), ('seed_d', c_uint64),
+                ('vp', c_void_p), ('dp', c_void_p), ('pw', c_void_p), ('pp', c_void_p), ('ldpp', c_int)]
+
+
+class SpkStepABwd(Structure):
+    """ekaid_spk_step_a_bwd_t (include/ekaid_hip.h)."""
+    _fields_ = [('B', c_int), ('R', c_int), ('A', c_int), ('P', c_int),
+                ('dpa_src', Slabs), ('d_gated', c_void_p), ('gate', c_void_p),
+                ('mw', c_void_p), ('bef', c_void_p), ('diff', c_void_p), ('aft', c_void_p), ('w_fc', c_void_p),
+                ('dz_fc', c_void_p), ('d_bef', c_void_p), ('d_diff', c_void_p), ('d_aft', c_void_p),
+                ('dh_carry', Slabs), ('dc_in', c_void_p), ('gate_save', c_void_p), ('c_prev', c_void_p), ('c_cur', c_void_p),
+                ('dgates', c_void_p), ('lddg', c_int), ('dc_out', c_void_p),
+                ('pw', c_void_p), ('dhead', c_void_p), ('w_p2', c_void_p), ('w_wp', c_void_p), ('vp', c_void_p),
+                ('p_v', c_float), ('seed_v', c_uint64), ('p_d', c_float), ('seed_d', c_uint64),
+                ('dpp_out', c_void_p), ('lddpp', c_int), ('dwp_out', c_void_p), ('dx_out', c_void_p), ('lddx', c_int)]
+
+
 P, I, L, F, U64 = c_void_p, c_int, c_longlong, c_float, c_uint64
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/ekaid_hip.h 1:1
@@ -53,6 +83,19 @@ SIGNATURES = {
     'ekaid_set_gemm_mode': [I],
     'ekaid_get_gemm_mode': [],
     'ekaid_gemm_f32': [POINTER(GemmDesc), P, c_size_t, P],
+    'ekaid_gemm_slab_count': [POINTER(GemmDesc)],
+    'ekaid_gemm_slabs': [POINTER(GemmDesc), P, c_size_t, P],
+    'ekaid_gemm_slabs2': [POINTER(GemmDesc), P, c_size_t, POINTER(GemmDesc), P, c_size_t, P],
+    'ekaid_slab_epilogue': [POINTER(Slabs), I, P, I, I, I, F, U64, P, I, P],
+    'ekaid_drop_act_slabs_bwd': [POINTER(Slabs), P, I, I, I, I, F, U64, P, I, P],
+    'ekaid_lstm_cell_slabs_fwd': [P, POINTER(Slabs), I, P, P, I, I, P, P, P, P],
+    'ekaid_lstm_cell_slabs_bwd': [POINTER(Slabs), P, P, P, P, P, I, I, P, I, P, P],
+    'ekaid_gru_cell_slabs_fwd': [P, I, POINTER(Slabs), P, P, I, I, I, P, I, P, P],
+    'ekaid_gru_cell_slabs_bwd': [P, I, P, POINTER(Slabs), P, P, I, I, I, P, I, P, P, P],
+    'ekaid_gate_mul_slabs_fwd': [POINTER(Slabs), P, P, I, I, P, P, P],
+    'ekaid_gate_slabs_bwd': [POINTER(Slabs), P, P, I, I, P, P, P],
+    'ekaid_spk_step_a_fwd': [POINTER(SpkStepAFwd), P],
+    'ekaid_spk_step_a_bwd': [POINTER(SpkStepABwd), P],
     'ekaid_wn_scale_fwd': [P, P, L, P, P, P],
     'ekaid_wn_scale_bwd': [P, P, P, P, L, P, I, P, P],
     'ekaid_scale_dot': [P, P, P, L, P, P],

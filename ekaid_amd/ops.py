@@ -179,7 +179,99 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=N
         prof.append((e0, e1, 2.0 * M * N * K * nb, (int(transA), int(transB), M, N, K, nb)))
 
 
+# --------------------------------------------------------------------------- #
+# raw partial products ("slabs") for consumers that finish the reduction themselves (include/ekaid_hip.h: ekaid_gemm_slabs)
+# --------------------------------------------------------------------------- #
+class SlabSet:
+    """Slabs [n][M][N] of one product (``buf``), addressed by consumers through ``cols(c0)`` = the ``ekaid_slabs_t`` of the
+    column block starting at column c0."""
+    __slots__ = ('buf', 'n', 'M', 'N')
+
+    def __init__(self, buf, n, M, N):
+        self.buf, self.n, self.M, self.N = buf, n, M, N
+
+    def cols(self, c0=0):
+        return hip.Slabs(self.buf.data_ptr() + 4 * c0, self.n, self.M * self.N, self.N)
+
+    def total(self):
+        """The reduced product as a tensor (tests)."""
+        return self.buf.view(self.n, self.M, self.N).sum(0)
+
+
+NO_SLABS = hip.Slabs(None, 0, 0, 0)
+
+
+def _slab_desc(A, B, M, N, K, lda, ldb, transA, transB, a_off, b_off):
+    d = GemmDesc()
+    d.A = A.data_ptr() + 4 * a_off
+    d.B = B.data_ptr() + 4 * b_off
+    d.C = None
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = lda, ldb, N
+    d.transA, d.transB = int(transA), int(transB)
+    d.batch1 = d.batch2 = 1
+    d.alpha = 1.0
+    d.rdiv = 1
+    return d
+
+
+def gemm_slabs(A, B, M, N, K, lda, ldb, transA, transB, a_off=0, b_off=0):
+    """op(A) . op(B) as raw K-slabs (no epilogue): returns a ``SlabSet``."""
+    d = _slab_desc(A, B, M, N, K, lda, ldb, transA, transB, a_off, b_off)
+    L = hip.lib()
+    n = L.ekaid_gemm_slab_count(ctypes.byref(d))
+    if n < 1:
+        check(n, 'ekaid_gemm_slab_count')
+    buf = torch.empty(n * M * N, device=A.device, dtype=torch.float32)
+    e0 = _prof_begin()
+    check(L.ekaid_gemm_slabs(ctypes.byref(d), ptr(buf), buf.numel() * 4, stream()), 'ekaid_gemm_slabs')
+    _prof_end(e0, 2.0 * M * N * K, (int(transA), int(transB), M, N, K, 1))
+    return SlabSet(buf, n, M, N)
+
+
+def gemm_slabs2(g0, g1):
+    """Two independent products in one launch; g = (A, B, M, N, K, lda, ldb, transA, transB, a_off, b_off)."""
+    L = hip.lib()
+    ds, bufs, outs = [], [], []
+    for g in (g0, g1):
+        d = _slab_desc(*g)
+        n = L.ekaid_gemm_slab_count(ctypes.byref(d))
+        if n < 1:
+            check(n, 'ekaid_gemm_slab_count')
+        buf = torch.empty(n * g[2] * g[3], device=g[0].device, dtype=torch.float32)
+        ds.append(d)
+        bufs.append(buf)
+        outs.append(SlabSet(buf, n, g[2], g[3]))
+    e0 = _prof_begin()
+    check(L.ekaid_gemm_slabs2(ctypes.byref(ds[0]), ptr(bufs[0]), bufs[0].numel() * 4, ctypes.byref(ds[1]), ptr(bufs[1]),
+                              bufs[1].numel() * 4, stream()), 'ekaid_gemm_slabs2')
+    _prof_end(e0, 2.0 * (g0[2] * g0[3] * g0[4] + g1[2] * g1[3] * g1[4]),
+              (int(g0[7]), int(g0[8]), g0[2], g0[3] + g1[3], g0[4], 2))
+    return outs[0], outs[1]
+
+
+def slab_array(*srcs):
+    """ctypes array of ``ekaid_slabs_t`` + its length."""
+    arr = (hip.Slabs * max(len(srcs), 1))(*srcs)
+    return arr, len(srcs)
+
+
 _gemm_profile = None
+
+
+def _prof_begin():
+    if _gemm_profile is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def _prof_end(e0, flops, shape):
+    if e0 is not None and _gemm_profile is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        _gemm_profile.append((e0, e1, flops, shape))
 
 
 def gemm_profile_begin():
@@ -930,13 +1022,15 @@ class GRUSeqFn(Function):
         gemm(x, w_ih, gi, B * T, 3 * H, E, E, E, 3 * H, 0, 1, bias=b_ih)
         hall = torch.zeros(T + 1, B, H, device=dev, dtype=torch.float32)     # time-major states, hall[0] = h0 = 0
         save = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
-        gh = torch.empty(B, 3 * H, device=dev, dtype=torch.float32)
         for t in range(T):
-            gemm(hall, w_hh, gh, B, 3 * H, H, H, H, 3 * H, 0, 1, bias=b_hh, a_off=t * B * H)
-            check(L.ekaid_gru_cell_fwd(gi.data_ptr() + 4 * t * 3 * H, T * 3 * H, ptr(gh), 3 * H,
-                                       hall.data_ptr() + 4 * t * B * H, H, B, H,
-                                       hall.data_ptr() + 4 * (t + 1) * B * H, H, save.data_ptr() + 4 * t * B * 4 * H,
-                                       stream()), 'gru_cell_fwd')
+            # h_{t-1} . W_hh^T as raw K-slabs; the cell kernel sums them, adds b_hh and applies the gates (one launch fewer
+            # per step than GEMM + reduce + cell)
+            S = gemm_slabs(hall, w_hh, B, 3 * H, H, H, H, 0, 1, a_off=t * B * H)
+            sl = S.cols(0)
+            check(L.ekaid_gru_cell_slabs_fwd(gi.data_ptr() + 4 * t * 3 * H, T * 3 * H, ctypes.byref(sl), ptr(b_hh),
+                                             hall.data_ptr() + 4 * t * B * H, H, B, H,
+                                             hall.data_ptr() + 4 * (t + 1) * B * H, H, save.data_ptr() + 4 * t * B * 4 * H,
+                                             stream()), 'gru_cell_slabs_fwd')
         ctx.save_for_backward(x, w_ih, w_hh, hall, save)
         ctx.b_refs = (b_ih.detach(), b_hh.detach())          # (aliases: their data_ptr finds the gradient slots)
         return hall[1:].transpose(0, 1)          # (B, T, H) view of the time-major buffer
@@ -952,14 +1046,16 @@ class GRUSeqFn(Function):
         dout = _c(dout)                                   # (B, T, H)
         dgi = torch.empty(B, T, 3 * H, device=dev, dtype=torch.float32)
         dgh = torch.empty(T, B, 3 * H, device=dev, dtype=torch.float32)
-        dh = torch.empty(B, H, device=dev, dtype=torch.float32)
+        dh_dir = [torch.empty(B, H, device=dev, dtype=torch.float32) for _ in range(2)]    # z * d of step t (ping-pong)
+        carry = None                                      # slabs of dgh_{t+1} . W_hh
         for t in range(T - 1, -1, -1):
-            carry = None if t == T - 1 else dh.data_ptr()
-            check(L.ekaid_gru_cell_bwd(dout.data_ptr() + 4 * t * H, T * H, carry, save.data_ptr() + 4 * t * B * 4 * H,
-                                       hall.data_ptr() + 4 * t * B * H, H, B, H, dgi.data_ptr() + 4 * t * 3 * H, T * 3 * H,
-                                       dgh.data_ptr() + 4 * t * B * 3 * H, ptr(dh), stream()), 'gru_cell_bwd')
-            if t > 0:       # dh_{t-1} = z*d (written by the kernel) + dgh_t . W_hh
-                gemm(dgh, w_hh, dh, B, H, 3 * H, 3 * H, H, H, 0, 0, accumulate=True, a_off=t * B * 3 * H)
+            csl = carry.cols(0) if carry is not None else NO_SLABS
+            check(L.ekaid_gru_cell_slabs_bwd(dout.data_ptr() + 4 * t * H, T * H, ptr(dh_dir[(t + 1) & 1]) if t < T - 1 else None,
+                                             ctypes.byref(csl), save.data_ptr() + 4 * t * B * 4 * H,
+                                             hall.data_ptr() + 4 * t * B * H, H, B, H, dgi.data_ptr() + 4 * t * 3 * H, T * 3 * H,
+                                             dgh.data_ptr() + 4 * t * B * 3 * H, ptr(dh_dir[t & 1]), stream()), 'gru_cell_slabs_bwd')
+            if t > 0:       # dh_{t-1} = z*d (dh_dir) + dgh_t . W_hh (slabs, summed by the next cell kernel)
+                carry = gemm_slabs(dgh, w_hh, B, H, 3 * H, 3 * H, H, 0, 0, a_off=t * B * 3 * H)
         # weight gradients batched over time: K = T*B rows (previous states are the contiguous slice hall[0:T])
         dw_hh = grad_out(w_hh)
         gemm(dgh, hall, dw_hh, 3 * H, H, T * B, 3 * H, H, H, 1, 0)

@@ -12,6 +12,8 @@ and only the truly sequential part (two LSTM cells, the POS branch and the gate 
 stays in the time loop.  All activations are stored time-major (T, B, .) so that "previous hidden state
 for every t" is a contiguous slice of the (T+1, B, R) state buffer.
 """
+import ctypes
+
 import torch
 from torch.autograd import Function
 
@@ -103,7 +105,7 @@ class SpeakerSeqFn(Function):
         HA, CA, HL, CL = ops.zeros_pool(dev, (T + 1, B, R), (T + 1, B, R), (T + 1, B, R), (T + 1, B, R))
         SA = torch.empty(T, B, 4 * R, **f32)      # gate activations (i,f,g,o)
         SL = torch.empty(T, B, 4 * R, **f32)
-        HLW = torch.empty(T, B, NW, **f32)        # see class docstring; the G1 block ends up holding dropout(relu(gate1x))
+        G1D = torch.empty(T, B, G1, **f32)        # dropout(relu(gate1x)): input of gate2x
         MW = torch.empty(T, B, 3, **f32)
         VP = torch.empty(T, B, R, **f32)          # dropout(relu(pos1(h_lang)))
         DP = torch.empty(T, B, NP, **f32)         # dropout(weight_pos(vpos))   (= output_pos of the core)
@@ -113,39 +115,48 @@ class SpeakerSeqFn(Function):
         GT = torch.empty(T, B, A, **f32)          # gate (sigmoid)
         GA = torch.empty(T, B, A, **f32)          # gated att feat
 
+        # Per step: 4 GEMM launches whose K-slabs are summed by their consumers (csrc/steps.hip), 4 consumer kernels.
+        sa = hip.SpkStepAFwd()
+        sa.B, sa.R, sa.A, sa.P = B, R, A, NP
+        sa.b_hh, sa.w_fc, sa.b_fc = ptr(bhh_a), ptr(w_fc), ptr(b_fc)
+        sa.bef, sa.diff, sa.aft = ptr(bef), ptr(diff), ptr(aft)
+        sa.b_p1, sa.w_wp, sa.b_wp, sa.w_p2, sa.b_p2 = ptr(b_p1), ptr(w_wp), ptr(b_wp), ptr(w_p2), ptr(b_p2)
+        sa.p_v, sa.p_d, sa.ld2, sa.ldpp, sa.n_gates_src = p, p5, R + A, R + A, 2
         for t in range(T):
             o_prev, o_t = t * B * R, (t + 1) * B * R
-            ow = t * B * NW
             sv, sd, sg = seeds_t[t]
-            # 0. everything h_lang_{t-1} feeds, in one GEMM
-            _nt(HL, o_prev, R, Wcat, 0, R, HLW, ow, NW, B, NW, R)
-            # 1. module-attention LSTM: gates = GXA[t] + (block 0 += h_att_{t-1} W_hh^T + b_hh)
-            _nt(HA, o_prev, R, whh_a, 0, R, HLW, ow, NW, B, 4 * R, R, bias=bhh_a, acc=True)
-            check(L.ekaid_lstm_cell_fwd(GXA.data_ptr() + 4 * t * B * 4 * R, HLW.data_ptr() + 4 * ow, NW,
-                                        CA.data_ptr() + 4 * o_prev, B, R, HA.data_ptr() + 4 * o_t, CA.data_ptr() + 4 * o_t,
-                                        SA.data_ptr() + 4 * t * B * 4 * R, stream()), 'lstm_cell_fwd')
-            # 2.+4. module weights and attended feature: fc -> softmax(3) -> mix of (bef, diff, aft), one kernel;
-            #        att goes to AT[t] and to the right part of PA[t]
-            check(L.ekaid_spk_modmix_fwd(HA.data_ptr() + 4 * o_t, B, R, ptr(w_fc), ptr(b_fc), ptr(bef), ptr(diff), ptr(aft), A,
-                                         MW.data_ptr() + 4 * t * B * 3, AT.data_ptr() + 4 * t * B * A,
-                                         PA.data_ptr() + 4 * (t * B * (R + A) + R), R + A, stream()), 'spk_modmix_fwd')
-            # 3. POS chain: relu/dropout(block 1 + b) -> weight_pos -> dropout -> softmax -> pos2, one kernel;
-            #    pos_feat goes to the left part of PA[t]
-            check(L.ekaid_spk_pos_fwd(HLW.data_ptr() + 4 * (ow + oP1), NW, ptr(b_p1), B, R, ptr(w_wp), ptr(b_wp), NP, ptr(w_p2),
-                                      ptr(b_p2), p, sv, p5, sd, VP.data_ptr() + 4 * t * B * R, DP.data_ptr() + 4 * t * B * NP,
-                                      PW.data_ptr() + 4 * t * B * NP, PA.data_ptr() + 4 * t * B * (R + A), R + A, stream()),
-                  'spk_pos_fwd')
-            # 5. gate MLP: block 2 += [pos_feat | att] W[:, R:]^T + b, relu, dropout (in place, GEMM epilogue)
-            gemm(PA, w_g1, HLW, B, G1, R + A, R + A, G1, NW, 0, 1, accumulate=True, bias=b_g1, act=ACT_RELU,
-                 a_off=t * B * (R + A), b_off=R, c_off=ow + oG1, drop_p=p, drop_seed=sg)
-            _nt(HLW, ow + oG1, NW, w_g2, 0, G1, GT, t * B * A, A, B, A, G1, bias=b_g2, act=ACT_SIGMOID)
-            check(L.ekaid_mul(GT.data_ptr() + 4 * t * B * A, AT.data_ptr() + 4 * t * B * A, GA.data_ptr() + 4 * t * B * A,
-                              B * A, stream()), 'mul')
-            # 6. language LSTM: gates = GXL[t] + (block 3 += gated W_ih[:, We:]^T + b_hh)
-            _nt(GA, t * B * A, A, wih_l, We, We + A, HLW, ow + oGL, NW, B, 4 * R, A, bias=bhh_l, acc=True)
-            check(L.ekaid_lstm_cell_fwd(GXL.data_ptr() + 4 * t * B * 4 * R, HLW.data_ptr() + 4 * (ow + oGL), NW,
-                                        CL.data_ptr() + 4 * o_prev, B, R, HL.data_ptr() + 4 * o_t, CL.data_ptr() + 4 * o_t,
-                                        SL.data_ptr() + 4 * t * B * 4 * R, stream()), 'lstm_cell_fwd')
+            # 0.+1. everything h_lang_{t-1} feeds (P0, NW columns) and h_att_{t-1} . W_hh_att^T (P1): two products, one launch
+            P0, P1 = ops.gemm_slabs2((HL, Wcat, B, NW, R, R, R, 0, 1, o_prev, 0), (HA, whh_a, B, 4 * R, R, R, R, 0, 1, o_prev, 0))
+            # att-LSTM cell -> module weights + attended feature -> POS chain: one row-local kernel
+            sa.gxa = GXA.data_ptr() + 4 * t * B * 4 * R
+            sa.gates_src[0], sa.gates_src[1] = P0.cols(0), P1.cols(0)
+            sa.c_prev = CA.data_ptr() + 4 * o_prev
+            sa.h_out, sa.c_out = HA.data_ptr() + 4 * o_t, CA.data_ptr() + 4 * o_t
+            sa.gate_save = SA.data_ptr() + 4 * t * B * 4 * R
+            sa.mw = MW.data_ptr() + 4 * t * B * 3
+            sa.att = AT.data_ptr() + 4 * t * B * A
+            sa.att2 = PA.data_ptr() + 4 * (t * B * (R + A) + R)
+            sa.pos_src = P0.cols(oP1)
+            sa.seed_v, sa.seed_d = sv, sd
+            sa.vp, sa.dp, sa.pw = VP.data_ptr() + 4 * t * B * R, DP.data_ptr() + 4 * t * B * NP, PW.data_ptr() + 4 * t * B * NP
+            sa.pp = PA.data_ptr() + 4 * t * B * (R + A)
+            check(L.ekaid_spk_step_a_fwd(ctypes.byref(sa), stream()), 'spk_step_a_fwd')
+            # gate MLP, layer 1: relu/dropout(P0 block + [pos_feat | att] W_g1[:, R:]^T + b)
+            P2 = ops.gemm_slabs(PA, w_g1, B, G1, R + A, R + A, G1, 0, 1, a_off=t * B * (R + A), b_off=R)
+            arr, n = ops.slab_array(P0.cols(oG1), P2.cols(0))
+            check(L.ekaid_slab_epilogue(arr, n, ptr(b_g1), B, G1, ACT_RELU, p, sg, G1D.data_ptr() + 4 * t * B * G1, G1, stream()),
+                  'slab_epilogue')
+            # layer 2 + gating: gate = sigmoid(. W_g2^T + b); gated = gate * att
+            P3 = ops.gemm_slabs(G1D, w_g2, B, A, G1, G1, G1, 0, 1, a_off=t * B * G1)
+            s3 = P3.cols(0)
+            check(L.ekaid_gate_mul_slabs_fwd(ctypes.byref(s3), ptr(b_g2), AT.data_ptr() + 4 * t * B * A, B, A,
+                                             GT.data_ptr() + 4 * t * B * A, GA.data_ptr() + 4 * t * B * A, stream()), 'gate_mul_slabs_fwd')
+            # language LSTM: gates = GXL[t] + P0 block + gated W_ih[:, We:]^T + b_hh
+            P4 = ops.gemm_slabs(GA, wih_l, B, 4 * R, A, A, We + A, 0, 1, a_off=t * B * A, b_off=We)
+            arr, n = ops.slab_array(P0.cols(oGL), P4.cols(0))
+            check(L.ekaid_lstm_cell_slabs_fwd(GXL.data_ptr() + 4 * t * B * 4 * R, arr, n, ptr(bhh_l), CL.data_ptr() + 4 * o_prev, B, R,
+                                              HL.data_ptr() + 4 * o_t, CL.data_ptr() + 4 * o_t, SL.data_ptr() + 4 * t * B * 4 * R,
+                                              stream()), 'lstm_cell_slabs_fwd')
 
         # ---- time-batched head: dropout(h_lang) -> logit -> log-softmax;  log-softmax of the POS logits
         HO = torch.empty(T, B, R, **f32)
@@ -163,14 +174,14 @@ class SpeakerSeqFn(Function):
         ctx.wrefs = (w_p1.detach(), whh_l.detach())   # (read through Wcat in the backward pass; needed for their slots only)
         ctx.pp = (p, p5, seeds, seeds_t)
         ctx.save_for_backward(bef, aft, diff, tok_tb, embed_pre, ED, Xd, HA, CA, HL, CL, SA, SL, MW, VP, PW, PA, AT,
-                              HLW, GT, GA, HO, logp, logpos, emb, w_e, wih_a, whh_a, w_fc, w_wp, w_p2, w_g1, w_g2,
+                              G1D, GT, GA, HO, logp, logpos, emb, w_e, wih_a, whh_a, w_fc, w_wp, w_p2, w_g1, w_g2,
                               wih_l, w_lo, Wcat)
         ctx.mark_non_differentiable(MW)
         return logp, logpos, MW
 
     @staticmethod
     def backward(ctx, dlogp, dlogpos, _dmw):
-        (bef, aft, diff, tok_tb, embed_pre, ED, Xd, HA, CA, HL, CL, SA, SL, MW, VP, PW, PA, AT, HLW, GT, GA, HO,
+        (bef, aft, diff, tok_tb, embed_pre, ED, Xd, HA, CA, HL, CL, SA, SL, MW, VP, PW, PA, AT, G1D, GT, GA, HO,
          logp, logpos, emb, w_e, wih_a, whh_a, w_fc, w_wp, w_p2, w_g1, w_g2, wih_l, w_lo, Wcat) = ctx.saved_tensors
         T, B, A, E, R, We, V, G1 = ctx.dims
         NP = w_wp.shape[0]
@@ -194,62 +205,71 @@ class SpeakerSeqFn(Function):
         _nn(dlogits, 0, V, w_lo, 0, R, dHO, 0, R, TB, R, V)
         dHLo = torch.empty(T, B, R, **f32)        # gradient reaching h_lang_t through the output dropout
         _drop(dHO, dHLo, TB * R, p, seeds['out'])
-        # dDPl: gradient reaching dpos through log_softmax(output_pos); d_bef/d_diff/d_aft and the four carries
-        # (gradient w.r.t. h_lang_t / c_lang_t / h_att_t / c_att_t) start at zero: one allocation, one fill
-        dDPl, d_bef, d_diff, d_aft, dh_l, dc_l, dh_a, dc_a = ops.zeros_pool(
-            dev, (T, B, NP), (B, A), (B, A), (B, A), (B, R), (B, R), (B, R), (B, R))
+        # dDPl: gradient reaching dpos through log_softmax(output_pos); d_bef/d_diff/d_aft and the cell-state carries start at
+        # zero: one allocation, one fill
+        dDPl, d_bef, d_diff, d_aft, dc_l, dc_a = ops.zeros_pool(dev, (T, B, NP), (B, A), (B, A), (B, A), (B, R), (B, R))
         if dlogpos is not None:
             check(L.ekaid_softmax_bwd(ptr(logpos), ptr(dlogpos.contiguous()), ptr(dDPl), TB, NP, 1, stream()), 'softmax_bwd')
 
         DCAT = torch.empty(T, B, NW, **f32)       # [d att gates | d pos1 pre-act | d gate1x pre-act | d lang gates] per step
         DZFC = torch.empty(T, B, 3, **f32)
         DWP = torch.empty(T, B, NP, **f32)
-        DPA = torch.empty(T, B, R + A, **f32)     # [d pos_feat | d att_feat (gate-MLP path)] per step, one dgrad GEMM
+        DPP = torch.empty(T, B, R, **f32)         # d pos_feat per step (gradient at the pos2 output)
         DZ2 = torch.empty(T, B, A, **f32)
-        dh_l_prev = torch.empty(B, R, **f32)
-        dh_a_prev = torch.empty(B, R, **f32)
         dc_tmp = torch.empty(B, R, **f32)
-        t_BA = torch.empty(B, A, **f32)
-        t_BG = torch.empty(B, G1, **f32)
+        t_BA = torch.empty(B, A, **f32)           # d gated of the current step
 
+        sb = hip.SpkStepABwd()
+        sb.B, sb.R, sb.A, sb.P = B, R, A, NP
+        sb.d_gated, sb.bef, sb.diff, sb.aft, sb.w_fc = ptr(t_BA), ptr(bef), ptr(diff), ptr(aft), ptr(w_fc)
+        sb.d_bef, sb.d_diff, sb.d_aft = ptr(d_bef), ptr(d_diff), ptr(d_aft)
+        sb.w_p2, sb.w_wp = ptr(w_p2), ptr(w_wp)
+        sb.p_v, sb.p_d, sb.lddg, sb.lddpp, sb.lddx = p, p5, NW, R, NW
+        carry_l = carry_a = None                  # slabs of DCAT_{t+1} . Wcat (-> h_lang_t) and DCAT_{t+1}[att gates] . W_hh_att (-> h_att_t)
         for t in range(T - 1, -1, -1):
             o_prev, o_t = t * B * R, (t + 1) * B * R
             ow = t * B * NW
             sv, sd, sg = seeds_t[t]
-            # 6'. language LSTM (upstream on h_lang_t = carry + output path)
-            check(L.ekaid_lstm_cell_bwd(ptr(dh_l), dHLo.data_ptr() + 4 * t * B * R, ptr(dc_l), SL.data_ptr() + 4 * t * B * 4 * R,
-                                        CL.data_ptr() + 4 * o_prev, CL.data_ptr() + 4 * o_t, B, R,
-                                        DCAT.data_ptr() + 4 * (ow + oGL), NW, ptr(dc_tmp), stream()), 'lstm_cell_bwd')
+            # 6'. language LSTM (upstream on h_lang_t = carry slabs + output path)
+            csl = carry_l.cols(0) if carry_l is not None else ops.NO_SLABS
+            check(L.ekaid_lstm_cell_slabs_bwd(ctypes.byref(csl), dHLo.data_ptr() + 4 * t * B * R, ptr(dc_l),
+                                              SL.data_ptr() + 4 * t * B * 4 * R, CL.data_ptr() + 4 * o_prev, CL.data_ptr() + 4 * o_t, B, R,
+                                              DCAT.data_ptr() + 4 * (ow + oGL), NW, ptr(dc_tmp), stream()), 'lstm_cell_slabs_bwd')
             dc_l, dc_tmp = dc_tmp, dc_l
-            _nn(DCAT, ow + oGL, NW, wih_l, We, We + A, t_BA, 0, A, B, A, 4 * R)                  # d gated
+            # d gated = d lang gates . W_ih_lang[:, We:]
+            Q1 = ops.gemm_slabs(DCAT, wih_l, B, A, 4 * R, NW, We + A, 0, 0, a_off=ow + oGL, b_off=We)
             # 5'. gated = gate * att ; gate = sigmoid(W_g2 g1d + b):  d z2 = d gated * att * gate'
-            check(L.ekaid_spk_gate_bwd(ptr(t_BA), AT.data_ptr() + 4 * t * B * A, GT.data_ptr() + 4 * t * B * A, B * A,
-                                       DZ2.data_ptr() + 4 * t * B * A, stream()), 'spk_gate_bwd')
-            _nn(DZ2, t * B * A, A, w_g2, 0, G1, t_BG, 0, G1, B, G1, A)                            # d g1d
-            check(L.ekaid_drop_act_bwd(ptr(t_BG), HLW.data_ptr() + 4 * (ow + oG1), NW, B, G1, ACT_RELU, p, sg,
-                                       DCAT.data_ptr() + 4 * (ow + oG1), NW, stream()), 'drop_act_bwd')
+            s1 = Q1.cols(0)
+            check(L.ekaid_gate_slabs_bwd(ctypes.byref(s1), AT.data_ptr() + 4 * t * B * A, GT.data_ptr() + 4 * t * B * A, B, A,
+                                         DZ2.data_ptr() + 4 * t * B * A, ptr(t_BA), stream()), 'gate_slabs_bwd')
+            Q2 = ops.gemm_slabs(DZ2, w_g2, B, G1, A, A, G1, 0, 0, a_off=t * B * A)                  # d g1d
+            s2 = Q2.cols(0)
+            check(L.ekaid_drop_act_slabs_bwd(ctypes.byref(s2), G1D.data_ptr() + 4 * t * B * G1, G1, B, G1, ACT_RELU, p, sg,
+                                             DCAT.data_ptr() + 4 * (ow + oG1), NW, stream()), 'drop_act_slabs_bwd')
             # [d pos_feat | d att (gate-MLP path)] = d gate1x . W_g1[:, R:]   (one GEMM, N = R + A)
-            _nn(DCAT, ow + oG1, NW, w_g1, R, G1, DPA, t * B * (R + A), R + A, B, R + A, G1)
-            # 4'.+2'. att = mix3(mw, bef, diff, aft); d att = gate-MLP path + d gated * gate; module weights: softmax, fc
-            check(L.ekaid_spk_modmix_bwd(MW.data_ptr() + 4 * t * B * 3, ptr(bef), ptr(diff), ptr(aft), B, A,
-                                         DPA.data_ptr() + 4 * (t * B * (R + A) + R), R + A, ptr(t_BA), GT.data_ptr() + 4 * t * B * A,
-                                         ptr(w_fc), R, DZFC.data_ptr() + 4 * t * B * 3, ptr(d_bef), ptr(d_diff), ptr(d_aft),
-                                         ptr(dh_a), stream()), 'spk_modmix_bwd')
-            # 3'. POS chain
-            check(L.ekaid_spk_pos_bwd(DPA.data_ptr() + 4 * t * B * (R + A), R + A, PW.data_ptr() + 4 * t * B * NP,
-                                      dDPl.data_ptr() + 4 * t * B * NP, B, NP, ptr(w_p2), ptr(w_wp), VP.data_ptr() + 4 * t * B * R, R,
-                                      p, sv, p5, sd, DWP.data_ptr() + 4 * t * B * NP, DCAT.data_ptr() + 4 * (ow + oP1), NW,
-                                      stream()), 'spk_pos_bwd')
-            # 1'. module-attention LSTM
-            check(L.ekaid_lstm_cell_bwd(ptr(dh_a), None, ptr(dc_a), SA.data_ptr() + 4 * t * B * 4 * R, CA.data_ptr() + 4 * o_prev,
-                                        CA.data_ptr() + 4 * o_t, B, R, DCAT.data_ptr() + 4 * ow, NW, ptr(dc_tmp), stream()),
-                  'lstm_cell_bwd')
+            Q3 = ops.gemm_slabs(DCAT, w_g1, B, R + A, G1, NW, G1, 0, 0, a_off=ow + oG1, b_off=R)
+            # 4'.+2'.+1'.+3'. module mix, att-LSTM cell, POS chain: one row-local kernel
+            sb.dpa_src = Q3.cols(0)
+            sb.gate = GT.data_ptr() + 4 * t * B * A
+            sb.mw = MW.data_ptr() + 4 * t * B * 3
+            sb.dz_fc = DZFC.data_ptr() + 4 * t * B * 3
+            sb.dh_carry = carry_a.cols(0) if carry_a is not None else ops.NO_SLABS
+            sb.dc_in, sb.dc_out = ptr(dc_a), ptr(dc_tmp)
+            sb.gate_save = SA.data_ptr() + 4 * t * B * 4 * R
+            sb.c_prev, sb.c_cur = CA.data_ptr() + 4 * o_prev, CA.data_ptr() + 4 * o_t
+            sb.dgates = DCAT.data_ptr() + 4 * ow
+            sb.pw = PW.data_ptr() + 4 * t * B * NP
+            sb.dhead = dDPl.data_ptr() + 4 * t * B * NP
+            sb.vp = VP.data_ptr() + 4 * t * B * R
+            sb.seed_v, sb.seed_d = sv, sd
+            sb.dpp_out = DPP.data_ptr() + 4 * t * B * R
+            sb.dwp_out = DWP.data_ptr() + 4 * t * B * NP
+            sb.dx_out = DCAT.data_ptr() + 4 * (ow + oP1)
+            check(L.ekaid_spk_step_a_bwd(ctypes.byref(sb), stream()), 'spk_step_a_bwd')
             dc_a, dc_tmp = dc_tmp, dc_a
-            _nn(DCAT, ow, NW, whh_a, 0, R, dh_a_prev, 0, R, B, R, 4 * R)                          # -> h_att_{t-1}
-            # 0'. everything that flowed out of h_lang_{t-1}: one GEMM against the concatenated weight
-            _nn(DCAT, ow, NW, Wcat, 0, R, dh_l_prev, 0, R, B, R, NW)
-            dh_l, dh_l_prev = dh_l_prev, dh_l
-            dh_a, dh_a_prev = dh_a_prev, dh_a
+            if t > 0:
+                # 0'. what flowed out of h_att_{t-1} (att gates . W_hh) and out of h_lang_{t-1} (everything . Wcat): one launch
+                carry_a, carry_l = ops.gemm_slabs2((DCAT, whh_a, B, R, 4 * R, NW, R, 0, 0, ow, 0), (DCAT, Wcat, B, R, NW, NW, R, 0, 0, ow, 0))
 
         # ---- time-batched weight gradients (K = T*B) and input gradients; DCAT column blocks with ld = NW
         d_wih_a = ops.grad_out(wih_a)
@@ -269,14 +289,14 @@ class SpeakerSeqFn(Function):
         _tn(DWP, NP, VP, R, d_w_wp, 0, R, NP, R, TB)
         d_b_wp = ops.bias_grad(b_wp, DWP, TB, NP, NP)
         d_w_p2 = ops.grad_out(w_p2)
-        _tn(DPA, R + A, PW, NP, d_w_p2, 0, NP, R, NP, TB)
-        d_b_p2 = ops.bias_grad(b_p2, DPA, TB, R, R + A)
+        _tn(DPP, R, PW, NP, d_w_p2, 0, NP, R, NP, TB)
+        d_b_p2 = ops.bias_grad(b_p2, DPP, TB, R, R)
         d_w_g1 = ops.grad_out(w_g1)
         _tn(DCAT, NW, HL, R, d_w_g1, 0, G1, G1, R, TB, doff=oG1)
         _tn(DCAT, NW, PA, R + A, d_w_g1, R, G1, G1, R + A, TB, doff=oG1)
         d_b_g1 = ops.bias_grad(b_g1, DCAT, TB, G1, NW, oG1)
         d_w_g2 = ops.grad_out(w_g2)
-        _tn(DZ2, A, HLW, NW, d_w_g2, 0, G1, A, G1, TB, xoff=oG1)                                  # input = dropout(relu(gate1x)) block
+        _tn(DZ2, A, G1D, G1, d_w_g2, 0, G1, A, G1, TB)                                            # input = dropout(relu(gate1x))
         d_b_g2 = ops.bias_grad(b_g2, DZ2, TB, A, A)
         d_wih_l = ops.grad_out(wih_l)
         _tn(DCAT, NW, Xd, We, d_wih_l, 0, We + A, 4 * R, We, TB, doff=oGL)

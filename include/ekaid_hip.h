@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EKAID_ABI_VERSION 3
+#define EKAID_ABI_VERSION 4
 
 int ekaid_version(void);
 const char* ekaid_last_error(void);        /* thread-local */
@@ -85,6 +85,33 @@ typedef struct ekaid_gemm {
 
 size_t ekaid_gemm_workspace_bytes(const ekaid_gemm_t* g);
 int ekaid_gemm_f32(const ekaid_gemm_t* g, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Raw partial products for consumers that finish the reduction themselves ("slabs").
+ * The small recurrent GEMMs (M = batch rows) are cut along K so that their grids fill the chip; instead of a reduce kernel
+ * between the GEMM and its consumer, the consumer (an LSTM / GRU cell, a row-local chain, a bias + activation epilogue) sums
+ * the slabs itself, in a fixed order (deterministic).
+ *   ekaid_gemm_slab_count(g)  number of slabs n the planner cuts g into (>= 1; host-side, no launch);
+ *   ekaid_gemm_slabs(g, ...)  slabs[s][M][N] (s < n, row-major, leading dim N) with sum_s slabs[s] = op(A).op(B): no alpha,
+ *                             bias, residual, activation or dropout (those fields of g are ignored), g->C unused;
+ *                             slab_bytes >= n * M * N * 4.  One batch only.
+ *   ekaid_gemm_slabs2         two independent products in ONE launch when both use the 64x64-tile kernel and the same operand
+ *                             layout (otherwise two launches, same results).
+ * A consumer addresses a slab set through ekaid_slabs_t: element (row, col) of slab s is p[s * stride + row * ld + col];
+ * `p` may point at a column block of the slabs, n = 0 (or p = NULL) means "no such source"; a plain matrix is n = 1.
+ * ref: the nn.Linear / nn.LSTMCell / nn.GRU products inside the time loops, dynamic_speaker_change_pos.py:94-131,
+ *      language_model.py:106-115.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ekaid_slabs {
+    const float* p;
+    int n;
+    long long stride;       /* elements between consecutive slabs (M * N of the producing GEMM) */
+    int ld;                 /* leading dimension inside a slab (N of the producing GEMM) */
+} ekaid_slabs_t;
+int ekaid_gemm_slab_count(const ekaid_gemm_t* g);
+int ekaid_gemm_slabs(const ekaid_gemm_t* g, float* slabs, size_t slab_bytes, void* stream);
+int ekaid_gemm_slabs2(const ekaid_gemm_t* g0, float* slabs0, size_t slab_bytes0, const ekaid_gemm_t* g1, float* slabs1,
+                      size_t slab_bytes1, void* stream);
 
 /* Arithmetic of ekaid_gemm_f32 (per device; both take and return f32 and accumulate in f32):
  *   EKAID_GEMM_F32_MFMA   (0)  v_mfma_f32_32x32x2_f32, an exact f32 fma chain;
@@ -248,6 +275,85 @@ int ekaid_spk_pos_bwd(const float* dpp, int lddpp, const float* pw, const float*
                       const float* w_wp, const float* vp, int R, float p_v, uint64_t seed_v, float p_d, uint64_t seed_d,
                       float* dwp_out, float* dx_out, int lddx, void* stream);
 int ekaid_spk_gate_bwd(const float* d_gated, const float* att, const float* gate, long long n, float* dz, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Slab-consuming forms of the recurrent steps (csrc/steps.hip): every `*_src` / `carry` argument is a slab set produced by
+ * ekaid_gemm_slabs; sources are summed (all slabs of all sources, fixed order) before the arithmetic of the plain form.
+ *
+ * slab_epilogue        out[r*ldo + c] = dropout(act(sum + bias[c]))      (mask index r*cols + c; up to 3 sources)
+ *                      ref: the gate MLP's first layer, dynamic_speaker_change_pos.py:122-124 (Linear + ReLU + Dropout)
+ * drop_act_slabs_bwd   out[r*ldo + c] = sum[r][c] * keep(seed, r*cols + c)/(1-p) * act'(y[r*ldy + c])
+ * lstm_cell_slabs_fwd  gates = gx + sum + bias (i,f,g,o), then as ekaid_lstm_cell_fwd     (nn.LSTMCell, :57,88,102,126)
+ * lstm_cell_slabs_bwd  upstream gradient on h2 = sum(carry) + dh_b (either may be absent), then as ekaid_lstm_cell_bwd
+ * gru_cell_slabs_fwd   gh = sum + b_hh, then as ekaid_gru_cell_fwd                          (nn.GRU, language_model.py:113)
+ * gru_cell_slabs_bwd   upstream = dhnew + dh_direct + sum(carry); writes dgi, dgh and dh_out = z * upstream (the direct term
+ *                      the PREVIOUS step adds to its upstream gradient; the W_hh term arrives as that step's carry slabs)
+ * gate_mul_slabs_fwd   gate = sigmoid(sum + bias); gated = gate * att                       (:122-125)
+ * gate_slabs_bwd       d_gated = sum; dz = d_gated * att * gate * (1 - gate)
+ * ------------------------------------------------------------------------------------------ */
+int ekaid_slab_epilogue(const ekaid_slabs_t* src, int nsrc, const float* bias, int rows, int cols, int act, float p, uint64_t seed,
+                        float* out, int ldo, void* stream);
+int ekaid_drop_act_slabs_bwd(const ekaid_slabs_t* src, const float* y, int ldy, int rows, int cols, int act, float p, uint64_t seed,
+                             float* out, int ldo, void* stream);
+int ekaid_lstm_cell_slabs_fwd(const float* gx, const ekaid_slabs_t* src, int nsrc, const float* bias, const float* c, int B, int H,
+                              float* h2, float* c2, float* save, void* stream);
+int ekaid_lstm_cell_slabs_bwd(const ekaid_slabs_t* carry, const float* dh_b, const float* dc2, const float* save, const float* c,
+                              const float* c2, int B, int H, float* dgates, int lddg, float* dc, void* stream);
+int ekaid_gru_cell_slabs_fwd(const float* gi, int ldgi, const ekaid_slabs_t* gh, const float* b_hh, const float* h, int ldh, int B,
+                             int H, float* hnew, int ldhn, float* save, void* stream);
+int ekaid_gru_cell_slabs_bwd(const float* dhnew, int lddh, const float* dh_direct, const ekaid_slabs_t* carry, const float* save,
+                             const float* h, int ldh, int B, int H, float* dgi, int lddgi, float* dgh, float* dh_out, void* stream);
+int ekaid_gate_mul_slabs_fwd(const ekaid_slabs_t* src, const float* bias, const float* att, int B, int A, float* gate, float* gated,
+                             void* stream);
+int ekaid_gate_slabs_bwd(const ekaid_slabs_t* src, const float* att, const float* gate, int B, int A, float* dz, float* d_gated,
+                         void* stream);
+
+/* Row-local first half of ONE decoder step for the whole batch, one workgroup per batch row (descriptor by pointer: too
+ * many operands for a flat signature).  ref: DynamicCore.forward, dynamic_speaker_change_pos.py:102-121.
+ *   1. module-attention LSTM cell: gates = gxa + sum(gates_src) + b_hh  ->  h_out, c_out, gate_save (i,f,g,o)       (:102)
+ *   2. mw = softmax(h_out . w_fc^T + b_fc); att = mw0*bef + mw1*diff + mw2*aft -> att (B x A) and att2 (ld2, may be NULL) (:104-113)
+ *   3. v = dropout(relu(sum(pos_src) + b_p1), p_v); dpos = dropout(w_wp v + b_wp, p_d); pw = softmax(dpos);
+ *      pp = w_p2 pw + b_p2 -> vp, dp, pw, pp (leading dim ldpp)                                                     (:115-121)
+ * Dropout mask indices as ekaid_spk_pos_fwd.  R <= 2048, P <= 64. */
+typedef struct ekaid_spk_step_a_fwd {
+    int B, R, A, P;
+    const float* gxa;                 /* [B][4R] input-side gate pre-activations (bias_ih included) */
+    ekaid_slabs_t gates_src[3];       /* hidden-side gate products, [B][4R] each */
+    int n_gates_src;
+    const float* b_hh;                /* [4R] */
+    const float* c_prev;              /* [B][R] */
+    float *h_out, *c_out, *gate_save; /* [B][R], [B][R], [B][4R] */
+    const float *w_fc, *b_fc;         /* [3][R], [3] */
+    const float *bef, *diff, *aft;    /* [B][A] */
+    float *mw, *att, *att2;           /* [B][3], [B][A], strided copy (ld2) or NULL */
+    int ld2;
+    ekaid_slabs_t pos_src;            /* pos1 product [B][R] */
+    const float *b_p1, *w_wp, *b_wp, *w_p2, *b_p2;     /* [R], [P][R], [P], [R][P], [R] */
+    float p_v; uint64_t seed_v; float p_d; uint64_t seed_d;
+    float *vp, *dp, *pw, *pp;         /* [B][R], [B][P], [B][P], strided (ldpp) */
+    int ldpp;
+} ekaid_spk_step_a_fwd_t;
+int ekaid_spk_step_a_fwd(const ekaid_spk_step_a_fwd_t* d, void* stream);
+
+/* The same chain backwards (autograd of :102-121), one workgroup per batch row:
+ *   1. d_att[k] = sum(dpa_src)[R + k] + d_gated * gate;  d_bef/d_diff/d_aft += mw_c * d_att;  dz_fc = softmax'(mw) <d_att, feat_c>
+ *   2. att-LSTM cell: dh = sum(dh_carry) + dz_fc . w_fc; dc = dc_in -> dgates (leading dim lddg), dc_out
+ *   3. POS chain from dpp = sum(dpa_src)[k < R] (also written to dpp_out, leading dim lddpp) -> dwp_out, dx_out (lddx);
+ *      dhead (may be NULL) is added at dpos. */
+typedef struct ekaid_spk_step_a_bwd {
+    int B, R, A, P;
+    ekaid_slabs_t dpa_src;            /* [B][R + A]: d [pos_feat | att (gate-MLP path)] */
+    const float *d_gated, *gate;      /* [B][A] */
+    const float *mw, *bef, *diff, *aft, *w_fc;
+    float *dz_fc, *d_bef, *d_diff, *d_aft;          /* [B][3]; [B][A] accumulated in place */
+    ekaid_slabs_t dh_carry;           /* [B][R] gradient arriving at h_att from the following step (absent at the last step) */
+    const float *dc_in, *gate_save, *c_prev, *c_cur;
+    float* dgates; int lddg; float* dc_out;
+    const float *pw, *dhead, *w_p2, *w_wp, *vp;
+    float p_v; uint64_t seed_v; float p_d; uint64_t seed_d;
+    float* dpp_out; int lddpp; float* dwp_out; float* dx_out; int lddx;
+} ekaid_spk_step_a_bwd_t;
+int ekaid_spk_step_a_bwd(const ekaid_spk_step_a_bwd_t* d, void* stream);
 
 /* out[r][c] = dropout(act(x[r*ldx + c] + bias[c]))   (contiguous out; mask index r*cols + c)
  * drop_act_bwd: out[r*ldo + c] = dy[r][c] * keep(seed, r*cols + c)/(1-p) * act'(y[r*ldy + c])  (y = activation output,

@@ -889,3 +889,235 @@ def test_fanout_sums_bias_slots_and_batched_step_dropout():
     z = ops.zeros_pool(DEV, (3, 5), (7,), (2, 2))
     assert [tuple(t.shape) for t in z] == [(3, 5), (7,), (2, 2)] and all(float(t.abs().sum()) == 0 for t in z)
     assert all(t.data_ptr() % 16 == 0 for t in z)
+
+
+# --------------------------------------------------------------------------- slabs: GEMMs whose consumers reduce
+@pytest.mark.parametrize('mode,M,N,K', [('nt', 32, 6656, 512), ('nt', 256, 2048, 1536), ('nn', 32, 512, 6656), ('nn', 7, 100, 50),
+                                        ('nt', 2, 64, 31), ('nn', 256, 1024, 2048), ('nt', 600, 256, 512)])
+def test_gemm_slabs_sum_to_the_product(mode, M, N, K, gemm_arith):
+    """ekaid_gemm_slabs: the K-slabs add up to op(A).op(B) (float64 reference), also when the planner does not split."""
+    from ekaid_amd import ops
+    A, Bm = rnd(M, K, seed=3), rnd(K, N, seed=4)
+    want = A.double() @ Bm.double()
+    if mode == 'nt':
+        a, b, ta, tb, lda, ldb = A, Bm.t().contiguous(), 0, 1, K, K
+    else:
+        a, b, ta, tb, lda, ldb = A, Bm, 0, 0, K, N
+    S = ops.gemm_slabs(a.to(DEV), b.to(DEV), M, N, K, lda, ldb, ta, tb)
+    assert S.n >= 1 and S.buf.numel() == S.n * M * N
+    check(S.total(), want, 2e-6 * max(1.0, math.sqrt(K) / 4), 'slabs %s %dx%dx%d (%d slabs)' % (mode, M, N, K, S.n))
+
+
+@pytest.mark.parametrize('mode', ['nt', 'nn'])
+def test_gemm_slab_pairs_in_one_launch(mode, gemm_arith):
+    """ekaid_gemm_slabs2: two independent products (different N, K and split counts, operand offsets) from one launch equal
+    the two single launches bit for bit."""
+    from ekaid_amd import ops
+    M = 48
+    shapes = [(6656, 512), (2048, 512)] if mode == 'nt' else [(512, 2048), (512, 6656)]
+    gs, singles = [], []
+    for i, (N, K) in enumerate(shapes):
+        Awide = rnd(3, M, K, seed=10 + i).to(DEV)                       # the product reads slice 1 (element offset)
+        Bm = (rnd(N, K, seed=20 + i) if mode == 'nt' else rnd(K, N, seed=20 + i)).to(DEV)
+        g = (Awide, Bm, M, N, K, K, K if mode == 'nt' else N, 0, 1 if mode == 'nt' else 0, M * K, 0)
+        gs.append(g)
+        singles.append(ops.gemm_slabs(*g[:9], a_off=g[9], b_off=g[10]))
+    p0, p1 = ops.gemm_slabs2(gs[0], gs[1])
+    for s, p, g in zip(singles, (p0, p1), gs):
+        assert p.n == s.n
+        assert torch.equal(p.buf, s.buf)
+        Aw, Bm = g[0][1].double().cpu(), g[1].double().cpu()
+        check(p.total(), Aw @ (Bm.t() if mode == 'nt' else Bm), 5e-6, 'pair member')
+
+
+def _rand_slabs(n, M, N, seed):
+    """n random slabs [n][M][N] on the device + their float64 sum."""
+    from ekaid_amd import ops
+    buf = rnd(n, M, N, seed=seed).to(DEV)
+    return ops.SlabSet(buf.view(-1), n, M, N), buf.double().cpu().sum(0)
+
+
+def test_slab_consumers_equal_the_plain_kernels():
+    """Every slab-consuming kernel == summing the slabs first and calling the plain kernel it replaces."""
+    import ctypes
+    from ekaid_amd import hip, ops
+    from ekaid_amd.hip import ACT_RELU, ACT_TANH, check as hcheck, ptr, stream
+    L = hip.lib()
+    B, H = 37, 24
+    f = dict(device=DEV, dtype=torch.float32)
+    # ---- slab_epilogue (two sources, a column block of a wider slab set, bias, relu, dropout) vs bias_act_drop
+    S0, t0 = _rand_slabs(5, B, 3 * H, 1)
+    S1, t1 = _rand_slabs(2, B, H, 2)
+    bias = rnd(H, seed=3).to(DEV)
+    for p, seed in ((0.0, 0), (0.5, 77)):
+        arr, n = ops.slab_array(S0.cols(H), S1.cols(0))
+        out = torch.empty(B, H, **f)
+        hcheck(L.ekaid_slab_epilogue(arr, n, ptr(bias), B, H, ACT_RELU, p, seed, ptr(out), H, stream()), 'slab_epilogue')
+        x = (t0[:, H:2 * H] + t1).float().to(DEV).contiguous()
+        want = torch.empty(B, H, **f)
+        hcheck(L.ekaid_bias_act_drop(ptr(x), H, ptr(bias), B, H, ACT_RELU, p, seed, ptr(want), stream()), 'bias_act_drop')
+        assert float((out - want).abs().max()) < 2e-5
+        assert torch.equal(out == 0, want == 0) or p == 0.0
+    # odd width -> scalar path
+    S2, t2 = _rand_slabs(3, B, 7, 4)
+    arr, n = ops.slab_array(S2.cols(0))
+    out = torch.empty(B, 7, **f)
+    hcheck(L.ekaid_slab_epilogue(arr, n, None, B, 7, ACT_TANH, 0.0, 0, ptr(out), 7, stream()), 'slab_epilogue')
+    check(out, torch.tanh(t2), 2e-6, 'slab_epilogue scalar path')
+    # ---- drop_act_slabs_bwd vs drop_act_bwd
+    y = torch.relu(rnd(B, H, seed=5)).to(DEV)
+    S3, t3 = _rand_slabs(4, B, H, 6)
+    s3 = S3.cols(0)
+    out = torch.empty(B, 2 * H, **f)
+    want = torch.empty(B, 2 * H, **f)
+    hcheck(L.ekaid_drop_act_slabs_bwd(ctypes.byref(s3), ptr(y), H, B, H, ACT_RELU, 0.3, 5, ptr(out), 2 * H, stream()), 'drop_act_slabs_bwd')
+    dy = t3.float().to(DEV).contiguous()
+    hcheck(L.ekaid_drop_act_bwd(ptr(dy), ptr(y), H, B, H, ACT_RELU, 0.3, 5, ptr(want), 2 * H, stream()), 'drop_act_bwd')
+    assert float((out[:, :H] - want[:, :H]).abs().max()) < 2e-5
+    # ---- LSTM cell forward / backward
+    gx, c0 = rnd(B, 4 * H, seed=7).to(DEV), rnd(B, H, seed=8).to(DEV)
+    Sg0, tg0 = _rand_slabs(3, B, 6 * H, 9)            # gates sit in columns [H, 5H) of a wider product
+    Sg1, tg1 = _rand_slabs(6, B, 4 * H, 10)
+    b4 = rnd(4 * H, seed=11).to(DEV)
+    h2, c2, sv = torch.empty(B, H, **f), torch.empty(B, H, **f), torch.empty(B, 4 * H, **f)
+    arr, n = ops.slab_array(Sg0.cols(H), Sg1.cols(0))
+    hcheck(L.ekaid_lstm_cell_slabs_fwd(ptr(gx), arr, n, ptr(b4), ptr(c0), B, H, ptr(h2), ptr(c2), ptr(sv), stream()), 'lstm_cell_slabs_fwd')
+    gh = (tg0[:, H:5 * H] + tg1).float().to(DEV) + b4
+    h2w, c2w, svw = torch.empty(B, H, **f), torch.empty(B, H, **f), torch.empty(B, 4 * H, **f)
+    hcheck(L.ekaid_lstm_cell_fwd(ptr(gx), ptr(gh), 4 * H, ptr(c0), B, H, ptr(h2w), ptr(c2w), ptr(svw), stream()), 'lstm_cell_fwd')
+    for a, w, nm in ((h2, h2w, 'h'), (c2, c2w, 'c'), (sv, svw, 'gates')):
+        assert float((a - w).abs().max()) < 3e-6, nm
+    Sc, tc = _rand_slabs(5, B, H, 12)
+    dhb, dc2 = rnd(B, H, seed=13).to(DEV), rnd(B, H, seed=14).to(DEV)
+    for carry, dh_b in ((Sc.cols(0), dhb), (ops.NO_SLABS, dhb), (Sc.cols(0), None)):
+        dg, dc = torch.zeros(B, 5 * H, **f), torch.empty(B, H, **f)
+        hcheck(L.ekaid_lstm_cell_slabs_bwd(ctypes.byref(carry), ptr(dh_b), ptr(dc2), ptr(svw), ptr(c0), ptr(c2w), B, H, ptr(dg), 5 * H,
+                                           ptr(dc), stream()), 'lstm_cell_slabs_bwd')
+        dh_a = tc.float().to(DEV).contiguous() if carry.n else None
+        dgw, dcw = torch.zeros(B, 5 * H, **f), torch.empty(B, H, **f)
+        hcheck(L.ekaid_lstm_cell_bwd(ptr(dh_a), ptr(dh_b), ptr(dc2), ptr(svw), ptr(c0), ptr(c2w), B, H, ptr(dgw), 5 * H, ptr(dcw),
+                                     stream()), 'lstm_cell_bwd')
+        assert float((dg - dgw).abs().max()) < 3e-6 and float((dc - dcw).abs().max()) < 3e-6
+    # ---- GRU cell forward / backward
+    gi, h0 = rnd(B, 3 * H, seed=15).to(DEV), rnd(B, H, seed=16).to(DEV)
+    Sh, th = _rand_slabs(4, B, 3 * H, 17)
+    b3 = rnd(3 * H, seed=18).to(DEV)
+    hn, sg = torch.empty(B, H, **f), torch.empty(B, 4 * H, **f)
+    sh = Sh.cols(0)
+    hcheck(L.ekaid_gru_cell_slabs_fwd(ptr(gi), 3 * H, ctypes.byref(sh), ptr(b3), ptr(h0), H, B, H, ptr(hn), H, ptr(sg), stream()),
+           'gru_cell_slabs_fwd')
+    ghw = th.float().to(DEV) + b3
+    hnw, sgw = torch.empty(B, H, **f), torch.empty(B, 4 * H, **f)
+    hcheck(L.ekaid_gru_cell_fwd(ptr(gi), 3 * H, ptr(ghw), 3 * H, ptr(h0), H, B, H, ptr(hnw), H, ptr(sgw), stream()), 'gru_cell_fwd')
+    assert float((hn - hnw).abs().max()) < 3e-6 and float((sg - sgw).abs().max()) < 3e-6
+    dhn, dhd = rnd(B, H, seed=19).to(DEV), rnd(B, H, seed=20).to(DEV)
+    Sk, tk = _rand_slabs(3, B, H, 21)
+    sk = Sk.cols(0)
+    dgi, dgh, dho = torch.empty(B, 3 * H, **f), torch.empty(B, 3 * H, **f), torch.empty(B, H, **f)
+    hcheck(L.ekaid_gru_cell_slabs_bwd(ptr(dhn), H, ptr(dhd), ctypes.byref(sk), ptr(sgw), ptr(h0), H, B, H, ptr(dgi), 3 * H, ptr(dgh),
+                                      ptr(dho), stream()), 'gru_cell_slabs_bwd')
+    carry = (dhd + tk.float().to(DEV)).contiguous()
+    dgiw, dghw, dhw = torch.empty(B, 3 * H, **f), torch.empty(B, 3 * H, **f), torch.empty(B, H, **f)
+    hcheck(L.ekaid_gru_cell_bwd(ptr(dhn), H, ptr(carry), ptr(sgw), ptr(h0), H, B, H, ptr(dgiw), 3 * H, ptr(dghw), ptr(dhw), stream()),
+           'gru_cell_bwd')
+    for a, w in ((dgi, dgiw), (dgh, dghw), (dho, dhw)):
+        assert float((a - w).abs().max()) < 3e-6
+    # ---- gate: sigmoid(sum + b) * att, and its backward
+    A = 40
+    Sa, ta = _rand_slabs(4, B, A, 22)
+    ba, att = rnd(A, seed=23).to(DEV), rnd(B, A, seed=24).to(DEV)
+    gate, gated = torch.empty(B, A, **f), torch.empty(B, A, **f)
+    sa = Sa.cols(0)
+    hcheck(L.ekaid_gate_mul_slabs_fwd(ctypes.byref(sa), ptr(ba), ptr(att), B, A, ptr(gate), ptr(gated), stream()), 'gate_mul_slabs_fwd')
+    gw = torch.sigmoid(ta + ba.double().cpu())
+    check(gate, gw, 2e-6, 'gate')
+    check(gated, gw * att.double().cpu(), 2e-6, 'gated')
+    dz, dgd = torch.empty(B, A, **f), torch.empty(B, A, **f)
+    hcheck(L.ekaid_gate_slabs_bwd(ctypes.byref(sa), ptr(att), ptr(gate), B, A, ptr(dz), ptr(dgd), stream()), 'gate_slabs_bwd')
+    check(dgd, ta, 2e-6, 'd_gated')
+    check(dz, ta * att.double().cpu() * gw * (1 - gw), 5e-6, 'dz gate')
+
+
+@pytest.mark.parametrize('B,R,A,P,drop', [(5, 64, 96, 16, 0.0), (33, 512, 1024, 16, 0.5), (3, 100, 40, 5, 0.3)])
+def test_spk_step_a_equals_the_kernel_sequence_it_fuses(B, R, A, P, drop):
+    """spk_step_a_fwd / _bwd (att-LSTM cell + module mix + POS chain in one row-local kernel, slab inputs) == the plain
+    kernels lstm_cell / spk_modmix / spk_pos applied to the summed slabs, forward and backward, with dropout."""
+    import ctypes
+    from ekaid_amd import hip, ops
+    from ekaid_amd.hip import check as hcheck, ptr, stream
+    L = hip.lib()
+    f = dict(device=DEV, dtype=torch.float32)
+    NW = 6 * R + 8
+    gxa, c_prev = rnd(B, 4 * R, seed=1).to(DEV), rnd(B, R, seed=2).to(DEV)
+    S0, t0 = _rand_slabs(3, B, NW, 3)                 # block [0, 4R): gates; block [4R + 8, 5R + 8): pos1 pre-activation
+    S1, t1 = _rand_slabs(4, B, 4 * R, 4)
+    oP = 4 * R + 8
+    bhh, w_fc, b_fc = rnd(4 * R, seed=5).to(DEV), rnd(3, R, seed=6, scale=0.2).to(DEV), rnd(3, seed=7).to(DEV)
+    bef, diff, aft = (rnd(B, A, seed=8 + i).to(DEV) for i in range(3))
+    b1, w_wp, b_wp = rnd(R, seed=11).to(DEV), rnd(P, R, seed=12, scale=0.2).to(DEV), rnd(P, seed=13).to(DEV)
+    w_p2, b_p2 = rnd(R, P, seed=14, scale=0.3).to(DEV), rnd(R, seed=15).to(DEV)
+    sv, sd = 1234567, 7654321
+    d = hip.SpkStepAFwd()
+    d.B, d.R, d.A, d.P = B, R, A, P
+    h_out, c_out, save = torch.empty(B, R, **f), torch.empty(B, R, **f), torch.empty(B, 4 * R, **f)
+    mw, att, PA = torch.empty(B, 3, **f), torch.empty(B, A, **f), torch.zeros(B, R + A, **f)
+    vp, dp, pw = torch.empty(B, R, **f), torch.empty(B, P, **f), torch.empty(B, P, **f)
+    d.gxa, d.b_hh, d.c_prev = ptr(gxa), ptr(bhh), ptr(c_prev)
+    d.gates_src[0], d.gates_src[1], d.n_gates_src = S0.cols(0), S1.cols(0), 2
+    d.h_out, d.c_out, d.gate_save = ptr(h_out), ptr(c_out), ptr(save)
+    d.w_fc, d.b_fc, d.bef, d.diff, d.aft = ptr(w_fc), ptr(b_fc), ptr(bef), ptr(diff), ptr(aft)
+    d.mw, d.att, d.att2, d.ld2 = ptr(mw), ptr(att), PA.data_ptr() + 4 * R, R + A
+    d.pos_src = S0.cols(oP)
+    d.b_p1, d.w_wp, d.b_wp, d.w_p2, d.b_p2 = ptr(b1), ptr(w_wp), ptr(b_wp), ptr(w_p2), ptr(b_p2)
+    d.p_v, d.seed_v, d.p_d, d.seed_d = drop, sv, drop, sd
+    d.vp, d.dp, d.pw, d.pp, d.ldpp = ptr(vp), ptr(dp), ptr(pw), ptr(PA), R + A
+    hcheck(L.ekaid_spk_step_a_fwd(ctypes.byref(d), stream()), 'spk_step_a_fwd')
+    # the sequence it replaces
+    gh = ((t0[:, :4 * R] + t1).float().to(DEV) + bhh).contiguous()
+    h_w, c_w, save_w = torch.empty(B, R, **f), torch.empty(B, R, **f), torch.empty(B, 4 * R, **f)
+    hcheck(L.ekaid_lstm_cell_fwd(ptr(gxa), ptr(gh), 4 * R, ptr(c_prev), B, R, ptr(h_w), ptr(c_w), ptr(save_w), stream()), 'lstm_cell_fwd')
+    mw_w, att_w, PA_w = torch.empty(B, 3, **f), torch.empty(B, A, **f), torch.zeros(B, R + A, **f)
+    hcheck(L.ekaid_spk_modmix_fwd(ptr(h_w), B, R, ptr(w_fc), ptr(b_fc), ptr(bef), ptr(diff), ptr(aft), A, ptr(mw_w), ptr(att_w),
+                                  PA_w.data_ptr() + 4 * R, R + A, stream()), 'spk_modmix_fwd')
+    x = t0[:, oP:oP + R].float().to(DEV).contiguous()
+    vp_w, dp_w, pw_w = torch.empty(B, R, **f), torch.empty(B, P, **f), torch.empty(B, P, **f)
+    hcheck(L.ekaid_spk_pos_fwd(ptr(x), R, ptr(b1), B, R, ptr(w_wp), ptr(b_wp), P, ptr(w_p2), ptr(b_p2), drop, sv, drop, sd, ptr(vp_w),
+                               ptr(dp_w), ptr(pw_w), ptr(PA_w), R + A, stream()), 'spk_pos_fwd')
+    for nm, a, w in (('h', h_out, h_w), ('c', c_out, c_w), ('gates', save, save_w), ('mw', mw, mw_w), ('att', att, att_w),
+                     ('PA', PA, PA_w), ('vp', vp, vp_w), ('dp', dp, dp_w), ('pw', pw, pw_w)):
+        assert float((a - w).abs().max()) <= 2e-5 * max(1.0, float(w.abs().max())), nm
+    # ---- backward
+    Sd, td = _rand_slabs(3, B, R + A, 20)
+    Sc, tcar = _rand_slabs(2, B, R, 21)
+    d_gated, gate = rnd(B, A, seed=22).to(DEV), torch.sigmoid(rnd(B, A, seed=23)).to(DEV)
+    dc_in, dhead = rnd(B, R, seed=24).to(DEV), rnd(B, P, seed=25).to(DEV)
+    for carry in (Sc.cols(0), ops.NO_SLABS):
+        q = hip.SpkStepABwd()
+        q.B, q.R, q.A, q.P = B, R, A, P
+        dfe = [rnd(B, A, seed=30 + i).to(DEV) for i in range(3)]              # accumulated in place: start from non-zero
+        dfe_w = [t.clone() for t in dfe]
+        dz_fc, dgates, dc_out = torch.empty(B, 3, **f), torch.zeros(B, NW, **f), torch.empty(B, R, **f)
+        dpp, dwp = torch.empty(B, R, **f), torch.empty(B, P, **f)
+        q.dpa_src, q.d_gated, q.gate = Sd.cols(0), ptr(d_gated), ptr(gate)
+        q.mw, q.bef, q.diff, q.aft, q.w_fc = ptr(mw_w), ptr(bef), ptr(diff), ptr(aft), ptr(w_fc)
+        q.dz_fc, q.d_bef, q.d_diff, q.d_aft = ptr(dz_fc), ptr(dfe[0]), ptr(dfe[1]), ptr(dfe[2])
+        q.dh_carry, q.dc_in, q.gate_save, q.c_prev, q.c_cur = carry, ptr(dc_in), ptr(save_w), ptr(c_prev), ptr(c_w)
+        q.dgates, q.lddg, q.dc_out = ptr(dgates), NW, ptr(dc_out)
+        q.pw, q.dhead, q.w_p2, q.w_wp, q.vp = ptr(pw_w), ptr(dhead), ptr(w_p2), ptr(w_wp), ptr(vp_w)
+        q.p_v, q.seed_v, q.p_d, q.seed_d = drop, sv, drop, sd
+        q.dpp_out, q.lddpp, q.dwp_out = ptr(dpp), R, ptr(dwp)
+        q.dx_out, q.lddx = dgates.data_ptr() + 4 * oP, NW
+        hcheck(L.ekaid_spk_step_a_bwd(ctypes.byref(q), stream()), 'spk_step_a_bwd')
+        DPA = td.float().to(DEV).contiguous()
+        dh = (tcar.float().to(DEV).contiguous() if carry.n else torch.zeros(B, R, **f))
+        dz_w = torch.empty(B, 3, **f)
+        hcheck(L.ekaid_spk_modmix_bwd(ptr(mw_w), ptr(bef), ptr(diff), ptr(aft), B, A, DPA.data_ptr() + 4 * R, R + A, ptr(d_gated), ptr(gate),
+                                      ptr(w_fc), R, ptr(dz_w), ptr(dfe_w[0]), ptr(dfe_w[1]), ptr(dfe_w[2]), ptr(dh), stream()), 'spk_modmix_bwd')
+        dwp_w, dg_w, dc_w = torch.empty(B, P, **f), torch.zeros(B, NW, **f), torch.empty(B, R, **f)
+        hcheck(L.ekaid_spk_pos_bwd(ptr(DPA), R + A, ptr(pw_w), ptr(dhead), B, P, ptr(w_p2), ptr(w_wp), ptr(vp_w), R, drop, sv, drop, sd,
+                                   ptr(dwp_w), dg_w.data_ptr() + 4 * oP, NW, stream()), 'spk_pos_bwd')
+        hcheck(L.ekaid_lstm_cell_bwd(ptr(dh), None, ptr(dc_in), ptr(save_w), ptr(c_prev), ptr(c_w), B, R, ptr(dg_w), NW, ptr(dc_w), stream()),
+               'lstm_cell_bwd')
+        for nm, a, w in (('dz_fc', dz_fc, dz_w), ('d_bef', dfe[0], dfe_w[0]), ('d_diff', dfe[1], dfe_w[1]), ('d_aft', dfe[2], dfe_w[2]),
+                         ('dgates', dgates, dg_w), ('dc', dc_out, dc_w), ('dwp', dwp, dwp_w), ('dpp', dpp, DPA[:, :R])):
+            assert float((a - w).abs().max()) <= 3e-5 * max(1.0, float(w.abs().max())), nm
