@@ -12,8 +12,9 @@ every dropout active, float32 arithmetic end to end.
 
 Scaling: BASELINE.json's metric is GLOBAL batch 256 at 1/2/4/8 GPUs, so the default is STRONG scaling (``--batch`` =
 global batch, 256/N pairs per GPU; configs[2] at N = 1).  ``--scaling weak`` keeps 256 pairs per GPU (configs[3]:
-global 2048 at N = 8).  At N > 1 the iteration is replayed from a captured hipGraph by default (``--hip-graph auto``;
-ekaid_amd/engine.py), the gradient all-reduce (RCCL) and the Adam kernel are issued after the replay.
+global 2048 at N = 8).  At N > 1 the bucketed gradient all-reduce (RCCL) always overlaps backward: launched from gradient
+hooks in eager mode (>= 128 pairs per GPU), captured inside the replayed hipGraph below that (``--hip-graph auto``;
+ekaid_amd/engine.py); the JSON line carries ``comm.exposed_comm_ms`` = step time minus the same step without collectives.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   "roofline":     the dominant kernel (the 128x128-tile f32 GEMM on the bf16 matrix pipe), timed with HIP events around
@@ -50,9 +51,11 @@ def parse():
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='strong')
     ap.add_argument('--graph', default='all')
     ap.add_argument('--hip-graph', choices=['auto', 'on', 'off'], default='auto',
-                    help='replay the iteration from a captured hipGraph (auto: when more than one GPU)')
-    ap.add_argument('--graph-comm', choices=['eager', 'captured'], default='eager',
-                    help='with --hip-graph: gradient all-reduce after the replay (eager) or inside the graph (captured)')
+                    help='replay the iteration from a captured hipGraph (auto: at N > 1 with fewer than 128 pairs per GPU, where '
+                         'the host cannot issue ~900 launches as fast as the GPU retires them; eager hook-driven launches above)')
+    ap.add_argument('--graph-comm', choices=['auto', 'eager', 'captured'], default='auto',
+                    help='with --hip-graph: bucketed all-reduce captured INSIDE the graph, overlapped with backward (captured; auto '
+                         'picks it, and falls back to eager if the capture fails) or issued after the replay (eager: serialised)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the forward-only B=64 and T=90 lines')
     ap.add_argument('--cpu-batch', type=int, default=64)
@@ -200,7 +203,11 @@ def main():
         per_gpu, global_batch = args.batch // world, args.batch
     else:
         per_gpu, global_batch = args.batch, args.batch * world
-    use_graph = args.hip_graph == 'on' or (args.hip_graph == 'auto' and world > 1)
+    # N > 1: every default path overlaps the gradient all-reduce with backward -- hook-driven eager launches at >= 128
+    # pairs per GPU (the GPU step is longer than the host's issue time), below that the whole step incl. the RCCL calls
+    # is replayed from one hipGraph (the collectives sit on a side branch of the graph, ekaid_amd/engine.py)
+    use_graph = args.hip_graph == 'on' or (args.hip_graph == 'auto' and world > 1 and per_gpu < 128)
+    graph_comm = 'captured' if args.graph_comm == 'auto' else args.graph_comm
     cfg = bench_cfg(D=SHAPE['D'], seq_length=SHAPE['seq_length'], graph=args.graph)
     cd, sp = build_models(cfg, 147, 148, dev, train=not args.eval)      # closed-form weights, identical on every rank
     if args.global_qc and world > 1:
@@ -220,9 +227,18 @@ def main():
     h2d_ms = (time.perf_counter() - th2d) * 1e3                        # pageable host -> device copy of one batch (reported, never in `value`)
     h2d_bytes = sum(v.numel() * v.element_size() for v in host_batch.values())
     ops.manual_seed(1238 + rank)
-    step = TrainStep(cfg, cd, sp, opt, args.graph, use_graph=use_graph, comm=args.graph_comm)
+    step = TrainStep(cfg, cd, sp, opt, args.graph, use_graph=use_graph, comm=graph_comm)
     eager = TrainStep(cfg, cd, sp, opt, args.graph)
 
+    comm_fallback = None
+    if use_graph and graph_comm == 'captured' and args.graph_comm == 'auto' and world > 1:
+        try:                                   # first call = capture; a failure there is raised on every rank alike
+            step(b, T)
+        except Exception as e:                 # noqa: BLE001
+            comm_fallback = '%s: %s' % (type(e).__name__, str(e)[:200])
+            step.close()
+            graph_comm = 'eager'
+            step = TrainStep(cfg, cd, sp, opt, args.graph, use_graph=True, comm='eager')
     for _ in range(args.warmup):
         step(b, T)
     torch.cuda.synchronize()
@@ -333,10 +349,46 @@ def main():
     if world > 1:
         dist.barrier()
 
+    # ---- exposed communication (N > 1): the same step timed again WITHOUT collectives (local gradients, local Adam); the
+    # difference to the timed run is what the all-reduce costs after overlap.  Last thing the run does: weights diverge.
+    comm = None
+    if world > 1:
+        opt.comm_suspended = True
+        nocomm = TrainStep(cfg, cd, sp, opt, args.graph, use_graph=use_graph, comm=graph_comm)
+        k = min(args.steps, 30)
+        for _ in range(3):
+            nocomm(b, T)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(k):
+            nocomm(b, T)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_nc = torch.tensor([(time.perf_counter() - tc) / k], device=dev, dtype=torch.float64)
+        dist.all_reduce(t_nc, op=dist.ReduceOp.MAX)
+        opt.comm_suspended = False
+        nocomm.close()
+        ms_nc = float(t_nc.item()) * 1e3
+        comm = {'exposed_comm_ms': round(max(0.0, elapsed / args.steps * 1e3 - ms_nc), 3), 'ms_per_step_without_comm': round(ms_nc, 3),
+                'allreduce_bytes': int(opt.total) * 4, 'buckets': len(opt.buckets),
+                'mode': ('captured in the hipGraph, overlapped' if graph_comm == 'captured' else 'after the replay, serialised')
+                if use_graph else 'eager, launched from gradient hooks, overlapped', 'capture_fallback': comm_fallback}
+
     if rank == 0:
-        cfg_idx = 2 if world == 1 else (3 if (args.scaling == 'weak' and global_batch == 2048) else None)
-        workload = ('BASELINE.json configs[%d]' % cfg_idx) if cfg_idx is not None else \
-            ('BASELINE.json metric point (global batch %d over %d GPUs; between configs[2] and configs[3])' % (global_batch, world))
+        cfg_idx = None
+        if args.graph == 'all' and not args.eval:
+            if world == 1 and global_batch == 256:
+                cfg_idx = 2
+            elif args.scaling == 'weak' and global_batch == 2048 and world == 8:
+                cfg_idx = 3
+        if cfg_idx is not None:
+            workload = 'BASELINE.json configs[%d]' % cfg_idx
+        elif args.scaling == 'strong' and global_batch == 256 and args.graph == 'all':
+            workload = 'BASELINE.json metric point (global batch 256 cut over %d GPUs, %d pairs per GPU)' % (world, per_gpu)
+        else:
+            workload = 'off-metric run (global batch %d on %d GPU%s, graph=%s)' % (global_batch, world, 's' if world > 1 else '', args.graph)
         out = {
             'metric': 'QA-pairs/sec (train fwd+bwd+Adam), global batch %d on %d GPU%s' % (global_batch, world, 's' if world > 1 else ''),
             'value': round(global_batch * args.steps / elapsed, 2),
@@ -351,7 +403,7 @@ def main():
                                        workload, args.graph, 'off' if args.eval else 'on'),
                        'global_batch': global_batch, 'per_gpu_batch': per_gpu,
                        'parallelism': 'dp%d' % world, 'question_attention': 'global-batch' if args.global_qc else 'local-batch',
-                       'launch_path': ('hipGraph replay, all-reduce %s' % args.graph_comm) if use_graph else 'eager launches',
+                       'launch_path': ('hipGraph replay, all-reduce %s' % graph_comm) if use_graph else 'eager launches',
                        'params_total': sum(p.numel() for m in (cd, sp) for p in m.parameters()), 'loss': round(loss_val, 5)},
             'roofline': roof,
             'phases_ms': phases if rank == 0 else None,
@@ -362,6 +414,8 @@ def main():
                             '(f64 100x100 label matrices); not part of value',
                     'value_if_serialised': round(global_batch / (elapsed / args.steps + h2d_ms * 1e-3), 2)},
         }
+        if comm is not None:
+            out['comm'] = comm
         if extra is not None:
             out['extra'] = extra
         if world == 1 and not args.no_cpu_baseline:

@@ -72,6 +72,46 @@ __global__ __launch_bounds__(256) void scale_finish_kernel(float* G, const float
     }
 }
 
+// ---- weight norm of MANY layers at once (the weights do not change inside a step: all norms in two launches at its start)
+constexpr int WN_MULTI_MAX = 32, WN_MULTI_NB = 32;
+struct WnMulti { const float* v[WN_MULTI_MAX]; const float* g[WN_MULTI_MAX]; long long n[WN_MULTI_MAX]; int count; };
+__global__ __launch_bounds__(256) void wn_multi_sumsq_kernel(WnMulti a, double* part /* [count][NB] */) {
+    const int t = blockIdx.y, j = blockIdx.x;
+    const float* v = a.v[t];
+    const long long n = a.n[t];
+    double s = 0.0;
+    for (long long i = (long long)j * 256 + threadIdx.x; i < n; i += (long long)WN_MULTI_NB * 256) { const double x = v[i]; s += x * x; }
+    s = wave_sum_f64(s);
+    __shared__ double w[4];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[t * WN_MULTI_NB + j] = (w[0] + w[1]) + (w[2] + w[3]);
+}
+__global__ __launch_bounds__(64) void wn_multi_finish_kernel(WnMulti a, const double* part, float* scales, float* norms) {
+    const int t = blockIdx.x, l = threadIdx.x;
+    double s = l < WN_MULTI_NB ? part[t * WN_MULTI_NB + l] : 0.0;
+    s = wave_sum_f64(s);
+    if (l == 0) {
+        const float nrm = (float)sqrt(s);
+        norms[t] = nrm;
+        scales[t] = a.g[t][0] / nrm;
+    }
+}
+// ---- fused backward of one weight-normed layer: G (unscaled wgrad, in place) -> dv = scale * G - (<G, v> g / ||v||^3) v;
+// dg = <G, v> / ||v||.  Every workgroup re-reads the <= 256 dot partials (fixed order: deterministic).
+__global__ __launch_bounds__(256) void wn_grad_finish_kernel(float* G, const float* __restrict__ v, const float* g, const float* norm,
+                                                             const float* scale, long long n, const double* part, int nparts, float* dg) {
+    const double tot = sum_partials_256(part, nparts);
+    __shared__ float bc[1];
+    if (threadIdx.x == 0) bc[0] = (float)tot;
+    __syncthreads();
+    const float dscale = bc[0];
+    const float nrm = norm[0], sc = scale[0];
+    const float coef = -dscale * g[0] / (nrm * nrm * nrm);
+    GS_LOOP(i, n) G[i] = sc * G[i] + coef * v[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) dg[0] = dscale / nrm;
+}
+
 // ------------------------------------------------------------------ reductions
 // column sums of [M][N]: one thread per column (coalesced rows), four independent accumulators so four row loads are
 // in flight per lane; the grid is cut along rows so that ~1024 workgroups stream concurrently; partial sums by atomics
@@ -672,6 +712,37 @@ extern "C" int ekaid_scale_dot(float* G, const float* w, const float* scale_dev,
     hipLaunchKernelGGL(scale_finish_kernel, grid1d(n), dim3(256), 0, ST, G, scale_dev, n, (const double*)(acc + RED_SLOT), (int)grid.x,
                        dot_out);
     return check_launch("scale_dot");
+}
+extern "C" int ekaid_wn_scale_multi(const float* const* v, const float* const* g, const long long* n, int count, float* scales,
+                                    float* norms, void* stream) {
+    if (count < 1 || count > WN_MULTI_MAX || !v || !g || !n || !scales || !norms) {
+        set_error("wn_scale_multi: 1 <= count <= %d layers, non-null arrays", WN_MULTI_MAX);
+        return EKAID_ERR_ARG;
+    }
+    double* acc = reduction_scratch();
+    if (!acc) { set_error("wn_scale_multi: scratch alloc failed"); return EKAID_ERR_LAUNCH; }
+    WnMulti a;
+    a.count = count;
+    for (int i = 0; i < WN_MULTI_MAX; ++i) {
+        a.v[i] = i < count ? v[i] : nullptr; a.g[i] = i < count ? g[i] : nullptr; a.n[i] = i < count ? n[i] : 0;
+        if (i < count && (!v[i] || !g[i] || n[i] < 1)) { set_error("wn_scale_multi: null / empty layer %d", i); return EKAID_ERR_ARG; }
+    }
+    hipLaunchKernelGGL(wn_multi_sumsq_kernel, dim3(WN_MULTI_NB, count), dim3(256), 0, ST, a, acc);
+    hipLaunchKernelGGL(wn_multi_finish_kernel, dim3(count), dim3(64), 0, ST, a, (const double*)acc, scales, norms);
+    return check_launch("wn_scale_multi");
+}
+extern "C" int ekaid_wn_grad_fused(float* G, const float* v, const float* g, const float* norm, const float* scale, long long n,
+                                   float* dg, void* stream) {
+    if (!G || !v || !g || !norm || !scale || !dg) { set_error("wn_grad_fused: null pointer"); return EKAID_ERR_ARG; }
+    if (n <= 0) return EKAID_OK;
+    double* acc = reduction_scratch();
+    if (!acc) { set_error("wn_grad_fused: scratch alloc failed"); return EKAID_ERR_LAUNCH; }
+    dim3 grid = grid1d(n, 8);
+    if (grid.x > 256) grid.x = 256;                 // <= 256 partials: every workgroup of the finish kernel re-sums them
+    hipLaunchKernelGGL(dot_kernel, grid, dim3(256), 0, ST, (const float*)G, v, n, acc + RED_SLOT);
+    hipLaunchKernelGGL(wn_grad_finish_kernel, grid1d(n), dim3(256), 0, ST, G, v, g, norm, scale, n, (const double*)(acc + RED_SLOT),
+                       (int)grid.x, dg);
+    return check_launch("wn_grad_fused");
 }
 // column sums: one row block -> plain store; several -> per-block partials in the per-device scratch + fixed-order finish
 static int colsum_impl(const float* x, int M, int N, int ldx, float* out, int accumulate, hipStream_t st) {

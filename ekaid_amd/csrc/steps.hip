@@ -282,46 +282,50 @@ struct StepAFwd {
     float* vp; float* dp; float* pw; float* pp; int ldpp;
 };
 __global__ __launch_bounds__(256) void spk_step_a_fwd_kernel(StepAFwd a) {
-    __shared__ float sh[STEP_MAXR];     // h_att row, then the POS vector v
+    // Two workgroups per batch row: blockIdx.y = 0 runs the cell + module-weight chain, 1 the POS chain (it depends on the
+    // h_lang product only, not on the cell), so the two dependent chains of a row overlap instead of adding up.
+    __shared__ float sh[STEP_MAXR];     // h_att row (y = 0) / the POS vector v (y = 1)
     __shared__ float sz[STEP_MAXP];
     __shared__ float red[12];
     const int b = blockIdx.x, tid = threadIdx.x, R = a.R, A = a.A, P = a.P;
-    // 1. LSTM cell
-    for (int j = tid; j < R; j += 256) {
-        float pre[4];
+    if (blockIdx.y == 0) {
+        // 1. LSTM cell
+        for (int j = tid; j < R; j += 256) {
+            float pre[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            pre[g] = a.gxa[(long long)b * 4 * R + g * R + j] + slab_sum_all(a.Satt, b, g * R + j) + a.bhh[g * R + j];
-        float ig, fg, gg, og, cn, hn;
-        const long long i = (long long)b * R + j;
-        lstm_point(pre[0], pre[1], pre[2], pre[3], a.c_prev[i], ig, fg, gg, og, cn, hn);
-        a.c_out[i] = cn;
-        a.h_out[i] = hn;
-        sh[j] = hn;
-        float* sp = a.save + (long long)b * 4 * R;
-        sp[j] = ig; sp[R + j] = fg; sp[2 * R + j] = gg; sp[3 * R + j] = og;
+            for (int g = 0; g < 4; ++g)
+                pre[g] = a.gxa[(long long)b * 4 * R + g * R + j] + slab_sum_all(a.Satt, b, g * R + j) + a.bhh[g * R + j];
+            float ig, fg, gg, og, cn, hn;
+            const long long i = (long long)b * R + j;
+            lstm_point(pre[0], pre[1], pre[2], pre[3], a.c_prev[i], ig, fg, gg, og, cn, hn);
+            a.c_out[i] = cn;
+            a.h_out[i] = hn;
+            sh[j] = hn;
+            float* sp = a.save + (long long)b * 4 * R;
+            sp[j] = ig; sp[R + j] = fg; sp[2 * R + j] = gg; sp[3 * R + j] = og;
+        }
+        __syncthreads();
+        // 2. module weights + attended feature
+        float z[3] = {0.f, 0.f, 0.f};
+        for (int k = tid; k < R; k += 256) {
+            const float x = sh[k];
+            z[0] += x * a.w_fc[k]; z[1] += x * a.w_fc[R + k]; z[2] += x * a.w_fc[2 * R + k];
+        }
+        block_sum<3>(z, red);
+        z[0] += a.b_fc[0]; z[1] += a.b_fc[1]; z[2] += a.b_fc[2];
+        const float mx = fmaxf(z[0], fmaxf(z[1], z[2]));
+        const float e0 = __expf(z[0] - mx), e1 = __expf(z[1] - mx), e2 = __expf(z[2] - mx);
+        const float inv = 1.f / (e0 + e1 + e2);
+        const float w0 = e0 * inv, w1 = e1 * inv, w2 = e2 * inv;
+        if (tid == 0) { a.mw[b * 3] = w0; a.mw[b * 3 + 1] = w1; a.mw[b * 3 + 2] = w2; }
+        for (int k = tid; k < A; k += 256) {
+            const long long i = (long long)b * A + k;
+            const float v = w0 * a.bef[i] + w1 * a.diff[i] + w2 * a.aft[i];
+            a.att[i] = v;
+            if (a.att2) a.att2[(long long)b * a.ld2 + k] = v;
+        }
+        return;
     }
-    __syncthreads();
-    // 2. module weights + attended feature
-    float z[3] = {0.f, 0.f, 0.f};
-    for (int k = tid; k < R; k += 256) {
-        const float x = sh[k];
-        z[0] += x * a.w_fc[k]; z[1] += x * a.w_fc[R + k]; z[2] += x * a.w_fc[2 * R + k];
-    }
-    block_sum<3>(z, red);
-    z[0] += a.b_fc[0]; z[1] += a.b_fc[1]; z[2] += a.b_fc[2];
-    const float mx = fmaxf(z[0], fmaxf(z[1], z[2]));
-    const float e0 = __expf(z[0] - mx), e1 = __expf(z[1] - mx), e2 = __expf(z[2] - mx);
-    const float inv = 1.f / (e0 + e1 + e2);
-    const float w0 = e0 * inv, w1 = e1 * inv, w2 = e2 * inv;
-    if (tid == 0) { a.mw[b * 3] = w0; a.mw[b * 3 + 1] = w1; a.mw[b * 3 + 2] = w2; }
-    for (int k = tid; k < A; k += 256) {
-        const long long i = (long long)b * A + k;
-        const float v = w0 * a.bef[i] + w1 * a.diff[i] + w2 * a.aft[i];
-        a.att[i] = v;
-        if (a.att2) a.att2[(long long)b * a.ld2 + k] = v;
-    }
-    __syncthreads();            // everybody is done reading h_att from sh
     // 3. POS chain
     for (int k = tid; k < R; k += 256) {
         float v = slab_sum(a.Spos, (long long)b * a.Spos.ld + k) + a.b1[k];
@@ -347,13 +351,16 @@ __global__ __launch_bounds__(256) void spk_step_a_fwd_kernel(StepAFwd a) {
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        float m2 = sz[0];
-        for (int j = 1; j < P; ++j) m2 = fmaxf(m2, sz[j]);
-        float sum = 0.f;
-        for (int j = 0; j < P; ++j) { const float e = __expf(sz[j] - m2); sz[j] = e; sum += e; }
-        const float iv = 1.f / sum;
-        for (int j = 0; j < P; ++j) { sz[j] *= iv; a.pw[(long long)b * P + j] = sz[j]; }
+    if (tid < 64) {                      // softmax over the P <= 64 classes: one lane per class
+        const float x = tid < P ? sz[tid] : -INFINITY;
+        const float m2 = wave_max(x);
+        const float e = tid < P ? __expf(x - m2) : 0.f;
+        const float sum = wave_sum(e);
+        if (tid < P) {
+            const float w = e / sum;
+            sz[tid] = w;
+            a.pw[(long long)b * P + tid] = w;
+        }
     }
     __syncthreads();
     for (int k = tid; k < R; k += 256) {
@@ -377,39 +384,43 @@ struct StepABwd {
     float* dpp_out; int lddpp; float* dwp_out; float* dx_out; int lddx;
 };
 __global__ __launch_bounds__(256) void spk_step_a_bwd_kernel(StepABwd a) {
+    // two workgroups per batch row, as in the forward kernel: blockIdx.y = 0 module mix + cell, 1 the POS chain
     __shared__ float sd[STEP_MAXR];
     __shared__ float sg[STEP_MAXP];
     __shared__ float sp[256];
     __shared__ float red[12];
     const int b = blockIdx.x, tid = threadIdx.x, R = a.R, A = a.A, P = a.P;
-    // 1. module mix
-    const float w0 = a.mw[b * 3], w1 = a.mw[b * 3 + 1], w2 = a.mw[b * 3 + 2];
-    float s[3] = {0.f, 0.f, 0.f};
-    for (int k = tid; k < A; k += 256) {
-        const long long i = (long long)b * A + k;
-        const float d = slab_sum(a.Sdpa, (long long)b * a.Sdpa.ld + R + k) + a.d_gated[i] * a.gate[i];
-        s[0] += d * a.bef[i]; s[1] += d * a.diff[i]; s[2] += d * a.aft[i];
-        a.d_bef[i] += w0 * d; a.d_diff[i] += w1 * d; a.d_aft[i] += w2 * d;
-    }
-    block_sum<3>(s, red);
-    const float dot = w0 * s[0] + w1 * s[1] + w2 * s[2];
-    const float dz0 = w0 * (s[0] - dot), dz1 = w1 * (s[1] - dot), dz2 = w2 * (s[2] - dot);
-    if (tid == 0) { a.dz_fc[b * 3] = dz0; a.dz_fc[b * 3 + 1] = dz1; a.dz_fc[b * 3 + 2] = dz2; }
-    // 2. att-LSTM cell
-    for (int j = tid; j < R; j += 256) {
-        const long long i = (long long)b * R + j;
-        const float dh = (a.Sdha.n ? slab_sum(a.Sdha, (long long)b * a.Sdha.ld + j) : 0.f) +
-                         dz0 * a.w_fc[j] + dz1 * a.w_fc[R + j] + dz2 * a.w_fc[2 * R + j];
-        const float* sv = a.save + (long long)b * 4 * R;
-        const float ig = sv[j], fg = sv[R + j], gg = sv[2 * R + j], og = sv[3 * R + j];
-        const float tc = tanhf(a.c_cur[i]);
-        const float dct = a.dc_in[i] + dh * og * (1.f - tc * tc);
-        float* o = a.dgates + (long long)b * a.lddg;
-        o[j] = dct * gg * ig * (1.f - ig);
-        o[R + j] = dct * a.c_prev[i] * fg * (1.f - fg);
-        o[2 * R + j] = dct * ig * (1.f - gg * gg);
-        o[3 * R + j] = dh * tc * og * (1.f - og);
-        a.dc_out[i] = dct * fg;
+    if (blockIdx.y == 0) {
+        // 1. module mix
+        const float w0 = a.mw[b * 3], w1 = a.mw[b * 3 + 1], w2 = a.mw[b * 3 + 2];
+        float s[3] = {0.f, 0.f, 0.f};
+        for (int k = tid; k < A; k += 256) {
+            const long long i = (long long)b * A + k;
+            const float d = slab_sum(a.Sdpa, (long long)b * a.Sdpa.ld + R + k) + a.d_gated[i] * a.gate[i];
+            s[0] += d * a.bef[i]; s[1] += d * a.diff[i]; s[2] += d * a.aft[i];
+            a.d_bef[i] += w0 * d; a.d_diff[i] += w1 * d; a.d_aft[i] += w2 * d;
+        }
+        block_sum<3>(s, red);
+        const float dot = w0 * s[0] + w1 * s[1] + w2 * s[2];
+        const float dz0 = w0 * (s[0] - dot), dz1 = w1 * (s[1] - dot), dz2 = w2 * (s[2] - dot);
+        if (tid == 0) { a.dz_fc[b * 3] = dz0; a.dz_fc[b * 3 + 1] = dz1; a.dz_fc[b * 3 + 2] = dz2; }
+        // 2. att-LSTM cell
+        for (int j = tid; j < R; j += 256) {
+            const long long i = (long long)b * R + j;
+            const float dh = (a.Sdha.n ? slab_sum(a.Sdha, (long long)b * a.Sdha.ld + j) : 0.f) +
+                             dz0 * a.w_fc[j] + dz1 * a.w_fc[R + j] + dz2 * a.w_fc[2 * R + j];
+            const float* sv = a.save + (long long)b * 4 * R;
+            const float ig = sv[j], fg = sv[R + j], gg = sv[2 * R + j], og = sv[3 * R + j];
+            const float tc = tanhf(a.c_cur[i]);
+            const float dct = a.dc_in[i] + dh * og * (1.f - tc * tc);
+            float* o = a.dgates + (long long)b * a.lddg;
+            o[j] = dct * gg * ig * (1.f - ig);
+            o[R + j] = dct * a.c_prev[i] * fg * (1.f - fg);
+            o[2 * R + j] = dct * ig * (1.f - gg * gg);
+            o[3 * R + j] = dh * tc * og * (1.f - og);
+            a.dc_out[i] = dct * fg;
+        }
+        return;
     }
     // 3. POS chain
     for (int k = tid; k < R; k += 256) {
@@ -433,15 +444,16 @@ __global__ __launch_bounds__(256) void spk_step_a_bwd_kernel(StepABwd a) {
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        float dt = 0.f;
-        for (int j = 0; j < P; ++j) dt += a.pw[(long long)b * P + j] * sg[j];
-        for (int j = 0; j < P; ++j) {
-            float g = a.pw[(long long)b * P + j] * (sg[j] - dt);
-            if (a.dhead) g += a.dhead[(long long)b * P + j];
-            g *= dropout_scale(a.seed_d, (uint64_t)b * P + j, a.p5, a.inv5);
-            sg[j] = g;
-            a.dwp_out[(long long)b * P + j] = g;
+    if (tid < 64) {                      // softmax backward over the P <= 64 classes: one lane per class
+        const float pwj = tid < P ? a.pw[(long long)b * P + tid] : 0.f;
+        const float sgj = tid < P ? sg[tid] : 0.f;
+        const float dt = wave_sum(pwj * sgj);
+        if (tid < P) {
+            float g = pwj * (sgj - dt);
+            if (a.dhead) g += a.dhead[(long long)b * P + tid];
+            g *= dropout_scale(a.seed_d, (uint64_t)b * P + tid, a.p5, a.inv5);
+            sg[tid] = g;
+            a.dwp_out[(long long)b * P + tid] = g;
         }
     }
     __syncthreads();
@@ -566,7 +578,7 @@ extern "C" int ekaid_spk_step_a_fwd(const ekaid_spk_step_a_fwd_t* q, void* strea
         set_error("spk_step_a_fwd: null pointer in the descriptor");
         return EKAID_ERR_ARG;
     }
-    hipLaunchKernelGGL(spk_step_a_fwd_kernel, dim3(q->B), dim3(256), 0, ST, a);
+    hipLaunchKernelGGL(spk_step_a_fwd_kernel, dim3(q->B, 2), dim3(256), 0, ST, a);
     return check_launch("spk_step_a_fwd");
 }
 
@@ -591,6 +603,6 @@ extern "C" int ekaid_spk_step_a_bwd(const ekaid_spk_step_a_bwd_t* q, void* strea
         set_error("spk_step_a_bwd: null pointer in the descriptor");
         return EKAID_ERR_ARG;
     }
-    hipLaunchKernelGGL(spk_step_a_bwd_kernel, dim3(q->B), dim3(256), 0, ST, a);
+    hipLaunchKernelGGL(spk_step_a_bwd_kernel, dim3(q->B, 2), dim3(256), 0, ST, a);
     return check_launch("spk_step_a_bwd");
 }

@@ -69,6 +69,7 @@ class TrainStep:
         self._pool = None
         self._epoch = None
         self.marks = None
+        self.calls_after_backward = None
 
     def close(self):
         """Drop the captured graphs and detach the dropout epoch word from the library.  Must run before the object goes
@@ -118,6 +119,7 @@ class TrainStep:
         self.opt.zero_grad()
         loss, sp_loss, _, _ = forward_loss(self.cfg, self.cd, self.sp, static, T, self.graph, self.setting, denom)
         loss.backward()
+        self.calls_after_backward = hip.calls_issued()      # (tests: the first bucket's all-reduce was enqueued before this)
         if self.comm == 'captured' or not self.opt.comm_active():
             self.opt.step()
         return loss, sp_loss

@@ -99,6 +99,8 @@ SIGNATURES = {
     'ekaid_wn_scale_fwd': [P, P, L, P, P, P],
     'ekaid_wn_scale_bwd': [P, P, P, P, L, P, I, P, P],
     'ekaid_scale_dot': [P, P, P, L, P, P],
+    'ekaid_wn_scale_multi': [P, P, P, I, P, P, P],
+    'ekaid_wn_grad_fused': [P, P, P, P, P, L, P, P],
     'ekaid_colsum': [P, I, I, I, P, P],
     'ekaid_colsum_acc': [P, I, I, I, P, P],
     'ekaid_sum_n': [P, I, P, L, P],

@@ -133,6 +133,33 @@ class ChangeDetector(nn.Module):
         M = min(self.nongt_dim, bb.shape[1])
         return ops.geom_embed(bb, M, self.pos_emb_dim, self._dim_mat)
 
+    def _wn_layers(self, setting, graph):
+        """(weight_v, weight_g) of the weight-normed layers a forward call with this setting / graph runs: the encoders
+        selected by ``graph``, minus the dead direction (quirk Q-B) unless it is computed for its attention maps."""
+        from .fc import WNLinear
+        roots = [('q_att', self.q_att)]
+        if setting == 'mode2':
+            if graph in ('semantic', 'all') and hasattr(self, 'semantic_relation'):
+                roots.append(('semantic_relation', self.semantic_relation))
+            if graph in ('spatial', 'all', 'i+s') and hasattr(self, 'spatial_relation'):
+                roots.append(('spatial_relation', self.spatial_relation))
+            if graph in ('implicit', 'all', 'i+s') and hasattr(self, 'imp_relation'):
+                roots.append(('imp_relation', self.imp_relation))
+        out = []
+        for _, root in roots:
+            gats = [m for m in root.modules() if hasattr(m, 'compute_dead_directions')]
+            dead_ok = any(g.compute_dead_directions for g in gats)
+            last = max([g.dir_num for g in gats], default=1) - 1
+            for name, m in root.named_modules():
+                if not isinstance(m, WNLinear):
+                    continue
+                if 'neighbor_net.' in name and not dead_ok and ('neighbor_net.%d.' % last) not in name:
+                    continue
+                if 'pair_pos_fc1' in name and not hasattr(root, 'implicit_relation'):
+                    continue
+                out.append((m.weight_v, m.weight_g))
+        return out
+
     def encode_question(self, question):
         return self.q_att(self.q_emb.forward_all(self.w_emb(question)))
 
@@ -146,6 +173,10 @@ class ChangeDetector(nn.Module):
             d_bb, q_bb = torch.ones_like(d_bb), torch.ones_like(q_bb)
         B, N, C = input_1.size()
         A = self.att_dim
+        # ||v|| of every weight-normed layer this call will run, in two launches (the layers pick the values up)
+        wn = self._wn_layers(setting, graph)
+        if wn and input_1.is_cuda:
+            ops.wn_prepare(wn)
 
         # both images through the shared ROI projection, stacked: rows [0, B*N) = main, [B*N, 2*B*N) = reference
         x = ops.linear_rowstack((input_1, input_2), self.img.weight, self.img.bias).view(2 * B, N, A)
@@ -201,6 +232,7 @@ class ChangeDetector(nn.Module):
         attended_2 = ops.weighted_pool(att_a, aft_p)
         input_attended = ops.sub(attended_2, attended_1)
         pred = self.fc1(input_attended)
+        ops.wn_release()
         return pred, att_b.view(B, 1, N), att_a.view(B, 1, N), attended_1, attended_2, input_attended
 
 

@@ -318,6 +318,7 @@ class LinearFn(Function):
         """``drops``: None, or one dropout probability per input (0 = none): the FCNet's input dropout (fc.py:36-37)
         applied here so that its backward is the epilogue of the dgrad GEMM instead of a pass of its own."""
         require_cuda(W, *xs)
+        ctx.wn = None
         N, Ktot = W.shape
         W = _c(W)
         xs2, lds = zip(*[_rows2d(x) for x in xs])
@@ -393,11 +394,79 @@ class LinearFn(Function):
                 K = x.shape[1]
                 gemm(dz, x, dW, N, K, M, N, ld, Ktot, 1, 0, c_off=off)
                 off += K
-            if ctx.has_scale:
+            if ctx.has_scale and ctx.wn is not None:
+                # weight-normed layer (WNLinearFn): the unscaled wgrad becomes dv in place and dg comes out of the same two
+                # launches (was: dot + scale, then a third pass for the norm's own backward)
+                g, norm = ctx.wn
+                dg = grad_out(g)
+                check(L.ekaid_wn_grad_fused(ptr(dW), ptr(W), ptr(g), ptr(norm), ptr(scale), dW.numel(), ptr(dg), stream()),
+                      'wn_grad_fused')
+                dscale = dg.view(g.shape)
+            elif ctx.has_scale:
                 dscale = torch.empty((), device=W.device, dtype=torch.float32)
                 check(L.ekaid_scale_dot(ptr(dW), ptr(W), ptr(scale), dW.numel(), ptr(dscale), stream()),
                       'scale_dot')
         return (dW, db, dscale, None, None) + tuple(dxs)
+
+
+# --------------------------------------------------------------------------- #
+# weight norm (dim=None): all layers of a module tree at once
+# --------------------------------------------------------------------------- #
+_wn_cache = {}
+
+
+def wn_prepare(layers):
+    """scale = g / ||v|| and ||v|| of every (v, g) in ``layers`` (<= 32 per call) in two launches; the following
+    ``wn_linear`` calls on these weights pick their values up (each entry is used once).  Call ``wn_release`` when the
+    forward pass that owns the layers is over: the values are only valid until the next optimizer step."""
+    _wn_cache.clear()
+    L = hip.lib()
+    for i0 in range(0, len(layers), 32):
+        chunk = layers[i0:i0 + 32]
+        n = len(chunk)
+        dev = chunk[0][0].device
+        scales = torch.empty(n, device=dev, dtype=torch.float32)
+        norms = torch.empty(n, device=dev, dtype=torch.float32)
+        vs = (ctypes.c_void_p * n)(*[v.data_ptr() for v, _ in chunk])
+        gs = (ctypes.c_void_p * n)(*[g.data_ptr() for _, g in chunk])
+        ns = (ctypes.c_longlong * n)(*[v.numel() for v, _ in chunk])
+        check(L.ekaid_wn_scale_multi(vs, gs, ns, n, ptr(scales), ptr(norms), stream()), 'wn_scale_multi')
+        for i, (v, _) in enumerate(chunk):
+            _wn_cache[v.data_ptr()] = (scales[i], norms[i])
+
+
+def wn_release():
+    _wn_cache.clear()
+
+
+def wn_scale(v, g):
+    """(scale, ||v||) device scalars of one weight-normed layer: prepared values (``wn_prepare``) or two launches."""
+    ent = _wn_cache.pop(v.data_ptr(), None) if v.is_contiguous() else None
+    if ent is not None:
+        return ent
+    v = _c(v)
+    scale = torch.empty((), device=v.device, dtype=torch.float32)
+    norm = torch.empty((), device=v.device, dtype=torch.float32)
+    check(hip.lib().ekaid_wn_scale_fwd(ptr(v), ptr(g), v.numel(), ptr(scale), ptr(norm), stream()), 'wn_scale_fwd')
+    return scale, norm
+
+
+class WNLinearFn(Function):
+    """weight_norm(Linear, dim=None) as ONE node: y = act((g / ||v||) x v^T + b); backward through the norm fused into the
+    weight-gradient epilogue.  Argument positions match LinearFn (v, b, g in place of W, b, scale).  ref: fc.py:26-33."""
+
+    @staticmethod
+    def forward(ctx, v, b, g, act, drops, *xs):
+        require_cuda(v, g)
+        with torch.no_grad():
+            scale, norm = wn_scale(v.detach(), g.detach())
+        out = LinearFn.forward(ctx, v, b, scale, act, drops, *xs)
+        ctx.wn = (g.detach(), norm)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return LinearFn.backward(ctx, dy)
 
 
 def linear(xs, W, b=None, scale=None, act=ACT_NONE, drops=None):
@@ -494,7 +563,11 @@ class WNScaleFn(Function):
 
 
 def wn_linear(xs, v, g, b=None, act=ACT_NONE, drops=None):
-    return linear(xs, v, b, WNScaleFn.apply(v, g), act, drops)
+    if isinstance(xs, torch.Tensor):
+        xs = (xs,)
+    if drops is not None and not any(d > 0.0 for d in drops):
+        drops = None
+    return WNLinearFn.apply(v, b, g, act, drops, *xs)
 
 
 # --------------------------------------------------------------------------- #

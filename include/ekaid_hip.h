@@ -138,6 +138,16 @@ int ekaid_wn_scale_fwd(const float* v, const float* g, long long n, float* scale
 int ekaid_wn_scale_bwd(const float* v, const float* g, const float* norm, const float* dscale, long long n,
                        float* dv, int accumulate_dv, float* dg, void* stream);
 int ekaid_scale_dot(float* G, const float* w, const float* scale_dev, long long n, float* dot_out, void* stream);
+/* The same for a whole model at once and fused:
+ * wn_scale_multi: scales[i] = g_i / ||v_i||, norms[i] = ||v_i|| for `count` <= 32 layers in two launches (v, g, n are HOST
+ *                 arrays of device pointers / element counts) -- the weights do not change inside a training step, so all
+ *                 norms are taken once at its start instead of two launches per layer.
+ * wn_grad_fused:  backward of one layer in two launches: G holds the UNSCALED weight gradient dy^T x on entry and
+ *                 dv = scale * G - (<G, v> g / ||v||^3) v on exit; dg[0] = <G, v> / ||v||   (= scale_dot + wn_scale_bwd). */
+int ekaid_wn_scale_multi(const float* const* v, const float* const* g, const long long* n, int count, float* scales, float* norms,
+                         void* stream);
+int ekaid_wn_grad_fused(float* G, const float* v, const float* g, const float* norm, const float* scale, long long n, float* dg,
+                        void* stream);
 
 /* column sum of an [M][N] matrix (bias gradient), out[N]; row-block partials summed in a fixed order (deterministic) */
 int ekaid_colsum(const float* x, int M, int N, int ldx, float* out, void* stream);

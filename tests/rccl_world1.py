@@ -32,10 +32,13 @@ def main(out_path):
         return real(*a, **k)
     dist.all_reduce = counted
 
+    order = {}
+
     def run(force, use_graph, comm):
         cd, sp = build_models(cfg, 147, 148, 'cuda', train=True)
         opt = FlatAdam([cd, sp], lr=1e-3, bucket_mb=8.0)
         opt.force_comm = force
+        opt.launch_log = []
         ts = TrainStep(cfg, cd, sp, opt, use_graph=use_graph, comm=comm)
         ops.manual_seed(99)
         try:
@@ -50,6 +53,10 @@ def main(out_path):
                     ts._body(b, 5, None)
         finally:
             ts.close()
+        # when was each bucket's all-reduce enqueued, counted in C-ABI calls, vs the end of backward (last step / the capture)
+        nb = len(opt.buckets)
+        order[(force, use_graph, comm)] = {'launches': opt.launch_log[-nb:] if force else [], 'after_backward': ts.calls_after_backward,
+                                           'n_logged': len(opt.launch_log)}
         # flat live parameters and Adam first moments (same layout in every run: the order autograd finishes gradients)
         return opt.pflat.detach().double().clone(), len(opt.buckets), opt.m.detach().double().clone()
     base, _, m = run(False, False, 'captured')
@@ -62,7 +69,9 @@ def main(out_path):
     travel = 3 * 1e-3
     sig = torch.ones(1)
     json.dump({'buckets': nb, 'collectives': n_eager, 'noise': rms(base - base2), 'travel': travel, 'signal_fraction': float(sig.double().mean()),
-               'delta_eager': rms(base - eager), 'delta_graph': max(rms(base - graph), rms(base - graph2))}, open(out_path, 'w'))
+               'delta_eager': rms(base - eager), 'delta_graph': max(rms(base - graph), rms(base - graph2)),
+               'order_eager': order[(True, False, 'captured')], 'order_captured': order[(True, True, 'captured')],
+               'order_after_replay': order[(True, True, 'eager')]}, open(out_path, 'w'))
     dist.destroy_process_group()
 
 

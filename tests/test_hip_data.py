@@ -211,3 +211,15 @@ def test_rccl_path_on_one_gpu(tmp_path):
     assert out['buckets'] > 1 and out['collectives'] > 0
     # bit-reproducible path + an all-reduce over one rank (identity) + 1/world = 1: every variant ends at the same bits
     assert out['noise'] == 0.0 and out['delta_eager'] == 0.0 and out['delta_graph'] == 0.0, out
+    # overlap, in BOTH default multi-GPU modes (hook-driven eager launches; collectives captured inside the hipGraph): the
+    # first gradient bucket's all-reduce is enqueued while backward still has kernels to issue, the buckets go out in order,
+    # and only the LAST bucket can land after backward's final kernel.  (comm='eager' after a replay is the serialised
+    # form: there every collective comes after backward.)
+    for mode in ('order_eager', 'order_captured'):
+        o = out[mode]
+        calls = [c for _, c in o['launches']]
+        assert [b for b, _ in o['launches']] == list(range(out['buckets'])), o
+        assert calls == sorted(calls) and calls[0] < o['after_backward'], (mode, o)
+        assert sum(c < o['after_backward'] for c in calls) >= out['buckets'] - 1, (mode, o)
+    assert out['order_captured']['n_logged'] == out['buckets'], 'warm-up iterations of a capture must not communicate'
+    assert all(c >= out['order_after_replay']['after_backward'] for _, c in out['order_after_replay']['launches'])

@@ -84,3 +84,88 @@ def test_two_ranks_match_one_process(tmp_path):
     noisy = set(negligible_grad_names(g1['grad_names'], g1['grad_rows']))
     worst = max(abs(a['norms'][k] - b['norms'][k]) / max(a['norms'][k], 1e-9) for k in a['norms'] if k not in noisy)
     assert worst < 1e-5, worst
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# --hip_graph under data parallelism with RAGGED answers: the ranks meet new (shape, decode steps) keys at different
+# iterations, so one rank captures (warm-up iterations included) while the other just replays.  The collective sequence must
+# stay aligned: capture warm-ups run without collectives (engine.TrainStep._capture).
+RAGGED = [  # per iteration: answer tokens kept by the 4 samples of the global batch (rank 0: samples 0/1, rank 1: samples 2/3)
+    (4, 2, 3, 2),   # T = 4 | 3
+    (3, 2, 4, 2),   # T = 3 | 4   (each rank meets the other's key: capture on both, one iteration late)
+    (4, 3, 2, 2),   # T = 4 | 2   (rank 0 replays, rank 1 captures)
+    (2, 2, 4, 3),   # T = 2 | 4   (rank 0 captures, rank 1 replays)
+    (4, 2, 3, 2),   # all replays
+]
+
+
+def _run_graph(rank, world, port, out_path, use_graph):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    from common import SMALL, small_models
+    from ekaid_amd.dp import FlatAdam, enable_global_question_attention
+    from ekaid_amd.engine import TrainStep
+    from ekaid_amd.models.dynamic_speaker_change_pos import DynamicSpeaker
+    from ekaid_amd.synthetic import make_batch, slice_batch
+    cfg, cd, sp = small_models('all', device='cuda')
+    if world > 1:
+        enable_global_question_attention(cd)
+    opt = FlatAdam([cd, sp], lr=1e-3, bucket_mb=0.5)
+    ts = TrainStep(cfg, cd, sp, opt, use_graph=use_graph, comm='eager')
+    per = 4 // world
+    losses, keys = [], []
+    try:
+        for it, keep in enumerate(RAGGED):
+            full = make_batch(**dict(SMALL, B=4, seed=100 + it))
+            for b, n in enumerate(keep):
+                full['labels'][b, n:] = 0
+                full['masks'][b] = 0
+                full['masks'][b, :n + 1] = 1
+            msum = float(full['masks'][:, 1:].sum())
+            batch = slice_batch(full, rank * per, (rank + 1) * per)
+            dev_batch = {k: v.cuda() for k, v in batch.items()}
+            T = DynamicSpeaker.count_steps(batch['labels'], cfg.model.speaker.seq_length)
+            keys.append(T)
+            denom = torch.tensor([msum / world], dtype=torch.float32, device='cuda') if world > 1 else None
+            loss, _ = ts(dev_batch, T, denom)
+            losses.append(float(loss.detach()))
+    finally:
+        n_graphs = len(ts._graphs)
+        ts.close()
+    if world > 1:
+        t = torch.tensor(losses, device='cuda')
+        dist.all_reduce(t)
+        losses = (t / world).tolist()
+    if rank == 0:
+        norms = {('cd.' + k): p.detach().cpu().double().norm().item() for k, p in cd.named_parameters()}
+        norms.update({('sp.' + k): p.detach().cpu().double().norm().item() for k, p in sp.named_parameters()})
+        json.dump({'losses': losses, 'norms': norms, 'keys': keys, 'graphs': n_graphs, 'steps': opt.step_count}, open(out_path, 'w'))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_replaying_hip_graphs_with_ragged_answers_match_one_process(tmp_path):
+    ctx = mp.get_context('spawn')
+    single = str(tmp_path / 'single.json')
+    p = ctx.Process(target=_run_graph, args=(0, 1, 29741, single, False))
+    p.start(); p.join(600)
+    assert p.exitcode == 0
+    multi = str(tmp_path / 'multi.json')
+    procs = [ctx.Process(target=_run_graph, args=(r, 2, 29743, multi, True)) for r in range(2)]
+    for q in procs:
+        q.start()
+    for q in procs:
+        q.join(600)                         # a desynchronised collective sequence shows up here as a hang / non-zero exit
+        assert q.exitcode == 0
+    a, b = json.load(open(single)), json.load(open(multi))
+    assert b['graphs'] == 3 and b['steps'] == a['steps'] == len(RAGGED), (b['graphs'], b['steps'])
+    assert np.allclose(a['losses'], b['losses'], rtol=5e-5), (a['losses'], b['losses'])
+    from golden_util import load_golden, negligible_grad_names
+    g1 = load_golden('f1_all')
+    noisy = set(negligible_grad_names(g1['grad_names'], g1['grad_rows']))
+    worst = max(abs(a['norms'][k] - b['norms'][k]) / max(a['norms'][k], 1e-9) for k in a['norms'] if k not in noisy)
+    assert worst < 2e-5, worst

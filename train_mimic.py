@@ -14,7 +14,9 @@ Differences from the reference script (ref: train_mimic.py:1-386), all deliberat
     and each rank's language-model loss is divided by (global mask sum / world) so that the averaged gradient is the
     reference's global-batch gradient also for ragged answers (utils/utils.py:213-214);
   * batches come through ``DevicePrefetcher``: int8 adjacency, pinned double buffers, copies on a side stream;
-  * ``--hip_graph`` replays the whole iteration from a captured hipGraph (ekaid_amd/engine.py);
+  * ``--hip_graph`` replays the whole iteration from a captured hipGraph (ekaid_amd/engine.py), on several GPUs with the
+    bucketed all-reduce captured inside it (overlapped with backward); ragged answers give every rank its own sequence of
+    (shape, decode steps) graphs -- the collectives inside them line up because every graph issues the same buckets;
   * no ``.item()`` synchronisation per iteration: losses are read only every ``log_interval`` iterations;
   * the in-loop evaluation greedy-decodes the validation split and scores exact-match accuracy (evaluate_score.py:216-251);
     BLEU/METEOR/CIDEr need pycocoevalcap + Java (absent here): the COCO-format json the reference's ``evaluation.py``
@@ -74,6 +76,9 @@ def parse(argv=None):
     p.add_argument('--answer_steps', type=int, default=16)
     p.add_argument('--global_qc', action='store_true', help='global-batch semantics for the question attention (Q-C)')
     p.add_argument('--hip_graph', action='store_true', help='replay each iteration from a captured hipGraph')
+    p.add_argument('--graph_comm', choices=['auto', 'captured', 'eager'], default='auto',
+                   help='with --hip_graph on several GPUs: gradient all-reduce captured inside the graph and overlapped with '
+                        'backward (captured; auto) or issued after each replay (eager)')
     p.add_argument('--eval_batches', type=int, default=None, help='cap on validation batches per in-loop evaluation')
     p.add_argument('--exp_dir', default=None)
     p.add_argument('--quiet', action='store_true')
@@ -200,7 +205,8 @@ def main(argv=None):
     if o.type != 'adam':
         raise SystemExit('only the configured optimiser (adam, utils.py:96-99) is implemented')
     optimizer = FlatAdam([change_detector, speaker], lr=o.lr, betas=(o.alpha, o.beta), eps=o.epsilon)
-    step = TrainStep(cfg, change_detector, speaker, optimizer, args.graph, args.setting, use_graph=args.hip_graph)
+    graph_comm = args.graph_comm if args.graph_comm != 'auto' else ('captured' if world > 1 else 'eager')
+    step = TrainStep(cfg, change_detector, speaker, optimizer, args.graph, args.setting, use_graph=args.hip_graph, comm=graph_comm)
     shape = dict(N=args.nodes, D=D, Lq=20, T=args.answer_steps, seq_length=cfg.model.speaker.seq_length, V=V)
 
     def named():
