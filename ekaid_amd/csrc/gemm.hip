@@ -1072,7 +1072,10 @@ static int plan_splitk(int tiles, int K, int batch, long long MN, int BK, bool b
     // (128x128 tiles are different: 256 tiles leave two of the three workgroup slots of every CU empty for the whole K
     // range -- wgrad 1024x4096x18432: 156-162 TF unsplit, 199 TF as 3 x 256 workgroups + reduce)
     if (tiles >= 256 && gemm_mode() == 1 && !big_tiles) return 1;
-    int s = (target + tiles - 1) / tiles;
+    // as many slabs as still fit ONE wave of resident workgroups: rounding up (144 tiles -> 6 slabs = 864 workgroups on 768
+    // slots) left a second, nearly empty wave that doubled the time of the 2304-row products (61 -> 44 us at 32 pairs / GPU)
+    int s = target / tiles;
+    if (s < 1) s = 1;
     const int ksteps = cdiv(K, BK);
     static const char* mk = getenv("EKAID_GEMM_MIN_KSTEPS");     // tuning aid
     const int min_ksteps = mk ? atoi(mk) : (128 / BK);     // a split shorter than this is all prologue/epilogue + slab traffic
