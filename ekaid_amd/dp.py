@@ -34,8 +34,20 @@ import torch.distributed as dist
 from . import hip
 
 
+_comm_suspended = False      # process-wide: no collective of this module runs while set (capture warm-ups, engine.py)
+
+
 class GradBuckets:
     """Device-agnostic flat-gradient bookkeeping + bucketed all-reduce (tested on CPU with gloo)."""
+
+    @property
+    def comm_suspended(self):
+        return _comm_suspended
+
+    @comm_suspended.setter
+    def comm_suspended(self, value):
+        global _comm_suspended
+        _comm_suspended = bool(value)
 
     def __init__(self, params, process_group=None, bucket_mb=32.0, overlap=True):
         self.params = [p for p in params if p.requires_grad]
@@ -44,7 +56,6 @@ class GradBuckets:
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.overlap = overlap
         self.force_comm = False       # issue the collectives even at world size 1 (exercises the RCCL path on one GPU)
-        self.comm_suspended = False   # True: no collectives at all (warm-up iterations of a hipGraph capture, engine.py)
         self.launch_log = None        # list -> (bucket, C-ABI calls issued so far) per all-reduce launch (tests, bench)
         self.built = False
         self.order = []             # parameters in first-backward completion order
@@ -334,15 +345,20 @@ class _AllGatherRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, group):
         world = dist.get_world_size(group)
+        ctx.group, ctx.rows, ctx.live = group, x.shape[0], not _comm_suspended
+        if not ctx.live:
+            # warm-up iteration of a hipGraph capture (its results are discarded): same shapes, no collective -- the peers
+            # may be replaying a graph they already hold and would not answer
+            return torch.cat([x] * world, 0)
         parts = [torch.empty_like(x) for _ in range(world)]
         dist.all_gather(parts, x.contiguous(), group=group)
-        ctx.group, ctx.rows = group, x.shape[0]
         return torch.cat(parts, 0)
 
     @staticmethod
     def backward(ctx, d):
         d = d.contiguous()
-        dist.all_reduce(d, op=dist.ReduceOp.SUM, group=ctx.group)
+        if ctx.live:
+            dist.all_reduce(d, op=dist.ReduceOp.SUM, group=ctx.group)
         r = dist.get_rank(ctx.group)
         return d[r * ctx.rows:(r + 1) * ctx.rows].clone(), None
 
