@@ -63,6 +63,8 @@ def parse():
     ap.add_argument('--eval', action='store_true', help='dropout off (parity mode); default is train mode')
     ap.add_argument('--backend', default='nccl', help='collective backend (nccl = RCCL; gloo only for single-GPU plumbing tests)')
     ap.add_argument('--gemm-shapes', action='store_true', help='print the per-shape GEMM time table to stderr')
+    ap.add_argument('--real-only', action='store_true', help='run only the real-data loop (extra.real_b64) and print its JSON: profiling target')
+    ap.add_argument('--no-real', action='store_true', help='skip the real-data loop of the extra block')
     return ap.parse_args()
 
 
@@ -157,6 +159,39 @@ def cpu_baseline(cfg, cd, sp, batch_size, graph, budget_s=25.0):
                           torch.__version__, cores, os.cpu_count() or 0, batch_size, iters, batch_size)}
 
 
+def real_data_loop(graph, iters=120, time_from=80):
+    """BASELINE.json configs[4] on one GPU: train_mimic.py itself (HDF5 reader -> RCCDataLoader -> DevicePrefetcher -> one
+    hipGraph per (shape, decode steps)) on a generated dataset of the REAL shapes -- 52 regions per image, 1024-d ROI features,
+    the yaml's batch 64, ragged answers.  Answer lengths of the generator: uniform 2..40 tokens, every 50th pair 90 tokens (the
+    maximum), so most batches decode 90 steps and the rest 38-40: on real data the decoder, not the detector, sets the step."""
+    import shutil
+    import tempfile
+    import train_mimic
+    from ekaid_amd.datasets.generate import make_dataset
+    d = tempfile.mkdtemp(prefix='ekaid_real_')
+    try:
+        t0 = time.perf_counter()
+        make_dataset(d, n_images=512, n_pairs=3200, nodes=52, D=1024)
+        gen_s = time.perf_counter() - t0
+        out = train_mimic.main(['--data_dir', d, '--graph', graph, '--hip_graph', '--max_iter', str(iters), '--time_from', str(time_from),
+                                '--snapshot_interval', '1000000', '--no_final_snapshot', '--quiet', '--exp_dir', os.path.join(d, 'exp')])
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    tm = out['timing'] or {}
+    step_ms = tm.get('ms_per_iteration', 0.0)
+    return {'workload': 'BASELINE.json configs[4] on one GPU: train_mimic.py --hip_graph on a generated dataset in the reference layout '
+                        '(52 regions x 2 images, 1024-d ROI features, batch 64, answers uniform 2..40 tokens, every 50th pair 90 tokens), '
+                        'reader + prefetcher + one hipGraph per (shape, decode steps); %d timed iterations after %d' % (
+                            tm.get('iterations', 0), time_from),
+            'qa_pairs_per_s': round(tm.get('qa_pairs_per_s', 0.0), 1), 'ms_per_iteration': round(step_ms, 3),
+            'loader_wait_ms_per_iteration': round(tm.get('loader_wait_ms_per_iteration', 0.0), 3),
+            'loader_wait_fraction': round(tm.get('loader_wait_ms_per_iteration', 0.0) / step_ms, 4) if step_ms else None,
+            'h2d_ms_per_batch': round(tm.get('h2d_ms_per_batch', 0.0), 3), 'h2d_bytes_per_batch': tm.get('h2d_bytes_per_batch'),
+            'exposed_h2d_ms_per_iteration': round(tm.get('exposed_h2d_ms_per_iteration', 0.0), 3),
+            'graphs_captured': out['graphs_captured'], 'decode_steps_histogram': tm.get('decode_steps_histogram'),
+            'dataset_generation_s': round(gen_s, 2)}
+
+
 def timed(fn, steps, warmup):
     for _ in range(warmup):
         fn()
@@ -196,6 +231,9 @@ def main():
     from ekaid_amd.synthetic import make_batch, slice_batch
     hip.load()
     hip.check(hip.lib().ekaid_init(local_rank), 'ekaid_init')
+    if args.real_only:
+        print(json.dumps({'real_b64': real_data_loop(args.graph)}))
+        return
 
     if args.scaling == 'strong':
         if args.batch % world:
@@ -346,6 +384,9 @@ def main():
         extra['train_T90'] = {'ms_per_step': round(ms90, 3), 'pairs_per_s': round(per_gpu / ms90 * 1e3, 1), 'decode_steps': T90,
                               'workload': 'train step, batch %d, answers of the maximum length (90 decode steps)' % per_gpu}
         del b64, b90
+        if not args.no_real:
+            step.close()
+            extra['real_b64'] = real_data_loop(args.graph)
     if world > 1:
         dist.barrier()
 

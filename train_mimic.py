@@ -82,6 +82,9 @@ def parse(argv=None):
     p.add_argument('--eval_batches', type=int, default=None, help='cap on validation batches per in-loop evaluation')
     p.add_argument('--exp_dir', default=None)
     p.add_argument('--quiet', action='store_true')
+    p.add_argument('--no_final_snapshot', action='store_true', help='benchmark aid: no checkpoint / evaluation at max_iter')
+    p.add_argument('--time_from', type=int, default=None,
+                   help='benchmark aid: time the loop from this iteration on (QA-pairs/s, loader wait, exposed host->device copy)')
     return p.parse_args(argv)
 
 
@@ -234,13 +237,30 @@ def main(argv=None):
             return
         from ekaid_amd.datasets.rcc_dataset_pos_mimic import DevicePrefetcher
         train_loader.rank_slice.skip = skip
-        for b in DevicePrefetcher(train_loader, device):
+        pf = DevicePrefetcher(train_loader, device, timing=args.time_from is not None)
+        prefetchers.append(pf)
+        for b in pf:
             gidx = b['_meta']['global_indices']
             yield b, b['_host_labels'], (train_dataset.mask_sum(gidx) if world > 1 else None)
 
     set_mode('train', [change_detector, speaker])
     loss_avg = AverageMeter()
     last = {}
+    prefetchers, timing, t_clock, steps_hist = [], None, None, {}
+
+    def stop_clock():
+        torch.cuda.synchronize()
+        dt, n_it = time.perf_counter() - t_clock[0], t - t_clock[1]
+        keys = ('h2d_ms', 'stall_ms', 'loader_wait_s', 'batches', 'h2d_bytes')
+        before = {k: sum(d[k] for d in t_clock[2]) for k in keys}
+        after = {k: sum(pf.stats()[k] for pf in prefetchers) for k in keys}
+        nb = max(after['batches'] - before['batches'], 1)
+        return {'iterations': n_it, 'ms_per_iteration': dt / n_it * 1e3, 'qa_pairs_per_s': global_bs * n_it / dt,
+                'loader_wait_ms_per_iteration': (after['loader_wait_s'] - before['loader_wait_s']) / nb * 1e3,
+                'h2d_ms_per_batch': (after['h2d_ms'] - before['h2d_ms']) / nb,
+                'exposed_h2d_ms_per_iteration': (after['stall_ms'] - before['stall_ms']) / nb,
+                'h2d_bytes_per_batch': (after['h2d_bytes'] - before['h2d_bytes']) // nb,
+                'decode_steps_histogram': dict(sorted(steps_hist.items()))}
     while t < cfg.train.max_iter:
         say('Starting epoch %d' % epoch)
         optimizer.lr = step_lr(o.lr, o.gamma, o.step_size, epoch)
@@ -253,19 +273,25 @@ def main(argv=None):
             if t >= cfg.train.max_iter:
                 break
             t0 = time.time()
+            if args.time_from is not None and t == args.time_from:
+                torch.cuda.synchronize()
+                t_clock = (time.perf_counter(), t, [pf.stats() for pf in prefetchers])
             steps = DynamicSpeaker.count_steps(host_labels, shape['seq_length'])
+            steps_hist[steps] = steps_hist.get(steps, 0) + 1
             denom = None
             if world > 1 and msum is not None:
                 denom = torch.tensor([msum / world], dtype=torch.float32, device=device)
             loss, speaker_loss = step(b, steps, denom)
             t += 1
             i += 1
+            if t_clock is not None and timing is None and t == cfg.train.max_iter:
+                timing = stop_clock()           # before the final snapshot / evaluation
             if t % cfg.train.log_interval == 0 or t == cfg.train.max_iter:
                 val = float(loss.item())
                 loss_avg.update(val, 2 * per_gpu)
                 last = {'speaker_loss': float(speaker_loss.item()), 'total_loss': val, 'avg_total_loss': loss_avg.avg}
                 say(epoch, i - 1, t, last, time.time() - t0)
-            if t % cfg.train.snapshot_interval == 0 or t == cfg.train.max_iter:
+            if t % cfg.train.snapshot_interval == 0 or (t == cfg.train.max_iter and not args.no_final_snapshot):
                 end_of_epoch = i >= iters_per_epoch
                 checkpoint = None
                 if rank == 0:
@@ -316,7 +342,7 @@ def main(argv=None):
         dist.destroy_process_group()
     return {'iteration': t, 'epoch': epoch, 'lr': optimizer.lr, 'last': last, 'snapshot_dir': snapshot_dir,
             'change_detector': change_detector, 'speaker': speaker, 'optimizer': optimizer,
-            'graphs_captured': graphs_captured}
+            'graphs_captured': graphs_captured, 'timing': timing}
 
 
 if __name__ == '__main__':
