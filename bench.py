@@ -378,6 +378,20 @@ def main():
         cd.train(not args.eval); sp.train(not args.eval)             # noqa: E702
         extra['forward_only_b64'] = {'ms': round(ms64, 3), 'pairs_per_s': round(64 / ms64 * 1e3, 1),
                                      'workload': 'BASELINE.json configs[1]: eval forward, batch 64, T=16'}
+        # test_mimic.py's path (configs[1] + answer generation): eval forward, then greedy decode to completion -- the stop test
+        # is polled every 8 steps; the synthetic model's answers rarely emit the end token, so this is the 90-step worst case
+        def decode():
+            _, _, outs, _ = forward_loss(cfg, cd, sp, b64, T, args.graph)
+            return sp._sample(outs[3], outs[4], outs[5], None, cfg, sample_max=1)
+        cd.eval(); sp.eval()                                         # noqa: E702
+        with torch.no_grad():
+            msd = timed(decode, 5, 1)
+            seq, _ = decode()
+        cd.train(not args.eval); sp.train(not args.eval)             # noqa: E702
+        nsteps = int((seq != 0).any(0).sum().item())
+        extra['greedy_decode_b64'] = {'ms': round(msd, 3), 'pairs_per_s': round(64 / msd * 1e3, 1), 'decode_steps_run': nsteps,
+                                      'workload': 'eval forward (teacher-forced pass included, as test_mimic.py:116-122 runs it) + '
+                                                  'greedy _sample, batch 64'}
         h90 = make_batch(B=per_gpu, seed=78, **dict(SHAPE, T=90))
         b90 = {k: v.to(dev) for k, v in h90.items()}
         T90 = DynamicSpeaker.count_steps(h90['labels'], SHAPE['seq_length'])

@@ -26,6 +26,18 @@ class PreDropped:
         self.tensor = tensor
 
 
+class RowBroadcast:
+    """Stands for the rows ``mask[r] * q[(r // group) % len(q)]`` without materialising them (the question half of
+    ``q_expand_v_cat`` under ``torch.no_grad()`` with dropout off): the FCNet that consumes it computes ``q . Wq^T`` once per
+    sample and adds it as a row-broadcast residual in the epilogue of ``v . Wv^T`` -- ``[v | q] W^T = v Wv^T + q Wq^T``."""
+
+    def __init__(self, q, mask, group):
+        self.q, self.mask, self.group = q, mask, group
+
+    def materialise(self):
+        return ops.expand_rows(self.q, self.mask, self.group)
+
+
 class Linear(nn.Linear):
     """``nn.Linear`` parameters, HIP arithmetic. ``xs`` may be a tuple of tensors whose feature axes are
     concatenated (replaces ``torch.cat`` + Linear of the reference)."""
@@ -78,6 +90,13 @@ class FCNet(nn.Module):
     def forward(self, x):
         """``x``: tensor or tuple of tensors (feature-axis concatenation)."""
         pending = 0.0                                        # dropout of the layer input, applied inside the linear node
+        if isinstance(x, (tuple, list)) and any(isinstance(t, RowBroadcast) for t in x):
+            lin = [m for m in self.main if isinstance(m, WNLinear)]
+            if (len(x) == 2 and isinstance(x[1], RowBroadcast) and len(lin) == 1 and not torch.is_grad_enabled()
+                    and not (self.training and self.input_dropout() > 0)):
+                rb = x[1]
+                return ops.wn_linear_rowbcast(x[0], rb.q, rb.mask, rb.group, lin[0].weight_v, lin[0].weight_g, lin[0].bias, self.act)
+            x = tuple(t.materialise() if isinstance(t, RowBroadcast) else t for t in x)
         for layer in self.main:
             if isinstance(layer, nn.Dropout):
                 pending = float(layer.p) if self.training else 0.0

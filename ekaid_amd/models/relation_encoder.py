@@ -9,11 +9,11 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .fc import FCNet, PreDropped
+from .fc import FCNet, PreDropped, RowBroadcast
 from .graph_att import GAttNet as GAT
 
 
-def q_expand_v_cat(q, v, mask=True, p=0.0, training=False):
+def q_expand_v_cat(q, v, mask=True, p=0.0, training=False, lazy=False):
     """Returns the PAIR (v [R*N, A], q_expanded [R*N, Q]) that stands for ``cat((v, q_expand), -1)``
     (relation_encoder.py:19-29): the question vector of each sample broadcast to its nodes and zeroed
     on nodes whose feature row sums to exactly 0.  ``q`` may hold fewer rows than R (R = 2B image
@@ -25,6 +25,9 @@ def q_expand_v_cat(q, v, mask=True, p=0.0, training=False):
         keep = torch.ones(R * N, device=v.device, dtype=torch.float32)
     if training and p > 0:      # the consumer FCNet's input dropout, fused into the expansion kernel
         return v.reshape(R * N, A), PreDropped(ops.expand_rows(q, keep, N, p, True))
+    if lazy and not torch.is_grad_enabled():
+        # inference: nothing is expanded; the consumer FCNet takes q . Wq^T once per sample (fc.RowBroadcast)
+        return v.reshape(R * N, A), RowBroadcast(q, keep, N)
     return v.reshape(R * N, A), ops.expand_rows(q, keep, N)
 
 
@@ -51,7 +54,7 @@ class ImplicitRelationEncoder(nn.Module):
         for _ in range(self.num_steps):
             fc = self.implicit_relation.self_weights
             v_in, v_res = ops.fanout(imp_v, 2) if self.residual_connection else (imp_v, None)
-            v_cat_q = q_expand_v_cat(q, v_in, True, fc.input_dropout(), fc.training)
+            v_cat_q = q_expand_v_cat(q, v_in, True, fc.input_dropout(), fc.training, lazy=True)
             imp_v, aff = self.implicit_relation.forward(v_cat_q, imp_adj_mat, position_embedding, residual=v_res)
             affs.append(aff)
         return imp_v, affs[0]
@@ -78,6 +81,6 @@ class ExplicitRelationEncoder(nn.Module):
         for _ in range(self.num_steps):
             fc = self.explicit_relation.self_weights
             v_in, v_res = ops.fanout(exp_v, 2) if self.residual_connection else (exp_v, None)
-            v_cat_q = q_expand_v_cat(q, v_in, True, fc.input_dropout(), fc.training)
+            v_cat_q = q_expand_v_cat(q, v_in, True, fc.input_dropout(), fc.training, lazy=True)
             exp_v, aff = self.explicit_relation.forward(v_cat_q, exp_adj_matrix, residual=v_res)
         return exp_v, aff

@@ -562,6 +562,32 @@ class WNScaleFn(Function):
         return (None if slot is not None else dv), dg.view(g.shape)
 
 
+def wn_linear_rowbcast(x, q, mask, group, v, g, b=None, act=ACT_NONE):
+    """Inference form of ``wn_linear((x, expand_rows(q, mask, group)), v, g, b, act)`` without the expansion:
+    y[r] = act(scale * x[r] . Wx^T + b + mask[r] * (scale * q[(r // group) % len(q)] . Wq^T)),  W = [Wx | Wq].
+    The question product is taken once per sample (B rows instead of 2*B*N) and rides in the GEMM epilogue as a row-broadcast
+    residual.  No autograd (callers use it under ``torch.no_grad()``).  ref: relation_encoder.py:19-29 + graph_att.py:80."""
+    require_cuda(x, q, mask, v, g)
+    x2, ldx = _rows2d(x)
+    q2, ldq = _rows2d(q)
+    mask = _c(mask)
+    v = _c(v)
+    M, Kx = x2.shape
+    Kq = q2.shape[1]
+    N = v.shape[0]
+    assert v.shape[1] == Kx + Kq and M % group == 0 and mask.numel() == M
+    scale, _ = wn_scale(v.detach(), g.detach())
+    qw = torch.empty(q2.shape[0], N, device=x.device, dtype=torch.float32)
+    gemm(q2, v, qw, q2.shape[0], N, Kq, ldq, Kx + Kq, N, 0, 1, alpha_dev=scale, b_off=Kx)
+    slices = M // group
+    if slices != qw.shape[0]:                       # the main and the reference image share the question rows
+        assert slices % qw.shape[0] == 0
+        qw = qw.repeat(slices // qw.shape[0], 1)
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    gemm(x2, v, y, M, N, Kx, ldx, Kx + Kq, N, 0, 1, alpha_dev=scale, bias=b, R=qw, ldr=N, rdiv=group, rowmask=mask, act=act)
+    return y.view(*x.shape[:-1], N)
+
+
 def wn_linear(xs, v, g, b=None, act=ACT_NONE, drops=None):
     if isinstance(xs, torch.Tensor):
         xs = (xs,)

@@ -1121,3 +1121,28 @@ def test_spk_step_a_equals_the_kernel_sequence_it_fuses(B, R, A, P, drop):
         for nm, a, w in (('dz_fc', dz_fc, dz_w), ('d_bef', dfe[0], dfe_w[0]), ('d_diff', dfe[1], dfe_w[1]), ('d_aft', dfe[2], dfe_w[2]),
                          ('dgates', dgates, dg_w), ('dc', dc_out, dc_w), ('dwp', dwp, dwp_w), ('dpp', dpp, DPA[:, :R])):
             assert float((a - w).abs().max()) <= 3e-5 * max(1.0, float(w.abs().max())), nm
+
+
+def test_wn_linear_rowbcast_equals_the_expanded_form():
+    """Inference form of the question-conditioned FCNet: q . Wq^T once per sample + row-broadcast residual in the epilogue ==
+    the layer applied to the materialised [v | mask * q_expand] rows, incl. masked (all-zero) node rows and the two images
+    sharing the question rows.  ref: relation_encoder.py:19-29, graph_att.py:80."""
+    from ekaid_amd import ops
+    from ekaid_amd.hip import ACT_NONE, ACT_RELU
+    B, N, A, Q, O = 3, 5, 24, 16, 20
+    R = 2 * B
+    x = rnd(R * N, A, seed=1).to(DEV)
+    q = rnd(B, Q, seed=2).to(DEV)
+    mask = (torch.rand(R * N, generator=torch.Generator().manual_seed(3)) > 0.3).float().to(DEV)
+    v, g, b = rnd(O, A + Q, seed=4, scale=0.3).to(DEV), torch.tensor(1.7, device=DEV), rnd(O, seed=5).to(DEV)
+    for act in (ACT_NONE, ACT_RELU):
+        with torch.no_grad():
+            lazy = ops.wn_linear_rowbcast(x, q, mask, N, v, g, b, act)
+            full = ops.wn_linear((x, ops.expand_rows(q, mask, N)), v, g, b, act)
+        W = (v * (g / v.norm())).double().cpu()
+        qe = (q.double().cpu().repeat(2, 1).repeat_interleave(N, 0)) * mask.double().cpu()[:, None]
+        want = torch.cat([x.double().cpu(), qe], 1) @ W.t() + b.double().cpu()
+        if act == ACT_RELU:
+            want = torch.relu(want)
+        check(full, want, 3e-6, 'expanded form')
+        check(lazy, want, 3e-6, 'row-broadcast form')
