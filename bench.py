@@ -173,10 +173,8 @@ def real_data_loop(graph, iters=120, time_from=80):
         t0 = time.perf_counter()
         make_dataset(d, n_images=512, n_pairs=3200, nodes=52, D=1024)
         gen_s = time.perf_counter() - t0
-        import contextlib
-        with contextlib.redirect_stdout(sys.stderr):        # (the dataset announces itself on stdout: keep the JSON line alone there)
-            out = train_mimic.main(['--data_dir', d, '--graph', graph, '--hip_graph', '--max_iter', str(iters), '--time_from', str(time_from),
-                                    '--snapshot_interval', '1000000', '--no_final_snapshot', '--quiet', '--exp_dir', os.path.join(d, 'exp')])
+        out = train_mimic.main(['--data_dir', d, '--graph', graph, '--hip_graph', '--max_iter', str(iters), '--time_from', str(time_from),
+                                '--snapshot_interval', '1000000', '--no_final_snapshot', '--quiet', '--exp_dir', os.path.join(d, 'exp')])
     finally:
         shutil.rmtree(d, ignore_errors=True)
     tm = out['timing'] or {}

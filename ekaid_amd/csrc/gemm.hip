@@ -79,8 +79,6 @@ struct GemmArgs {
     float* ws;            // slabs [splitk][M][N] when splitk > 1
     int tiles_m, tiles_n;
     int slab_mode;        // 1: raw partial products go to ws even when splitk == 1 (ekaid_gemm_slabs: the consumer reduces)
-    const char* Bp;       // B operand pre-split into three bf16 planes (plane 0 address of B's first element) or NULL
-    long long bp_stride;  // bytes between planes
     Epi e;
 };
 
@@ -514,15 +512,10 @@ __device__ __forceinline__ void write_tiles16(const GemmArgs& g, f32x4 (&acc)[TM
 // products per element and the same LDS plane images; under the clock the part holds in MFMA-dense loops the 16x16x32 shape
 // sustains more FLOP/s than 32x32x16 (MI355X_MICROARCH.md, DVFS give-back item 7).  Non-pipelined K loop only (KB = 32 = one
 // instruction's contraction depth).
-// BPL: the B operand arrives PRE-SPLIT (three bf16 planes laid out like the f32 matrix, GemmArgs::Bp): 16-byte plane loads go
-// straight to the LDS images, no conversion work for B in the K loop.  For the recurrent products, whose weights are split
-// once per training step and then read by 16 (or 90) time steps forward and backward (ekaid_gemm_slabs_wp).  64x64 tiles,
-// 32-deep plain loop, N % 64 == 0, K % 32 == 0, ldb % 8 == 0 (host-checked).
-template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE, int M16 = 0, bool BPL = false>
+template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE, int M16 = 0>
 __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int block_x, const int z) {
     static_assert(!PIPE || (KB == 32 && PF == 1), "the pipelined loop shares the 32-deep LDS footprint");
     static_assert(!M16 || (!PIPE && KB == 32 && PF == 1), "16x16x32 variant: plain 32-deep K loop");
-    static_assert(!BPL || (TM == 1 && TN == 1 && KB == 32 && PF == 1 && !PIPE && !M16), "pre-split B: 64x64 tiles, plain loop");
     constexpr int BM = 64 * TM, BN = 64 * TN;
     static_assert(KB == 32 || KB == 64 || KB == 128, "K-step");
     static_assert(PF == 1 || PF == 2, "prefetch depth");
@@ -600,27 +593,8 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
         voffB[i] = B_KC ? ((unsigned)(n0 + idx / (KB / 4)) * (unsigned)g.ldb + 4u * (idx % (KB / 4))) * 4u
                         : ((unsigned)(idx / (BN / 4)) * (unsigned)g.ldb + (unsigned)n0 + 4u * (idx % (BN / 4))) * 4u;
     }
-    // pre-split B (BPL): this thread's 16 bytes of each plane image per K-step -- k-contiguous: row tid / 4, k-slot tid % 4;
-    // n-contiguous: k-row tid / 8, columns 8 (tid % 8) ..+7 -- and where they go in the LDS image (same swizzles as above)
-    u32x4 rbp[3];
-    int bp_lds_off = 0;
-    const char* bp_src = nullptr;           // plane 0, K offset 0
-    long long bp_kstep = 0;                 // bytes per K-step
-    if constexpr (BPL) {
-        if (B_KC) {
-            const int row = tid >> 2, sl = tid & 3;
-            bp_lds_off = kc_read_off<KB>(row, sl);
-            bp_src = g.Bp + 2 * ((long long)(n0 + row) * g.ldb + 8 * sl);
-            bp_kstep = 2 * KB;
-        } else {
-            const int k = tid >> 3, c8 = tid & 7;
-            bp_lds_off = k * (2 * BN) + 64 * ((c8 >> 2) ^ ((k >> 1) & 1)) + 16 * (c8 & 3);
-            bp_src = g.Bp + 2 * ((long long)k * g.ldb + n0 + 8 * c8);
-            bp_kstep = 2ll * KB * g.ldb;
-        }
-    }
-    const bool ragged = !BPL && (((kend - kbeg) % KB) != 0 || !vecA || !vecB || !buf_ok ||
-                                 (!A_KC && (m0 + BM > g.M)) || (!B_KC && (n0 + BN > g.N)));
+    const bool ragged = ((kend - kbeg) % KB) != 0 || !vecA || !vecB || !buf_ok ||
+                        (!A_KC && (m0 + BM > g.M)) || (!B_KC && (n0 + BN > g.N));
     auto lstore = [&](auto set_tag, bool need_mask) {
         constexpr int S = decltype(set_tag)::value;
         if (need_mask) {
@@ -637,20 +611,15 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
             *reinterpret_cast<u32x2*>(ldsA + A_PLANE + off) = M;
             *reinterpret_cast<u32x2*>(ldsA + 2 * A_PLANE + off) = L;
         }
-        if constexpr (BPL) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(ldsB + pl * B_PLANE + bp_lds_off) = rbp[pl];
-        } else {
-#pragma unroll
-            for (int i = 0; i < B_V4; ++i) {
-                const int idx = tid + i * 256;
-                const int off = B_KC ? kc_store_off<KB>(idx) : mc_store_off<BN>(idx);
-                u32x2 H, M, L;
-                split4(rb[S][i], H, M, L);
-                *reinterpret_cast<u32x2*>(ldsB + off) = H;
-                *reinterpret_cast<u32x2*>(ldsB + B_PLANE + off) = M;
-                *reinterpret_cast<u32x2*>(ldsB + 2 * B_PLANE + off) = L;
-            }
+        for (int i = 0; i < B_V4; ++i) {
+            const int idx = tid + i * 256;
+            const int off = B_KC ? kc_store_off<KB>(idx) : mc_store_off<BN>(idx);
+            u32x2 H, M, L;
+            split4(rb[S][i], H, M, L);
+            *reinterpret_cast<u32x2*>(ldsB + off) = H;
+            *reinterpret_cast<u32x2*>(ldsB + B_PLANE + off) = M;
+            *reinterpret_cast<u32x2*>(ldsB + 2 * B_PLANE + off) = L;
         }
     };
     // per-lane offsets of the fragment reads (bytes inside a plane): see the image layouts above
@@ -760,15 +729,9 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
 #pragma unroll
                 for (int i = 0; i < A_V4; ++i)
                     ra[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, voffA[i], soA, 0));
-                if constexpr (BPL) {
-                    const char* q = bp_src + (long long)(k0 / KB) * bp_kstep;
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) rbp[pl] = *reinterpret_cast<const u32x4*>(q + pl * g.bp_stride);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < B_V4; ++i)
-                        rb[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, voffB[i], soB, 0));
-                }
+                for (int i = 0; i < B_V4; ++i)
+                    rb[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, voffB[i], soB, 0));
             } else {
                 loader_fetch<A_KC, BM, A_V4, KB, FAST>(LA, ra[S], g.lda, k0, g.K, g.M, m0, tid, vecA);
                 loader_fetch<B_KC, BN, B_V4, KB, FAST>(LB, rb[S], g.ldb, k0, g.K, g.N, n0, tid, vecB);
@@ -976,15 +939,15 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
     else write_tiles<TM, TN>(g, acc, m0, n0, wm, wn, r, h, z);
 }
 
-template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE, int M16 = 0, bool BPL = false>
+template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE, int M16 = 0>
 __global__ __launch_bounds__(256, (M16 == 1 ? 2 : TM * TN >= 4 ? EKAID_SPLIT_OCC_BIG : (TM * TN == 2 ? 2 : EKAID_SPLIT_OCC_SMALL))) void gemm_split_kernel(GemmArgs g) {
-    gemm_split_body<A_KC, B_KC, TM, TN, KB, PF, PIPE, M16, BPL>(g, blockIdx.x, blockIdx.z);
+    gemm_split_body<A_KC, B_KC, TM, TN, KB, PF, PIPE, M16>(g, blockIdx.x, blockIdx.z);
 }
 
 // TWO independent products of the same operand layout in one launch (64x64 tiles): workgroups [0, tiles of g0) work on g0,
 // the rest on g1; grid.z = the larger of the two K splits, a workgroup beyond its own problem's split count leaves at once.
 // For the recurrent steps, where two small GEMMs of one step have no dependence on each other (ekaid_gemm_slabs2).
-template <bool A_KC, bool B_KC, bool BIG, bool BPL = false>
+template <bool A_KC, bool B_KC, bool BIG>
 __global__ __launch_bounds__(256, BIG ? EKAID_SPLIT_OCC_BIG : EKAID_SPLIT_OCC_SMALL) void gemm_split_pair_kernel(GemmArgs g0, GemmArgs g1) {
     const int n0 = g0.tiles_m * g0.tiles_n;
     const bool first = (int)blockIdx.x < n0;
@@ -992,7 +955,6 @@ __global__ __launch_bounds__(256, BIG ? EKAID_SPLIT_OCC_BIG : EKAID_SPLIT_OCC_SM
     if ((int)blockIdx.z >= g.splitk) return;
     const int bx = first ? blockIdx.x : blockIdx.x - n0;
     if constexpr (BIG) gemm_split_body<A_KC, B_KC, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG>(g, bx, blockIdx.z);
-    else if constexpr (BPL) gemm_split_body<A_KC, B_KC, 1, 1, 32, 1, false, 0, true>(g, bx, blockIdx.z);
     else gemm_split_body<A_KC, B_KC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL, false>(g, bx, blockIdx.z);
 }
 
@@ -1281,7 +1243,6 @@ static int fill_args(const ekaid_gemm_t* d, GemmArgs& a, int& TMN, void* workspa
     a.e.R = d->R; a.e.ldr = d->ldr; a.e.rdiv = d->rdiv < 1 ? 1 : d->rdiv; a.e.rowmask = d->rowmask; a.e.act = d->act;
     a.e.drop_p = d->drop_p; a.e.drop_inv = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f; a.e.drop_seed = d->drop_seed; a.e.drop_epoch = dropout_epoch_ptr(); a.e.n_cols = d->N;
     a.slab_mode = slab_mode;
-    a.Bp = nullptr; a.bp_stride = 0;
     plan_full(d, TMN, a.splitk, a.k_per_split, a.tiles_m, a.tiles_n);
     a.ws = nullptr;
     if (a.splitk > 1 || slab_mode) {
@@ -1332,14 +1293,14 @@ static int launch_product(const GemmArgs& a, int TMN, bool akc, bool bkc, int ba
     return check_launch("gemm kernel");
 }
 
-template <bool AK, bool BKC, bool BIG, bool BPL = false>
+template <bool AK, bool BKC, bool BIG>
 static int launch_pair(const GemmArgs& a0, const GemmArgs& a1, hipStream_t st) {
     constexpr int KB = BIG ? 32 : EKAID_SPLIT_KB_SMALL;
     constexpr size_t lds = 3 * 2 * KB * (BIG ? 256 : 128);
     static_assert(lds <= 64 * 1024, "pair kernel: the tiles fit the default dynamic LDS limit");
     const int sk = a0.splitk > a1.splitk ? a0.splitk : a1.splitk;
     dim3 grid(a0.tiles_m * a0.tiles_n + a1.tiles_m * a1.tiles_n, 1, sk);
-    hipLaunchKernelGGL((gemm_split_pair_kernel<AK, BKC, BIG, BPL>), grid, dim3(256), lds, st, a0, a1);
+    hipLaunchKernelGGL((gemm_split_pair_kernel<AK, BKC, BIG>), grid, dim3(256), lds, st, a0, a1);
     return check_launch("gemm_split_pair_kernel");
 }
 }  // namespace ekaid
@@ -1479,96 +1440,4 @@ extern "C" int ekaid_gemm_slabs2(const ekaid_gemm_t* d0, float* slabs0, size_t s
     if (akc && bkc) return launch_pair<true, true, false>(a0, a1, st);
     if (akc && !bkc) return launch_pair<true, false, false>(a0, a1, st);
     return launch_pair<false, false, false>(a0, a1, st);
-}
-
-// ---- weights pre-split once per step for the recurrent products (include/ekaid_hip.h: ekaid_split_planes / ekaid_gemm_slabs_wp)
-namespace ekaid {
-// f32 -> three bf16 planes (plane-major; truncation split, hi + mid + lo == x exactly).  One thread per group of 8 elements.
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, long long ngroups, long long n,
-                                                           u32x4* __restrict__ out, long long plane_stride16) {
-    for (long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += (long long)gridDim.x * blockDim.x) {
-        f32x4 v0, v1;
-        const long long e = gi * 8;
-        if (e + 8 <= n) {
-            v0 = *reinterpret_cast<const f32x4*>(x + e);
-            v1 = *reinterpret_cast<const f32x4*>(x + e + 4);
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { v0[c] = e + c < n ? x[e + c] : 0.f; v1[c] = e + 4 + c < n ? x[e + 4 + c] : 0.f; }
-        }
-        u32x2 H0, M0, L0, H1, M1, L1;
-        split4(v0, H0, M0, L0);
-        split4(v1, H1, M1, L1);
-        out[gi] = u32x4{H0[0], H0[1], H1[0], H1[1]};
-        out[gi + plane_stride16] = u32x4{M0[0], M0[1], M1[0], M1[1]};
-        out[gi + 2 * plane_stride16] = u32x4{L0[0], L0[1], L1[0], L1[1]};
-    }
-}
-// can this product run on the pre-split-B kernel?  (64x64 tiles, bf16-split arithmetic, A k-contiguous and 16-byte loadable,
-// whole column tiles and K-steps, 16-byte aligned plane rows)
-static bool wp_ok(const ekaid_gemm_t* d, const GemmArgs& a, int TMN, const void* Bp, long long stride) {
-    if (!Bp || gemm_mode() != 1 || TMN != 1 || d->transA) return false;
-    if ((d->N & 63) || (d->K & 31) || (d->ldb & 7) || (d->lda & 3) || (reinterpret_cast<uintptr_t>(d->A) & 15)) return false;
-    if ((reinterpret_cast<uintptr_t>(Bp) & 15) || (stride & 15) || a.k_per_split % 32) return false;
-    const long long spanA = (long long)(d->M - 1) * d->lda + d->K;
-    return spanA < (1ll << 29);
-}
-template <bool BKC>
-static int launch_wp(const GemmArgs& a, hipStream_t st) {
-    constexpr size_t lds = 3 * 2 * 32 * 128;
-    dim3 grid(a.tiles_m * a.tiles_n, 1, a.splitk > 1 ? a.splitk : 1);
-    hipLaunchKernelGGL((gemm_split_kernel<true, BKC, 1, 1, 32, 1, false, 0, true>), grid, dim3(256), lds, st, a);
-    return check_launch("gemm_split_kernel (pre-split B)");
-}
-}  // namespace ekaid
-
-extern "C" int ekaid_split_planes(const float* x, long long n, void* planes, long long plane_stride_bytes, void* stream) {
-    if (n <= 0) return EKAID_OK;
-    const long long ngroups = (n + 7) / 8;
-    if (!x || !planes || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(planes) & 15) ||
-        (plane_stride_bytes & 15) || plane_stride_bytes < 16 * ngroups) {
-        set_error("ekaid_split_planes: null / unaligned pointer, or plane stride %lld not a multiple of 16 >= %lld", plane_stride_bytes, 16 * ngroups);
-        return EKAID_ERR_ARG;
-    }
-    long long blocks = (ngroups + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ngroups, n, (u32x4*)planes,
-                       plane_stride_bytes / 16);
-    return check_launch("split_planes");
-}
-
-extern "C" int ekaid_gemm_slabs_wp(const ekaid_gemm_t* d, const void* B_planes, long long plane_stride_bytes, float* slabs,
-                                   size_t slab_bytes, void* stream) {
-    int rc = slabs_check(d, "ekaid_gemm_slabs_wp");
-    if (rc) return rc;
-    GemmArgs a;
-    int TMN;
-    rc = fill_args(d, a, TMN, slabs, slab_bytes, 1);
-    if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    if (!wp_ok(d, a, TMN, B_planes, plane_stride_bytes)) return launch_product(a, TMN, !d->transA, d->transB != 0, 1, st);
-    a.Bp = (const char*)B_planes;
-    a.bp_stride = plane_stride_bytes;
-    return d->transB ? launch_wp<true>(a, st) : launch_wp<false>(a, st);
-}
-
-extern "C" int ekaid_gemm_slabs2_wp(const ekaid_gemm_t* d0, const void* Bp0, long long stride0, float* slabs0, size_t slab_bytes0,
-                                    const ekaid_gemm_t* d1, const void* Bp1, long long stride1, float* slabs1, size_t slab_bytes1,
-                                    void* stream) {
-    int rc = slabs_check(d0, "ekaid_gemm_slabs2_wp");
-    if (!rc) rc = slabs_check(d1, "ekaid_gemm_slabs2_wp");
-    if (rc) return rc;
-    GemmArgs a0, a1;
-    int T0, T1;
-    rc = fill_args(d0, a0, T0, slabs0, slab_bytes0, 1);
-    if (!rc) rc = fill_args(d1, a1, T1, slabs1, slab_bytes1, 1);
-    if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    const bool same = (d0->transB != 0) == (d1->transB != 0);
-    if (!same || !wp_ok(d0, a0, T0, Bp0, stride0) || !wp_ok(d1, a1, T1, Bp1, stride1))
-        return ekaid_gemm_slabs2(d0, slabs0, slab_bytes0, d1, slabs1, slab_bytes1, stream);
-    a0.Bp = (const char*)Bp0; a0.bp_stride = stride0;
-    a1.Bp = (const char*)Bp1; a1.bp_stride = stride1;
-    if (d0->transB) return launch_pair<true, true, false, true>(a0, a1, st);
-    return launch_pair<true, false, false, true>(a0, a1, st);
 }

@@ -86,9 +86,6 @@ SIGNATURES = {
     'ekaid_gemm_slab_count': [POINTER(GemmDesc)],
     'ekaid_gemm_slabs': [POINTER(GemmDesc), P, c_size_t, P],
     'ekaid_gemm_slabs2': [POINTER(GemmDesc), P, c_size_t, POINTER(GemmDesc), P, c_size_t, P],
-    'ekaid_split_planes': [P, L, P, L, P],
-    'ekaid_gemm_slabs_wp': [POINTER(GemmDesc), P, L, P, c_size_t, P],
-    'ekaid_gemm_slabs2_wp': [POINTER(GemmDesc), P, L, P, c_size_t, POINTER(GemmDesc), P, L, P, c_size_t, P],
     'ekaid_slab_epilogue': [POINTER(Slabs), I, P, I, I, I, F, U64, P, I, P],
     'ekaid_drop_act_slabs_bwd': [POINTER(Slabs), P, I, I, I, I, F, U64, P, I, P],
     'ekaid_lstm_cell_slabs_fwd': [P, POINTER(Slabs), I, P, P, I, I, P, P, P, P],

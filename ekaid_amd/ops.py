@@ -215,30 +215,8 @@ def _slab_desc(A, B, M, N, K, lda, ldb, transA, transB, a_off, b_off):
     return d
 
 
-class Planes:
-    """Three bf16 planes (hi | mid | lo, ``stride`` bytes apart) of a contiguous f32 tensor: ``ekaid_split_planes``."""
-    __slots__ = ('buf', 'stride')
-
-    def __init__(self, buf, stride):
-        self.buf, self.stride = buf, stride
-
-    def at(self, elem_off=0):
-        return self.buf.data_ptr() + 2 * elem_off
-
-
-def split_planes(t):
-    """Pre-split a weight for the recurrent products (once per training step; read by every time step)."""
-    require_cuda(t)
-    t = _c(t)
-    n = t.numel()
-    stride = 2 * ((n + 7) // 8 * 8)
-    buf = torch.empty(3 * stride, dtype=torch.uint8, device=t.device)
-    check(hip.lib().ekaid_split_planes(ptr(t), n, ptr(buf), stride, stream()), 'split_planes')
-    return Planes(buf, stride)
-
-
-def gemm_slabs(A, B, M, N, K, lda, ldb, transA, transB, a_off=0, b_off=0, B_planes=None):
-    """op(A) . op(B) as raw K-slabs (no epilogue): returns a ``SlabSet``.  ``B_planes``: ``Planes`` of the WHOLE buffer B."""
+def gemm_slabs(A, B, M, N, K, lda, ldb, transA, transB, a_off=0, b_off=0):
+    """op(A) . op(B) as raw K-slabs (no epilogue): returns a ``SlabSet``."""
     d = _slab_desc(A, B, M, N, K, lda, ldb, transA, transB, a_off, b_off)
     L = hip.lib()
     n = L.ekaid_gemm_slab_count(ctypes.byref(d))
@@ -246,18 +224,13 @@ def gemm_slabs(A, B, M, N, K, lda, ldb, transA, transB, a_off=0, b_off=0, B_plan
         check(n, 'ekaid_gemm_slab_count')
     buf = torch.empty(n * M * N, device=A.device, dtype=torch.float32)
     e0 = _prof_begin()
-    if B_planes is not None:
-        check(L.ekaid_gemm_slabs_wp(ctypes.byref(d), B_planes.at(b_off), B_planes.stride, ptr(buf), buf.numel() * 4, stream()),
-              'ekaid_gemm_slabs_wp')
-    else:
-        check(L.ekaid_gemm_slabs(ctypes.byref(d), ptr(buf), buf.numel() * 4, stream()), 'ekaid_gemm_slabs')
+    check(L.ekaid_gemm_slabs(ctypes.byref(d), ptr(buf), buf.numel() * 4, stream()), 'ekaid_gemm_slabs')
     _prof_end(e0, 2.0 * M * N * K, (int(transA), int(transB), M, N, K, 1))
     return SlabSet(buf, n, M, N)
 
 
-def gemm_slabs2(g0, g1, planes=None):
-    """Two independent products in one launch; g = (A, B, M, N, K, lda, ldb, transA, transB, a_off, b_off); ``planes``:
-    optional pair of ``Planes`` of the two B buffers."""
+def gemm_slabs2(g0, g1):
+    """Two independent products in one launch; g = (A, B, M, N, K, lda, ldb, transA, transB, a_off, b_off)."""
     L = hip.lib()
     ds, bufs, outs = [], [], []
     for g in (g0, g1):
@@ -270,13 +243,8 @@ def gemm_slabs2(g0, g1, planes=None):
         bufs.append(buf)
         outs.append(SlabSet(buf, n, g[2], g[3]))
     e0 = _prof_begin()
-    if planes is not None:
-        check(L.ekaid_gemm_slabs2_wp(ctypes.byref(ds[0]), planes[0].at(g0[10]), planes[0].stride, ptr(bufs[0]), bufs[0].numel() * 4,
-                                     ctypes.byref(ds[1]), planes[1].at(g1[10]), planes[1].stride, ptr(bufs[1]), bufs[1].numel() * 4,
-                                     stream()), 'ekaid_gemm_slabs2_wp')
-    else:
-        check(L.ekaid_gemm_slabs2(ctypes.byref(ds[0]), ptr(bufs[0]), bufs[0].numel() * 4, ctypes.byref(ds[1]), ptr(bufs[1]),
-                                  bufs[1].numel() * 4, stream()), 'ekaid_gemm_slabs2')
+    check(L.ekaid_gemm_slabs2(ctypes.byref(ds[0]), ptr(bufs[0]), bufs[0].numel() * 4, ctypes.byref(ds[1]), ptr(bufs[1]),
+                              bufs[1].numel() * 4, stream()), 'ekaid_gemm_slabs2')
     _prof_end(e0, 2.0 * (g0[2] * g0[3] * g0[4] + g1[2] * g1[3] * g1[4]),
               (int(g0[7]), int(g0[8]), g0[2], g0[3] + g1[3], g0[4], 2))
     return outs[0], outs[1]

@@ -21,10 +21,6 @@ from . import hip, ops
 from .hip import ACT_NONE, ACT_RELU, ACT_SIGMOID, check, ptr, stream
 from .ops import gemm
 
-import os
-
-USE_WEIGHT_PLANES = os.environ.get('EKAID_WEIGHT_PLANES', '1') not in ('0', 'off', 'false')     # A/B aid
-
 PARAM_NAMES = ('embed.0.weight', 'core.embed.0.weight', 'core.embed.0.bias',
                'core.module_att_lstm.weight_ih', 'core.module_att_lstm.weight_hh',
                'core.module_att_lstm.bias_ih', 'core.module_att_lstm.bias_hh',
@@ -104,12 +100,6 @@ class SpeakerSeqFn(Function):
         _nt(Xd, 0, We, wih_l, 0, We + A, GXL, 0, 4 * R, TB, 4 * R, We, bias=bih_l)
         # row-concatenated weights applied to h_lang_{t-1} (a copy, no arithmetic)
         Wcat = torch.cat([wih_a[:, E:], w_p1, w_g1[:, :R], whh_l], 0).contiguous()          # (NW, R)
-        # the five weights the time loops read, split into their bf16 planes once (32 .. 180 products per step read them)
-        # (the attended-feature block of the language LSTM's input weight as a matrix of its own: its row stride We + A = 1324
-        # floats is not a multiple of 8, which the 16-byte plane loads need)
-        Wl2 = wih_l[:, We:].contiguous()                                                     # (4R, A)
-        WP = [ops.split_planes(w) for w in (Wcat, whh_a, w_g1, w_g2, Wl2)] if USE_WEIGHT_PLANES else [None] * 5
-        pl_cat, pl_hha, pl_g1, pl_g2, pl_ihl = WP
 
         # HA / HL: h of the module-attention / language LSTM, CA / CL their cells; row 0 = the zero initial state
         HA, CA, HL, CL = ops.zeros_pool(dev, (T + 1, B, R), (T + 1, B, R), (T + 1, B, R), (T + 1, B, R))
@@ -136,8 +126,7 @@ class SpeakerSeqFn(Function):
             o_prev, o_t = t * B * R, (t + 1) * B * R
             sv, sd, sg = seeds_t[t]
             # 0.+1. everything h_lang_{t-1} feeds (P0, NW columns) and h_att_{t-1} . W_hh_att^T (P1): two products, one launch
-            P0, P1 = ops.gemm_slabs2((HL, Wcat, B, NW, R, R, R, 0, 1, o_prev, 0), (HA, whh_a, B, 4 * R, R, R, R, 0, 1, o_prev, 0),
-                                     (pl_cat, pl_hha) if pl_cat is not None else None)
+            P0, P1 = ops.gemm_slabs2((HL, Wcat, B, NW, R, R, R, 0, 1, o_prev, 0), (HA, whh_a, B, 4 * R, R, R, R, 0, 1, o_prev, 0))
             # att-LSTM cell -> module weights + attended feature -> POS chain: one row-local kernel
             sa.gxa = GXA.data_ptr() + 4 * t * B * 4 * R
             sa.gates_src[0], sa.gates_src[1] = P0.cols(0), P1.cols(0)
@@ -153,17 +142,17 @@ class SpeakerSeqFn(Function):
             sa.pp = PA.data_ptr() + 4 * t * B * (R + A)
             check(L.ekaid_spk_step_a_fwd(ctypes.byref(sa), stream()), 'spk_step_a_fwd')
             # gate MLP, layer 1: relu/dropout(P0 block + [pos_feat | att] W_g1[:, R:]^T + b)
-            P2 = ops.gemm_slabs(PA, w_g1, B, G1, R + A, R + A, G1, 0, 1, a_off=t * B * (R + A), b_off=R, B_planes=pl_g1)
+            P2 = ops.gemm_slabs(PA, w_g1, B, G1, R + A, R + A, G1, 0, 1, a_off=t * B * (R + A), b_off=R)
             arr, n = ops.slab_array(P0.cols(oG1), P2.cols(0))
             check(L.ekaid_slab_epilogue(arr, n, ptr(b_g1), B, G1, ACT_RELU, p, sg, G1D.data_ptr() + 4 * t * B * G1, G1, stream()),
                   'slab_epilogue')
             # layer 2 + gating: gate = sigmoid(. W_g2^T + b); gated = gate * att
-            P3 = ops.gemm_slabs(G1D, w_g2, B, A, G1, G1, G1, 0, 1, a_off=t * B * G1, B_planes=pl_g2)
+            P3 = ops.gemm_slabs(G1D, w_g2, B, A, G1, G1, G1, 0, 1, a_off=t * B * G1)
             s3 = P3.cols(0)
             check(L.ekaid_gate_mul_slabs_fwd(ctypes.byref(s3), ptr(b_g2), AT.data_ptr() + 4 * t * B * A, B, A,
                                              GT.data_ptr() + 4 * t * B * A, GA.data_ptr() + 4 * t * B * A, stream()), 'gate_mul_slabs_fwd')
             # language LSTM: gates = GXL[t] + P0 block + gated W_ih[:, We:]^T + b_hh
-            P4 = ops.gemm_slabs(GA, Wl2, B, 4 * R, A, A, A, 0, 1, a_off=t * B * A, B_planes=pl_ihl)
+            P4 = ops.gemm_slabs(GA, wih_l, B, 4 * R, A, A, We + A, 0, 1, a_off=t * B * A, b_off=We)
             arr, n = ops.slab_array(P0.cols(oGL), P4.cols(0))
             check(L.ekaid_lstm_cell_slabs_fwd(GXL.data_ptr() + 4 * t * B * 4 * R, arr, n, ptr(bhh_l), CL.data_ptr() + 4 * o_prev, B, R,
                                               HL.data_ptr() + 4 * o_t, CL.data_ptr() + 4 * o_t, SL.data_ptr() + 4 * t * B * 4 * R,
@@ -184,23 +173,21 @@ class SpeakerSeqFn(Function):
         ctx.biases = tuple(t.detach() for t in (b_e, bih_a, bhh_a, b_fc, b_p1, b_wp, b_p2, b_g1, b_g2, bih_l, bhh_l, b_lo))
         ctx.wrefs = (w_p1.detach(), whh_l.detach())   # (read through Wcat in the backward pass; needed for their slots only)
         ctx.pp = (p, p5, seeds, seeds_t)
-        ctx.planes = WP                              # (the weights do not change between this forward and its backward)
         ctx.save_for_backward(bef, aft, diff, tok_tb, embed_pre, ED, Xd, HA, CA, HL, CL, SA, SL, MW, VP, PW, PA, AT,
                               G1D, GT, GA, HO, logp, logpos, emb, w_e, wih_a, whh_a, w_fc, w_wp, w_p2, w_g1, w_g2,
-                              wih_l, w_lo, Wcat, Wl2)
+                              wih_l, w_lo, Wcat)
         ctx.mark_non_differentiable(MW)
         return logp, logpos, MW
 
     @staticmethod
     def backward(ctx, dlogp, dlogpos, _dmw):
         (bef, aft, diff, tok_tb, embed_pre, ED, Xd, HA, CA, HL, CL, SA, SL, MW, VP, PW, PA, AT, G1D, GT, GA, HO,
-         logp, logpos, emb, w_e, wih_a, whh_a, w_fc, w_wp, w_p2, w_g1, w_g2, wih_l, w_lo, Wcat, Wl2) = ctx.saved_tensors
+         logp, logpos, emb, w_e, wih_a, whh_a, w_fc, w_wp, w_p2, w_g1, w_g2, wih_l, w_lo, Wcat) = ctx.saved_tensors
         T, B, A, E, R, We, V, G1 = ctx.dims
         NP = w_wp.shape[0]
         NW = 9 * R + G1
         oP1, oG1, oGL = 4 * R, 5 * R, 5 * R + G1
         p, p5, seeds, seeds_t = ctx.pp
-        pl_cat, pl_hha, pl_g1, pl_g2, pl_ihl = ctx.planes
         b_e, bih_a, bhh_a, b_fc, b_p1, b_wp, b_p2, b_g1, b_g2, bih_l, bhh_l, b_lo = ctx.biases
         w_p1, whh_l = ctx.wrefs
         dev = bef.device
@@ -250,17 +237,17 @@ class SpeakerSeqFn(Function):
                                               DCAT.data_ptr() + 4 * (ow + oGL), NW, ptr(dc_tmp), stream()), 'lstm_cell_slabs_bwd')
             dc_l, dc_tmp = dc_tmp, dc_l
             # d gated = d lang gates . W_ih_lang[:, We:]
-            Q1 = ops.gemm_slabs(DCAT, Wl2, B, A, 4 * R, NW, A, 0, 0, a_off=ow + oGL, B_planes=pl_ihl)
+            Q1 = ops.gemm_slabs(DCAT, wih_l, B, A, 4 * R, NW, We + A, 0, 0, a_off=ow + oGL, b_off=We)
             # 5'. gated = gate * att ; gate = sigmoid(W_g2 g1d + b):  d z2 = d gated * att * gate'
             s1 = Q1.cols(0)
             check(L.ekaid_gate_slabs_bwd(ctypes.byref(s1), AT.data_ptr() + 4 * t * B * A, GT.data_ptr() + 4 * t * B * A, B, A,
                                          DZ2.data_ptr() + 4 * t * B * A, ptr(t_BA), stream()), 'gate_slabs_bwd')
-            Q2 = ops.gemm_slabs(DZ2, w_g2, B, G1, A, A, G1, 0, 0, a_off=t * B * A, B_planes=pl_g2)  # d g1d
+            Q2 = ops.gemm_slabs(DZ2, w_g2, B, G1, A, A, G1, 0, 0, a_off=t * B * A)                  # d g1d
             s2 = Q2.cols(0)
             check(L.ekaid_drop_act_slabs_bwd(ctypes.byref(s2), G1D.data_ptr() + 4 * t * B * G1, G1, B, G1, ACT_RELU, p, sg,
                                              DCAT.data_ptr() + 4 * (ow + oG1), NW, stream()), 'drop_act_slabs_bwd')
             # [d pos_feat | d att (gate-MLP path)] = d gate1x . W_g1[:, R:]   (one GEMM, N = R + A)
-            Q3 = ops.gemm_slabs(DCAT, w_g1, B, R + A, G1, NW, G1, 0, 0, a_off=ow + oG1, b_off=R, B_planes=pl_g1)
+            Q3 = ops.gemm_slabs(DCAT, w_g1, B, R + A, G1, NW, G1, 0, 0, a_off=ow + oG1, b_off=R)
             # 4'.+2'.+1'.+3'. module mix, att-LSTM cell, POS chain: one row-local kernel
             sb.dpa_src = Q3.cols(0)
             sb.gate = GT.data_ptr() + 4 * t * B * A
@@ -282,8 +269,7 @@ class SpeakerSeqFn(Function):
             dc_a, dc_tmp = dc_tmp, dc_a
             if t > 0:
                 # 0'. what flowed out of h_att_{t-1} (att gates . W_hh) and out of h_lang_{t-1} (everything . Wcat): one launch
-                carry_a, carry_l = ops.gemm_slabs2((DCAT, whh_a, B, R, 4 * R, NW, R, 0, 0, ow, 0), (DCAT, Wcat, B, R, NW, NW, R, 0, 0, ow, 0),
-                                                   (pl_hha, pl_cat) if pl_cat is not None else None)
+                carry_a, carry_l = ops.gemm_slabs2((DCAT, whh_a, B, R, 4 * R, NW, R, 0, 0, ow, 0), (DCAT, Wcat, B, R, NW, NW, R, 0, 0, ow, 0))
 
         # ---- time-batched weight gradients (K = T*B) and input gradients; DCAT column blocks with ld = NW
         d_wih_a = ops.grad_out(wih_a)

@@ -113,22 +113,6 @@ int ekaid_gemm_slabs(const ekaid_gemm_t* g, float* slabs, size_t slab_bytes, voi
 int ekaid_gemm_slabs2(const ekaid_gemm_t* g0, float* slabs0, size_t slab_bytes0, const ekaid_gemm_t* g1, float* slabs1,
                       size_t slab_bytes1, void* stream);
 
-/* Weights PRE-SPLIT for the recurrent products.  The decoder's weights are read by every time step, forward and backward
- * (2 x 16 .. 2 x 90 products per training step); splitting them into their three bf16 planes ONCE per step removes half of the
- * conversion work from those K loops (EKAID_GEMM_BF16_SPLIT arithmetic; bit-identical results: same truncation split).
- *   ekaid_split_planes:   x (n floats, 16-byte aligned) -> planes: three bf16 arrays hi, mid, lo (hi + mid + lo == x exactly), each
- *                         laid out like x, plane_stride_bytes apart (multiple of 16, >= 2 * ceil8(n)); a row-major view of x
- *                         addresses its planes with the same (row, column) arithmetic at 2 bytes per element.
- *   ekaid_gemm_slabs_wp / ekaid_gemm_slabs2_wp: as ekaid_gemm_slabs / _slabs2 with B_planes = the address, inside plane 0, of the
- *                         element g->B points at.  Outside the kernel's envelope (64x64-tile plan, N % 64 == 0, K % 32 == 0,
- *                         ldb % 8 == 0, 16-byte aligned operands) the call uses g->B instead: same results either way. */
-int ekaid_split_planes(const float* x, long long n, void* planes, long long plane_stride_bytes, void* stream);
-int ekaid_gemm_slabs_wp(const ekaid_gemm_t* g, const void* B_planes, long long plane_stride_bytes, float* slabs, size_t slab_bytes,
-                        void* stream);
-int ekaid_gemm_slabs2_wp(const ekaid_gemm_t* g0, const void* B_planes0, long long plane_stride_bytes0, float* slabs0,
-                         size_t slab_bytes0, const ekaid_gemm_t* g1, const void* B_planes1, long long plane_stride_bytes1,
-                         float* slabs1, size_t slab_bytes1, void* stream);
-
 /* Arithmetic of ekaid_gemm_f32 (per device; both take and return f32 and accumulate in f32):
  *   EKAID_GEMM_F32_MFMA   (0)  v_mfma_f32_32x32x2_f32, an exact f32 fma chain;
  *   EKAID_GEMM_BF16_SPLIT (1)  every f32 operand element is split EXACTLY into three bf16 values (8+8+8 significant

@@ -1146,32 +1146,3 @@ def test_wn_linear_rowbcast_equals_the_expanded_form():
             want = torch.relu(want)
         check(full, want, 3e-6, 'expanded form')
         check(lazy, want, 3e-6, 'row-broadcast form')
-
-
-@pytest.mark.parametrize('mode,M,N,K,ldb_extra,b_off', [('nt', 256, 2048, 1536, 512, 512), ('nt', 32, 6656, 512, 0, 0), ('nn', 256, 1536, 2048, 512, 512),
-                                                        ('nn', 48, 512, 6656, 0, 0), ('nt', 64, 192, 96, 8, 8), ('nt', 40, 100, 70, 0, 0)])
-def test_gemm_slabs_on_presplit_weight_planes(mode, M, N, K, ldb_extra, b_off):
-    """ekaid_gemm_slabs_wp: the B operand read from its three bf16 planes (split once, ekaid_split_planes) gives bit-identical
-    slabs to the in-kernel split -- also for a column block of a wider weight (leading dim > extent, plane offset) -- and falls
-    back to the f32 operand outside the kernel's envelope (last shape: N, K not multiples of 64 / 32)."""
-    from ekaid_amd import ops
-    A = rnd(M, K, seed=1).to(DEV)
-    if mode == 'nt':
-        Bw = rnd(N, K + ldb_extra, seed=2).to(DEV)
-        ldb, ta, tb = K + ldb_extra, 0, 1
-        want = A.double().cpu() @ Bw[:, b_off:b_off + K].double().cpu().t()
-    else:
-        Bw = rnd(K, N + ldb_extra, seed=2).to(DEV)
-        ldb, ta, tb = N + ldb_extra, 0, 0
-        want = A.double().cpu() @ Bw[:, b_off:b_off + N].double().cpu()
-    pl = ops.split_planes(Bw)
-    raw = pl.buf.cpu().view(torch.int16).view(3, -1)[:, :Bw.numel()]
-    back = (raw.to(torch.int32) << 16).view(torch.float32).sum(0)
-    assert torch.equal(back.view_as(Bw), Bw.cpu()), 'hi + mid + lo must give the weight back bit for bit'
-    s_f32 = ops.gemm_slabs(A, Bw, M, N, K, K, ldb, ta, tb, b_off=b_off)
-    s_pl = ops.gemm_slabs(A, Bw, M, N, K, K, ldb, ta, tb, b_off=b_off, B_planes=pl)
-    assert s_pl.n == s_f32.n and torch.equal(s_pl.buf, s_f32.buf)
-    check(s_pl.total(), want, 2e-6 * max(1.0, math.sqrt(K) / 4), 'planes slabs')
-    # pair launch on planes
-    p0, p1 = ops.gemm_slabs2((A, Bw, M, N, K, K, ldb, ta, tb, 0, b_off), (A, Bw, M, N, K, K, ldb, ta, tb, 0, b_off), (pl, pl))
-    assert torch.equal(p0.buf, s_f32.buf) and torch.equal(p1.buf, s_f32.buf)
