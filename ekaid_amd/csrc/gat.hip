@@ -36,6 +36,9 @@ __device__ __forceinline__ float row_softmax(float x, bool active) {
     return e / s;
 }
 
+// The next q/k column chunk is fetched into registers while the current one is multiplied out (without it every chunk paid a
+// full, un-hidden HBM round trip between two barriers): -3 % at N = 36, -6.5 % at N = 52, -15 % at 64 slices
+// (profiles/r03_gat_experiments.txt, which also lists what did NOT help: a per-head pipeline and LDS-staged edge terms).
 template <int VEC, int MMAX>
 __global__ __launch_bounds__(256) void gat_fused_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                             const float* __restrict__ S, const float* __restrict__ cond,
@@ -72,18 +75,34 @@ __global__ __launch_bounds__(256) void gat_fused_fwd_kernel(const float* __restr
         for (int j = 0; j < 4; ++j) acc[p][j] = 0.f;
 
     const int dc4 = DC >> 2;
-    for (int c0 = 0; c0 < A; c0 += DC) {
-        for (int i = tid; i < NL * dc4; i += 256) {
-            const int row = i / dc4, c4 = i % dc4;
-            *reinterpret_cast<f32x4*>(&qs[row * LDC + 4 * c4]) =
-                *reinterpret_cast<const f32x4*>(&qr[(long long)row * A + c0 + 4 * c4]);
+    constexpr int QV = 4, KV = (MMAX * 16 + 255) / 256;       // float4 per thread per chunk (N <= 64, DC <= 64)
+    f32x4 pq[QV], pk[KV];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int j = 0; j < QV; ++j) {
+            const int i = tid + j * 256;
+            if (i < NL * dc4) pq[j] = *reinterpret_cast<const f32x4*>(&qr[(long long)(i / dc4) * A + c0 + 4 * (i % dc4)]);
         }
-        for (int i = tid; i < M * dc4; i += 256) {
-            const int row = i / dc4, c4 = i % dc4;
-            *reinterpret_cast<f32x4*>(&ks[row * LDC + 4 * c4]) =
-                *reinterpret_cast<const f32x4*>(&kr[(long long)row * A + c0 + 4 * c4]);
+#pragma unroll
+        for (int j = 0; j < KV; ++j) {
+            const int i = tid + j * 256;
+            if (i < M * dc4) pk[j] = *reinterpret_cast<const f32x4*>(&kr[(long long)(i / dc4) * A + c0 + 4 * (i % dc4)]);
+        }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < A; c0 += DC) {
+#pragma unroll
+        for (int j = 0; j < QV; ++j) {
+            const int i = tid + j * 256;
+            if (i < NL * dc4) *reinterpret_cast<f32x4*>(&qs[(i / dc4) * LDC + 4 * (i % dc4)]) = pq[j];
+        }
+#pragma unroll
+        for (int j = 0; j < KV; ++j) {
+            const int i = tid + j * 256;
+            if (i < M * dc4) *reinterpret_cast<f32x4*>(&ks[(i / dc4) * LDC + 4 * (i % dc4)]) = pk[j];
         }
         __syncthreads();
+        if (c0 + DC < A) fetch(c0 + DC);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int t = tid + p * 256;

@@ -1151,6 +1151,8 @@ static int launch_split(const GemmArgs& a, int batch, hipStream_t st) {
 // arithmetic of the MFMA kernels: 0 = v_mfma_f32_32x32x2_f32, 1 = exact 3-way bf16 split (6 x v_mfma_f32_32x32x16_bf16);
 // kept in the per-device state (api.hip: gemm_mode / set_gemm_mode)
 
+static thread_local int t_plan_slab = 0;      // set while a slab-mode product is being planned (fill_args)
+
 static int plan_splitk(int tiles, int K, int batch, long long MN, int BK, bool big_tiles) {
     if (batch > 1) return 1;
     static const char* tgt = getenv("EKAID_GEMM_SPLIT_TARGET");   // tuning aid
@@ -1190,6 +1192,11 @@ static void plan(const ekaid_gemm_t* d, int& TMN, int& splitk, int& tiles_m, int
     if (TMN == 2 && batch == 1 && gemm_mode() == 1 && d->M >= 4096 && !d->transA) {
         if (d->transB && d->N <= 128) TMN = 3;
         else if (!d->transB && d->K <= 128) TMN = 1;
+    }
+    {
+        // slab-mode products (consumer-reduced, the recurrent steps) with 64 < M: tuning aid EKAID_GEMM_SLAB_TILE=3 (128x64) / 4
+        static const char* st = getenv("EKAID_GEMM_SLAB_TILE");
+        if (st && t_plan_slab && TMN == 1 && d->M > 64 && (st[0] == '3' || st[0] == '4')) TMN = st[0] - '0';
     }
     static const char* force = getenv("EKAID_GEMM_TILE");         // tuning aid: "1" (64x64), "2" (128x128), "3" (128x64), "4" (64x128)
     if (force && force[0] >= '1' && force[0] <= '4' && (force[0] < '3' || TMN == 2)) TMN = force[0] - '0';
@@ -1243,7 +1250,9 @@ static int fill_args(const ekaid_gemm_t* d, GemmArgs& a, int& TMN, void* workspa
     a.e.R = d->R; a.e.ldr = d->ldr; a.e.rdiv = d->rdiv < 1 ? 1 : d->rdiv; a.e.rowmask = d->rowmask; a.e.act = d->act;
     a.e.drop_p = d->drop_p; a.e.drop_inv = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f; a.e.drop_seed = d->drop_seed; a.e.drop_epoch = dropout_epoch_ptr(); a.e.n_cols = d->N;
     a.slab_mode = slab_mode;
+    t_plan_slab = slab_mode;
     plan_full(d, TMN, a.splitk, a.k_per_split, a.tiles_m, a.tiles_n);
+    t_plan_slab = 0;
     a.ws = nullptr;
     if (a.splitk > 1 || slab_mode) {
         const size_t need = (size_t)a.splitk * d->M * d->N * sizeof(float);
@@ -1402,7 +1411,9 @@ static int slabs_check(const ekaid_gemm_t* d, const char* who) {
 extern "C" int ekaid_gemm_slab_count(const ekaid_gemm_t* d) {
     if (slabs_check(d, "ekaid_gemm_slab_count")) return EKAID_ERR_ARG;
     int TMN, splitk, kps, tm, tn;
+    t_plan_slab = 1;
     plan_full(d, TMN, splitk, kps, tm, tn);
+    t_plan_slab = 0;
     return splitk;
 }
 extern "C" int ekaid_gemm_slabs(const ekaid_gemm_t* d, float* slabs, size_t slab_bytes, void* stream) {
