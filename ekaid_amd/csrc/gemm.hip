@@ -472,50 +472,9 @@ __device__ __forceinline__ int mc_read_off(int k, int row0, int tg, int tp) {   
 
 // PF = K-steps of global loads kept in flight (1: the next step's loads hide under this step's MFMAs -- enough for the
 // large tiles; 2: for the 64x64 tile, whose 12 MFMAs per 32-deep step are far shorter than a load round trip)
-// 16x16-tile epilogue (v_mfma_f32_16x16x32_bf16 accumulators: col = lane & 15, row = 4 * (lane >> 4) + t)
-template <int TM16, int TN16>
-__device__ __forceinline__ void write_tiles16(const GemmArgs& g, f32x4 (&acc)[TM16][TN16], int m0, int n0, int wm, int wn, int lane, int z) {
-    const bool slab = g.splitk > 1 || g.slab_mode;
-    float* C;
-    int ldc;
-    if (slab) {
-        C = g.ws + (long long)z * g.M * g.N;
-        ldc = g.N;
-    } else {
-        const long long z1 = z / g.nb2, z2 = z % g.nb2;
-        C = g.C + z1 * g.sC1 + z2 * g.sC2;
-        ldc = g.ldc;
-    }
-    const float alpha = g.e.alpha_dev ? g.e.alpha * g.e.alpha_dev[0] : g.e.alpha;
-    const int r = lane & 15, q = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < TM16; ++i)
-#pragma unroll
-        for (int j = 0; j < TN16; ++j) {
-            const int n = n0 + wn + 16 * j + r;
-            if (n >= g.N) continue;
-            const int mb = m0 + wm + 16 * i + 4 * q;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (mb + t >= g.M) continue;
-                float* cp = C + (long long)(mb + t) * ldc + n;
-                if (slab) *cp = acc[i][j][t];
-                else {
-                    const float cold = g.e.beta ? *cp : 0.f;
-                    *cp = epilogue(acc[i][j][t], cold, mb + t, n, g.e, alpha);
-                }
-            }
-        }
-}
-
-// M16: the multiply phase on v_mfma_f32_16x16x32_bf16 (4 x 4 tiles of 16x16 per wave instead of 2 x 2 of 32x32): the same six
-// products per element and the same LDS plane images; under the clock the part holds in MFMA-dense loops the 16x16x32 shape
-// sustains more FLOP/s than 32x32x16 (MI355X_MICROARCH.md, DVFS give-back item 7).  Non-pipelined K loop only (KB = 32 = one
-// instruction's contraction depth).
-template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE, int M16 = 0>
+template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE>
 __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int block_x, const int z) {
     static_assert(!PIPE || (KB == 32 && PF == 1), "the pipelined loop shares the 32-deep LDS footprint");
-    static_assert(!M16 || (!PIPE && KB == 32 && PF == 1), "16x16x32 variant: plain 32-deep K loop");
     constexpr int BM = 64 * TM, BN = 64 * TN;
     static_assert(KB == 32 || KB == 64 || KB == 128, "K-step");
     static_assert(PF == 1 || PF == 2, "prefetch depth");
@@ -647,52 +606,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
             return __builtin_bit_cast(bf16x8, v);
         }
     };
-    // ---- 16x16x32 variant: 2*TM x 2*TN accumulator tiles of 4 registers, fragments per 16-row tile
-    constexpr int T16M = M16 ? 2 * TM : 1, T16N = M16 ? 2 * TN : 1;
-    f32x4 acc16[T16M][T16N];
-    int a16_off[T16M], b16_off[T16N];
-    if constexpr (M16) {
-        const int l15 = lane & 15, lg = lane >> 4;
-#pragma unroll
-        for (int i = 0; i < T16M; ++i) {
-#pragma unroll
-            for (int j = 0; j < T16N; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int row0 = wm + 16 * i;
-            a16_off[i] = A_KC ? kc_read_off<KB>(row0 + l15, lg) : mc_read_off<BM>(8 * lg + tq, row0, (row0 >> 4) & 1, tp);
-        }
-#pragma unroll
-        for (int j = 0; j < T16N; ++j) {
-            const int col0 = wn + 16 * j;
-            b16_off[j] = B_KC ? kc_read_off<KB>(col0 + l15, lg) : mc_read_off<BN>(8 * lg + tq, col0, (col0 >> 4) & 1, tp);
-        }
-    }
-    auto mfma16x6 = [&](f32x4& c, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c, 0, 0, 0);
-    };
-    auto compute16 = [&]() {
-        {                                   // all A fragments resident, B one column tile at a time (60 fragment registers)
-            bf16x8 fa[T16M][3];
-#pragma unroll
-            for (int i = 0; i < T16M; ++i)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) fa[i][p] = frag(ldsA + p * A_PLANE, a16_off[i], A_KC, A_RS);
-#pragma unroll
-            for (int j = 0; j < T16N; ++j) {
-                bf16x8 fb[3];
-#pragma unroll
-                for (int p = 0; p < 3; ++p) fb[p] = frag(ldsB + p * B_PLANE, b16_off[j], B_KC, B_RS);
-#pragma unroll
-                for (int i = 0; i < T16M; ++i) mfma16x6(acc16[i][j], fa[i], fb);
-            }
-        }
-    };
     auto compute = [&]() {
-        if constexpr (M16) { compute16(); return; }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             bf16x8 fa[TM][3], fb[TN][3];
@@ -935,13 +849,12 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
         else if constexpr (PIPE) pipelined();
         else mainloop(std::true_type{});
     }
-    if constexpr (M16) write_tiles16<T16M, T16N>(g, acc16, m0, n0, wm, wn, lane, z);
-    else write_tiles<TM, TN>(g, acc, m0, n0, wm, wn, r, h, z);
+    write_tiles<TM, TN>(g, acc, m0, n0, wm, wn, r, h, z);
 }
 
-template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE, int M16 = 0>
-__global__ __launch_bounds__(256, (M16 == 1 ? 2 : TM * TN >= 4 ? EKAID_SPLIT_OCC_BIG : (TM * TN == 2 ? 2 : EKAID_SPLIT_OCC_SMALL))) void gemm_split_kernel(GemmArgs g) {
-    gemm_split_body<A_KC, B_KC, TM, TN, KB, PF, PIPE, M16>(g, blockIdx.x, blockIdx.z);
+template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE>
+__global__ __launch_bounds__(256, (TM * TN >= 4 ? EKAID_SPLIT_OCC_BIG : (TM * TN == 2 ? 2 : EKAID_SPLIT_OCC_SMALL))) void gemm_split_kernel(GemmArgs g) {
+    gemm_split_body<A_KC, B_KC, TM, TN, KB, PF, PIPE>(g, blockIdx.x, blockIdx.z);
 }
 
 // TWO independent products of the same operand layout in one launch (64x64 tiles): workgroups [0, tiles of g0) work on g0,
@@ -1128,11 +1041,11 @@ static int launch(const GemmArgs& a, int batch, hipStream_t st) {
     return EKAID_OK;
 }
 
-template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE, int M16 = 0>
+template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE>
 static int launch_split(const GemmArgs& a, int batch, hipStream_t st) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr size_t lds = 3 * 2 * KB * (BM + BN);      // three bf16 planes per operand, unpadded
-    auto kern = gemm_split_kernel<A_KC, B_KC, TM, TN, KB, PF, PIPE, M16>;
+    auto kern = gemm_split_kernel<A_KC, B_KC, TM, TN, KB, PF, PIPE>;
     if (lds > 64 * 1024) {
         constexpr int slot = 16 + (A_KC ? 1 : 0) + (B_KC ? 2 : 0) + 4 * (TM - 1) + 8 * (TN - 1);
         if (func_attr_once(slot)) {
@@ -1266,14 +1179,14 @@ static int fill_args(const ekaid_gemm_t* d, GemmArgs& a, int& TMN, void* workspa
 }
 
 
-// 128x128-tile arm (tuning aid, EKAID_GEMM_BIG): 0 = software-pipelined 16-deep stages on 32x32x16 (default), 1 = plain 32-deep
-// loop on 32x32x16 ("plain"), 2 = plain loop on 16x16x32, A fragments resident, 2 workgroups / CU ("m16"; a 2 x 2-blocked
-// form that would fit 3 workgroups / CU spills 100-270 registers and was dropped)
-// Default: the plain loop when both operands are k-contiguous (forward products; +4 % at K = 1024, +2.6 % at K = 4096), the
-// pipelined loop otherwise (+2 % on the weight-gradient form, equal on the input-gradient form): profiles/r03_gemm_arms.txt.
+// 128x128-tile arm (EKAID_GEMM_BIG = pipe | plain overrides): the software-pipelined loop (two 16-deep LDS stages) or the plain
+// 32-deep loop.  Default: plain when both operands are k-contiguous (forward products: +4 % at K = 1024, +2.6 % at K = 4096),
+// pipelined otherwise (+2 % on the weight-gradient form, equal on the input-gradient form).  A third arm on
+// v_mfma_f32_16x16x32_bf16 was built, measured 3-8 % slower (its 198-213 registers allow 2 workgroups per CU only; counters:
+// MFMA busy 0.39 at 2.14 GHz against 0.52 at 1.87 GHz) and moved to tools/experiments: profiles/r03_gemm_arms.txt.
 static int big_arm(bool akc, bool bkc) {
     static const char* e = getenv("EKAID_GEMM_BIG");
-    if (e) return e[0] == 'm' ? 2 : (e[0] == 'p' && e[1] == 'l' ? 1 : 0);
+    if (e) return (e[0] == 'p' && e[1] == 'l') ? 1 : 0;
     return (akc && bkc) ? 1 : 0;
 }
 
@@ -1281,8 +1194,7 @@ static int big_arm(bool akc, bool bkc) {
 static int launch_product(const GemmArgs& a, int TMN, bool akc, bool bkc, int batch, hipStream_t st) {
     int rc;
     if (gemm_mode() == 1 && TMN >= 1 && TMN <= 4) {
-#define EKAID_LAUNCH_SPLIT(AK, BKC) (TMN == 2 ? (big_arm(AK, BKC) == 2 ? launch_split<AK, BKC, 2, 2, 32, 1, false, 1>(a, batch, st) \
-                                                  : big_arm(AK, BKC) == 1 ? launch_split<AK, BKC, 2, 2, 32, 1, false>(a, batch, st) \
+#define EKAID_LAUNCH_SPLIT(AK, BKC) (TMN == 2 ? (big_arm(AK, BKC) == 1 ? launch_split<AK, BKC, 2, 2, 32, 1, false>(a, batch, st) \
                                                   : launch_split<AK, BKC, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG>(a, batch, st)) \
                                      : TMN == 1 ? launch_split<AK, BKC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL, false>(a, batch, st) \
                                      : TMN == 3 ? launch_split<AK, BKC, 2, 1, 32, 1, false>(a, batch, st) : launch_split<AK, BKC, 1, 2, 32, 1, false>(a, batch, st))
