@@ -1081,3 +1081,23 @@ extern "C" int ekaid_drop_act_bwd(const float* dy, const float* y, int ldy, int 
                        INVK(p), DS(seed), out, ldo);
     return ekaid::check_launch("drop_act_bwd");
 }
+
+// ------------------------------------------------------------------ debug: count of non-finite values (EKAID_CHECK_FINITE=1)
+namespace ekaid {
+__global__ __launch_bounds__(256) void nonfinite_count_kernel(const float* __restrict__ x, long long n, int* count) {
+    int c = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const unsigned u = __float_as_uint(x[i]);
+        c += ((u & 0x7F800000u) == 0x7F800000u) ? 1 : 0;         // Inf or NaN
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);      // integer atomics: order-independent
+}
+}  // namespace ekaid
+extern "C" int ekaid_nonfinite_count(const float* x, long long n, int* count, void* stream) {
+    if (!count) { ekaid::set_error("nonfinite_count: null counter"); return EKAID_ERR_ARG; }
+    if (n <= 0 || !x) return EKAID_OK;
+    hipLaunchKernelGGL(ekaid::nonfinite_count_kernel, ekaid::grid1d(n, 4), dim3(256), 0, ST, x, n, count);
+    return ekaid::check_launch("nonfinite_count");
+}

@@ -152,6 +152,7 @@ SIGNATURES = {
     'ekaid_process_matrix': [P, I, I, I, I, I, P, P],
     'ekaid_greedy_step': [P, I, I, I, P, P, P, P, I, P, P],
     'ekaid_transpose': [P, I, I, I, P, I, P],
+    'ekaid_nonfinite_count': [P, L, P, P],
     'ekaid_adam_step': [P, P, P, P, L, F, F, F, F, I, F, P],
     'ekaid_adam_step_dev': [P, P, P, P, L, P, P, P, P],
 }

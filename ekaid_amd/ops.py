@@ -7,7 +7,6 @@ HIP device -- there is no CPU fallback (the CPU restatement is ``oracle/``, test
 """
 import ctypes
 import math
-
 import os
 
 import torch
@@ -25,6 +24,25 @@ _seed_counter = 0
 
 
 GEMM_F32_MFMA, GEMM_BF16_SPLIT = 0, 1
+
+# Debug mode: with EKAID_CHECK_FINITE=1 every layer output is checked for Inf / NaN (one small reduction + one host read per
+# check: a synchronisation each, like the reference's `assert not x.isnan().any()` after every layer, fc.py:42-48).  Off by
+# default; never inside a hipGraph capture.
+CHECK_FINITE = os.environ.get('EKAID_CHECK_FINITE', '0') not in ('0', 'off', 'false', '')
+
+
+def assert_finite(t, what):
+    """AssertionError naming the producer if ``t`` holds an Inf / NaN (only when CHECK_FINITE is on)."""
+    if not CHECK_FINITE or t is None or not t.is_cuda or not t.dtype.is_floating_point:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return
+    x = t.detach()
+    x = x if x.is_contiguous() else x.contiguous()
+    cnt = torch.zeros(1, dtype=torch.int32, device=x.device)
+    check(hip.lib().ekaid_nonfinite_count(ptr(x), x.numel(), ptr(cnt), stream()), 'nonfinite_count')
+    n = int(cnt.item())
+    assert n == 0, '%s: %d non-finite values in a tensor of shape %s' % (what, n, tuple(t.shape))
 
 
 def set_gemm_mode(mode):
@@ -355,6 +373,7 @@ class LinearFn(Function):
         ctx.lead = [x.shape[:-1] for x in xs]
         ctx.save_for_backward(W, scale, y if act != ACT_NONE else None, *xs2)
         ctx.lds = lds
+        assert_finite(y, 'linear layer (%d -> %d)' % (Ktot, N))
         return y.view(*xs[0].shape[:-1], N)
 
     @staticmethod
@@ -1170,7 +1189,9 @@ class GRUSeqFn(Function):
 
 
 def gru_sequence(x, w_ih, w_hh, b_ih, b_hh):
-    return GRUSeqFn.apply(x, w_ih, w_hh, b_ih, b_hh)
+    out = GRUSeqFn.apply(x, w_ih, w_hh, b_ih, b_hh)
+    assert_finite(out, 'question GRU')
+    return out
 
 
 class LSTMCellFn(Function):
@@ -1388,7 +1409,10 @@ class GatAttentionFn(Function):
 
 
 def gat_attention(q, k, S, cond, lbias, geo, H, direction, impl='fused'):
-    return GatAttentionFn.apply(q, k, S, cond, lbias, geo, H, direction, impl)
+    outT, P = GatAttentionFn.apply(q, k, S, cond, lbias, geo, H, direction, impl)
+    assert_finite(P, 'graph attention softmax')
+    assert_finite(outT, 'graph attention aggregation')
+    return outT, P
 
 
 def bmm(A, B, transA=False, transB=False, alpha=1.0):

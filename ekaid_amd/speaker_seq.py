@@ -336,5 +336,7 @@ def speaker_sequence(speaker, feat_bef, feat_aft, feat_diff, tok_tb):
     """tok_tb: (T, B) int64 teacher-forcing tokens, time-major.  Returns time-major (logp, logpos, module_weights)."""
     sd = dict(speaker.named_parameters())
     params = [sd[n] for n in PARAM_NAMES]
-    return SpeakerSeqFn.apply(feat_bef, feat_aft, feat_diff, tok_tb, speaker.drop_prob_lm, speaker.core.dropout.p,
-                              speaker.training, *params)
+    out = SpeakerSeqFn.apply(feat_bef, feat_aft, feat_diff, tok_tb, speaker.drop_prob_lm, speaker.core.dropout.p,
+                             speaker.training, *params)
+    ops.assert_finite(out[0], 'answer decoder log-probabilities')
+    return out

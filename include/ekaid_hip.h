@@ -421,6 +421,11 @@ int ekaid_greedy_step(const float* logp, int B, int V, int t, int* unfinished, i
  * W^T [in][out] with 512-byte row segments instead of W [out][in] with 128-byte segments (measured +15-20 %). */
 int ekaid_transpose(const float* src, int R, int C, int ld_src, float* dst, int ld_dst, void* stream);
 
+/* Debug aid (EKAID_CHECK_FINITE=1 in ekaid_amd/ops.py): count[0] += number of Inf / NaN values among x[0..n); the caller
+ * zero-fills count and reads it back.  ref: the reference's `assert not x.isnan().any()` after every layer, fc.py:42-48,
+ * graph_att_layer.py:71-177 passim, language_model.py:111-152 (one host synchronisation each; off by default here). */
+int ekaid_nonfinite_count(const float* x, long long n, int* count, void* stream);
+
 /* Adam, torch.optim.Adam semantics (no amsgrad, wd = 0), over one flat buffer.   ref: utils/utils.py:96-99
  * g is multiplied by grad_scale first (1/world_size after an all-reduce sum). */
 int ekaid_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,

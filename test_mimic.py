@@ -110,7 +110,14 @@ def main(argv=None):
     coco_gen_format_save(predictions, path)
     print(path)
     print('exact-match accuracy: %.4f (%d/%d)' % (correct / max(total, 1), correct, total))
-    return {'results_file': path, 'accuracy': correct / max(total, 1), 'n': total, 'predictions': predictions}
+    metrics = None
+    if loader is not None:
+        from ekaid_amd.evaluation import caption_metrics
+        from train_mimic import evaluate as _ev
+        metrics = caption_metrics(predictions, getattr(_ev, 'last_references', {}))        # test_mimic.py:143-152, when pycocoevalcap exists
+        if metrics:
+            print(', '.join('%s %.4f' % kv for kv in metrics.items()))
+    return {'results_file': path, 'accuracy': correct / max(total, 1), 'n': total, 'predictions': predictions, 'metrics': metrics}
 
 
 if __name__ == '__main__':

@@ -1146,3 +1146,28 @@ def test_wn_linear_rowbcast_equals_the_expanded_form():
             want = torch.relu(want)
         check(full, want, 3e-6, 'expanded form')
         check(lazy, want, 3e-6, 'row-broadcast form')
+
+
+def test_check_finite_debug_mode():
+    """EKAID_CHECK_FINITE=1 (ops.CHECK_FINITE): a NaN / Inf in a layer output raises AssertionError naming the layer, like the
+    reference's per-layer `assert not x.isnan().any()` (fc.py:42-48); clean tensors pass; off by default."""
+    from ekaid_amd import ops
+    x = rnd(64, 32, seed=1).to(DEV)
+    W = rnd(16, 32, seed=2).to(DEV)
+    was = ops.CHECK_FINITE
+    try:
+        ops.CHECK_FINITE = True
+        ops.linear(x, W)
+        bad = x.clone()
+        bad[3, 5] = float('nan')
+        with pytest.raises(AssertionError, match='linear layer'):
+            ops.linear(bad, W)
+        ops.assert_finite(x, 'clean')
+        with pytest.raises(AssertionError, match='2 non-finite'):
+            t = x.clone()
+            t[0, 0], t[1, 1] = float('inf'), float('-inf')
+            ops.assert_finite(t, 'probe')
+        ops.CHECK_FINITE = False
+        ops.linear(bad, W)                  # off: no check, no synchronisation
+    finally:
+        ops.CHECK_FINITE = was

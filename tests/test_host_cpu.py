@@ -248,3 +248,16 @@ def test_checkpoints_interoperate_with_the_reference_config_class(tmp_path):
         del sys.modules['utils'], sys.modules['utils.attr_dict']
     assert type(back['model_cfg']) is AttrDict and back['model_cfg'].model.change_detector.att_dim == 1024
     assert load_checkpoint(str(tmp_path / 'ours.pt'))['iteration'] == 3
+
+
+def test_caption_metrics_delegate_to_pycocoevalcap_or_step_aside():
+    """BLEU / ROUGE / CIDEr come from pycocoevalcap when it is importable (same scorers as the reference's evaluation.py:40-46);
+    without it the helper returns None and the entry points fall back to exact-match accuracy."""
+    from ekaid_amd import evaluation
+    preds = {'1': 'the heart is enlarged', '2': 'no'}
+    refs = {'1': 'the heart is enlarged', '2': 'yes'}
+    m = evaluation.caption_metrics(preds, refs)
+    if evaluation.available():
+        assert m is not None and 0.0 <= m['Bleu_1'] <= 1.0 and 'CIDEr' in m
+    else:
+        assert m is None

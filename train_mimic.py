@@ -19,8 +19,9 @@ Differences from the reference script (ref: train_mimic.py:1-386), all deliberat
     (shape, decode steps) graphs -- the collectives inside them line up because every graph issues the same buckets;
   * no ``.item()`` synchronisation per iteration: losses are read only every ``log_interval`` iterations;
   * the in-loop evaluation greedy-decodes the validation split and scores exact-match accuracy (evaluate_score.py:216-251);
-    BLEU/METEOR/CIDEr need pycocoevalcap + Java (absent here): the COCO-format json the reference's ``evaluation.py``
-    consumes is written next to it, and "best" is chosen by exact-match accuracy instead of BLEU-1 (:379-383);
+    BLEU/METEOR/ROUGE/CIDEr are delegated to pycocoevalcap when it is importable (ekaid_amd/evaluation.py) and "best" is then
+    chosen by BLEU-1 like the reference (:379-383); without the package (this image) the COCO-format json the reference's
+    ``evaluation.py`` consumes is still written and "best" falls back to exact-match accuracy;
   * checkpoints additionally carry optimizer moments / step, iteration, epoch position, RNG state at the start of the
     epoch and the dropout seed counter: ``--resume`` continues the run (the reference restarts Adam and the epoch);
   * ``--coef_sem/--coef_spa`` are accepted and, as in the reference (quirk Q-D, :53-54 vs modules.py:117-118),
@@ -97,7 +98,7 @@ def step_lr(base_lr, gamma, step_size, epoch):
 def evaluate(cfg, change_detector, speaker, loader, device, idx_to_word, graph, max_batches=None):
     """Greedy decode of a split (train_mimic.py:292-362): {pair index: sentence}, exact-match accuracy."""
     from ekaid_amd.datasets.rcc_dataset_pos_mimic import DevicePrefetcher
-    predictions, correct, total = {}, 0, 0
+    predictions, references, correct, total = {}, {}, 0, 0
     set_mode('eval', [change_detector, speaker])
     with torch.no_grad():
         for bi, b in enumerate(DevicePrefetcher(loader, device)):
@@ -110,9 +111,11 @@ def evaluate(cfg, change_detector, speaker, loader, device, idx_to_word, graph, 
             gts = decode_sequence(idx_to_word, b['_host_labels'][:, 1:])
             for j, s in enumerate(sents):
                 predictions[str(int(b['pair_index'][j]))] = s
+                references[str(int(b['pair_index'][j]))] = gts[j]
                 correct += int(s == gts[j])
                 total += 1
     set_mode('train', [change_detector, speaker])
+    evaluate.last_references = references          # (for the caption metrics; the return value keeps its three fields)
     return predictions, correct / max(total, 1), total
 
 
@@ -318,6 +321,14 @@ def main(argv=None):
                         coco_gen_format_save(preds, os.path.join(sent_dir, 'eval_results_%d.json' % t))
                         say('eval at iter %d: exact-match accuracy %.4f over %d pairs' % (t, acc, n))
                         last['eval_accuracy'] = acc
+                        # the reference picks its best checkpoint by BLEU-1 from pycocoevalcap (train_mimic.py:364-383): use it
+                        # where the package exists, exact-match accuracy otherwise
+                        from ekaid_amd.evaluation import caption_metrics
+                        metrics = caption_metrics(preds, getattr(evaluate, 'last_references', {}))
+                        if metrics:
+                            say('eval at iter %d: %s' % (t, ', '.join('%s %.4f' % kv for kv in metrics.items())))
+                            last['eval_metrics'] = metrics
+                            acc = metrics.get('Bleu_1', acc)
                         if acc > best:
                             best = acc
                             checkpoint['best'] = best
