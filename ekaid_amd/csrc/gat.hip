@@ -285,8 +285,13 @@ __global__ __launch_bounds__(256) void geom_embed_kernel(const double* bb, const
         const int j = (int)(rest % M); rest /= M;
         const int ii = (int)(rest % N);
         const long long r = rest / N;
-        const double* bi = bb + (r * N + ii) * 4;
-        const double* bj = bb + (r * N + j) * 4;
+        // M < N (nongt_dim below the node count): the reference keeps the first M ROWS of the N x N pair matrix
+        // (mimic_utils.py:186) and then re-reads that [M][N] block as [N][M] (graph_att_layer.py:117-126): output position
+        // (ii, j) holds the geometry of pair (p, q) with p * N + q = ii * M + j.  Reproduced as is.
+        const int flat = ii * M + j;
+        const int p = M < N ? flat / N : ii, qn = M < N ? flat % N : j;
+        const double* bi = bb + (r * N + p) * 4;
+        const double* bj = bb + (r * N + qn) * 4;
         const double wi = bi[2] - bi[0] + 1.0, hi = bi[3] - bi[1] + 1.0;
         const double wj = bj[2] - bj[0] + 1.0, hj = bj[3] - bj[1] + 1.0;
         double v;

@@ -199,9 +199,47 @@ __global__ __launch_bounds__(256) void spk_gate_bwd_kernel(const float* d_gated,
     }
 }
 
+// ---- scheduled sampling (dynamic_speaker_change_pos.py:197-208): with probability ss_prob per sample the teacher token of this
+// step is replaced by a draw from the previous step's output distribution exp(logp_prev).  One thread per sample: uniform u1
+// decides, inverse-CDF walk over the V <= a few hundred classes draws (the reference uses torch.multinomial: same
+// distribution, different random stream -- as for dropout, streams cannot match).
+__global__ __launch_bounds__(64) void ss_tokens_kernel(const float* __restrict__ logp_prev, const long long* __restrict__ teacher,
+                                                       int ld_teacher, int B, int V, float ss_prob, DropSeed seed,
+                                                       long long* __restrict__ it) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    long long tok = teacher[(long long)b * ld_teacher];
+    const uint64_t sd = drop_seed_value(seed);
+    const float u1 = (float)(hash_u32(sd, (uint64_t)b) >> 8) * (1.0f / 16777216.0f);
+    if (u1 < ss_prob) {
+        const float u2 = (float)(hash_u32(sd + 0x5851F42D4C957F2Dull, (uint64_t)b) >> 8) * (1.0f / 16777216.0f);
+        const float* p = logp_prev + (long long)b * V;
+        float tot = 0.f;
+        for (int v = 0; v < V; ++v) tot += __expf(p[v]);
+        const float target = u2 * tot;
+        float run = 0.f;
+        int pick = V - 1;
+        for (int v = 0; v < V; ++v) {
+            run += __expf(p[v]);
+            if (run > target) { pick = v; break; }
+        }
+        tok = pick;
+    }
+    it[b] = tok;
+}
+
 }  // namespace ekaid
 
 using namespace ekaid;
+
+extern "C" int ekaid_ss_tokens(const float* logp_prev, const int64_t* teacher, int ld_teacher, int B, int V, float ss_prob,
+                               uint64_t seed, int64_t* it, void* stream) {
+    if (!logp_prev || !teacher || !it || V < 1) { set_error("ss_tokens: null pointer / empty vocabulary"); return EKAID_ERR_ARG; }
+    if (B <= 0) return EKAID_OK;
+    hipLaunchKernelGGL(ss_tokens_kernel, dim3((B + 63) / 64), dim3(64), 0, ST, logp_prev, (const long long*)teacher, ld_teacher, B, V, ss_prob,
+                       DS(seed), (long long*)it);
+    return check_launch("ss_tokens");
+}
 
 extern "C" int ekaid_spk_modmix_fwd(const float* h, int B, int R, const float* w_fc, const float* b_fc, const float* bef,
                                     const float* diff, const float* aft, int A, float* mw, float* att, float* att2, int ld2,

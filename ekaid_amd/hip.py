@@ -139,6 +139,7 @@ SIGNATURES = {
     'ekaid_spk_pos_fwd': [P, I, P, I, I, P, P, I, P, P, F, U64, F, U64, P, P, P, P, I, P],
     'ekaid_spk_pos_bwd': [P, I, P, P, I, I, P, P, P, I, F, U64, F, U64, P, P, I, P],
     'ekaid_spk_gate_bwd': [P, P, P, L, P, P],
+    'ekaid_ss_tokens': [P, P, I, I, I, F, U64, P, P],
     'ekaid_softmax_fwd': [P, P, L, I, I, P],
     'ekaid_softmax_bwd': [P, P, P, L, I, I, P],
     'ekaid_mix3_fwd': [P, P, P, P, I, I, P, P],

@@ -8,8 +8,10 @@ Same constructors, ``_forward`` / ``_sample`` / ``get_logprobs_state`` / ``get_m
     it every step, :98-99); its Dropout is still drawn per step;
   * ``torch.cat`` inputs of the LSTM cells / gate MLP are fed as split-K GEMMs, never materialised;
   * the teacher-forced loop length is found with ONE host synchronisation instead of one per step (:213).
-Not supported (outside the path): multinomial / constrained sampling in ``_sample`` (the entry points decode greedily), scheduled sampling (``ss_prob > 0``: inactive with the shipped
-config, config.py:137), beam search (``beam_size > 1``: broken in the reference, :273).
+Scheduled sampling (``ss_prob > 0``, :197-208; inactive with the shipped config, config.py:137) runs step by step through
+autograd with the token draw on the device (``ekaid_ss_tokens``).
+Not supported (outside the path): multinomial / constrained sampling in ``_sample`` (the entry points decode greedily), beam
+search (``beam_size > 1``: broken in the reference, :273).
 """
 import torch
 import torch.nn as nn
@@ -134,14 +136,13 @@ class DynamicSpeaker(CaptionModel):
 
     def _forward(self, feat_bef, feat_aft, feat_diff, seq, num_steps=None):
         self.module_weights = []
-        if self.training and self.ss_prob > 0.0:
-            raise NotImplementedError('scheduled sampling (ss_prob > 0) is outside the EKAID path')
+        scheduled = self.training and self.ss_prob > 0.0
         batch_size = feat_bef.size(0)
         state = self.init_hidden(batch_size)
         # "break if all the sequences end" (:213): ``num_steps`` (optional, extension) lets the caller supply
         # the count computed on the host copy of the labels; otherwise it costs one device->host read
         steps = num_steps if num_steps is not None else self.count_steps(seq, self.seq_length)
-        if self.fused_sequence:
+        if self.fused_sequence and not scheduled:
             # whole teacher-forced sequence as one autograd node with explicit BPTT (ekaid_amd/speaker_seq.py)
             from ..speaker_seq import speaker_sequence
             tok_tb = seq[:, :steps].t().contiguous()
@@ -156,7 +157,16 @@ class DynamicSpeaker(CaptionModel):
         embed_pre = self.core.embed_pre(feat_bef, feat_aft, feat_diff)
         outs, outs_pos = [], []
         for i in range(steps):
-            output, state, output_pos = self.get_logprobs_state(seq[:, i].contiguous(), feat_bef, feat_aft, feat_diff,
+            it = seq[:, i].contiguous()
+            if scheduled and i >= 1:
+                # scheduled sampling (:197-208): per sample, with probability ss_prob, feed a draw from the previous step's
+                # output distribution instead of the teacher token (step by step: the next input depends on the last output)
+                from ..hip import check, lib, ptr, stream
+                drawn = torch.empty_like(it)
+                check(lib().ekaid_ss_tokens(ptr(outs[-1].detach().contiguous()), seq.data_ptr() + 8 * i, seq.stride(0), batch_size,
+                                            self.vocab_size, float(self.ss_prob), ops.next_seed(), ptr(drawn), stream()), 'ss_tokens')
+                it = drawn
+            output, state, output_pos = self.get_logprobs_state(it, feat_bef, feat_aft, feat_diff,
                                                                 state, embed_pre)
             outs.append(output)
             outs_pos.append(output_pos)

@@ -125,11 +125,9 @@ class ChangeDetector(nn.Module):
             feat_range = torch.arange(0, self.pos_emb_dim / 8)
             self._dim_mat = torch.pow(torch.ones((1,)) * 1000, (8. / self.pos_emb_dim) * feat_range).to(dev)
         bb = bb.to(device=dev, dtype=torch.float64)
-        if self.nongt_dim < bb.shape[1]:
-            # the reference slices the ROW axis of the pair matrix here (mimic_utils.py:186) and then re-reads the
-            # (nongt, N) block as (N, nongt) (graph_att_layer.py:117-126): a scrambled geometry that no shipped
-            # configuration uses (nongt_dim = 52 >= regions per image); refuse rather than guess
-            raise NotImplementedError('implicit relation with nongt_dim < num_rois is not supported')
+        # nongt_dim < regions per image: the reference slices the ROW axis of the pair matrix (mimic_utils.py:186) and then
+        # re-reads the (nongt, N) block as (N, nongt) (graph_att_layer.py:117-126); ekaid_geom_embed reproduces that
+        # re-indexing (no shipped configuration reaches it: nongt_dim = 52 >= regions per image)
         M = min(self.nongt_dim, bb.shape[1])
         return ops.geom_embed(bb, M, self.pos_emb_dim, self._dim_mat)
 

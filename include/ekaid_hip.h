@@ -365,6 +365,12 @@ typedef struct ekaid_spk_step_a_bwd {
 } ekaid_spk_step_a_bwd_t;
 int ekaid_spk_step_a_bwd(const ekaid_spk_step_a_bwd_t* d, void* stream);
 
+/* Scheduled sampling, one decode step for the whole batch: it[b] = teacher[b * ld_teacher] with probability 1 - ss_prob, else a
+ * draw from exp(logp_prev[b][:]) (counter-based uniforms from `seed`; the reference draws with torch.multinomial: same
+ * distribution, its own random stream).   ref: dynamic_speaker_change_pos.py:197-208, schedule train_mimic.py:194-202 */
+int ekaid_ss_tokens(const float* logp_prev, const int64_t* teacher, int ld_teacher, int B, int V, float ss_prob, uint64_t seed,
+                    int64_t* it, void* stream);
+
 /* out[r][c] = dropout(act(x[r*ldx + c] + bias[c]))   (contiguous out; mask index r*cols + c)
  * drop_act_bwd: out[r*ldo + c] = dy[r][c] * keep(seed, r*cols + c)/(1-p) * act'(y[r*ldy + c])  (y = activation output,
  * possibly after the same dropout: a dropped element has zero gradient either way) */

@@ -154,6 +154,20 @@ def gen_f6():
          grad_names=np.array(names), grad_rows=rows)
 
 
+def gen_f7():
+    """F7: IMPLICIT relation with nongt_dim (5) < regions (8): the reference keeps the first 5 ROWS of the pair-geometry matrix
+    (mimic_utils.py:186) and re-reads that (5, 8) block as (8, 5) (graph_att_layer.py:117-126)."""
+    cfg = small_cfg(graph='implicit')
+    cfg.model.change_detector.nongt_dim = 5
+    cd, sp = build(cfg, 30, 31)
+    batch = make_batch(**SMALL)
+    loss, sp_loss, outs, logp, logpos, _ = ref_step(cfg, cd, sp, batch, 'mode2', 'implicit')
+    loss.backward()
+    names, rows = summarize(named_grads(cd, sp))
+    save('f7_implicit_nongt5', loss=loss, feat_bef=outs[3], feat_diff=outs[5], att_bef=outs[1], logp=logp,
+         grad_names=np.array(names), grad_rows=rows)
+
+
 def gen_f2():
     """F2: batch-coupled question attention (quirk Q-C): B=2 vs B=4 sharing 2 samples."""
     cfg = small_cfg(graph='semantic')
@@ -296,6 +310,7 @@ if __name__ == '__main__':
     gen_keys()
     gen_f1()
     gen_f6()
+    gen_f7()
     gen_f2()
     gen_f3()
     gen_mode0()

@@ -405,6 +405,21 @@ def test_explicit_relation_nongt5_matches_reference_golden():
     assert_summary_close(g['grad_names'], g['grad_rows'], named_grads(cd, sp), 1e-3, 'grads[nongt5]')
 
 
+def test_implicit_relation_nongt5_matches_reference_golden():
+    """Implicit relation with nongt_dim < regions: ekaid_geom_embed reproduces the reference's re-read of the row-sliced pair
+    geometry; outputs and gradients against the fixture generated from the reference itself (make_golden.py: gen_f7)."""
+    g = load_golden('f7_implicit_nongt5')
+    cfg = small_cfg(graph='implicit')
+    cfg.model.change_detector.nongt_dim = 5
+    cd, sp = build_models(cfg, 30, 31, DEV)
+    loss, _, outs, logp, _ = hip_step(cfg, cd, sp, make_batch(**SMALL), 'mode2', 'implicit')
+    close(loss, g['loss'], 1e-4, 'loss')
+    close(logp, g['logp'], LOGIT_TOL, 'logp')
+    close(outs[3], g['feat_bef'], 1e-4, 'feat_bef')
+    loss.backward()
+    assert_summary_close(g['grad_names'], g['grad_rows'], named_grads(cd, sp), 1e-3, 'grads[implicit nongt5]')
+
+
 def test_explicit_encoders_with_fewer_neighbours_than_nodes():
     """nongt_dim < N on the explicit graphs (keys/values restricted to the first M nodes, graph_att_layer.py:74-101)."""
     for graph in ('semantic', 'spatial'):
@@ -412,11 +427,11 @@ def test_explicit_encoders_with_fewer_neighbours_than_nodes():
         cfg.model.change_detector.nongt_dim = 5
         cd, sp = build_models(cfg, 30, 31, DEV)
         _oracle_vs_hip(cfg, cd, sp, make_batch(**SMALL), graph, check=('img.weight', 'context1.weight'))
+    # implicit relation: the reference's row-sliced, re-read pair geometry (mimic_utils.py:186 + graph_att_layer.py:117-126)
     cfg = small_cfg(graph='implicit')
     cfg.model.change_detector.nongt_dim = 5
     cd, sp = build_models(cfg, 30, 31, DEV)
-    with pytest.raises(NotImplementedError):
-        hip_step(cfg, cd, sp, make_batch(**SMALL), 'mode2', 'implicit')
+    _oracle_vs_hip(cfg, cd, sp, make_batch(**SMALL), 'implicit', check=('img.weight', 'context1.weight'))
 
 
 def test_batch_of_one_and_empty_image_flag():
@@ -529,3 +544,41 @@ def test_training_step_is_bit_reproducible():
         losses.append(ls)
     assert losses[0] == losses[1] == losses[2], losses
     assert torch.equal(finals[0], finals[1]) and torch.equal(finals[0], finals[2])
+
+
+def test_scheduled_sampling_draws_from_the_previous_distribution_and_trains():
+    """ss_prob > 0 (dynamic_speaker_change_pos.py:197-208): (i) the device draw replaces a teacher token with probability
+    ss_prob by a sample of exp(logp_prev) -- frequencies checked against the distribution; (ii) _forward in train mode runs step
+    by step with those tokens, stays finite, back-propagates, and at ss_prob = 0 the fused node is used again."""
+    from ekaid_amd import hip, ops
+    from ekaid_amd.hip import check, ptr, stream
+    B, V = 4096, 7
+    probs = torch.tensor([0.05, 0.4, 0.0, 0.25, 0.1, 0.15, 0.05])
+    logp = torch.log(probs.clamp_min(1e-30)).repeat(B, 1).to(DEV)
+    teacher = torch.full((B, 3), 6, dtype=torch.int64, device=DEV)
+    it = torch.empty(B, dtype=torch.int64, device=DEV)
+    check(hip.lib().ekaid_ss_tokens(ptr(logp), teacher.data_ptr() + 8, 3, B, V, 1.0, 1234, ptr(it), stream()), 'ss_tokens')
+    freq = torch.bincount(it.cpu(), minlength=V).float() / B
+    assert float((freq - probs).abs().max()) < 0.03 and float(freq[2]) == 0.0, freq
+    check(hip.lib().ekaid_ss_tokens(ptr(logp), teacher.data_ptr() + 8, 3, B, V, 0.25, 99, ptr(it), stream()), 'ss_tokens')
+    kept = float((it.cpu() == 6).float().mean())
+    assert abs(kept - (0.75 + 0.25 * 0.05)) < 0.03, kept
+    check(hip.lib().ekaid_ss_tokens(ptr(logp), teacher.data_ptr() + 8, 3, B, V, 0.0, 5, ptr(it), stream()), 'ss_tokens')
+    assert bool((it == 6).all())
+    # model level
+    cfg, cd, sp = small_models('all', device=DEV)
+    sp.train()
+    cd.train()
+    batch = to_device(make_batch(**SMALL), DEV)
+    ops.manual_seed(7)
+    sp.ss_prob = 0.5
+    loss, _, outs, logp_ss, _ = hip_step(cfg, cd, sp, batch, 'mode2', 'all')
+    assert torch.isfinite(logp_ss).all() and torch.isfinite(loss)
+    loss.backward()
+    g = sp.logit.weight.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
+    sp.ss_prob = 0.0
+    sp.eval(); cd.eval()                                          # noqa: E702
+    with torch.no_grad():
+        _, _, _, logp_tf, _ = hip_step(cfg, cd, sp, batch, 'mode2', 'all')
+    assert torch.isfinite(logp_tf).all()

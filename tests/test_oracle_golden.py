@@ -64,6 +64,18 @@ def test_f6_explicit_relation_with_fewer_neighbours_than_nodes():
     assert_summary_close(g['grad_names'], g['grad_rows'], named, 2e-4, 'grads[nongt5]')
 
 
+def test_f7_implicit_relation_with_fewer_neighbours_than_nodes():
+    """The reference's row-sliced, re-read pair geometry (mimic_utils.py:186 + graph_att_layer.py:117-126): oracle == reference."""
+    g = load_golden('f7_implicit_nongt5')
+    cfg, cd, sp = small_models('implicit')
+    cfg.model.change_detector.nongt_dim = 5
+    loss, res, named = run_oracle(cfg, cd, sp, make_batch(**SMALL), 'mode2', 'implicit')
+    close(loss, g['loss'], what='loss')
+    close(res['logp'], g['logp'], what='logp')
+    close(res['outs'][3], g['feat_bef'], what='feat_bef')
+    assert_summary_close(g['grad_names'], g['grad_rows'], named, 2e-4, 'grads[implicit nongt5]')
+
+
 def test_f1_mode0_ssre_layernorm():
     g = load_golden('f1_mode0')
     cfg, cd, sp = small_models('all', 'mode0')

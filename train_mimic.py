@@ -269,6 +269,13 @@ def main(argv=None):
     while t < cfg.train.max_iter:
         say('Starting epoch %d' % epoch)
         optimizer.lr = step_lr(o.lr, o.gamma, o.step_size, epoch)
+        tr = cfg.train
+        if epoch > tr.scheduled_sampling_start and tr.scheduled_sampling_start >= 0:       # train_mimic.py:194-202
+            frac = (epoch - tr.scheduled_sampling_start) // tr.scheduled_sampling_increase_every
+            ss = min(tr.scheduled_sampling_increase_prob * frac, tr.scheduled_sampling_max_prob)
+            if ss != speaker.ss_prob:
+                say('Updating scheduled sampling rate: %.4f -> %.4f' % (speaker.ss_prob, ss))
+            speaker.ss_prob = ss
         if epoch_rng is not None:
             torch.set_rng_state(epoch_rng)                  # resumed mid-epoch: the sampler redraws the same permutation
         rng_at_epoch_start = torch.get_rng_state()
