@@ -131,15 +131,27 @@ def cpu_baseline(cfg, cd, sp, batch_size, graph, budget_s=25.0):
         bb = {k: v.to(dev) for k, v in batch.items()}
         T = SHAPE['T']
         _, _, _, logp = forward_loss(cfg, cd, sp, bb, T, graph)
+        from ekaid_amd import ops
+        logp_x2 = None
+        if ops.get_gemm_mode() == ops.GEMM_BF16_SPLIT:
+            ops.set_gemm_mode(ops.GEMM_BF16X2)
+            try:
+                _, _, _, logp_x2 = forward_loss(cfg, cd, sp, bb, T, graph)
+            finally:
+                ops.set_gemm_mode(ops.GEMM_BF16_SPLIT)
         cd.train(was[0])
         sp.train(was[1])
         ref = res['logp'][:, :T]
-        got = logp[:, :T].cpu()
-        d = (got - ref).abs()
-        parity = {'logit_max_abs_delta': float(d.max()),
-                  'logit_max_rel_delta_to_range': float(d.max() / ref.abs().max()),
-                  'logit_max_elementwise_rel_delta': float((d / ref.abs().clamp_min(1e-6)).max()),
-                  'argmax_identical': bool(torch.equal(got.argmax(-1), ref.argmax(-1)))}
+
+        def deltas(lp):
+            got = lp[:, :T].cpu()
+            d = (got - ref).abs()
+            return {'logit_max_abs_delta': float(d.max()),
+                    'logit_max_rel_delta_to_range': float(d.max() / ref.abs().max()),
+                    'logit_max_elementwise_rel_delta': float((d / ref.abs().clamp_min(1e-6)).max()),
+                    'argmax_identical': bool(torch.equal(got.argmax(-1), ref.argmax(-1)))}
+        parity = deltas(logp)
+        parity_x2 = deltas(logp_x2) if logp_x2 is not None else None
         t0 = time.perf_counter()
         O.train_loss(Pcd, Psp, cfg, batch, 'mode2', graph)
         fwd_s.append(time.perf_counter() - t0)
@@ -153,6 +165,7 @@ def cpu_baseline(cfg, cd, sp, batch_size, graph, budget_s=25.0):
     dt = (time.perf_counter() - t0) / iters
     return {'value': round(batch_size / dt, 3), 'unit': 'QA-pairs/s', 'cores': cores, 'kind': 'port',
             'eval_forward_pairs_per_s': round(batch_size / min(fwd_s), 3), 'parity_vs_hip': parity,
+            'parity_vs_hip_bf16x2': parity_x2,
             'sample': 'CPU oracle (PyTorch %s, %d threads = physical cores of this host, %d logical) full train step '
                       '(forward + backward + torch.optim.Adam) at batch %d: %d timed iterations after 1 warm-up; eval '
                       'forward at batch %d: best of 2; same shapes and weights as the GPU run, dropout off' % (
@@ -392,6 +405,18 @@ def main():
         extra['greedy_decode_b64'] = {'ms': round(msd, 3), 'pairs_per_s': round(64 / msd * 1e3, 1), 'decode_steps_run': nsteps,
                                       'workload': 'eval forward (teacher-forced pass included, as test_mimic.py:116-122 runs it) + '
                                                   'greedy _sample, batch 64'}
+        # opt-in reduced-precision GEMM arithmetic (two bf16 terms per operand, three products): the same train step, NOT the
+        # metric's arithmetic -- reported beside it with its measured log-prob deviation (cpu_baseline.parity_vs_hip_bf16x2)
+        if ops.get_gemm_mode() == ops.GEMM_BF16_SPLIT:
+            ops.set_gemm_mode(ops.GEMM_BF16X2)
+            try:
+                msx2 = timed(lambda: eager(b, T), 20, 3)
+            finally:
+                ops.set_gemm_mode(ops.GEMM_BF16_SPLIT)
+            extra['train_b%d_bf16x2' % per_gpu] = {
+                'ms_per_step': round(msx2, 3), 'pairs_per_s': round(per_gpu / msx2 * 1e3, 1),
+                'workload': 'the timed train step on the OPT-IN bf16x2 GEMM arithmetic (EKAID_GEMM_MODE=bf16x2: 16-17 significant bits per '
+                            'operand, 3 MFMA products instead of 6); reduced precision, not comparable with `value`'}
         h90 = make_batch(B=per_gpu, seed=78, **dict(SHAPE, T=90))
         b90 = {k: v.to(dev) for k, v in h90.items()}
         T90 = DynamicSpeaker.count_steps(h90['labels'], SHAPE['seq_length'])

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace ekaid {
 static thread_local char g_err[512] = "";
@@ -38,8 +39,10 @@ struct DeviceState {
 static DeviceState g_dev[MAX_DEVICES];
 
 static int default_gemm_mode() {
-    const char* m = getenv("EKAID_GEMM_MODE");
-    return (m && (m[0] == 'f' || m[0] == '0')) ? 0 : 1;
+    const char* m = getenv("EKAID_GEMM_MODE");       // "f32" / "0": f32 MFMA; "bf16x2" / "2": reduced-precision split; default: exact split
+    if (m && (m[0] == 'f' || m[0] == '0')) return 0;
+    if (m && (strcmp(m, "2") == 0 || strcmp(m, "bf16x2") == 0)) return 2;
+    return 1;
 }
 DeviceState& device_state() {
     int d = 0;

@@ -422,7 +422,22 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // equally exact, but the 64-bit register pairs of the packed subtracts push the 128x128 kernel over its 168-VGPR budget
 // (62-179 spilled registers in the k-contiguous variants: 2.5x slower) and, applied only where it fits, measured no
 // faster: 182 vs 187 TF on the wgrad form.)
+// NP = 3: exact split (h + m + l == v).  NP = 2 (EKAID_GEMM_BF16X2, opt-in): h + m only, m rounded to nearest -- 16-17
+// significant bits per operand, three products per block instead of six (L is left untouched).
+template <int NP = 3>
 __device__ __forceinline__ void split4(const f32x4& v, u32x2& H, u32x2& M, u32x2& L) {
+    if constexpr (NP == 2) {
+        unsigned u[4], m[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            u[e] = __float_as_uint(v[e]);
+            const float r1 = v[e] - __uint_as_float(u[e] & 0xFFFF0000u);
+            m[e] = __float_as_uint(r1) + 0x8000u;              // round the residual to the nearest bf16 (ties up)
+        }
+        H[0] = __builtin_amdgcn_perm(u[1], u[0], 0x07060302u); H[1] = __builtin_amdgcn_perm(u[3], u[2], 0x07060302u);
+        M[0] = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u); M[1] = __builtin_amdgcn_perm(m[3], m[2], 0x07060302u);
+        return;
+    }
 #if EKAID_SPLIT_ABLATE == 2              // timing-only: no split arithmetic (three copies of the raw words)
     H[0] = __float_as_uint(v[0]); H[1] = __float_as_uint(v[1]); M[0] = __float_as_uint(v[2]); M[1] = __float_as_uint(v[3]); L = H;
     return;
@@ -472,8 +487,9 @@ __device__ __forceinline__ int mc_read_off(int k, int row0, int tg, int tp) {   
 
 // PF = K-steps of global loads kept in flight (1: the next step's loads hide under this step's MFMAs -- enough for the
 // large tiles; 2: for the 64x64 tile, whose 12 MFMAs per 32-deep step are far shorter than a load round trip)
-template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE>
+template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE, int NP = 3>
 __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int block_x, const int z) {
+    static_assert(NP == 2 || NP == 3, "planes per operand");
     static_assert(!PIPE || (KB == 32 && PF == 1), "the pipelined loop shares the 32-deep LDS footprint");
     constexpr int BM = 64 * TM, BN = 64 * TN;
     static_assert(KB == 32 || KB == 64 || KB == 128, "K-step");
@@ -482,7 +498,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
     constexpr int B_RS = B_KC ? 2 * KB : 2 * BN;
     constexpr int A_PLANE = (A_KC ? BM : KB) * A_RS;
     constexpr int B_PLANE = (B_KC ? BN : KB) * B_RS;
-    constexpr int A_BYTES = 3 * A_PLANE;
+    constexpr int A_BYTES = NP * A_PLANE;
     constexpr int A_V4 = BM * KB / 4 / 256;
     constexpr int B_V4 = BN * KB / 4 / 256;
     constexpr int NCH = KB / 16;                          // 16-k MFMA chunks per K-step
@@ -565,20 +581,20 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
             const int idx = tid + i * 256;
             const int off = A_KC ? kc_store_off<KB>(idx) : mc_store_off<BM>(idx);
             u32x2 H, M, L;
-            split4(ra[S][i], H, M, L);
+            split4<NP>(ra[S][i], H, M, L);
             *reinterpret_cast<u32x2*>(ldsA + off) = H;
             *reinterpret_cast<u32x2*>(ldsA + A_PLANE + off) = M;
-            *reinterpret_cast<u32x2*>(ldsA + 2 * A_PLANE + off) = L;
+            if constexpr (NP == 3) *reinterpret_cast<u32x2*>(ldsA + 2 * A_PLANE + off) = L;
         }
 #pragma unroll
         for (int i = 0; i < B_V4; ++i) {
             const int idx = tid + i * 256;
             const int off = B_KC ? kc_store_off<KB>(idx) : mc_store_off<BN>(idx);
             u32x2 H, M, L;
-            split4(rb[S][i], H, M, L);
+            split4<NP>(rb[S][i], H, M, L);
             *reinterpret_cast<u32x2*>(ldsB + off) = H;
             *reinterpret_cast<u32x2*>(ldsB + B_PLANE + off) = M;
-            *reinterpret_cast<u32x2*>(ldsB + 2 * B_PLANE + off) = L;
+            if constexpr (NP == 3) *reinterpret_cast<u32x2*>(ldsB + 2 * B_PLANE + off) = L;
         }
     };
     // per-lane offsets of the fragment reads (bytes inside a plane): see the image layouts above
@@ -606,30 +622,33 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
             return __builtin_bit_cast(bf16x8, v);
         }
     };
+    auto products = [&](f32x16& c, const bf16x8 (&a)[NP], const bf16x8 (&b)[NP]) {
+        if constexpr (NP == 3) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+        }
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+    };
     auto compute = [&]() {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            bf16x8 fa[TM][3], fb[TN][3];
+            bf16x8 fa[TM][NP], fb[TN][NP];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) fa[i][p] = frag(ldsA + p * A_PLANE, a_off[i][c], A_KC, A_RS);
+                for (int p = 0; p < NP; ++p) fa[i][p] = frag(ldsA + p * A_PLANE, a_off[i][c], A_KC, A_RS);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) fb[j][p] = frag(ldsB + p * B_PLANE, b_off[j][c], B_KC, B_RS);
+                for (int p = 0; p < NP; ++p) fb[j][p] = frag(ldsB + p * B_PLANE, b_off[j][c], B_KC, B_RS);
             // smallest terms first
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < TN; ++j) products(acc[i][j], fa[i], fb[j]);
         }
     };
     auto mainloop = [&](auto fast_tag) {
@@ -714,7 +733,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
         constexpr int PA = BM * KS / 4 / 256, PB = BN * KS / 4 / 256;       // float4 per thread per stage
         constexpr int SA_RS = A_KC ? 2 * KS : 2 * BM, SB_RS = B_KC ? 2 * KS : 2 * BN;
         constexpr int SA_PLANE = (A_KC ? BM : KS) * SA_RS, SB_PLANE = (B_KC ? BN : KS) * SB_RS;
-        constexpr int STAGE_BYTES = 3 * (SA_PLANE + SB_PLANE);
+        constexpr int STAGE_BYTES = NP * (SA_PLANE + SB_PLANE);
         unsigned vA[PA], vB[PB];
         int stA[PA], stB[PB];                 // LDS store offsets inside a plane
 #pragma unroll
@@ -762,38 +781,33 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
         };
         auto cvt1 = [&](const f32x4& v, char* base, int plane, int off) {
             u32x2 H, M, L;
-            split4(v, H, M, L);
+            split4<NP>(v, H, M, L);
             *reinterpret_cast<u32x2*>(base + off) = H;
             *reinterpret_cast<u32x2*>(base + plane + off) = M;
-            *reinterpret_cast<u32x2*>(base + 2 * plane + off) = L;
+            if constexpr (NP == 3) *reinterpret_cast<u32x2*>(base + 2 * plane + off) = L;
         };
         // one stage: multiply out buffer `cur`, convert register set S into buffer `cur ^ 1`
         auto stage = [&](auto set_tag, int cur, bool convert) {
             constexpr int S = decltype(set_tag)::value;
             char* const cA = ldsA + cur * STAGE_BYTES;
-            char* const cB = cA + 3 * SA_PLANE;
+            char* const cB = cA + NP * SA_PLANE;
             char* const nA = ldsA + (cur ^ 1) * STAGE_BYTES;
-            char* const nB = nA + 3 * SA_PLANE;
-            bf16x8 fa[TM][3], fb[TN][3];
+            char* const nB = nA + NP * SA_PLANE;
+            bf16x8 fa[TM][NP], fb[TN][NP];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) fa[i][p] = frag(cA + p * SA_PLANE, fA[i], A_KC, SA_RS);
+                for (int p = 0; p < NP; ++p) fa[i][p] = frag(cA + p * SA_PLANE, fA[i], A_KC, SA_RS);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) fb[j][p] = frag(cB + p * SB_PLANE, fB[j], B_KC, SB_RS);
+                for (int p = 0; p < NP; ++p) fb[j][p] = frag(cB + p * SB_PLANE, fB[j], B_KC, SB_RS);
             constexpr int NCV = PA + PB;                        // conversions to spread over the TM*TN product groups
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                    products(acc[i][j], fa[i], fb[j]);
                     if (convert) {
                         const int grp = i * TN + j;
 #pragma unroll
@@ -813,7 +827,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
 #pragma unroll
         for (int c = 0; c < PA; ++c) cvt1(pa[0][c], ldsA, SA_PLANE, stA[c]);
 #pragma unroll
-        for (int c = 0; c < PB; ++c) cvt1(pb[0][c], ldsA + 3 * SA_PLANE, SB_PLANE, stB[c]);
+        for (int c = 0; c < PB; ++c) cvt1(pb[0][c], ldsA + NP * SA_PLANE, SB_PLANE, stB[c]);
         gload16(S0{}, 2);
         __syncthreads();
         for (int s0 = 0; s0 < nst; s0 += 2) {
@@ -852,25 +866,26 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
     write_tiles<TM, TN>(g, acc, m0, n0, wm, wn, r, h, z);
 }
 
-template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE>
+template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE, int NP = 3>
 __global__ __launch_bounds__(256, (TM * TN >= 4 ? EKAID_SPLIT_OCC_BIG : (TM * TN == 2 ? 2 : EKAID_SPLIT_OCC_SMALL))) void gemm_split_kernel(GemmArgs g) {
-    gemm_split_body<A_KC, B_KC, TM, TN, KB, PF, PIPE>(g, blockIdx.x, blockIdx.z);
+    gemm_split_body<A_KC, B_KC, TM, TN, KB, PF, PIPE, NP>(g, blockIdx.x, blockIdx.z);
 }
 
 // TWO independent products of the same operand layout in one launch (64x64 tiles): workgroups [0, tiles of g0) work on g0,
 // the rest on g1; grid.z = the larger of the two K splits, a workgroup beyond its own problem's split count leaves at once.
 // For the recurrent steps, where two small GEMMs of one step have no dependence on each other (ekaid_gemm_slabs2).
-template <bool A_KC, bool B_KC, bool BIG>
+template <bool A_KC, bool B_KC, bool BIG, int NP = 3>
 __global__ __launch_bounds__(256, BIG ? EKAID_SPLIT_OCC_BIG : EKAID_SPLIT_OCC_SMALL) void gemm_split_pair_kernel(GemmArgs g0, GemmArgs g1) {
     const int n0 = g0.tiles_m * g0.tiles_n;
     const bool first = (int)blockIdx.x < n0;
     const GemmArgs& g = first ? g0 : g1;
     if ((int)blockIdx.z >= g.splitk) return;
     const int bx = first ? blockIdx.x : blockIdx.x - n0;
-    if constexpr (BIG) gemm_split_body<A_KC, B_KC, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG>(g, bx, blockIdx.z);
-    else gemm_split_body<A_KC, B_KC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL, false>(g, bx, blockIdx.z);
+    if constexpr (BIG) gemm_split_body<A_KC, B_KC, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG, NP>(g, bx, blockIdx.z);
+    else gemm_split_body<A_KC, B_KC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL, false, NP>(g, bx, blockIdx.z);
 }
 
+#ifndef EKAID_GEMM_X2_TU      // (non-template kernels: defined once, in the main translation unit)
 // ---- tall-skinny wgrad: C[M][N] = A^T . B with M * N <= 256 outputs and a very long contraction (the label-bias and
 // pair-geometry layers: 1 x 11 and 4 x 64 outputs over K = R * N * N = 663 552 rows at B = 256).  As a tiled GEMM this is one
 // 64x64 tile cut into ~770 K slabs with scalar operand loads (M, N not multiples of 4): 113-146 us for 30-180 MB.  Here:
@@ -1019,6 +1034,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __r
     *cp = o;
 }
 
+#endif
+
 template <bool A_KC, bool B_KC, int TM, int TN, int KB>
 static int launch(const GemmArgs& a, int batch, hipStream_t st) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -1041,11 +1058,11 @@ static int launch(const GemmArgs& a, int batch, hipStream_t st) {
     return EKAID_OK;
 }
 
-template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE>
+template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE, int NP = 3>
 static int launch_split(const GemmArgs& a, int batch, hipStream_t st) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr size_t lds = 3 * 2 * KB * (BM + BN);      // three bf16 planes per operand, unpadded
-    auto kern = gemm_split_kernel<A_KC, B_KC, TM, TN, KB, PF, PIPE>;
+    constexpr size_t lds = NP * 2 * KB * (BM + BN);     // NP bf16 planes per operand, unpadded
+    auto kern = gemm_split_kernel<A_KC, B_KC, TM, TN, KB, PF, PIPE, NP>;
     if (lds > 64 * 1024) {
         constexpr int slot = 16 + (A_KC ? 1 : 0) + (B_KC ? 2 : 0) + 4 * (TM - 1) + 8 * (TN - 1);
         if (func_attr_once(slot)) {
@@ -1074,7 +1091,7 @@ static int plan_splitk(int tiles, int K, int batch, long long MN, int BK, bool b
     // 64x64 tiles, one workgroup per CU already: a 2-way split + reduce kernel measured no faster (256x6656x512: 23 vs 24 us).
     // (128x128 tiles are different: 256 tiles leave two of the three workgroup slots of every CU empty for the whole K
     // range -- wgrad 1024x4096x18432: 156-162 TF unsplit, 199 TF as 3 x 256 workgroups + reduce)
-    if (tiles >= 256 && gemm_mode() == 1 && !big_tiles) return 1;
+    if (tiles >= 256 && gemm_mode() >= 1 && !big_tiles) return 1;
     // as many slabs as still fit ONE wave of resident workgroups: rounding up (144 tiles -> 6 slabs = 864 workgroups on 768
     // slots) left a second, nearly empty wave that doubled the time of the 2304-row products (61 -> 44 us at 32 pairs / GPU)
     int s = target / tiles;
@@ -1102,7 +1119,7 @@ static void plan(const ekaid_gemm_t* d, int& TMN, int& splitk, int& tiles_m, int
     // bf16-split arithmetic, tall outputs with ONE 128-wide column tile or a 128-deep contraction (the 128-unit attention
     // layers, M = 9216): 72 tiles of 128x128 cannot fill the chip; measured 35.0 -> 28.5 us (nt 9216x128x1024 as 128x64
     // tiles) and 35.1 -> 28.7 us (nn 9216x1024x128 as 64x64 tiles)
-    if (TMN == 2 && batch == 1 && gemm_mode() == 1 && d->M >= 4096 && !d->transA) {
+    if (TMN == 2 && batch == 1 && gemm_mode() >= 1 && d->M >= 4096 && !d->transA) {
         if (d->transB && d->N <= 128) TMN = 3;
         else if (!d->transB && d->K <= 128) TMN = 1;
     }
@@ -1117,7 +1134,7 @@ static void plan(const ekaid_gemm_t* d, int& TMN, int& splitk, int& tiles_m, int
     const int bn = TMN == 3 ? 64 : (TMN == 4 ? 128 : 64 * TMN);
     tiles_m = cdiv(d->M, bm);
     tiles_n = cdiv(d->N, bn);
-    splitk = plan_splitk(tiles_m * tiles_n, d->K, batch, (long long)d->M * d->N, TMN >= 2 ? BK_BIG : (gemm_mode() == 1 && TMN == 1 ? EKAID_SPLIT_KB_SMALL : BK_SMALL), TMN == 2);
+    splitk = plan_splitk(tiles_m * tiles_n, d->K, batch, (long long)d->M * d->N, TMN >= 2 ? BK_BIG : (gemm_mode() >= 1 && TMN == 1 ? EKAID_SPLIT_KB_SMALL : BK_SMALL), TMN == 2);
 }
 
 // shapes of tn_skinny_kernel: (workgroups, outputs rounded up to a power of two), or false
@@ -1144,7 +1161,7 @@ static bool skinny_tn(const ekaid_gemm_t* d, int& G, int& NO) {
 static void plan_full(const ekaid_gemm_t* d, int& TMN, int& splitk, int& k_per_split, int& tiles_m, int& tiles_n) {
     plan(d, TMN, splitk, tiles_m, tiles_n);
     if (d->K == 0) splitk = 1;
-    const int BK = (TMN == 3 || TMN == 4 ? BK_HALF : (TMN >= 2 ? BK_BIG : (gemm_mode() == 1 && TMN == 1 ? EKAID_SPLIT_KB_SMALL : BK_SMALL)));
+    const int BK = (TMN == 3 || TMN == 4 ? BK_HALF : (TMN >= 2 ? BK_BIG : (gemm_mode() >= 1 && TMN == 1 ? EKAID_SPLIT_KB_SMALL : BK_SMALL)));
     k_per_split = cdiv(cdiv(d->K, BK), splitk) * BK;
     if (splitk > 1) {
         splitk = cdiv(d->K, k_per_split);
@@ -1190,18 +1207,28 @@ static int big_arm(bool akc, bool bkc) {
     return (akc && bkc) ? 1 : 0;
 }
 
+// the split-arithmetic kernels of one plane count: tile shape TMN from the planner, K-loop arm per operand layout
+template <int NP>
+static int split_dispatch(const GemmArgs& a, int TMN, bool akc, bool bkc, int batch, hipStream_t st) {
+#define EKAID_LAUNCH_SPLIT(AK, BKC) (TMN == 2 ? (big_arm(AK, BKC) == 1 ? launch_split<AK, BKC, 2, 2, 32, 1, false, NP>(a, batch, st) \
+                                                  : launch_split<AK, BKC, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG, NP>(a, batch, st)) \
+                                     : TMN == 1 ? launch_split<AK, BKC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL, false, NP>(a, batch, st) \
+                                     : TMN == 3 ? launch_split<AK, BKC, 2, 1, 32, 1, false, NP>(a, batch, st) : launch_split<AK, BKC, 1, 2, 32, 1, false, NP>(a, batch, st))
+    if (akc && bkc) return EKAID_LAUNCH_SPLIT(true, true);
+    if (akc && !bkc) return EKAID_LAUNCH_SPLIT(true, false);
+    return EKAID_LAUNCH_SPLIT(false, false);
+#undef EKAID_LAUNCH_SPLIT
+}
+// (the reduced-precision instantiations live in their own translation unit, gemm_x2.hip, so that the two compile in parallel)
+int split_dispatch_x2(const GemmArgs& a, int TMN, bool akc, bool bkc, int batch, hipStream_t st);
+int pair_dispatch_x2(const GemmArgs& a0, const GemmArgs& a1, bool big, bool akc, bool bkc, hipStream_t st);
+
+#ifndef EKAID_GEMM_X2_TU
 // the product kernel of one planned GEMM (arithmetic per device state, tile shape TMN from the planner)
 static int launch_product(const GemmArgs& a, int TMN, bool akc, bool bkc, int batch, hipStream_t st) {
     int rc;
-    if (gemm_mode() == 1 && TMN >= 1 && TMN <= 4) {
-#define EKAID_LAUNCH_SPLIT(AK, BKC) (TMN == 2 ? (big_arm(AK, BKC) == 1 ? launch_split<AK, BKC, 2, 2, 32, 1, false>(a, batch, st) \
-                                                  : launch_split<AK, BKC, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG>(a, batch, st)) \
-                                     : TMN == 1 ? launch_split<AK, BKC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL, false>(a, batch, st) \
-                                     : TMN == 3 ? launch_split<AK, BKC, 2, 1, 32, 1, false>(a, batch, st) : launch_split<AK, BKC, 1, 2, 32, 1, false>(a, batch, st))
-        if (akc && bkc) rc = EKAID_LAUNCH_SPLIT(true, true);
-        else if (akc && !bkc) rc = EKAID_LAUNCH_SPLIT(true, false);
-        else rc = EKAID_LAUNCH_SPLIT(false, false);
-#undef EKAID_LAUNCH_SPLIT
+    if (gemm_mode() >= 1 && TMN >= 1 && TMN <= 4) {
+        rc = gemm_mode() == 2 ? split_dispatch_x2(a, TMN, akc, bkc, batch, st) : split_dispatch<3>(a, TMN, akc, bkc, batch, st);
     } else {
 #define EKAID_LAUNCH(AK, BKC) (TMN == 2 ? launch<AK, BKC, 2, 2, BK_BIG>(a, batch, st) : TMN == 1 ? launch<AK, BKC, 1, 1, BK_SMALL>(a, batch, st) \
                                : TMN == 3 ? launch<AK, BKC, 2, 1, BK_HALF>(a, batch, st) : launch<AK, BKC, 1, 2, BK_HALF>(a, batch, st))
@@ -1213,23 +1240,36 @@ static int launch_product(const GemmArgs& a, int TMN, bool akc, bool bkc, int ba
     if (rc) return rc;
     return check_launch("gemm kernel");
 }
+#endif
 
-template <bool AK, bool BKC, bool BIG>
+template <bool AK, bool BKC, bool BIG, int NP = 3>
 static int launch_pair(const GemmArgs& a0, const GemmArgs& a1, hipStream_t st) {
     constexpr int KB = BIG ? 32 : EKAID_SPLIT_KB_SMALL;
-    constexpr size_t lds = 3 * 2 * KB * (BIG ? 256 : 128);
+    constexpr size_t lds = NP * 2 * KB * (BIG ? 256 : 128);
     static_assert(lds <= 64 * 1024, "pair kernel: the tiles fit the default dynamic LDS limit");
     const int sk = a0.splitk > a1.splitk ? a0.splitk : a1.splitk;
     dim3 grid(a0.tiles_m * a0.tiles_n + a1.tiles_m * a1.tiles_n, 1, sk);
-    hipLaunchKernelGGL((gemm_split_pair_kernel<AK, BKC, BIG>), grid, dim3(256), lds, st, a0, a1);
+    hipLaunchKernelGGL((gemm_split_pair_kernel<AK, BKC, BIG, NP>), grid, dim3(256), lds, st, a0, a1);
     return check_launch("gemm_split_pair_kernel");
 }
+template <int NP>
+static int pair_dispatch(const GemmArgs& a0, const GemmArgs& a1, bool big, bool akc, bool bkc, hipStream_t st) {
+#define EKAID_PAIR(BIG) (akc && bkc ? launch_pair<true, true, BIG, NP>(a0, a1, st) \
+                         : akc && !bkc ? launch_pair<true, false, BIG, NP>(a0, a1, st) : launch_pair<false, false, BIG, NP>(a0, a1, st))
+    return big ? EKAID_PAIR(true) : EKAID_PAIR(false);
+#undef EKAID_PAIR
+}
+#ifdef EKAID_GEMM_X2_TU
+int split_dispatch_x2(const GemmArgs& a, int TMN, bool akc, bool bkc, int batch, hipStream_t st) { return split_dispatch<2>(a, TMN, akc, bkc, batch, st); }
+int pair_dispatch_x2(const GemmArgs& a0, const GemmArgs& a1, bool big, bool akc, bool bkc, hipStream_t st) { return pair_dispatch<2>(a0, a1, big, akc, bkc, st); }
+#endif
 }  // namespace ekaid
 
+#ifndef EKAID_GEMM_X2_TU
 using namespace ekaid;
 
 extern "C" int ekaid_set_gemm_mode(int mode) {
-    if (mode != 0 && mode != 1) { set_error("ekaid_set_gemm_mode: mode must be 0 (f32 MFMA) or 1 (bf16 3-way split)"); return EKAID_ERR_ARG; }
+    if (mode < 0 || mode > 2) { set_error("ekaid_set_gemm_mode: mode must be 0 (f32 MFMA), 1 (exact bf16 3-way split) or 2 (bf16x2, reduced precision)"); return EKAID_ERR_ARG; }
     return set_gemm_mode(mode);
 }
 extern "C" int ekaid_get_gemm_mode(void) { return gemm_mode(); }
@@ -1349,18 +1389,13 @@ extern "C" int ekaid_gemm_slabs2(const ekaid_gemm_t* d0, float* slabs0, size_t s
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const bool same = (d0->transA != 0) == (d1->transA != 0) && (d0->transB != 0) == (d1->transB != 0);
-    if (gemm_mode() != 1 || T0 != T1 || (T0 != 1 && T0 != 2) || !same) {  // outside the pair kernel's envelope: two launches, same results
+    if (gemm_mode() < 1 || T0 != T1 || (T0 != 1 && T0 != 2) || !same) {  // outside the pair kernel's envelope: two launches, same results
         rc = launch_product(a0, T0, !d0->transA, d0->transB != 0, 1, st);
         if (rc) return rc;
         return launch_product(a1, T1, !d1->transA, d1->transB != 0, 1, st);
     }
     const bool akc = !d0->transA, bkc = d0->transB != 0;
-    if (T0 == 2) {
-        if (akc && bkc) return launch_pair<true, true, true>(a0, a1, st);
-        if (akc && !bkc) return launch_pair<true, false, true>(a0, a1, st);
-        return launch_pair<false, false, true>(a0, a1, st);
-    }
-    if (akc && bkc) return launch_pair<true, true, false>(a0, a1, st);
-    if (akc && !bkc) return launch_pair<true, false, false>(a0, a1, st);
-    return launch_pair<false, false, false>(a0, a1, st);
+    if (gemm_mode() == 2) return pair_dispatch_x2(a0, a1, T0 == 2, akc, bkc, st);
+    return pair_dispatch<3>(a0, a1, T0 == 2, akc, bkc, st);
 }
+#endif      // EKAID_GEMM_X2_TU

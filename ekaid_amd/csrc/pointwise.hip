@@ -73,14 +73,24 @@ __global__ __launch_bounds__(256) void scale_finish_kernel(float* G, const float
 }
 
 // ---- weight norm of MANY layers at once (the weights do not change inside a step: all norms in two launches at its start)
-constexpr int WN_MULTI_MAX = 32, WN_MULTI_NB = 32;
+constexpr int WN_MULTI_MAX = 32, WN_MULTI_NB = 128;
 struct WnMulti { const float* v[WN_MULTI_MAX]; const float* g[WN_MULTI_MAX]; long long n[WN_MULTI_MAX]; int count; };
 __global__ __launch_bounds__(256) void wn_multi_sumsq_kernel(WnMulti a, double* part /* [count][NB] */) {
     const int t = blockIdx.y, j = blockIdx.x;
     const float* v = a.v[t];
     const long long n = a.n[t];
     double s = 0.0;
-    for (long long i = (long long)j * 256 + threadIdx.x; i < n; i += (long long)WN_MULTI_NB * 256) { const double x = v[i]; s += x * x; }
+    if ((reinterpret_cast<uintptr_t>(v) & 15) == 0) {          // 16-byte loads, four independent accumulators in flight
+        const long long n4 = n >> 2;
+        const f32x4* v4 = reinterpret_cast<const f32x4*>(v);
+        for (long long i = (long long)j * 256 + threadIdx.x; i < n4; i += (long long)WN_MULTI_NB * 256) {
+            const f32x4 x = v4[i];
+            s += ((double)x[0] * x[0] + (double)x[1] * x[1]) + ((double)x[2] * x[2] + (double)x[3] * x[3]);
+        }
+        if (j == 0 && threadIdx.x < (n & 3)) { const double x = v[4 * n4 + threadIdx.x]; s += x * x; }
+    } else {
+        for (long long i = (long long)j * 256 + threadIdx.x; i < n; i += (long long)WN_MULTI_NB * 256) { const double x = v[i]; s += x * x; }
+    }
     s = wave_sum_f64(s);
     __shared__ double w[4];
     if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
@@ -89,7 +99,8 @@ __global__ __launch_bounds__(256) void wn_multi_sumsq_kernel(WnMulti a, double* 
 }
 __global__ __launch_bounds__(64) void wn_multi_finish_kernel(WnMulti a, const double* part, float* scales, float* norms) {
     const int t = blockIdx.x, l = threadIdx.x;
-    double s = l < WN_MULTI_NB ? part[t * WN_MULTI_NB + l] : 0.0;
+    double s = 0.0;
+    for (int q = l; q < WN_MULTI_NB; q += 64) s += part[t * WN_MULTI_NB + q];
     s = wave_sum_f64(s);
     if (l == 0) {
         const float nrm = (float)sqrt(s);
@@ -727,8 +738,9 @@ extern "C" int ekaid_wn_scale_multi(const float* const* v, const float* const* g
         a.v[i] = i < count ? v[i] : nullptr; a.g[i] = i < count ? g[i] : nullptr; a.n[i] = i < count ? n[i] : 0;
         if (i < count && (!v[i] || !g[i] || n[i] < 1)) { set_error("wn_scale_multi: null / empty layer %d", i); return EKAID_ERR_ARG; }
     }
-    hipLaunchKernelGGL(wn_multi_sumsq_kernel, dim3(WN_MULTI_NB, count), dim3(256), 0, ST, a, acc);
-    hipLaunchKernelGGL(wn_multi_finish_kernel, dim3(count), dim3(64), 0, ST, a, (const double*)acc, scales, norms);
+    double* part = acc + 2 * RED_SLOT;          // the column-sum partial area (1 MiB): 32 x 128 doubles = 32 KiB
+    hipLaunchKernelGGL(wn_multi_sumsq_kernel, dim3(WN_MULTI_NB, count), dim3(256), 0, ST, a, part);
+    hipLaunchKernelGGL(wn_multi_finish_kernel, dim3(count), dim3(64), 0, ST, a, (const double*)part, scales, norms);
     return check_launch("wn_scale_multi");
 }
 extern "C" int ekaid_wn_grad_fused(float* G, const float* v, const float* g, const float* norm, const float* scale, long long n,

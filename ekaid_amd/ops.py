@@ -23,7 +23,7 @@ _seed_base = 1238
 _seed_counter = 0
 
 
-GEMM_F32_MFMA, GEMM_BF16_SPLIT = 0, 1
+GEMM_F32_MFMA, GEMM_BF16_SPLIT, GEMM_BF16X2 = 0, 1, 2
 
 # Debug mode: with EKAID_CHECK_FINITE=1 every layer output is checked for Inf / NaN (one small reduction + one host read per
 # check: a synchronisation each, like the reference's `assert not x.isnan().any()` after every layer, fc.py:42-48).  Off by
@@ -46,8 +46,9 @@ def assert_finite(t, what):
 
 
 def set_gemm_mode(mode):
-    """Arithmetic of every GEMM on the path (include/ekaid_hip.h: ekaid_set_gemm_mode): GEMM_F32_MFMA or
-    GEMM_BF16_SPLIT (exact 3-way bf16 split, six bf16 MFMA products, f32 accumulation; the default)."""
+    """Arithmetic of every GEMM on the path (include/ekaid_hip.h: ekaid_set_gemm_mode): GEMM_F32_MFMA, GEMM_BF16_SPLIT
+    (exact 3-way bf16 split, six bf16 MFMA products, f32 accumulation; the default) or GEMM_BF16X2 (opt-in, reduced
+    precision: two bf16 terms per operand, three products)."""
     hip.check(hip.lib().ekaid_set_gemm_mode(int(mode)), 'set_gemm_mode')
 
 
@@ -315,6 +316,8 @@ TRANSPOSE_MIN_ROWS = int(os.environ.get('EKAID_TRANSPOSE_MIN_ROWS', 4096))     #
 
 
 def _use_transposed(M):
+    # (bf16-split arithmetic: re-measured in round 3 with the plain K loop for forward products -- a transposed copy of the
+    # weight costs more than the n-contiguous staging returns: 31.51 vs 31.30 ms per step)
     return M >= TRANSPOSE_MIN_ROWS and get_gemm_mode() == GEMM_F32_MFMA
 
 

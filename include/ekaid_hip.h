@@ -121,9 +121,15 @@ int ekaid_gemm_slabs2(const ekaid_gemm_t* g0, float* slabs0, size_t slab_bytes0,
  *                              2.67x the matrix rate.  Default; the environment variable EKAID_GEMM_MODE=f32 selects 0.
  * Inputs must be finite in mode 1: an Inf operand gives NaN where mode 0 gives Inf (Inf - Inf in the split).  Unreachable on
  * this path -- every GEMM operand is a finite activation, weight or gradient; a non-finite one is already a failed run, and
- * EKAID_CHECK_FINITE=1 (ekaid_amd/ops.py) asserts exactly that per module output. */
+ * EKAID_CHECK_FINITE=1 (ekaid_amd/ops.py) asserts exactly that per module output.
+ *   EKAID_GEMM_BF16X2     (2)  OPT-IN, REDUCED PRECISION: two bf16 terms per operand (16-17 significant bits: the second term
+ *                              is the residual rounded to nearest) and three products per block: half the matrix work of mode 1
+ *                              at ~2^-16 relative error per product (between TF32's 2^-11 and f32's 2^-24).  Never the default:
+ *                              the path's parity contract is stated for mode 1; bench.py reports mode 2 as an extra line with its
+ *                              measured log-prob deviation.  EKAID_GEMM_MODE=bf16x2 selects it. */
 #define EKAID_GEMM_F32_MFMA 0
 #define EKAID_GEMM_BF16_SPLIT 1
+#define EKAID_GEMM_BF16X2 2
 int ekaid_set_gemm_mode(int mode);
 int ekaid_get_gemm_mode(void);
 

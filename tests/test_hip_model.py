@@ -582,3 +582,34 @@ def test_scheduled_sampling_draws_from_the_previous_distribution_and_trains():
     with torch.no_grad():
         _, _, _, logp_tf, _ = hip_step(cfg, cd, sp, batch, 'mode2', 'all')
     assert torch.isfinite(logp_tf).all()
+
+
+def test_bf16x2_opt_in_arithmetic_stays_inside_the_logit_tolerance():
+    """The opt-in reduced-precision GEMM arithmetic (EKAID_GEMM_BF16X2: two bf16 terms, three products) on the whole path:
+    config 1 against the reference's golden vectors and config 2 (B = 64 forward) against the CPU oracle -- log-probs within the
+    path's 1e-3 tolerance, argmax answers identical.  (The default stays the exact split; this documents what the extra bench
+    line's arithmetic does to the outputs.)"""
+    from ekaid_amd import ops
+    from oracle import ekaid_oracle as O
+    old = ops.get_gemm_mode()
+    try:
+        ops.set_gemm_mode(ops.GEMM_BF16X2)
+        g = load_golden('f1_all')
+        cfg, cd, sp = small_models('all', device=DEV)
+        loss, sp_loss, outs, logp, logpos = hip_step(cfg, cd, sp, make_batch(**SMALL), 'mode2', 'all')
+        close(logp, g['logp'], LOGIT_TOL, 'logp (bf16x2)')
+        close(loss, g['loss'], 1e-3, 'loss (bf16x2)')
+        assert np.array_equal(logp[:, :SMALL['T']].argmax(-1).cpu().numpy(), g['logp'][:, :SMALL['T']].argmax(-1))
+        cfg = bench_cfg()
+        cd, sp = build_models(cfg, 147, 148, DEV)
+        batch = make_batch(B=64, **FULL)
+        with torch.no_grad():
+            _, _, _, logp, _ = hip_step(cfg, cd, sp, batch, 'mode2', 'all')
+            _, res = O.train_loss(oracle_params(cd), oracle_params(sp), cfg, batch, 'mode2', 'all')
+        e = close(logp[:, :16], res['logp'][:, :16], LOGIT_TOL, 'logp B=64 (bf16x2)')
+        ew, frac = elementwise_rel(logp[:, :16], res['logp'][:, :16], 1e-2)
+        print('bf16x2, B=64 logp vs CPU oracle: rel-to-max %.3e, element-wise rel %.3e' % (e, ew))
+        assert ew <= LOGIT_TOL
+        assert torch.equal(logp[:, :16].argmax(-1).cpu(), res['logp'][:, :16].argmax(-1))
+    finally:
+        ops.set_gemm_mode(old)

@@ -1171,3 +1171,39 @@ def test_check_finite_debug_mode():
         ops.linear(bad, W)                  # off: no check, no synchronisation
     finally:
         ops.CHECK_FINITE = was
+
+
+@pytest.mark.parametrize('mode', ['nt', 'nn', 'tn'])
+@pytest.mark.parametrize('M,N,K', [(256, 2048, 512), (4608, 1024, 2048), (700, 130, 333), (36, 36, 256)])
+def test_gemm_bf16x2_opt_in_arithmetic(M, N, K, mode):
+    """EKAID_GEMM_BF16X2 (opt-in, reduced precision): two bf16 terms per operand, three products.  Against float64 its error
+    stays below 6e-5 of |A|.|B| (2^-16 per product, three dropped / rounded terms) -- two decades tighter than bf16 itself,
+    a decade and a half looser than the default exact split, which the same data must still meet at 5e-7."""
+    from ekaid_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))
+    Bm = torch.randn(K, N, generator=g)
+    want = A.double() @ Bm.double()
+    mag = A.double().abs() @ Bm.double().abs()
+    if mode == 'nt':
+        a, b, ta, tb, lda, ldb = A, Bm.t().contiguous(), 0, 1, K, K
+    elif mode == 'nn':
+        a, b, ta, tb, lda, ldb = A, Bm, 0, 0, K, N
+    else:
+        a, b, ta, tb, lda, ldb = A.t().contiguous(), Bm, 1, 0, M, N
+    a, b = a.to(DEV), b.to(DEV)
+    old = ops.get_gemm_mode()
+    errs = {}
+    try:
+        for name, md in (('x3', ops.GEMM_BF16_SPLIT), ('x2', ops.GEMM_BF16X2)):
+            ops.set_gemm_mode(md)
+            C = torch.full((M, N), float('nan'), device=DEV)
+            ops.gemm(a, b, C, M, N, K, lda, ldb, N, ta, tb)
+            errs[name] = float(((C.double().cpu() - want).abs() / mag).max())
+            if ta == 0:
+                S = ops.gemm_slabs(a, b, M, N, K, lda, ldb, ta, tb)
+                assert float(((S.total().double().cpu() - want).abs() / mag).max()) <= (6e-5 if name == 'x2' else 5e-7)
+    finally:
+        ops.set_gemm_mode(old)
+    assert errs['x3'] <= 5e-7, errs
+    assert 1e-7 < errs['x2'] <= 6e-5, errs
