@@ -159,6 +159,7 @@ class TrainStep:
         # The warm-up iterations run WITHOUT collectives (local Adam on local gradients; everything is restored below): with
         # ragged answers the ranks meet a new (shape, decode steps) key at different iterations, so a rank that captures
         # must not issue all-reduces its peers (which already hold that key and just replay) would not match.
+        was_suspended = self.opt.comm_suspended
         self.opt.comm_suspended = True
         try:
             with torch.cuda.stream(s):
@@ -167,7 +168,7 @@ class TrainStep:
                     if self.comm == 'eager' and self.opt.comm_active():
                         self.opt.step()
         finally:
-            self.opt.comm_suspended = False
+            self.opt.comm_suspended = was_suspended
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
         ops.set_seed_state(seed_state)          # the capture draws the same site seeds as the first warm-up step

@@ -166,3 +166,30 @@ def test_two_ranks_replaying_hip_graphs_with_ragged_answers_match_two_eager_rank
     assert np.allclose(a['losses'], b['losses'], rtol=1e-6), (a['losses'], b['losses'])
     worst = max(abs(a['norms'][k] - b['norms'][k]) / max(a['norms'][k], 1e-9) for k in a['norms'])
     assert worst < 1e-6, worst
+
+
+@pytest.mark.parametrize('extra', [[], ['--batch', '16', '--hip-graph', 'on', '--graph-comm', 'eager']])
+def test_bench_runs_on_two_ranks(extra, tmp_path):
+    """bench.py the way the driver launches it at N > 1 (torch.distributed.run, one rank per GPU) -- here two ranks share the one
+    GPU of the box and talk over gloo, so the RCCL transport is not exercised but everything around it is: slicing of the
+    global batch, hook-driven overlapped all-reduce (128 pairs per GPU: eager launches) or hipGraph replay + collectives, the
+    max-over-ranks clock, the exposed-communication measurement and the one JSON line of rank 0."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--backend', 'gloo', '--no-cpu-baseline', '--no-extra'] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['scaling'] == 'strong' and out['value'] > 0
+    assert out['config']['per_gpu_batch'] * 2 == out['config']['global_batch']
+    c = out['comm']
+    assert c['allreduce_bytes'] > 200e6 and c['buckets'] > 1 and c['exposed_comm_ms'] >= 0.0 and c['ms_per_step_without_comm'] > 0
+    assert ('hipGraph' in out['config']['launch_path']) == bool(extra)
