@@ -363,7 +363,7 @@ def main():
         default_shape = args.graph == 'all'
         path_alg = FLOP_PER_PAIR_TRAIN * per_gpu * args.steps / elapsed / 1e12 if default_shape else None
         roof = {'bound': 'mfma',
-                'kernel': ('ekaid::gemm_split_kernel<.,.,2,2,32,1,true> (128x128 tiles; f32 operands split exactly into 3 bf16, '
+                'kernel': ('ekaid::gemm_split_kernel<.,.,2,2,32,1,.,3> (128x128 tiles; f32 operands split exactly into 3 bf16, '
                            '6 x v_mfma_f32_32x32x16_bf16 per product block, f32 accumulate)') if split else
                           'ekaid::gemm_mfma_kernel<.,.,2,2,32> (v_mfma_f32_32x32x2_f32)',
                 'achieved': round(mult * alg_big, 3), 'peak': peak, 'unit': 'TFLOP/s',

@@ -1085,8 +1085,9 @@ static thread_local int t_plan_slab = 0;      // set while a slab-mode product i
 
 static int plan_splitk(int tiles, int K, int batch, long long MN, int BK, bool big_tiles) {
     if (batch > 1) return 1;
-    static const char* tgt = getenv("EKAID_GEMM_SPLIT_TARGET");   // tuning aid
-    const int target = tgt ? atoi(tgt) : 768;     // ~3 workgroups per CU (the register budget admits 3 per SIMD)
+    static const char* tgt = getenv("EKAID_GEMM_SPLIT_TARGET");   // tuning aids
+    static const char* tgs = getenv("EKAID_GEMM_SPLIT_TARGET_SMALL");
+    const int target = (!big_tiles && tgs) ? atoi(tgs) : (tgt ? atoi(tgt) : 768);     // ~3 workgroups per CU (the register budget admits 3 per SIMD)
     if (tiles * 4 >= target * 3) return 1;
     // 64x64 tiles, one workgroup per CU already: a 2-way split + reduce kernel measured no faster (256x6656x512: 23 vs 24 us).
     // (128x128 tiles are different: 256 tiles leave two of the three workgroup slots of every CU empty for the whole K

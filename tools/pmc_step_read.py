@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise the output of tools/pmc_step.sh: per-kernel time table of the traced run and, for the dominant kernel
-(ekaid::gemm_split_kernel<..., 2, 2, 32, 1, true>), the PMC counters averaged per launch over every launch of the short
+(ekaid::gemm_split_kernel<..., 2, 2, 32, 1, ...>), the PMC counters averaged per launch over every launch of the short
 counter runs.  usage: python tools/pmc_step_read.py <outdir> <summary.json> [steps_in_trace]"""
 import csv
 import glob
@@ -39,7 +39,7 @@ def main():
         acc, n = {}, {}
         for r in csv.DictReader(open(cc)):
             name = r.get('Kernel_Name', '')
-            if key not in name or ', 2, 2, 32, 1, true>' not in name:
+            if key not in name or ', 2, 2, 32, 1, ' not in name:          # every 128x128-tile instantiation (pipelined and plain loop)
                 continue
             c = r['Counter_Name']
             acc[c] = acc.get(c, 0.0) + float(r['Counter_Value'])
@@ -50,9 +50,9 @@ def main():
         kt = find(g, 'kernel_trace.csv')
         if kt and not durs:
             for r in csv.DictReader(open(kt)):
-                if key in r['Kernel_Name'] and ', 2, 2, 32, 1, true>' in r['Kernel_Name']:
+                if key in r['Kernel_Name'] and ', 2, 2, 32, 1, ' in r['Kernel_Name']:
                     durs.append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
-    summary['dominant_kernel'] = 'ekaid::gemm_split_kernel<.,.,2,2,32,1,true> (all 128x128-tile instantiations, every launch of the counter runs)'
+    summary['dominant_kernel'] = 'ekaid::gemm_split_kernel<.,.,2,2,32,1,.,3> (all 128x128-tile instantiations, pipelined and plain K loop, every launch of the counter runs)'
     summary['counters_avg_per_launch'] = counters
     if durs:
         durs.sort()
