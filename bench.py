@@ -25,6 +25,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   "extra":        forward-only at batch 64 (configs[1]) and the T = 90 worst-case train step (N = 1 only).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -186,8 +187,9 @@ def real_data_loop(graph, iters=120, time_from=80):
         t0 = time.perf_counter()
         make_dataset(d, n_images=512, n_pairs=3200, nodes=52, D=1024)
         gen_s = time.perf_counter() - t0
-        out = train_mimic.main(['--data_dir', d, '--graph', graph, '--hip_graph', '--max_iter', str(iters), '--time_from', str(time_from),
-                                '--snapshot_interval', '1000000', '--no_final_snapshot', '--quiet', '--exp_dir', os.path.join(d, 'exp')])
+        with contextlib.redirect_stdout(sys.stderr):        # stdout carries the ONE JSON line of the contract, nothing else
+            out = train_mimic.main(['--data_dir', d, '--graph', graph, '--hip_graph', '--max_iter', str(iters), '--time_from', str(time_from),
+                                    '--snapshot_interval', '1000000', '--no_final_snapshot', '--quiet', '--exp_dir', os.path.join(d, 'exp')])
     finally:
         shutil.rmtree(d, ignore_errors=True)
     tm = out['timing'] or {}

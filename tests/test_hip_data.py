@@ -139,6 +139,30 @@ def test_resumed_run_continues_the_uninterrupted_run(tmp_path, stop):
     assert a['last']['total_loss'] == b2['last']['total_loss']
 
 
+@pytest.mark.parametrize('where', ['epoch_boundary', 'mid_epoch'])
+def test_resume_on_real_data_continues_the_shuffle(data_dir, tmp_path, where):
+    """The same equality on the HDF5 loader, whose per-epoch permutation comes from torch's global generator: a snapshot on an
+    epoch boundary stores the generator state the NEXT epoch will shuffle from (it used to store None, and the resumed run
+    replayed epoch 0's order); a mid-epoch snapshot stores the state the running epoch's sampler drew from."""
+    import train_mimic
+    common = ['--data_dir', data_dir, '--batch_size', '8', '--quiet', '--seed', '11', '--eval_batches', '1']
+    probe = train_mimic.main(common + ['--max_iter', '1', '--snapshot_interval', '1000', '--no_final_snapshot',
+                                       '--exp_dir', str(tmp_path / 'p')])
+    ipe = probe['iters_per_epoch']
+    assert ipe >= 3
+    stop = ipe if where == 'epoch_boundary' else ipe + 2
+    total = 2 * ipe + 1                                    # into the third epoch
+    a = train_mimic.main(common + ['--max_iter', str(total), '--snapshot_interval', '1000', '--exp_dir', str(tmp_path / 'a')])
+    b1 = train_mimic.main(common + ['--max_iter', str(stop), '--snapshot_interval', str(stop), '--exp_dir', str(tmp_path / 'b')])
+    ck = os.path.join(b1['snapshot_dir'], 'checkpoint_%d.pt' % stop)
+    b2 = train_mimic.main(common + ['--max_iter', str(total), '--snapshot_interval', '1000', '--exp_dir', str(tmp_path / 'c'),
+                                    '--resume', '1', '--checkpoint', ck])
+    assert a['iteration'] == b2['iteration'] == total and a['epoch'] == b2['epoch']
+    drift = float((_weights(a) - _weights(b2)).abs().max())
+    assert drift == 0.0, 'resumed real-data run left the uninterrupted one: max |dw| = %.3e' % drift
+    assert a['last']['total_loss'] == b2['last']['total_loss']
+
+
 def test_graph_replay_equals_eager():
     """Three training steps replayed from the captured hipGraph == the same three steps issued eagerly with the same
     dropout sites and epochs (weights agree to float-atomic noise); consecutive replays draw different masks."""
@@ -224,3 +248,16 @@ def test_rccl_path_on_one_gpu(tmp_path):
     # one eager layout-building pass (all buckets) + the capture itself; the capture's two warm-up iterations add nothing
     assert out['order_captured']['n_logged'] == 2 * out['buckets'], 'warm-up iterations of a capture must not communicate'
     assert all(c >= out['order_after_replay']['after_backward'] for _, c in out['order_after_replay']['launches'])
+
+
+def test_bench_real_data_line_is_the_only_thing_on_stdout():
+    """The driver parses bench.py's stdout as ONE JSON line; the real-data leg runs train_mimic.py and the dataset classes, whose
+    progress prints must all go to stderr."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--real-only'], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-3000:]
+    out = json.loads(lines[0])['real_b64']
+    assert out['qa_pairs_per_s'] > 0 and out['graphs_captured'] >= 2
+    assert out['loader_wait_fraction'] is not None and out['exposed_h2d_ms_per_iteration'] >= 0.0

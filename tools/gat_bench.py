@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the graph-attention core (fused forward kernel, composed backward) at the B=256 step's shape.
-usage: gat_bench.py [R N M A H]      (defaults 512 36 36 1024 4)"""
+usage: gat_bench.py [R N M A H]      (defaults 512 36 36 1024 4)
+       gat_bench.py --kernel LIB [R N M A H]   forward kernel only, 30 back-to-back launches through the C ABI of LIB
+                                                (any build of libekaid_hip.so: same-box comparisons against older trees)"""
 import os
 import sys
 
@@ -10,7 +12,43 @@ import torch  # noqa: E402
 from ekaid_amd import hip, ops  # noqa: E402
 
 
+def kernel_only(lib_path, R, N, M, A, H):
+    import ctypes
+    lib = ctypes.CDLL(lib_path)
+    P = ctypes.c_void_p
+    lib.ekaid_gat_fused_fwd.argtypes = [P] * 6 + [ctypes.c_int] * 6 + [P] * 3
+    lib.ekaid_gat_fused_fwd.restype = ctypes.c_int
+    g = torch.Generator().manual_seed(0)
+    q, k, S = (torch.randn(R, n, A, generator=g).cuda() for n in (N, M, N))
+    cond = (torch.rand(R, N, N, generator=g) > 0.4).float().cuda()
+    lb = (torch.randn(R, N, N, generator=g) * 0.3).cuda()
+    geo = torch.relu(torch.randn(R, N, M, H, generator=g)).cuda()
+    Pm, out = torch.empty(R, N, H, M, device='cuda'), torch.empty(R, N, H * A, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+
+    def launch():
+        rc = lib.ekaid_gat_fused_fwd(q.data_ptr(), k.data_ptr(), S.data_ptr(), cond.data_ptr(), lb.data_ptr(), geo.data_ptr(),
+                                     R, N, M, A, H, 1, Pm.data_ptr(), out.data_ptr(), st)
+        assert rc == 0, rc
+    for _ in range(5):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(30):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 30
+    nbytes = R * (3 * N * A * 4 + N * H * A * 4 + N * H * M * 4)
+    print('kernel    %8.1f us  %.2f TB/s of %d MB algorithmic  (R=%d N=%d M=%d, 30 back-to-back launches)' % (
+        us, nbytes / us / 1e6, nbytes >> 20, R, N, M))
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == '--kernel':
+        shape = [int(x) for x in (sys.argv[3:8] or (512, 36, 36, 1024, 4))]
+        return kernel_only(sys.argv[2], *shape)
     hip.load()
     R, N, M, A, H = [int(x) for x in (sys.argv[1:6] or (512, 36, 36, 1024, 4))]
     dev = 'cuda'

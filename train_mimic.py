@@ -362,7 +362,7 @@ def main(argv=None):
         dist.destroy_process_group()
     return {'iteration': t, 'epoch': epoch, 'lr': optimizer.lr, 'last': last, 'snapshot_dir': snapshot_dir,
             'change_detector': change_detector, 'speaker': speaker, 'optimizer': optimizer,
-            'graphs_captured': graphs_captured, 'timing': timing}
+            'graphs_captured': graphs_captured, 'timing': timing, 'iters_per_epoch': iters_per_epoch}
 
 
 if __name__ == '__main__':
