@@ -69,6 +69,7 @@ __device__ __forceinline__ float epilogue(float acc, float cold, int m, int n, c
     return v;
 }
 
+constexpr int ASUM_SHARE = 4;      // tile columns that share the A-row-sum work of a K-split product (partials per slab)
 struct GemmArgs {
     const float* A; const float* B; float* C;
     int M, N, K, lda, ldb, ldc;
@@ -79,6 +80,8 @@ struct GemmArgs {
     float* ws;            // slabs [splitk][M][N] when splitk > 1
     int tiles_m, tiles_n;
     int slab_mode;        // 1: raw partial products go to ws even when splitk == 1 (ekaid_gemm_slabs: the consumer reduces)
+    float* asum;          // optional (m-contiguous A only): asum[m] += sum_k op(A)[m][k] -- the bias gradient riding on a wgrad product
+    float* asum_ws;       // its K-split partials [splitk][M] (behind the slabs in the workspace), finished by the reduce kernel
     Epi e;
 };
 
@@ -487,9 +490,10 @@ __device__ __forceinline__ int mc_read_off(int k, int row0, int tg, int tp) {   
 
 // PF = K-steps of global loads kept in flight (1: the next step's loads hide under this step's MFMAs -- enough for the
 // large tiles; 2: for the 64x64 tile, whose 12 MFMAs per 32-deep step are far shorter than a load round trip)
-template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE, int NP = 3>
+template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE, int NP = 3, bool ASUM = false>
 __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int block_x, const int z) {
     static_assert(NP == 2 || NP == 3, "planes per operand");
+    static_assert(!ASUM || !A_KC, "the A row sums ride on the m-contiguous staging (weight-gradient form)");
     static_assert(!PIPE || (KB == 32 && PF == 1), "the pipelined loop shares the 32-deep LDS footprint");
     constexpr int BM = 64 * TM, BN = 64 * TN;
     static_assert(KB == 32 || KB == 64 || KB == 128, "K-step");
@@ -518,6 +522,17 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
         bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
     }
     const int m0 = (bid / g.tiles_n) * BM, n0 = (bid % g.tiles_n) * BN;
+    // ASUM: the workgroups of the first tile column also add up the A elements they stage (every staged float4 of a thread
+    // covers the same four tile rows m, 256 % (BM / 4) == 0), workgroup-uniform branch
+    // With a K split the K-steps are dealt round-robin to the workgroups of a tile row (each adds up 1 / tiles_n of the steps:
+    // the extra vector work is spread evenly instead of making the first tile column the straggler) and every workgroup
+    // leaves a partial [z][tile column][M] for the reduce kernel; without a split the first tile column does all of it.
+    const int tcol = bid % g.tiles_n;
+    const int asum_period = g.splitk > 1 ? min(g.tiles_n, ASUM_SHARE) : 1;      // workgroups of a tile row that take turns
+    const bool do_asum = ASUM && g.asum != nullptr && tcol < asum_period;
+    int asum_turn = tcol;                                 // K-steps until this workgroup's next turn
+    auto asum_mine = [&]() { const bool mine = asum_turn == 0; asum_turn = mine ? asum_period - 1 : asum_turn - 1; return mine; };
+    f32x4 asum4 = {0.f, 0.f, 0.f, 0.f};
 
     const float* A = g.A; const float* B = g.B;
     int kbeg = 0, kend = g.K;
@@ -575,6 +590,10 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
         if (need_mask) {
             loader_mask<A_KC, BM, A_V4, KB>(LA, ra[S], kload[S], kend, tid);
             loader_mask<B_KC, BN, B_V4, KB>(LB, rb[S], kload[S], kend, tid);
+        }
+        if constexpr (ASUM) if (do_asum && asum_mine()) {
+#pragma unroll
+            for (int i = 0; i < A_V4; ++i) asum4 += ra[S][i];
         }
 #pragma unroll
         for (int i = 0; i < A_V4; ++i) {
@@ -786,6 +805,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
             *reinterpret_cast<u32x2*>(base + plane + off) = M;
             if constexpr (NP == 3) *reinterpret_cast<u32x2*>(base + 2 * plane + off) = L;
         };
+        bool asum_cur = false;                    // is the 32-deep K-step being converted this workgroup's turn (A row sums)?
         // one stage: multiply out buffer `cur`, convert register set S into buffer `cur ^ 1`
         auto stage = [&](auto set_tag, int cur, bool convert) {
             constexpr int S = decltype(set_tag)::value;
@@ -793,6 +813,9 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
             char* const cB = cA + NP * SA_PLANE;
             char* const nA = ldsA + (cur ^ 1) * STAGE_BYTES;
             char* const nB = nA + NP * SA_PLANE;
+            // (the round-robin of the A row sums counts 32-deep K-steps, like the plain loop a ragged workgroup of the same
+            // tile row runs: stages 2u and 2u + 1 share a turn)
+            const bool mine = ASUM && convert && asum_cur;
             bf16x8 fa[TM][NP], fb[TN][NP];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -813,8 +836,10 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
 #pragma unroll
                         for (int c = 0; c < NCV; ++c) {
                             if (c * (TM * TN) / NCV != grp) continue;
-                            if (c < PA) cvt1(pa[S][c], nA, SA_PLANE, stA[c]);
-                            else cvt1(pb[S][c - PA], nB, SB_PLANE, stB[c - PA]);
+                            if (c < PA) {
+                                if constexpr (ASUM) if (mine) asum4 += pa[S][c];
+                                cvt1(pa[S][c], nA, SA_PLANE, stA[c]);
+                            } else cvt1(pb[S][c - PA], nB, SB_PLANE, stB[c - PA]);
                         }
                     }
                 }
@@ -824,8 +849,12 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
         const int nst = (kend - kbeg) / KS;        // even: (kend - kbeg) % 32 == 0 on this path
         gload16(S0{}, 0);
         gload16(S1{}, 1);
+        if constexpr (ASUM) asum_cur = do_asum && asum_mine();             // stage 0 (and 1)
 #pragma unroll
-        for (int c = 0; c < PA; ++c) cvt1(pa[0][c], ldsA, SA_PLANE, stA[c]);
+        for (int c = 0; c < PA; ++c) {
+            if constexpr (ASUM) if (asum_cur) asum4 += pa[0][c];
+            cvt1(pa[0][c], ldsA, SA_PLANE, stA[c]);
+        }
 #pragma unroll
         for (int c = 0; c < PB; ++c) cvt1(pb[0][c], ldsA + NP * SA_PLANE, SB_PLANE, stB[c]);
         gload16(S0{}, 2);
@@ -850,6 +879,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
             __syncthreads();
 #else
             stage(S1{}, 0, true);                  // buffer 0 = stage s0; registers set 1 = stage s0+1 -> buffer 1
+            if constexpr (ASUM) asum_cur = do_asum && asum_mine();          // stages s0+2, s0+3: the next 32-deep K-step
             gload16(S1{}, s0 + 3);
             __syncthreads();
             stage(S0{}, 1, s0 + 2 < nst);          // buffer 1 = stage s0+1; set 0 = stage s0+2 -> buffer 0
@@ -863,12 +893,26 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
         else if constexpr (PIPE) pipelined();
         else mainloop(std::true_type{});
     }
+    if constexpr (ASUM) if (do_asum) {
+        // the 256 / (BM / 4) threads that staged the same four rows are added up through LDS in thread order (deterministic)
+        constexpr int GR = 256 / (BM / 4);
+        __syncthreads();                                  // the last stage has been multiplied out: the LDS is free
+        *reinterpret_cast<f32x4*>(&lds[(tid / (BM / 4)) * BM + 4 * (tid % (BM / 4))]) = asum4;
+        __syncthreads();
+        if (tid < BM && m0 + tid < g.M) {
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < GR; ++j) sum += lds[j * BM + tid];
+            if (g.splitk > 1) g.asum_ws[((long long)z * asum_period + tcol) * g.M + m0 + tid] = sum;
+            else g.asum[m0 + tid] += sum;
+        }
+    }
     write_tiles<TM, TN>(g, acc, m0, n0, wm, wn, r, h, z);
 }
 
-template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE, int NP = 3>
+template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE, int NP = 3, bool ASUM = false>
 __global__ __launch_bounds__(256, (TM * TN >= 4 ? EKAID_SPLIT_OCC_BIG : (TM * TN == 2 ? 2 : EKAID_SPLIT_OCC_SMALL))) void gemm_split_kernel(GemmArgs g) {
-    gemm_split_body<A_KC, B_KC, TM, TN, KB, PF, PIPE, NP>(g, blockIdx.x, blockIdx.z);
+    gemm_split_body<A_KC, B_KC, TM, TN, KB, PF, PIPE, NP, ASUM>(g, blockIdx.x, blockIdx.z);
 }
 
 // TWO independent products of the same operand layout in one launch (64x64 tiles): workgroups [0, tiles of g0) work on g0,
@@ -989,9 +1033,26 @@ __global__ __launch_bounds__(256) void tn_skinny_finish_kernel(const float* __re
     }
 }
 
+// the K-split partials of the A row sums (GemmArgs::asum_ws) are finished by the first threads of the reduce grid, slab order
+__device__ __forceinline__ void asum_finish(const float* asum_ws, float* asum, int M, int nparts, long long gtid) {
+    if (asum == nullptr || gtid >= M) return;
+    float s = 0.f;
+    int k = 0;
+    for (; k + 8 <= nparts; k += 8) {             // eight independent loads in flight, added in index order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = asum_ws[(long long)(k + u) * M + gtid];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < nparts; ++k) s += asum_ws[(long long)k * M + gtid];
+    asum[gtid] += s;
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, float* C, int M, int N, int ldc,
-                                                            int splitk, Epi e) {
+                                                            int splitk, Epi e, const float* asum_ws, float* asum, int asum_parts) {
     const long long total = (long long)M * N;
+    asum_finish(asum_ws, asum, M, asum_parts, (long long)blockIdx.x * blockDim.x + threadIdx.x);
     const float alpha = e.alpha_dev ? e.alpha * e.alpha_dev[0] : e.alpha;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -1008,8 +1069,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, flo
 // loads of a thread are independent (all in flight together), 32-bit index math only
 template <int S_UNROLL>
 __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N4,
-                                                                int ldc, int splitk, Epi e) {
+                                                                int ldc, int splitk, Epi e, const float* asum_ws, float* asum, int asum_parts) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    asum_finish(asum_ws, asum, M, asum_parts, idx);        // M <= M * N4: the grid covers it
     if (idx >= M * N4) return;
     const int m = idx / N4, n = (idx - m * N4) * 4;
     const long long total4 = (long long)M * N4;
@@ -1058,13 +1120,13 @@ static int launch(const GemmArgs& a, int batch, hipStream_t st) {
     return EKAID_OK;
 }
 
-template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE, int NP = 3>
+template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE, int NP = 3, bool ASUM = false>
 static int launch_split(const GemmArgs& a, int batch, hipStream_t st) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr size_t lds = NP * 2 * KB * (BM + BN);     // NP bf16 planes per operand, unpadded
-    auto kern = gemm_split_kernel<A_KC, B_KC, TM, TN, KB, PF, PIPE, NP>;
+    auto kern = gemm_split_kernel<A_KC, B_KC, TM, TN, KB, PF, PIPE, NP, ASUM>;
     if (lds > 64 * 1024) {
-        constexpr int slot = 16 + (A_KC ? 1 : 0) + (B_KC ? 2 : 0) + 4 * (TM - 1) + 8 * (TN - 1);
+        constexpr int slot = (ASUM ? 32 : 16) + (A_KC ? 1 : 0) + (B_KC ? 2 : 0) + 4 * (TM - 1) + 8 * (TN - 1);
         if (func_attr_once(slot)) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
                 (void)hipGetLastError();
@@ -1181,6 +1243,7 @@ static int fill_args(const ekaid_gemm_t* d, GemmArgs& a, int& TMN, void* workspa
     a.e.R = d->R; a.e.ldr = d->ldr; a.e.rdiv = d->rdiv < 1 ? 1 : d->rdiv; a.e.rowmask = d->rowmask; a.e.act = d->act;
     a.e.drop_p = d->drop_p; a.e.drop_inv = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f; a.e.drop_seed = d->drop_seed; a.e.drop_epoch = dropout_epoch_ptr(); a.e.n_cols = d->N;
     a.slab_mode = slab_mode;
+    a.asum = nullptr; a.asum_ws = nullptr;
     t_plan_slab = slab_mode;
     plan_full(d, TMN, a.splitk, a.k_per_split, a.tiles_m, a.tiles_n);
     t_plan_slab = 0;
@@ -1217,6 +1280,13 @@ static int split_dispatch(const GemmArgs& a, int TMN, bool akc, bool bkc, int ba
                                      : TMN == 3 ? launch_split<AK, BKC, 2, 1, 32, 1, false, NP>(a, batch, st) : launch_split<AK, BKC, 1, 2, 32, 1, false, NP>(a, batch, st))
     if (akc && bkc) return EKAID_LAUNCH_SPLIT(true, true);
     if (akc && !bkc) return EKAID_LAUNCH_SPLIT(true, false);
+    if (a.asum != nullptr) {
+        // weight-gradient form with the bias gradient riding on the A operand: the default loop arm of each tile shape only
+        return TMN == 2 ? launch_split<false, false, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG, NP, true>(a, batch, st)
+             : TMN == 1 ? launch_split<false, false, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL, false, NP, true>(a, batch, st)
+             : TMN == 3 ? launch_split<false, false, 2, 1, 32, 1, false, NP, true>(a, batch, st)
+                        : launch_split<false, false, 1, 2, 32, 1, false, NP, true>(a, batch, st);
+    }
     return EKAID_LAUNCH_SPLIT(false, false);
 #undef EKAID_LAUNCH_SPLIT
 }
@@ -1283,7 +1353,8 @@ extern "C" size_t ekaid_gemm_workspace_bytes(const ekaid_gemm_t* d) {
         if (skinny_tn(d, G, NO)) return (size_t)G * d->M * d->N * sizeof(float);
     }
     plan(d, TMN, splitk, tm, tn);
-    return splitk > 1 ? (size_t)splitk * d->M * d->N * sizeof(float) : 0;
+    // (+ the K-split partials of the A row sums, d->a_rowsum, behind the slabs)
+    return splitk > 1 ? (size_t)splitk * d->M * ((size_t)d->N + (d->a_rowsum ? ASUM_SHARE : 0)) * sizeof(float) : 0;
 }
 
 extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t workspace_bytes, void* stream) {
@@ -1313,7 +1384,9 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
                                    d->K, rows_per_wg, NO, (float*)workspace);
             hipLaunchKernelGGL(tn_skinny_finish_kernel, dim3(d->M * d->N), dim3(256), 0, st, (const float*)workspace,
                                cdiv(d->K, rows_per_wg), d->M * d->N, d->N, d->C, d->ldc, d->alpha, d->accumulate);
-            return check_launch("tn_skinny_kernel");
+            const int rc_s = check_launch("tn_skinny_kernel");
+            if (rc_s || !d->a_rowsum) return rc_s;
+            return ekaid_colsum_acc(d->A, d->K, d->M, d->lda, d->a_rowsum, stream);
         }
     }
     GemmArgs a;
@@ -1324,6 +1397,23 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     }
     const int batch = d->batch1 * d->batch2;
     const bool akc = !d->transA, bkc = d->transB != 0;
+    // a_rowsum (the bias gradient of a weight-gradient product): folded into the A-operand staging of the split-arithmetic
+    // kernels -- the column sums read dY a second time otherwise (73 launches, 0.75 ms per step at B = 256) --, by a separate
+    // column-sum launch where that kernel does not apply
+    bool rowsum_after = false;
+    if (d->a_rowsum) {
+        if (akc) { set_error("ekaid_gemm_f32: a_rowsum needs transA (A stored [K][M])"); return EKAID_ERR_UNSUPPORTED; }
+        if (gemm_mode() >= 1 && TMN >= 1 && TMN <= 4 && batch == 1) {
+            a.asum = d->a_rowsum;
+            if (a.splitk > 1) {
+                const size_t need = (size_t)a.splitk * d->M * ((size_t)d->N + ASUM_SHARE) * sizeof(float);
+                if (workspace_bytes < need) { set_error("ekaid_gemm_f32: workspace too small for a_rowsum (%zu < %zu)", workspace_bytes, need); return EKAID_ERR_ARG; }
+                a.asum_ws = a.ws + (size_t)a.splitk * d->M * d->N;
+            }
+        } else {
+            rowsum_after = true;
+        }
+    }
     // (Split-K with the reduction done by the last workgroup of each tile -- arrival counter, device-scope slab accesses --
     // instead of the second kernel was measured and removed: bit-identical, but 0.97-2.9x the time of GEMM + reduce kernel on
     // the recurrent shapes (the reduce kernel uses every CU, the last arriver is one workgroup per tile), and 5x with
@@ -1341,14 +1431,19 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
         if (vec_ok) {
             const int n4 = d->N / 4;
             hipLaunchKernelGGL(splitk_reduce_vec_kernel<4>, dim3(cdiv((long long)d->M * n4, 256)), dim3(256), 0, st, a.ws, d->C,
-                               d->M, n4, d->ldc, a.splitk, a.e);
+                               d->M, n4, d->ldc, a.splitk, a.e, a.asum_ws, a.asum, a.splitk * (a.tiles_n < ASUM_SHARE ? a.tiles_n : ASUM_SHARE));
         } else {
             int blocks = cdiv(total, 256);
             if (blocks > 2048) blocks = 2048;
+            if (a.asum && (long long)blocks * 256 < d->M) blocks = cdiv(d->M, 256);
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.ws, d->C, d->M, d->N, d->ldc,
-                               a.splitk, a.e);
+                               a.splitk, a.e, a.asum_ws, a.asum, a.splitk * (a.tiles_n < ASUM_SHARE ? a.tiles_n : ASUM_SHARE));
         }
         rc = check_launch("splitk_reduce_kernel");
+    }
+    if (rc == EKAID_OK && rowsum_after) {
+        if (batch != 1) { set_error("ekaid_gemm_f32: a_rowsum with a batched product"); return EKAID_ERR_UNSUPPORTED; }
+        rc = ekaid_colsum_acc(d->A, d->K, d->M, d->lda, d->a_rowsum, stream);
     }
     return rc;
 }

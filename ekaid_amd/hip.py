@@ -37,6 +37,7 @@ class GemmDesc(Structure):
         ('R', c_void_p), ('ldr', c_int), ('rdiv', c_int), ('rowmask', c_void_p),
         ('act', c_int),
         ('drop_p', c_float), ('drop_seed', c_uint64),
+        ('a_rowsum', c_void_p),
     ]
 
 

@@ -138,6 +138,15 @@ def bias_grad(b, x, rows, cols, ld, x_off=0):
     return None if slot is not None else out
 
 
+def bias_grad_slot(b):
+    """(buffer the bias gradient is accumulated into -- the bias' zeroed slot of the flat gradient buffer --, what the backward
+    node hands to autograd for it).  The buffer goes to ``gemm(..., a_rowsum=)`` of the layer's weight-gradient product, whose
+    A operand is the very dY whose column sums the bias gradient is: dY is not read a second time."""
+    slot = grad_claimed_slot(b)
+    out = slot if slot is not None else grad_out(b, zero=True)
+    return out, (None if slot is not None else out)
+
+
 def zeros_pool(device, *shapes):
     """Several zero-initialised f32 tensors from ONE allocation and ONE fill launch."""
     sizes = [int(math.prod(sh)) for sh in shapes]
@@ -159,10 +168,14 @@ def grad_claimed_slot(W):
     return None
 
 
+_BIAS_IN_WGRAD = os.environ.get('EKAID_BIAS_IN_WGRAD', '1') != '0'
+
+
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=None,
          accumulate=False, bias=None, R=None, ldr=0, rdiv=1, rowmask=None, act=ACT_NONE,
-         batch=(1, 1), strides=(0, 0, 0, 0, 0, 0), a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_seed=0):
-    """C = act(alpha * op(A) op(B) [+C] [+bias] [+R]) on raw device buffers (element offsets a_off..)."""
+         batch=(1, 1), strides=(0, 0, 0, 0, 0, 0), a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_seed=0, a_rowsum=None):
+    """C = act(alpha * op(A) op(B) [+C] [+bias] [+R]) on raw device buffers (element offsets a_off..); ``a_rowsum`` (transA only):
+    a_rowsum[m] += sum_k op(A)[m][k], the bias gradient riding on a weight-gradient product."""
     d = GemmDesc()
     d.A = A.data_ptr() + 4 * a_off
     d.B = B.data_ptr() + 4 * b_off
@@ -183,6 +196,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=N
     d.act = act
     d.drop_p = drop_p
     d.drop_seed = drop_seed
+    d.a_rowsum = ptr(a_rowsum) if _BIAS_IN_WGRAD else None
     L = hip.lib()
     need = L.ekaid_gemm_workspace_bytes(ctypes.byref(d))
     ws = hip.workspace(need, C.device) if need else None
@@ -196,6 +210,8 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=N
         e1.record()
         nb = batch[0] * batch[1]
         prof.append((e0, e1, 2.0 * M * N * K * nb, (int(transA), int(transB), M, N, K, nb)))
+    if a_rowsum is not None and not _BIAS_IN_WGRAD:          # A/B knob: the column sums as their own launches
+        check(L.ekaid_colsum_acc(d.A, K, M, lda, ptr(a_rowsum), stream()), 'colsum_acc')
 
 
 # --------------------------------------------------------------------------- #
@@ -392,9 +408,9 @@ class LinearFn(Function):
         else:
             dz = dy
         need = ctx.needs_input_grad
-        db = None
+        db = db_buf = None
         if ctx.has_b and need[1]:
-            db = bias_grad(ctx.bias_ref, dz, M, N, N)
+            db_buf, db = bias_grad_slot(ctx.bias_ref)          # filled by the first weight-gradient product below
         dxs = []
         off = 0
         for i, x in enumerate(xs2):
@@ -414,7 +430,8 @@ class LinearFn(Function):
             off = 0
             for x, ld in zip(xs2, ctx.lds):
                 K = x.shape[1]
-                gemm(dz, x, dW, N, K, M, N, ld, Ktot, 1, 0, c_off=off)
+                gemm(dz, x, dW, N, K, M, N, ld, Ktot, 1, 0, c_off=off, a_rowsum=db_buf)
+                db_buf = None
                 off += K
             if ctx.has_scale and ctx.wn is not None:
                 # weight-normed layer (WNLinearFn): the unscaled wgrad becomes dv in place and dg comes out of the same two
@@ -428,6 +445,8 @@ class LinearFn(Function):
                 dscale = torch.empty((), device=W.device, dtype=torch.float32)
                 check(L.ekaid_scale_dot(ptr(dW), ptr(W), ptr(scale), dW.numel(), ptr(dscale), stream()),
                       'scale_dot')
+        if db_buf is not None:      # no weight-gradient product ran: the column sums on their own
+            check(L.ekaid_colsum_acc(ptr(dz), M, N, N, ptr(db_buf), stream()), 'colsum_acc')
         return (dW, db, dscale, None, None) + tuple(dxs)
 
 
@@ -532,16 +551,18 @@ class LinearRowStackFn(Function):
         dy = _c(dy)
         Mtot = dy.shape[0]
         need = ctx.needs_input_grad
-        db = None
+        db = db_buf = None
         if ctx.has_b and need[1]:
-            db = bias_grad(ctx.bias_ref, dy, Mtot, N, N)
+            db_buf, db = bias_grad_slot(ctx.bias_ref)
         dW = None
         if need[0]:
             dW = grad_out(W)
             r0 = 0
-            for i, (x, ld, M) in enumerate(zip(xs2, ctx.lds, ctx.Ms)):
-                gemm(dy, x, dW, N, K, M, N, ld, K, 1, 0, accumulate=i > 0, a_off=r0 * N)
+            for i, (x, ld, M) in enumerate(zip(xs2, ctx.lds, ctx.Ms)):     # every row block adds its rows' column sums
+                gemm(dy, x, dW, N, K, M, N, ld, K, 1, 0, accumulate=i > 0, a_off=r0 * N, a_rowsum=db_buf)
                 r0 += M
+        elif db_buf is not None:
+            check(hip.lib().ekaid_colsum_acc(ptr(dy), Mtot, N, N, ptr(db_buf), stream()), 'colsum_acc')
         dxs = []
         r0 = 0
         for i, (x, M) in enumerate(zip(xs2, ctx.Ms)):
@@ -1179,11 +1200,11 @@ class GRUSeqFn(Function):
                 carry = gemm_slabs(dgh, w_hh, B, H, 3 * H, 3 * H, H, 0, 0, a_off=t * B * 3 * H)
         # weight gradients batched over time: K = T*B rows (previous states are the contiguous slice hall[0:T])
         dw_hh = grad_out(w_hh)
-        gemm(dgh, hall, dw_hh, 3 * H, H, T * B, 3 * H, H, H, 1, 0)
-        db_hh = bias_grad(b_hh, dgh, T * B, 3 * H, 3 * H)
-        db_ih = bias_grad(b_ih, dgi, B * T, 3 * H, 3 * H)
+        hh_buf, db_hh = bias_grad_slot(b_hh)
+        gemm(dgh, hall, dw_hh, 3 * H, H, T * B, 3 * H, H, H, 1, 0, a_rowsum=hh_buf)
+        ih_buf, db_ih = bias_grad_slot(b_ih)
         dw_ih = grad_out(w_ih)
-        gemm(dgi, x, dw_ih, 3 * H, E, B * T, 3 * H, E, E, 1, 0)
+        gemm(dgi, x, dw_ih, 3 * H, E, B * T, 3 * H, E, E, 1, 0, a_rowsum=ih_buf)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)

@@ -42,9 +42,24 @@ def _nn(D, doff, ldd, W, woff, ldw, Y, yoff, ldy, M, N, K, acc=False):
     gemm(D, W, Y, M, N, K, ldd, ldw, ldy, 0, 0, accumulate=acc, a_off=doff, b_off=woff, c_off=yoff)
 
 
-def _tn(D, ldd, X, ldx, G, goff, ldg, Nout, Kin, rows, doff=0, xoff=0):
-    """G[Nout,Kin] = D[rows,Nout]^T . X[rows,Kin]   (wgrad over rows = T*B)."""
-    gemm(D, X, G, Nout, Kin, rows, ldd, ldx, ldg, 1, 0, a_off=doff, b_off=xoff, c_off=goff)
+def _tn(D, ldd, X, ldx, G, goff, ldg, Nout, Kin, rows, doff=0, xoff=0, bias=None):
+    """G[Nout,Kin] = D[rows,Nout]^T . X[rows,Kin]   (wgrad over rows = T*B); ``bias``: parameter(s) whose gradient is the column
+    sum of D -- it rides on this product (ops.gemm a_rowsum); returns their autograd values."""
+    if bias is None:
+        gemm(D, X, G, Nout, Kin, rows, ldd, ldx, ldg, 1, 0, a_off=doff, b_off=xoff, c_off=goff)
+        return None
+    biases = bias if isinstance(bias, (tuple, list)) else (bias,)
+    buf, ret = ops.bias_grad_slot(biases[0])
+    gemm(D, X, G, Nout, Kin, rows, ldd, ldx, ldg, 1, 0, a_off=doff, b_off=xoff, c_off=goff, a_rowsum=buf)
+    rets = [ret]
+    for b2 in biases[1:]:           # a second bias with the same gradient (bias_ih / bias_hh of an LSTM cell)
+        buf2, ret2 = ops.bias_grad_slot(b2)
+        if ret is not None and ret2 is not None:       # both slots fresh: buf IS the column sum, add it to the zeroed second slot
+            check(hip.lib().ekaid_axpby(ptr(buf), ptr(buf2), ptr(buf2), buf.numel(), 1.0, 1.0, stream()), 'axpby')
+        else:
+            check(hip.lib().ekaid_colsum_acc(D.data_ptr() + 4 * doff, rows, Nout, ldd, ptr(buf2), stream()), 'colsum_acc')
+        rets.append(ret2)
+    return rets[0] if len(rets) == 1 else rets
 
 
 def _drop(x, y, n, p, seed, xoff=0, yoff=0):
@@ -199,8 +214,7 @@ class SpeakerSeqFn(Function):
         dlogits = torch.empty(T, B, V, **f32)
         check(L.ekaid_softmax_bwd(ptr(logp), ptr(dlogp), ptr(dlogits), TB, V, 1, stream()), 'softmax_bwd')
         d_w_lo = ops.grad_out(w_lo)
-        _tn(dlogits, V, HO, R, d_w_lo, 0, R, V, R, TB)
-        d_b_lo = ops.bias_grad(b_lo, dlogits, TB, V, V)
+        d_b_lo = _tn(dlogits, V, HO, R, d_w_lo, 0, R, V, R, TB, bias=b_lo)
         dHO = torch.empty(T, B, R, **f32)
         _nn(dlogits, 0, V, w_lo, 0, R, dHO, 0, R, TB, R, V)
         dHLo = torch.empty(T, B, R, **f32)        # gradient reaching h_lang_t through the output dropout
@@ -276,35 +290,25 @@ class SpeakerSeqFn(Function):
         _tn(DCAT, NW, ED, E, d_wih_a, 0, E + R, 4 * R, E, TB)
         _tn(DCAT, NW, HL, R, d_wih_a, E, E + R, 4 * R, R, TB)
         d_whh_a = ops.grad_out(whh_a)
-        _tn(DCAT, NW, HA, R, d_whh_a, 0, R, 4 * R, R, TB)
-        d_bih_a = ops.bias_grad(bih_a, DCAT, TB, 4 * R, NW)          # bias_ih and bias_hh receive the same gradient
-        d_bhh_a = ops.bias_grad(bhh_a, DCAT, TB, 4 * R, NW)
+        d_bih_a, d_bhh_a = _tn(DCAT, NW, HA, R, d_whh_a, 0, R, 4 * R, R, TB, bias=(bih_a, bhh_a))   # the same gradient for both
         d_w_fc = ops.grad_out(w_fc)
-        _tn(DZFC, 3, HA, R, d_w_fc, 0, R, 3, R, TB, xoff=B * R)
-        d_b_fc = ops.bias_grad(b_fc, DZFC, TB, 3, 3)
+        d_b_fc = _tn(DZFC, 3, HA, R, d_w_fc, 0, R, 3, R, TB, xoff=B * R, bias=b_fc)
         d_w_p1 = ops.grad_out(w_p1)
-        _tn(DCAT, NW, HL, R, d_w_p1, 0, R, R, R, TB, doff=oP1)
-        d_b_p1 = ops.bias_grad(b_p1, DCAT, TB, R, NW, oP1)
+        d_b_p1 = _tn(DCAT, NW, HL, R, d_w_p1, 0, R, R, R, TB, doff=oP1, bias=b_p1)
         d_w_wp = ops.grad_out(w_wp)
-        _tn(DWP, NP, VP, R, d_w_wp, 0, R, NP, R, TB)
-        d_b_wp = ops.bias_grad(b_wp, DWP, TB, NP, NP)
+        d_b_wp = _tn(DWP, NP, VP, R, d_w_wp, 0, R, NP, R, TB, bias=b_wp)
         d_w_p2 = ops.grad_out(w_p2)
-        _tn(DPP, R, PW, NP, d_w_p2, 0, NP, R, NP, TB)
-        d_b_p2 = ops.bias_grad(b_p2, DPP, TB, R, R)
+        d_b_p2 = _tn(DPP, R, PW, NP, d_w_p2, 0, NP, R, NP, TB, bias=b_p2)
         d_w_g1 = ops.grad_out(w_g1)
-        _tn(DCAT, NW, HL, R, d_w_g1, 0, G1, G1, R, TB, doff=oG1)
+        d_b_g1 = _tn(DCAT, NW, HL, R, d_w_g1, 0, G1, G1, R, TB, doff=oG1, bias=b_g1)
         _tn(DCAT, NW, PA, R + A, d_w_g1, R, G1, G1, R + A, TB, doff=oG1)
-        d_b_g1 = ops.bias_grad(b_g1, DCAT, TB, G1, NW, oG1)
         d_w_g2 = ops.grad_out(w_g2)
-        _tn(DZ2, A, G1D, G1, d_w_g2, 0, G1, A, G1, TB)                                            # input = dropout(relu(gate1x))
-        d_b_g2 = ops.bias_grad(b_g2, DZ2, TB, A, A)
+        d_b_g2 = _tn(DZ2, A, G1D, G1, d_w_g2, 0, G1, A, G1, TB, bias=b_g2)                              # input = dropout(relu(gate1x))
         d_wih_l = ops.grad_out(wih_l)
         _tn(DCAT, NW, Xd, We, d_wih_l, 0, We + A, 4 * R, We, TB, doff=oGL)
         _tn(DCAT, NW, GA, A, d_wih_l, We, We + A, 4 * R, A, TB, doff=oGL)
         d_whh_l = ops.grad_out(whh_l)
-        _tn(DCAT, NW, HL, R, d_whh_l, 0, R, 4 * R, R, TB, doff=oGL)
-        d_bih_l = ops.bias_grad(bih_l, DCAT, TB, 4 * R, NW, oGL)
-        d_bhh_l = ops.bias_grad(bhh_l, DCAT, TB, 4 * R, NW, oGL)
+        d_bih_l, d_bhh_l = _tn(DCAT, NW, HL, R, d_whh_l, 0, R, 4 * R, R, TB, doff=oGL, bias=(bih_l, bhh_l))
         # embed path: dED = DGA . W_ih_att[:, :E]; per-step dropout backward; sum over t; relu; Linear(3A -> E)
         dED = torch.empty(T, B, E, **f32)
         _nn(DCAT, 0, NW, wih_a, 0, E + R, dED, 0, E, TB, E, 4 * R)
@@ -314,10 +318,9 @@ class SpeakerSeqFn(Function):
         d_ez = torch.empty(B, E, **f32)
         check(L.ekaid_act_bwd(ptr(d_epre), ptr(embed_pre), ptr(d_ez), B * E, ACT_RELU, stream()), 'act_bwd')
         d_w_e = ops.grad_out(w_e)
-        _tn(d_ez, E, bef, A, d_w_e, 0, 3 * A, E, A, B)
+        d_b_e = _tn(d_ez, E, bef, A, d_w_e, 0, 3 * A, E, A, B, bias=b_e)
         _tn(d_ez, E, diff, A, d_w_e, A, 3 * A, E, A, B)
         _tn(d_ez, E, aft, A, d_w_e, 2 * A, 3 * A, E, A, B)
-        d_b_e = ops.bias_grad(b_e, d_ez, B, E, E)
         _nn(d_ez, 0, E, w_e, 0, 3 * A, d_bef, 0, A, B, A, E, acc=True)
         _nn(d_ez, 0, E, w_e, A, 3 * A, d_diff, 0, A, B, A, E, acc=True)
         _nn(d_ez, 0, E, w_e, 2 * A, 3 * A, d_aft, 0, A, B, A, E, acc=True)

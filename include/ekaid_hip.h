@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EKAID_ABI_VERSION 4
+#define EKAID_ABI_VERSION 5
 
 int ekaid_version(void);
 const char* ekaid_last_error(void);        /* thread-local */
@@ -81,6 +81,9 @@ typedef struct ekaid_gemm {
     int act;
     float drop_p;           /* > 0: dropout of the activated output, keep(seed, m * N + n) / (1 - p) */
     uint64_t drop_seed;
+    float* a_rowsum;        /* optional, needs transA: a_rowsum[m] += sum_k op(A)[m][k] (f32, fixed order).  The bias gradient of a
+                               linear layer rides on its weight-gradient product dW = dY^T X this way (A = dY): dY is not read a
+                               second time by a column-sum kernel.  ekaid_gemm_f32 only; counted by ekaid_gemm_workspace_bytes. */
 } ekaid_gemm_t;
 
 size_t ekaid_gemm_workspace_bytes(const ekaid_gemm_t* g);

@@ -259,6 +259,36 @@ def test_gemm_tall_skinny_weight_gradient(M, N, K, gemm_arith):
     check(Cs, (Aw[:, 2:2 + M].double().t() @ Bw[:, 1:1 + N].double()).cpu(), 3e-6, 'tall-skinny wgrad on views')
 
 
+@pytest.mark.parametrize('M,N,K', [(1024, 1024, 18432), (1024, 4096, 2304), (2048, 512, 4096), (512, 1024, 300), (148, 1024, 4096),
+                                   (3, 1024, 4096), (130, 70, 1000), (64, 64, 64), (4096, 600, 1000), (128, 1024, 9216)])
+def test_gemm_weight_gradient_carries_the_bias_gradient(M, N, K, gemm_arith):
+    """a_rowsum: dW = dY^T X with db[m] += sum_rows dY[row][m] from the same launch (A-operand staging of the split kernels; a
+    separate column-sum launch under the f32 arithmetic and for tall-skinny shapes).  ref: autograd of every biased nn.Linear."""
+    from ekaid_amd import ops
+    dY, X = rnd(K, M, seed=51).to(DEV), rnd(K, N, seed=52).to(DEV)
+    db0 = rnd(M, seed=53).to(DEV)
+    want_w = (dY.double().t() @ X.double()).cpu()
+    want_b = (db0.double() + dY.double().sum(0)).cpu()
+    dW, db = torch.full((M, N), float('nan'), device=DEV), db0.clone()
+    ops.gemm(dY, X, dW, M, N, K, M, N, N, 1, 0, a_rowsum=db)
+    check(dW, want_w, 2e-6 * max(1.0, math.sqrt(K) / 4), 'wgrad with bias gradient')
+    check(db, want_b, 2e-6 * max(1.0, math.sqrt(K) / 4), 'bias gradient from the wgrad product')
+    dW2, db2 = torch.empty(M, N, device=DEV), db0.clone()
+    ops.gemm(dY, X, dW2, M, N, K, M, N, N, 1, 0, a_rowsum=db2)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)        # fixed summation order
+    dW3 = torch.empty(M, N, device=DEV)
+    ops.gemm(dY, X, dW3, M, N, K, M, N, N, 1, 0)
+    assert torch.equal(dW, dW3)                                 # the product itself is untouched
+    # a column block of a wider dY (the decoder's DCAT layout) into a column block of the gradient
+    if M >= 8:
+        dYw = rnd(K, M + 24, seed=54).to(DEV)
+        dbw = torch.zeros(M, device=DEV)
+        dWw = torch.zeros(M, N + 8, device=DEV)
+        ops.gemm(dYw, X, dWw, M, N, K, M + 24, N, N + 8, 1, 0, a_off=8, c_off=4, a_rowsum=dbw)
+        check(dbw, dYw[:, 8:8 + M].double().sum(0).cpu(), 2e-6 * max(1.0, math.sqrt(K) / 4), 'bias gradient of a column block')
+        check(dWw[:, 4:4 + N], (dYw[:, 8:8 + M].double().t() @ X.double()).cpu(), 2e-6 * max(1.0, math.sqrt(K) / 4), 'wgrad block')
+
+
 def test_gemm_rejects_bad_args():
     from ekaid_amd import hip, ops
     A = torch.zeros(4, 4, device=DEV)

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(hip.SIGNATURES), (declared ^ set(hip.SIGNATURES))
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.ekaid_version() == 4
+    assert lib.ekaid_version() == 5
 
 
 def test_ops_fail_loudly_without_the_hip_device():
