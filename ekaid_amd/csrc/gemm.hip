@@ -1187,6 +1187,18 @@ static void plan(const ekaid_gemm_t* d, int& TMN, int& splitk, int& tiles_m, int
         else if (!d->transB && d->K <= 128) TMN = 1;
     }
     {
+        // few 128x128 tiles but enough 64x64 ones to fill the chip WITHOUT a K split (the 2304- / 4608-row products of a 32- /
+        // 64-pair step: 144 tiles x 5 slabs + reduce kernel vs 576 unsplit tiles), short contractions only: same box, hipGraph
+        // replay, 9.55 -> 9.50 ms at 32 pairs, 12.68 -> 12.43 at 64, 19.40 -> 19.33 at 128; with K up to 4096 it loses
+        // (9.57 -> 9.71).  EKAID_GEMM_SMALL_UNSPLIT=<max K> overrides (0 = off).
+        static const char* su = getenv("EKAID_GEMM_SMALL_UNSPLIT");
+        const int su_k = su ? atoi(su) : 1024;
+        if (TMN == 2 && batch == 1 && gemm_mode() >= 1) {
+            const long long t128 = (long long)cdiv(d->M, 128) * cdiv(d->N, 128), t64 = (long long)cdiv(d->M, 64) * cdiv(d->N, 64);
+            if (t128 * 4 < 768 * 3 && t64 >= 512 && d->K <= su_k) TMN = 1;
+        }
+    }
+    {
         // slab-mode products (consumer-reduced, the recurrent steps) with 64 < M: tuning aid EKAID_GEMM_SLAB_TILE=3 (128x64) / 4
         static const char* st = getenv("EKAID_GEMM_SLAB_TILE");
         if (st && t_plan_slab && TMN == 1 && d->M > 64 && (st[0] == '3' || st[0] == '4')) TMN = st[0] - '0';

@@ -71,6 +71,21 @@ class SpkStepABwd(Structure):
                 ('dpp_out', c_void_p), ('lddpp', c_int), ('dwp_out', c_void_p), ('dx_out', c_void_p), ('lddx', c_int)]
 
 
+class SpeakerSeq(Structure):
+    """ekaid_speaker_seq_t (include/ekaid_hip.h): the recurrent part of the teacher-forced decoder behind one call."""
+    _fields_ = ([('T', c_int), ('B', c_int), ('R', c_int), ('A', c_int), ('P', c_int), ('G1', c_int), ('We', c_int),
+                 ('p_lm', c_float), ('p_pos', c_float), ('seeds', c_void_p)] +
+                [(k, c_void_p) for k in ('Wcat', 'whh_a', 'bhh_a', 'w_fc', 'b_fc', 'b_p1', 'w_wp', 'b_wp', 'w_p2', 'b_p2',
+                                         'w_g1', 'b_g1', 'w_g2', 'b_g2', 'wih_l', 'bhh_l', 'bef', 'diff', 'aft', 'GXA', 'GXL',
+                                         'HA', 'CA', 'HL', 'CL', 'SA', 'SL', 'G1D', 'MW', 'VP', 'DP', 'PW', 'PA', 'AT', 'GT', 'GA')])
+
+
+class SpeakerSeqBwd(Structure):
+    """ekaid_speaker_seq_bwd_t."""
+    _fields_ = [('f', SpeakerSeq)] + [(k, c_void_p) for k in ('dHLo', 'dDPl', 'DCAT', 'DZFC', 'DWP', 'DPP', 'DZ2',
+                                                               'd_bef', 'd_diff', 'd_aft')]
+
+
 P, I, L, F, U64 = c_void_p, c_int, c_longlong, c_float, c_uint64
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/ekaid_hip.h 1:1
@@ -95,6 +110,12 @@ SIGNATURES = {
     'ekaid_gru_cell_slabs_bwd': [P, I, P, POINTER(Slabs), P, P, I, I, I, P, I, P, P, P],
     'ekaid_gate_mul_slabs_fwd': [POINTER(Slabs), P, P, I, I, P, P, P],
     'ekaid_gate_slabs_bwd': [POINTER(Slabs), P, P, I, I, P, P, P],
+    'ekaid_gru_seq_workspace_bytes': [I, I, I, I],
+    'ekaid_gru_seq_fwd': [P, P, P, I, I, I, P, P, P, c_size_t, P],
+    'ekaid_gru_seq_bwd': [P, P, P, P, I, I, I, P, P, P, c_size_t, P],
+    'ekaid_speaker_seq_workspace_bytes': [POINTER(SpeakerSeq), I],
+    'ekaid_speaker_seq_fwd': [POINTER(SpeakerSeq), P, c_size_t, P],
+    'ekaid_speaker_seq_bwd': [POINTER(SpeakerSeqBwd), P, c_size_t, P],
     'ekaid_spk_step_a_fwd': [POINTER(SpkStepAFwd), P],
     'ekaid_spk_step_a_bwd': [POINTER(SpkStepABwd), P],
     'ekaid_wn_scale_fwd': [P, P, L, P, P, P],
@@ -158,7 +179,8 @@ SIGNATURES = {
     'ekaid_adam_step': [P, P, P, P, L, F, F, F, F, I, F, P],
     'ekaid_adam_step_dev': [P, P, P, P, L, P, P, P, P],
 }
-_RESTYPES = {'ekaid_last_error': c_char_p, 'ekaid_gemm_workspace_bytes': c_size_t}
+_RESTYPES = {'ekaid_last_error': c_char_p, 'ekaid_gemm_workspace_bytes': c_size_t, 'ekaid_gru_seq_workspace_bytes': c_size_t,
+             'ekaid_speaker_seq_workspace_bytes': c_size_t}
 
 _lib = None
 

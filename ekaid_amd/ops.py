@@ -169,6 +169,13 @@ def grad_claimed_slot(W):
 
 
 _BIAS_IN_WGRAD = os.environ.get('EKAID_BIAS_IN_WGRAD', '1') != '0'
+_SEQ_IN_C = os.environ.get('EKAID_SEQ_IN_C', '1') != '0'      # time loops of the GRU / decoder behind ONE C-ABI call each
+
+
+def seq_in_c():
+    """The sequence-level entry points are the default; the step-by-step Python loops (the same C-ABI calls, one by one) stay
+    for the per-launch GEMM profile of bench.py and as the cross-check of tests (EKAID_SEQ_IN_C=0)."""
+    return _SEQ_IN_C and _gemm_profile is None
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=None,
@@ -1164,7 +1171,12 @@ class GRUSeqFn(Function):
         gemm(x, w_ih, gi, B * T, 3 * H, E, E, E, 3 * H, 0, 1, bias=b_ih)
         hall = torch.zeros(T + 1, B, H, device=dev, dtype=torch.float32)     # time-major states, hall[0] = h0 = 0
         save = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
-        for t in range(T):
+        if seq_in_c():
+            need = L.ekaid_gru_seq_workspace_bytes(B, T, H, 0)
+            ws = hip.workspace(need, dev)
+            check(L.ekaid_gru_seq_fwd(ptr(gi), ptr(w_hh), ptr(b_hh), B, T, H, ptr(hall), ptr(save), ptr(ws), need, stream()),
+                  'gru_seq_fwd')
+        for t in range(0 if seq_in_c() else T):
             # h_{t-1} . W_hh^T as raw K-slabs; the cell kernel sums them, adds b_hh and applies the gates (one launch fewer
             # per step than GEMM + reduce + cell)
             S = gemm_slabs(hall, w_hh, B, 3 * H, H, H, H, 0, 1, a_off=t * B * H)
@@ -1190,7 +1202,12 @@ class GRUSeqFn(Function):
         dgh = torch.empty(T, B, 3 * H, device=dev, dtype=torch.float32)
         dh_dir = [torch.empty(B, H, device=dev, dtype=torch.float32) for _ in range(2)]    # z * d of step t (ping-pong)
         carry = None                                      # slabs of dgh_{t+1} . W_hh
-        for t in range(T - 1, -1, -1):
+        if seq_in_c():
+            need = L.ekaid_gru_seq_workspace_bytes(B, T, H, 1)
+            ws = hip.workspace(need, dev)
+            check(L.ekaid_gru_seq_bwd(ptr(dout), ptr(w_hh), ptr(hall), ptr(save), B, T, H, ptr(dgi), ptr(dgh), ptr(ws), need,
+                                      stream()), 'gru_seq_bwd')
+        for t in (() if seq_in_c() else range(T - 1, -1, -1)):
             csl = carry.cols(0) if carry is not None else NO_SLABS
             check(L.ekaid_gru_cell_slabs_bwd(dout.data_ptr() + 4 * t * H, T * H, ptr(dh_dir[(t + 1) & 1]) if t < T - 1 else None,
                                              ctypes.byref(csl), save.data_ptr() + 4 * t * B * 4 * H,

@@ -62,6 +62,21 @@ def _tn(D, ldd, X, ldx, G, goff, ldg, Nout, Kin, rows, doff=0, xoff=0, bias=None
     return rets[0] if len(rets) == 1 else rets
 
 
+def _seq_desc(T, B, R, A, NP, G1, We, p, p5, seeds_t, *tensors):
+    """ekaid_speaker_seq_t; ``tensors`` in the order of its pointer fields (None where a direction does not read one)."""
+    sq = hip.SpeakerSeq()
+    sq.T, sq.B, sq.R, sq.A, sq.P, sq.G1, sq.We = T, B, R, A, NP, G1, We
+    sq.p_lm, sq.p_pos = p, p5
+    flat = (ctypes.c_uint64 * (3 * T))(*[s for trip in seeds_t for s in trip])
+    sq._seeds_keepalive = flat                  # host array read during the call only
+    sq.seeds = ctypes.cast(flat, ctypes.c_void_p)
+    names = [k for k, _ in hip.SpeakerSeq._fields_[10:]]
+    assert len(names) == len(tensors)
+    for k, t in zip(names, tensors):
+        setattr(sq, k, ptr(t))
+    return sq
+
+
 def _drop(x, y, n, p, seed, xoff=0, yoff=0):
     check(hip.lib().ekaid_dropout(x.data_ptr() + 4 * xoff, y.data_ptr() + 4 * yoff, n, p, seed, stream()), 'dropout')
 
@@ -130,14 +145,23 @@ class SpeakerSeqFn(Function):
         GT = torch.empty(T, B, A, **f32)          # gate (sigmoid)
         GA = torch.empty(T, B, A, **f32)          # gated att feat
 
-        # Per step: 4 GEMM launches whose K-slabs are summed by their consumers (csrc/steps.hip), 4 consumer kernels.
+        # Per step: 4 GEMM launches whose K-slabs are summed by their consumers (csrc/steps.hip), 4 consumer kernels -- issued by
+        # ONE sequence-level call (csrc/sequence.hip); the loop below is the same chain call by call (GEMM profile, cross-check)
+        in_c = ops.seq_in_c()
+        if in_c:
+            sq = _seq_desc(T, B, R, A, NP, G1, We, p, p5, seeds_t, Wcat, whh_a, bhh_a, w_fc, b_fc, b_p1, w_wp, b_wp, w_p2, b_p2,
+                           w_g1, b_g1, w_g2, b_g2, wih_l, bhh_l, bef, diff, aft, GXA, GXL, HA, CA, HL, CL, SA, SL, G1D, MW, VP,
+                           DP, PW, PA, AT, GT, GA)
+            need = L.ekaid_speaker_seq_workspace_bytes(ctypes.byref(sq), 0)
+            ws = hip.workspace(need, dev)
+            check(L.ekaid_speaker_seq_fwd(ctypes.byref(sq), ptr(ws), need, stream()), 'speaker_seq_fwd')
         sa = hip.SpkStepAFwd()
         sa.B, sa.R, sa.A, sa.P = B, R, A, NP
         sa.b_hh, sa.w_fc, sa.b_fc = ptr(bhh_a), ptr(w_fc), ptr(b_fc)
         sa.bef, sa.diff, sa.aft = ptr(bef), ptr(diff), ptr(aft)
         sa.b_p1, sa.w_wp, sa.b_wp, sa.w_p2, sa.b_p2 = ptr(b_p1), ptr(w_wp), ptr(b_wp), ptr(w_p2), ptr(b_p2)
         sa.p_v, sa.p_d, sa.ld2, sa.ldpp, sa.n_gates_src = p, p5, R + A, R + A, 2
-        for t in range(T):
+        for t in range(0 if in_c else T):
             o_prev, o_t = t * B * R, (t + 1) * B * R
             sv, sd, sg = seeds_t[t]
             # 0.+1. everything h_lang_{t-1} feeds (P0, NW columns) and h_att_{t-1} . W_hh_att^T (P1): two products, one launch
@@ -240,7 +264,20 @@ class SpeakerSeqFn(Function):
         sb.w_p2, sb.w_wp = ptr(w_p2), ptr(w_wp)
         sb.p_v, sb.p_d, sb.lddg, sb.lddpp, sb.lddx = p, p5, NW, R, NW
         carry_l = carry_a = None                  # slabs of DCAT_{t+1} . Wcat (-> h_lang_t) and DCAT_{t+1}[att gates] . W_hh_att (-> h_att_t)
-        for t in range(T - 1, -1, -1):
+        in_c = ops.seq_in_c()
+        if in_c:
+            sqb = hip.SpeakerSeqBwd()
+            fdesc = _seq_desc(T, B, R, A, NP, G1, We, p, p5, seeds_t, Wcat, whh_a, None, w_fc, None, None, w_wp, None, w_p2, None,
+                              w_g1, None, w_g2, None, wih_l, None, bef, diff, aft, None, None, HA, CA, HL, CL, SA, SL, G1D, MW, VP,
+                              None, PW, PA, AT, GT, GA)      # (kept alive until the call returns: it owns the host seed array)
+            sqb.f = fdesc
+            sqb.dHLo, sqb.dDPl = ptr(dHLo), ptr(dDPl)
+            sqb.DCAT, sqb.DZFC, sqb.DWP, sqb.DPP, sqb.DZ2 = ptr(DCAT), ptr(DZFC), ptr(DWP), ptr(DPP), ptr(DZ2)
+            sqb.d_bef, sqb.d_diff, sqb.d_aft = ptr(d_bef), ptr(d_diff), ptr(d_aft)
+            need = L.ekaid_speaker_seq_workspace_bytes(ctypes.byref(sqb.f), 1)
+            ws = hip.workspace(need, dev)
+            check(L.ekaid_speaker_seq_bwd(ctypes.byref(sqb), ptr(ws), need, stream()), 'speaker_seq_bwd')
+        for t in (() if in_c else range(T - 1, -1, -1)):
             o_prev, o_t = t * B * R, (t + 1) * B * R
             ow = t * B * NW
             sv, sd, sg = seeds_t[t]

@@ -374,6 +374,53 @@ typedef struct ekaid_spk_step_a_bwd {
 } ekaid_spk_step_a_bwd_t;
 int ekaid_spk_step_a_bwd(const ekaid_spk_step_a_bwd_t* d, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Sequence-level entry points: the whole time loop of a recurrent block behind ONE call (csrc/sequence.hip).  Each step is
+ * the chain of slab products and slab-consuming kernels declared above, issued from C on `stream`; no allocation, no host
+ * synchronisation (graph-capturable).  `workspace` holds the K-slabs of one step and the small carries of the backward
+ * loops; its size comes from the matching *_workspace_bytes call (backward = 0 / 1).
+ *
+ * Question GRU, 1 layer, gate order r,z,n, h0 = hall[0] (ref: language_model.py:106-115, nn.GRU):
+ *   gi   [B][T][3H]  x W_ih^T + b_ih for all steps (one time-batched ekaid_gemm_f32 by the caller)
+ *   hall [T+1][B][H] time-major states, row 0 given, rows 1..T written;  save [T][B][4H] gate activations for the backward
+ *   bwd: dout [B][T][H] -> dgi [B][T][3H], dgh [T][B][3H]; the weight / bias gradients are time-batched products of the
+ *   caller (dW_hh = dgh^T hall[0:T], dW_ih = dgi^T x, a_rowsum for the biases). */
+size_t ekaid_gru_seq_workspace_bytes(int B, int T, int H, int backward);
+int ekaid_gru_seq_fwd(const float* gi, const float* w_hh, const float* b_hh, int B, int T, int H, float* hall, float* save,
+                      void* workspace, size_t workspace_bytes, void* stream);
+int ekaid_gru_seq_bwd(const float* dout, const float* w_hh, const float* hall, const float* save, int B, int T, int H, float* dgi,
+                      float* dgh, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Teacher-forced answer decoder, the recurrent part of DynamicSpeaker._forward (ref: dynamic_speaker_change_pos.py:94-131,
+ * 196-222): per step module-attention LSTM -> module weights + attended feature -> POS chain -> gate MLP -> language LSTM;
+ * 8 launches per step in each direction.  Time-batched around it by the caller: embeddings, input-side gates GXA / GXL
+ * (bias_ih included), logits / log-softmax heads, all weight and bias gradients (K = T*B products over the saved tensors).
+ * Layout of the NW = 9R + G1 wide "h_lang projection" block (Wcat rows, DCAT columns):
+ *   [0,4R) W_ih_att[:, E:] | [4R,5R) W_pos1 | [5R,5R+G1) W_g1[:, :R] | [5R+G1,NW) W_hh_lang.
+ * All activations time-major, contiguous. */
+typedef struct ekaid_speaker_seq {
+    int T, B, R, A, P, G1, We;        /* steps, batch, rnn size, feature width, POS classes, gate-MLP width, word-embedding width */
+    float p_lm, p_pos;                /* dropout probabilities (0 in eval mode) */
+    const uint64_t* seeds;            /* HOST array [T][3]: seeds of the vpos, dpos and gate-MLP dropouts of each step (NULL if p = 0) */
+    const float *Wcat, *whh_a, *bhh_a, *w_fc, *b_fc, *b_p1, *w_wp, *b_wp, *w_p2, *b_p2;
+    const float *w_g1, *b_g1, *w_g2, *b_g2, *wih_l, *bhh_l;   /* w_g1 [G1][2R+A], w_g2 [A][G1], wih_l [4R][We+A] */
+    const float *bef, *diff, *aft;    /* [B][A] */
+    const float *GXA, *GXL;           /* [T][B][4R] */
+    float *HA, *CA, *HL, *CL;         /* [T+1][B][R]: row 0 = initial state (given), rows 1..T written by fwd */
+    float *SA, *SL;                   /* [T][B][4R] gate activations */
+    float *G1D, *MW, *VP, *DP, *PW, *PA, *AT, *GT, *GA;   /* [T][B][G1], [..][3], [..][R], [..][P], [..][P], [..][R+A], [..][A] x3 */
+} ekaid_speaker_seq_t;
+typedef struct ekaid_speaker_seq_bwd {
+    ekaid_speaker_seq_t f;            /* the forward call's descriptor (weights and saved activations) */
+    const float* dHLo;                /* [T][B][R] gradient reaching h_lang_t through the output head */
+    const float* dDPl;                /* [T][B][P] gradient reaching the POS logits through their head, or NULL */
+    float *DCAT, *DZFC, *DWP, *DPP, *DZ2;   /* out: [T][B][NW], [..][3], [..][P], [..][R], [..][A] (operands of the weight gradients) */
+    float *d_bef, *d_diff, *d_aft;    /* [B][A], accumulated in place */
+} ekaid_speaker_seq_bwd_t;
+size_t ekaid_speaker_seq_workspace_bytes(const ekaid_speaker_seq_t* d, int backward);
+int ekaid_speaker_seq_fwd(const ekaid_speaker_seq_t* d, void* workspace, size_t workspace_bytes, void* stream);
+int ekaid_speaker_seq_bwd(const ekaid_speaker_seq_bwd_t* d, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Scheduled sampling, one decode step for the whole batch: it[b] = teacher[b * ld_teacher] with probability 1 - ss_prob, else a
  * draw from exp(logp_prev[b][:]) (counter-based uniforms from `seed`; the reference draws with torch.multinomial: same
  * distribution, its own random stream).   ref: dynamic_speaker_change_pos.py:197-208, schedule train_mimic.py:194-202 */

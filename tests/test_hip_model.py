@@ -299,6 +299,37 @@ def test_speaker_fused_sequence_equals_stepwise_autograd():
     close(res[True][3], res[False][3], 2e-4, 'grad img.weight (through the speaker inputs)')
 
 
+@pytest.mark.parametrize('train', [False, True])
+def test_sequence_entry_points_equal_the_step_by_step_loops(train):
+    """ekaid_gru_seq_fwd/bwd and ekaid_speaker_seq_fwd/bwd (the time loops issued from C, csrc/sequence.hip) against the same
+    chains issued call by call from Python (EKAID_SEQ_IN_C=0): identical launches in identical order, so every output and
+    every gradient must agree BIT FOR BIT -- also in train mode, where both draw the same per-step dropout seeds."""
+    from ekaid_amd import ops
+    cfg, cd, sp = small_models('all', device=DEV)
+    if train:
+        cd.train()
+        sp.train()
+    batch = make_batch(**SMALL)
+    res = {}
+    old = ops._SEQ_IN_C
+    try:
+        for in_c in (True, False):
+            ops._SEQ_IN_C = in_c
+            ops.manual_seed(123)
+            cd.zero_grad()
+            sp.zero_grad()
+            loss, _, outs, logp, logpos = hip_step(cfg, cd, sp, batch, 'mode2', 'all')
+            (loss + logpos.sum() * 1e-2).backward()
+            grads = {k: p.grad.clone() for m in (cd, sp) for k, p in m.named_parameters() if p.grad is not None}
+            res[in_c] = (logp.detach().clone(), logpos.detach().clone(), grads)
+    finally:
+        ops._SEQ_IN_C = old
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert res[True][2].keys() == res[False][2].keys() and len(res[True][2]) > 40
+    for k in res[True][2]:
+        assert torch.equal(res[True][2][k], res[False][2][k]), k
+
+
 def test_ops_refuse_cpu_tensors():
     from ekaid_amd import hip, ops
     with pytest.raises(hip.EkaidError):
