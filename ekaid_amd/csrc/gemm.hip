@@ -1154,7 +1154,8 @@ static int plan_splitk(int tiles, int K, int batch, long long MN, int BK, bool b
     // 64x64 tiles, one workgroup per CU already: a 2-way split + reduce kernel measured no faster (256x6656x512: 23 vs 24 us).
     // (128x128 tiles are different: 256 tiles leave two of the three workgroup slots of every CU empty for the whole K
     // range -- wgrad 1024x4096x18432: 156-162 TF unsplit, 199 TF as 3 x 256 workgroups + reduce)
-    if (tiles >= 256 && gemm_mode() >= 1 && !big_tiles) return 1;
+    // (except a long contraction: the weight-gradient products that plan() moves to this tile at small batch, 256 tiles x K >= 1536)
+    if (tiles >= 256 && gemm_mode() >= 1 && !big_tiles && K < 1536) return 1;
     // as many slabs as still fit ONE wave of resident workgroups: rounding up (144 tiles -> 6 slabs = 864 workgroups on 768
     // slots) left a second, nearly empty wave that doubled the time of the 2304-row products (61 -> 44 us at 32 pairs / GPU)
     int s = target / tiles;
@@ -1196,6 +1197,19 @@ static void plan(const ekaid_gemm_t* d, int& TMN, int& splitk, int& tiles_m, int
         if (TMN == 2 && batch == 1 && gemm_mode() >= 1) {
             const long long t128 = (long long)cdiv(d->M, 128) * cdiv(d->N, 128), t64 = (long long)cdiv(d->M, 64) * cdiv(d->N, 64);
             if (t128 * 4 < 768 * 3 && t64 >= 512 && d->K <= su_k) TMN = 1;
+        }
+    }
+    {
+        // a weight-gradient product whose 128x128 grid needs so many K slabs to fill the chip that each slab is only a few K-steps
+        // deep (1024x1024x2304 at 32 pairs: 64 tiles x 12 slabs of 192 -- all prologue, epilogue and slab traffic) runs on 64x64
+        // tiles with a 3-way split instead (256 tiles x 3 slabs of 768).  Same box, hipGraph replay: 9.35 -> 9.05 ms at 32 pairs,
+        // 12.25 -> 12.18 at 64, nothing applies at 256.  EKAID_GEMM_WGRAD_SMALL=<min slab depth> overrides (0 = off).
+        static const char* wsm = getenv("EKAID_GEMM_WGRAD_SMALL");
+        const int min_depth = wsm ? atoi(wsm) : 512;
+        if (TMN == 2 && batch == 1 && gemm_mode() >= 1 && d->transA) {
+            const long long t128 = (long long)cdiv(d->M, 128) * cdiv(d->N, 128), t64 = (long long)cdiv(d->M, 64) * cdiv(d->N, 64);
+            const long long slabs = t128 > 0 ? 768 / t128 : 1;
+            if (slabs >= 2 && d->K / slabs < min_depth && t64 >= 192 && t64 <= 768) TMN = 1;
         }
     }
     {
