@@ -393,20 +393,27 @@ def main():
         cd.train(not args.eval); sp.train(not args.eval)             # noqa: E702
         extra['forward_only_b64'] = {'ms': round(ms64, 3), 'pairs_per_s': round(64 / ms64 * 1e3, 1),
                                      'workload': 'BASELINE.json configs[1]: eval forward, batch 64, T=16'}
-        # test_mimic.py's path (configs[1] + answer generation): eval forward, then greedy decode to completion -- the stop test
-        # is polled every 8 steps; the synthetic model's answers rarely emit the end token, so this is the 90-step worst case
+        # test_mimic.py's path (configs[1] + answer generation): eval forward, then greedy decode.  On freshly initialised weights (a
+        # second model pair: the trained one stops after as many steps as its training length happens to teach it) the answers never
+        # emit the end token, so every run decodes all seq_length (90) steps: a fixed worst-case workload
+        cd0, sp0 = build_models(cfg, 147, 148, dev, train=False)
+        cd0.eval(); sp0.eval()                                       # noqa: E702
+
         def decode():
-            _, _, outs, _ = forward_loss(cfg, cd, sp, b64, T, args.graph)
-            return sp._sample(outs[3], outs[4], outs[5], None, cfg, sample_max=1)
-        cd.eval(); sp.eval()                                         # noqa: E702
+            _, _, outs, _ = forward_loss(cfg, cd0, sp0, b64, T, args.graph)
+            return sp0._sample(outs[3], outs[4], outs[5], None, cfg, sample_max=1)
         with torch.no_grad():
-            msd = timed(decode, 5, 1)
+            msd = timed(decode, 10, 2)
             seq, _ = decode()
-        cd.train(not args.eval); sp.train(not args.eval)             # noqa: E702
+            ms_f0 = timed(lambda: forward_loss(cfg, cd0, sp0, b64, T, args.graph), 10, 2)
         nsteps = int((seq != 0).any(0).sum().item())
+        del cd0, sp0
         extra['greedy_decode_b64'] = {'ms': round(msd, 3), 'pairs_per_s': round(64 / msd * 1e3, 1), 'decode_steps_run': nsteps,
+                                      'ms_per_decode_step': round((msd - ms_f0) / max(nsteps, 1), 4),
                                       'workload': 'eval forward (teacher-forced pass included, as test_mimic.py:116-122 runs it) + '
-                                                  'greedy _sample, batch 64'}
+                                                  'greedy _sample (ekaid_speaker_greedy_steps, stop test polled every 8 steps), batch 64, '
+                                                  'freshly initialised weights: the end token never comes, all %d steps of the maximum '
+                                                  'answer length are decoded' % nsteps}
         # opt-in reduced-precision GEMM arithmetic (two bf16 terms per operand, three products): the same train step, NOT the
         # metric's arithmetic -- reported beside it with its measured log-prob deviation (cpu_baseline.parity_vs_hip_bf16x2)
         if ops.get_gemm_mode() == ops.GEMM_BF16_SPLIT:

@@ -312,3 +312,80 @@ extern "C" int ekaid_speaker_seq_bwd(const ekaid_speaker_seq_bwd_t* b, void* wor
     }
     return EKAID_OK;
 }
+
+// ---------------------------------------------------------------- greedy decoding (sample_max = 1), eval mode
+// Steps t0 .. t1-1 of DynamicSpeaker._sample's loop without a host round trip per step: token embedding -> word-side gates of
+// the language LSTM -> the recurrent step (ekaid_speaker_seq_fwd on the rows of step t) -> logits -> log-softmax -> arg-max /
+// stop-flag bookkeeping (ekaid_greedy_step), the chosen tokens feeding the next step on the device.  The host polls
+// n_unfinished every few steps (the reference tests "all finished" every step, dynamic_speaker_change_pos.py:354).
+namespace ekaid {
+namespace {
+struct GreedyPlan { ekaid_gemm_t gxl, lo; float *ws_gxl, *ws_lo; void* ws_seq; size_t seq_bytes, bytes; };
+
+ekaid_gemm_t dense_nt(const float* A, int lda, const float* W, int ldw, float* C, int M, int N, int K, const float* bias) {
+    ekaid_gemm_t g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.B = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldw; g.ldc = N;
+    g.transA = 0; g.transB = 1; g.batch1 = g.batch2 = 1; g.alpha = 1.f; g.rdiv = 1; g.bias = bias;
+    return g;
+}
+
+bool greedy_plan(const ekaid_speaker_greedy_t* q, void* ws, GreedyPlan& pl) {
+    const ekaid_speaker_seq_t* d = &q->f;
+    const int B = d->B, R = d->R, A = d->A, We = d->We;
+    pl.gxl = dense_nt(q->xt, We, d->wih_l, We + A, const_cast<float*>(d->GXL), B, 4 * R, We, q->bih_l);
+    pl.lo = dense_nt(nullptr, R, q->w_lo, R, q->logits, B, q->V, R, q->b_lo);
+    Carver c{(char*)ws, 0};
+    pl.ws_gxl = c.take(ekaid_gemm_workspace_bytes(&pl.gxl));
+    pl.ws_lo = c.take(ekaid_gemm_workspace_bytes(&pl.lo));
+    ekaid_speaker_seq_t one = *d;
+    one.T = 1;
+    pl.seq_bytes = ekaid_speaker_seq_workspace_bytes(&one, 0);
+    if (pl.seq_bytes == 0) return false;
+    pl.ws_seq = c.take(pl.seq_bytes);
+    pl.bytes = c.used;
+    return true;
+}
+}  // namespace
+}  // namespace ekaid
+
+extern "C" size_t ekaid_speaker_greedy_workspace_bytes(const ekaid_speaker_greedy_t* q) {
+    if (!q || !spk_args_ok(&q->f, "ekaid_speaker_greedy_workspace_bytes") || q->V < 1) return 0;
+    GreedyPlan pl;
+    return greedy_plan(q, nullptr, pl) ? pl.bytes : 0;
+}
+
+extern "C" int ekaid_speaker_greedy_steps(const ekaid_speaker_greedy_t* q, int t0, int t1, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+    if (!q || !spk_args_ok(&q->f, "ekaid_speaker_greedy_steps")) return EKAID_ERR_ARG;
+    const ekaid_speaker_seq_t* d = &q->f;
+    if (d->p_lm != 0.f || d->p_pos != 0.f) { set_error("ekaid_speaker_greedy_steps: eval mode only (dropout probabilities must be 0)"); return EKAID_ERR_UNSUPPORTED; }
+    if (q->V < 1 || t0 < 0 || t1 > d->T || t0 >= t1 || q->seq_len < t1 || !q->emb || !q->bih_l || !q->w_lo || !q->b_lo || !q->xt || !q->logits ||
+        !q->logp || !q->it || !q->unfinished || !q->seq || !q->seq_logp || !q->n_unfinished || !d->GXL || !d->GXA) {
+        set_error("ekaid_speaker_greedy_steps: bad arguments (steps [%d, %d) of %d)", t0, t1, d->T);
+        return EKAID_ERR_ARG;
+    }
+    GreedyPlan pl;
+    if (!greedy_plan(q, workspace, pl)) return EKAID_ERR_ARG;
+    if (!workspace || workspace_bytes < pl.bytes) { set_error("ekaid_speaker_greedy_steps: workspace too small (%zu < %zu)", workspace_bytes, pl.bytes); return EKAID_ERR_ARG; }
+    const int B = d->B, R = d->R, We = d->We;
+    const size_t BR = (size_t)B * R;
+    for (int t = t0; t < t1; ++t) {
+        // word side of the language LSTM: relu(emb[it]) . W_ih[:, :We]^T + b_ih   (:229, eval: no dropout)
+        EKAID_TRY(ekaid_embedding_fwd(q->it, B, q->emb, We, q->xt, We, 0, 1, stream));
+        EKAID_TRY(ekaid_gemm_f32(&pl.gxl, pl.ws_gxl, ekaid_gemm_workspace_bytes(&pl.gxl), stream));
+        // the recurrent step on the state rows t -> t + 1 (the per-step activation buffers are reused, the module weights kept)
+        ekaid_speaker_seq_t one = *d;
+        one.T = 1;
+        one.seeds = nullptr;
+        one.HA = d->HA + t * BR; one.CA = d->CA + t * BR; one.HL = d->HL + t * BR; one.CL = d->CL + t * BR;
+        one.MW = d->MW + (size_t)t * B * 3;
+        EKAID_TRY(ekaid_speaker_seq_fwd(&one, pl.ws_seq, pl.seq_bytes, stream));
+        // logits -> log-softmax -> arg-max, stop flags, next tokens (:238-239, :316-352)
+        pl.lo.A = d->HL + (t + 1) * BR;
+        EKAID_TRY(ekaid_gemm_f32(&pl.lo, pl.ws_lo, ekaid_gemm_workspace_bytes(&pl.lo), stream));
+        EKAID_TRY(ekaid_softmax_fwd(q->logits, q->logp, B, q->V, 1, stream));
+        EKAID_TRY(ekaid_greedy_step(q->logp, B, q->V, t, q->unfinished, q->it, q->seq, q->seq_logp, q->seq_len, q->n_unfinished + t, stream));
+    }
+    return EKAID_OK;
+}

@@ -86,6 +86,13 @@ class SpeakerSeqBwd(Structure):
                                                                'd_bef', 'd_diff', 'd_aft')]
 
 
+class SpeakerGreedy(Structure):
+    """ekaid_speaker_greedy_t."""
+    _fields_ = [('f', SpeakerSeq), ('emb', c_void_p), ('bih_l', c_void_p), ('w_lo', c_void_p), ('b_lo', c_void_p), ('V', c_int),
+                ('xt', c_void_p), ('logits', c_void_p), ('logp', c_void_p), ('it', c_void_p), ('unfinished', c_void_p),
+                ('seq', c_void_p), ('seq_logp', c_void_p), ('seq_len', c_int), ('n_unfinished', c_void_p)]
+
+
 P, I, L, F, U64 = c_void_p, c_int, c_longlong, c_float, c_uint64
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/ekaid_hip.h 1:1
@@ -116,6 +123,8 @@ SIGNATURES = {
     'ekaid_speaker_seq_workspace_bytes': [POINTER(SpeakerSeq), I],
     'ekaid_speaker_seq_fwd': [POINTER(SpeakerSeq), P, c_size_t, P],
     'ekaid_speaker_seq_bwd': [POINTER(SpeakerSeqBwd), P, c_size_t, P],
+    'ekaid_speaker_greedy_workspace_bytes': [POINTER(SpeakerGreedy)],
+    'ekaid_speaker_greedy_steps': [POINTER(SpeakerGreedy), I, I, P, c_size_t, P],
     'ekaid_spk_step_a_fwd': [POINTER(SpkStepAFwd), P],
     'ekaid_spk_step_a_bwd': [POINTER(SpkStepABwd), P],
     'ekaid_wn_scale_fwd': [P, P, L, P, P, P],
@@ -180,7 +189,7 @@ SIGNATURES = {
     'ekaid_adam_step_dev': [P, P, P, P, L, P, P, P, P],
 }
 _RESTYPES = {'ekaid_last_error': c_char_p, 'ekaid_gemm_workspace_bytes': c_size_t, 'ekaid_gru_seq_workspace_bytes': c_size_t,
-             'ekaid_speaker_seq_workspace_bytes': c_size_t}
+             'ekaid_speaker_seq_workspace_bytes': c_size_t, 'ekaid_speaker_greedy_workspace_bytes': c_size_t}
 
 _lib = None
 

@@ -209,9 +209,15 @@ class DynamicSpeaker(CaptionModel):
         seq_logprobs = feat_bef.new_zeros(batch_size, self.seq_length)
         embed_pre = self.core.embed_pre(feat_bef, feat_aft, feat_diff)
         it = feat_bef.new_zeros(batch_size, dtype=torch.long) + 2          # <bos> hard-coded as id 2 (:311)
+        if sample_max and not decoding_constraint and not self.training and self.fused_sequence:
+            # greedy path (test_mimic.py:119-122), eval mode: ``greedy_poll`` decode steps per C-ABI call
+            # (ekaid_speaker_greedy_steps: the chosen tokens feed the next step on the device), one host read per call
+            from ..speaker_seq import greedy_decode
+            seq, seq_logprobs, self.module_weights = greedy_decode(self, feat_bef, feat_aft, feat_diff, self.greedy_poll)
+            return seq, seq_logprobs
         if sample_max and not decoding_constraint:
-            # greedy path (test_mimic.py:119-122): argmax / stop-flag bookkeeping in one kernel per step; the
-            # "all finished" test (:354) is polled every ``self.greedy_poll`` steps instead of synchronising each step
+            # the same loop step by step (train mode / under autograd / fused_sequence off): argmax / stop-flag bookkeeping in one
+            # kernel per step; the "all finished" test (:354) is polled every ``self.greedy_poll`` steps
             from ..hip import check, lib, ptr, stream
             unfinished = torch.zeros(batch_size, dtype=torch.int32, device=feat_bef.device)
             counts = torch.zeros(self.seq_length, dtype=torch.int32, device=feat_bef.device)

@@ -380,3 +380,63 @@ def speaker_sequence(speaker, feat_bef, feat_aft, feat_diff, tok_tb):
                              speaker.training, *params)
     ops.assert_finite(out[0], 'answer decoder log-probabilities')
     return out
+
+
+@torch.no_grad()
+def greedy_decode(speaker, feat_bef, feat_aft, feat_diff, poll=8):
+    """Greedy ``_sample`` (eval mode) through ``ekaid_speaker_greedy_steps``: ``poll`` decode steps per C-ABI call, the chosen
+    tokens feed the next step on the device, the host reads the "still running" counters once per call.  Returns
+    (seq, seq_logprobs, module weights per step run), seq zeroed after the step at which every sample had finished -- what the
+    reference's loop leaves behind (dynamic_speaker_change_pos.py:309-357, test_mimic.py:119-122)."""
+    sd = dict(speaker.named_parameters())
+    (emb, w_e, b_e, wih_a, whh_a, bih_a, bhh_a, w_fc, b_fc, w_p1, b_p1, w_wp, b_wp, w_p2, b_p2,
+     w_g1, b_g1, w_g2, b_g2, wih_l, whh_l, bih_l, bhh_l, w_lo, b_lo) = [sd[n].detach().contiguous() for n in PARAM_NAMES]
+    hip.require_cuda(feat_bef, feat_aft, feat_diff, emb)
+    bef, aft, diff = feat_bef.contiguous(), feat_aft.contiguous(), feat_diff.contiguous()
+    B, A = bef.shape
+    E, R, We, V = w_e.shape[0], whh_a.shape[1], emb.shape[1], w_lo.shape[0]
+    G1, NP = w_g1.shape[0], w_wp.shape[0]
+    Tm = speaker.seq_length
+    dev = bef.device
+    L = hip.lib()
+    f32 = dict(device=dev, dtype=torch.float32)
+    # loop invariants (no dropout in eval mode): relu(embed(bef | diff | aft)) and its gates of the attention LSTM
+    embed_pre = torch.empty(B, E, **f32)
+    _nt(bef, 0, A, w_e, 0, 3 * A, embed_pre, 0, E, B, E, A)
+    _nt(diff, 0, A, w_e, A, 3 * A, embed_pre, 0, E, B, E, A, acc=True)
+    _nt(aft, 0, A, w_e, 2 * A, 3 * A, embed_pre, 0, E, B, E, A, bias=b_e, acc=True, act=ACT_RELU)
+    GXA = torch.empty(B, 4 * R, **f32)
+    _nt(embed_pre, 0, E, wih_a, 0, E + R, GXA, 0, 4 * R, B, 4 * R, E, bias=bih_a)
+    Wcat = torch.cat([wih_a[:, E:], w_p1, w_g1[:, :R], whh_l], 0).contiguous()
+    HA, CA, HL, CL = ops.zeros_pool(dev, (Tm + 1, B, R), (Tm + 1, B, R), (Tm + 1, B, R), (Tm + 1, B, R))
+    MW = torch.zeros(Tm, B, 3, **f32)
+    one = [torch.empty(B, n, **f32) for n in (4 * R, 4 * R, 4 * R, G1, R, NP, NP, R + A, A, A, A)]   # GXL SA SL G1D VP DP PW PA AT GT GA
+    GXL, SA, SL, G1D, VP, DP, PW, PA, AT, GT, GA = one
+    g = hip.SpeakerGreedy()
+    fdesc = _seq_desc(Tm, B, R, A, NP, G1, We, 0.0, 0.0, [(0, 0, 0)] * Tm, Wcat, whh_a, bhh_a, w_fc, b_fc, b_p1, w_wp, b_wp, w_p2, b_p2,
+                      w_g1, b_g1, w_g2, b_g2, wih_l, bhh_l, bef, diff, aft, GXA, GXL, HA, CA, HL, CL, SA, SL, G1D, MW, VP,
+                      DP, PW, PA, AT, GT, GA)
+    g.f = fdesc
+    g.emb, g.bih_l, g.w_lo, g.b_lo, g.V = ptr(emb), ptr(bih_l), ptr(w_lo), ptr(b_lo), V
+    xt, logits, logp = torch.empty(B, We, **f32), torch.empty(B, V, **f32), torch.empty(B, V, **f32)
+    it = torch.full((B,), 2, dtype=torch.long, device=dev)               # <bos> hard-coded as id 2 (:311)
+    unfinished = torch.zeros(B, dtype=torch.int32, device=dev)
+    counts = torch.zeros(Tm, dtype=torch.int32, device=dev)
+    seq = torch.zeros(B, Tm, dtype=torch.long, device=dev)
+    seq_logp = torch.zeros(B, Tm, **f32)
+    g.xt, g.logits, g.logp, g.it, g.unfinished = ptr(xt), ptr(logits), ptr(logp), ptr(it), ptr(unfinished)
+    g.seq, g.seq_logp, g.seq_len, g.n_unfinished = ptr(seq), ptr(seq_logp), Tm, ptr(counts)
+    need = L.ekaid_speaker_greedy_workspace_bytes(ctypes.byref(g))
+    ws = hip.workspace(need, dev)
+    steps_run = Tm
+    for t0 in range(0, Tm, poll):
+        t1 = min(Tm, t0 + poll)
+        check(L.ekaid_speaker_greedy_steps(ctypes.byref(g), t0, t1, ptr(ws), need, stream()), 'speaker_greedy_steps')
+        done = (counts[:t1] == 0).nonzero()
+        if done.numel():                                                 # everything had finished at step `first`
+            first = int(done[0])
+            seq[:, first + 1:] = 0
+            seq_logp[:, first + 1:] = 0
+            steps_run = first + 1
+            break
+    return seq, seq_logp, list(MW[:steps_run].unbind(0))

@@ -421,6 +421,29 @@ size_t ekaid_speaker_seq_workspace_bytes(const ekaid_speaker_seq_t* d, int backw
 int ekaid_speaker_seq_fwd(const ekaid_speaker_seq_t* d, void* workspace, size_t workspace_bytes, void* stream);
 int ekaid_speaker_seq_bwd(const ekaid_speaker_seq_bwd_t* d, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Greedy decoding (sample_max = 1, eval mode) of steps t0 .. t1-1 without a host round trip per step: token embedding, word-side
+ * gates, the recurrent step, logits, log-softmax and ekaid_greedy_step per step, the chosen tokens feeding the next step on
+ * the device.  The caller polls n_unfinished[t] (samples still running after step t) every few steps and stops once it is 0.
+ * ref: DynamicSpeaker._sample, dynamic_speaker_change_pos.py:287-357 (greedy branch), test_mimic.py:119-122.
+ *   f        weights as for ekaid_speaker_seq_fwd, p_lm = p_pos = 0, T = the maximum number of steps (seq_length);
+ *            f.HA / CA / HL / CL [T+1][B][R] (row 0 = initial state), f.MW [T][B][3] (kept per step), f.GXA [B][4R] = the
+ *            embed-side gates of the attention LSTM (constant over the steps without dropout), f.GXL [B][4R] scratch, every
+ *            other activation buffer of f ONE step large */
+typedef struct ekaid_speaker_greedy {
+    ekaid_speaker_seq_t f;
+    const float* emb;                 /* token table [vocabulary + 1][We] */
+    const float *bih_l, *w_lo, *b_lo; /* language-LSTM input bias [4R], logit layer [V][R], [V] */
+    int V;
+    float *xt, *logits, *logp;        /* scratch [B][We], [B][V], [B][V] */
+    int64_t* it;                      /* [B] current tokens: <bos> ids before step 0, updated every step */
+    int* unfinished;                  /* [B], zero before step 0 */
+    int64_t* seq; float* seq_logp;    /* [B][seq_len], zero-filled by the caller */
+    int seq_len;
+    int* n_unfinished;                /* [seq_len], zero-filled by the caller */
+} ekaid_speaker_greedy_t;
+size_t ekaid_speaker_greedy_workspace_bytes(const ekaid_speaker_greedy_t* g);
+int ekaid_speaker_greedy_steps(const ekaid_speaker_greedy_t* g, int t0, int t1, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Scheduled sampling, one decode step for the whole batch: it[b] = teacher[b * ld_teacher] with probability 1 - ss_prob, else a
  * draw from exp(logp_prev[b][:]) (counter-based uniforms from `seed`; the reference draws with torch.multinomial: same
  * distribution, its own random stream).   ref: dynamic_speaker_change_pos.py:197-208, schedule train_mimic.py:194-202 */

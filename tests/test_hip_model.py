@@ -167,6 +167,25 @@ def test_greedy_decode_ids_match_reference():
     close(seq_lp, g['seq_logp'], LOGIT_TOL, 'seq_logp')
 
 
+def test_greedy_decode_sequence_call_equals_the_step_by_step_loop():
+    """ekaid_speaker_greedy_steps (8 decode steps per C-ABI call, tokens fed back on the device) against the step-by-step greedy
+    loop through get_logprobs_state: same token ids, same stop positions, log-probs and module weights within rounding."""
+    cfg, cd, sp = small_models('all', device=DEV)
+    with torch.no_grad():
+        _, _, outs, _, _ = hip_step(cfg, cd, sp, make_batch(**SMALL), 'mode2', 'all')
+        res = {}
+        for fused in (True, False):
+            sp.fused_sequence = fused
+            seq, seq_lp = sp._sample(outs[3], outs[4], outs[5], None, cfg, sample_max=1)
+            res[fused] = (seq.clone(), seq_lp.clone(), torch.stack(sp.module_weights, 1).clone())
+        sp.fused_sequence = True
+    assert torch.equal(res[True][0], res[False][0])
+    close(res[True][1], res[False][1], 1e-5, 'greedy log-probs')
+    n = min(res[True][2].shape[1], res[False][2].shape[1])
+    assert n >= 1
+    close(res[True][2][:, :n], res[False][2][:, :n], 1e-5, 'module weights per decode step')
+
+
 def test_fused_adam_two_steps_match_reference():
     from ekaid_amd.dp import FlatAdam
     g = load_golden('f5_adam')
