@@ -30,6 +30,34 @@ def test_library_exports_every_declared_symbol():
     assert lib.ekaid_version() == 5
 
 
+def test_ctypes_mirrors_have_the_layout_of_the_c_structs(tmp_path):
+    """Every descriptor struct of include/ekaid_hip.h against its ctypes mirror in ekaid_amd/hip.py: size and the offset of the LAST
+    field, as a C compiler lays them out (gcc on the header itself) -- a field added on one side only shows up here, not as a
+    wrong pointer on the GPU."""
+    import ctypes
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('no C compiler')
+    pairs = [('ekaid_gemm_t', hip.GemmDesc), ('ekaid_slabs_t', hip.Slabs), ('ekaid_spk_step_a_fwd_t', hip.SpkStepAFwd),
+             ('ekaid_spk_step_a_bwd_t', hip.SpkStepABwd), ('ekaid_speaker_seq_t', hip.SpeakerSeq),
+             ('ekaid_speaker_seq_bwd_t', hip.SpeakerSeqBwd), ('ekaid_speaker_greedy_t', hip.SpeakerGreedy)]
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % os.path.join(ROOT, 'include', 'ekaid_hip.h'), 'int main(void) {']
+    for cname, mirror in pairs:
+        last = mirror._fields_[-1][0]
+        src.append('  printf("%%zu %%zu\\n", sizeof(%s), offsetof(%s, %s));' % (cname, cname, last))
+    src += ['  return 0;', '}']
+    c = tmp_path / 'layout.c'
+    c.write_text('\n'.join(src))
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-std=c99', str(c), '-o', str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    for i, (cname, mirror) in enumerate(pairs):
+        size, off = int(out[2 * i]), int(out[2 * i + 1])
+        assert ctypes.sizeof(mirror) == size, (cname, ctypes.sizeof(mirror), size)
+        assert getattr(mirror, mirror._fields_[-1][0]).offset == off, (cname, 'offset of the last field')
+
+
 def test_ops_fail_loudly_without_the_hip_device():
     from ekaid_amd import ops
     with pytest.raises(hip.EkaidError):
