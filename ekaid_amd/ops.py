@@ -128,16 +128,6 @@ def grad_out(W, zero=False):
     return torch.zeros_like(W) if zero else torch.empty_like(W)
 
 
-def bias_grad(b, x, rows, cols, ld, x_off=0):
-    """Gradient of bias ``b`` = column sums of x[rows, cols] (leading dim ``ld``, element offset ``x_off``), accumulated
-    straight into the bias' zeroed slot of the flat gradient buffer (no zero-fill launch, no copy afterwards); a second
-    contribution of a shared bias is accumulated onto the first.  Returns what the backward node hands to autograd."""
-    slot = grad_claimed_slot(b)
-    out = slot if slot is not None else grad_out(b, zero=True)
-    check(hip.lib().ekaid_colsum_acc(x.data_ptr() + 4 * x_off, rows, cols, ld, ptr(out), stream()), 'colsum_acc')
-    return None if slot is not None else out
-
-
 def bias_grad_slot(b):
     """(buffer the bias gradient is accumulated into -- the bias' zeroed slot of the flat gradient buffer --, what the backward
     node hands to autograd for it).  The buffer goes to ``gemm(..., a_rowsum=)`` of the layer's weight-gradient product, whose

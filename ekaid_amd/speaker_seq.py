@@ -208,7 +208,7 @@ class SpeakerSeqFn(Function):
         check(L.ekaid_softmax_fwd(ptr(DP), ptr(logpos), TB, NP, 1, stream()), 'softmax_fwd')
 
         ctx.dims = (T, B, A, E, R, We, V, G1)
-        # aliases of the bias parameters: their data_ptr finds the gradient slots (ops.bias_grad)
+        # aliases of the bias parameters: their data_ptr finds the gradient slots (ops.bias_grad_slot)
         ctx.biases = tuple(t.detach() for t in (b_e, bih_a, bhh_a, b_fc, b_p1, b_wp, b_p2, b_g1, b_g2, bih_l, bhh_l, b_lo))
         ctx.wrefs = (w_p1.detach(), whh_l.detach())   # (read through Wcat in the backward pass; needed for their slots only)
         ctx.pp = (p, p5, seeds, seeds_t)
