@@ -336,9 +336,10 @@ static int launch_fused(const float* q, const float* k, const float* S, const fl
             }
         }
     }
-    // fewer slices than ~1.5 per CU (the strong-scaling batches): split the query nodes of a slice over up to 4 workgroups
+    // fewer slices than ~1.5 per CU (the strong-scaling batches): split the query nodes of a slice over up to 8 workgroups
+    // (64 slices of 36 nodes: 4 parts 65 us, 8 parts 48 us; 128 slices of 52 nodes: 4 parts 134 us, 6-8 parts 168-185 us)
     static const char* force = getenv("EKAID_GAT_PARTS");       // tuning aid
-    int parts = force ? atoi(force) : (R >= 384 ? 1 : (R >= 192 ? 2 : 4));
+    int parts = force ? atoi(force) : (R >= 384 ? 1 : (R >= 192 ? 2 : (R >= 96 ? 4 : 8)));
     parts = parts < 1 ? 1 : (parts > N ? N : parts);
     hipLaunchKernelGGL(kern, dim3(R, parts), dim3(256), lds, st, q, k, S, cond, lbias, geo, N, M, A, H, dir, DC, P, outT);
     return check_launch("gat_fused_fwd");
