@@ -1,19 +1,25 @@
 // Graph-attention core of GraphSelfAttentionLayer (ref: graph_att_layer.py:105-172) for the
 // difference graph: per (sample, image) R-slice, N <= 64 region nodes attend over M <= 64 neighbours.
 //
-// gat_fused_fwd_kernel: one workgroup per R-slice, three phases, nothing but q/k/S in and P/outT out:
-//   1. affinities  aff[n][h][m] = <q[n,h,:], k[m,h,:]> / sqrt(dh): q/k column chunks staged through LDS
-//      (16-B coalesced HBM loads), 2x2 register-blocked dot products, accumulators live across chunks;
+// ekaid_gat_fused_fwd = two launches, nothing but q/k/S in and P/outT out:
+//   1. affinities  aff[r][n][h][m] = <q[n,h,:], k[m,h,:]> / sqrt(dh) of ALL (slice, head) pairs as ONE batched product on the
+//      matrix pipe (R x H problems of N x M x dh through ekaid_gemm_f32, written into P in its final layout).  Round 3: the
+//      LDS-staged f32 FMA version of this phase inside the kernel below took 5-20 % of the kernel's time more than the product.
+//   gat_fused_fwd_kernel, one workgroup per R-slice (or per group of query nodes of a slice):
 //   2. edge softmax: + log(max(geo,1e-6)) (implicit relation), adjacency mask with -9e15 (NOT -inf:
 //      an isolated node gets a uniform row), + label bias AFTER masking, softmax over the <= 64
-//      neighbours of a node held one-per-lane in a wave64 (shuffle max/sum reductions);
+//      neighbours of a node held one-per-lane in a wave64 (shuffle max/sum reductions); each affinity is read from P and
+//      overwritten with its probability by the same lane, the rows are kept in LDS (row stride MMAX, zero padded);
 //   3. aggregation outT[n][h][:] = sum_m P[n][h][m] * S[m][:]: every thread owns VEC feature columns,
-//      keeps the whole neighbour tile S[0..M)[cols] in VGPRs (read from HBM exactly once, 16 B/lane)
-//      and streams the P rows from LDS as broadcast ds_read_b128.
-// The kernel is HBM-bound: algorithmic bytes per slice = 3*N*A*4 (q,k,S) + N*H*A*4 (outT) + N*H*M*4 (P).
+//      keeps the whole neighbour tile S[0..MMAX)[cols] in VGPRs (read from HBM exactly once, 16 B/lane, rows >= M zero)
+//      and streams the P rows from LDS as broadcast ds_read_b128.  Everything in the row loop has compile-time bounds: the
+//      reads of a row go out together and the FMAs follow as one straight-line block (with run-time bounds on the neighbour
+//      count the compiler emitted one [ds_read, wait, 8 FMAs, branch] block per four neighbours: 2.8x the FMA issue time).
+// Algorithmic bytes per slice = 3*N*A*4 (q,k,S) + N*H*A*4 (outT) + N*H*M*4 (P).
 #include "common.h"
 #include "../../include/ekaid_hip.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace ekaid {
 
@@ -36,171 +42,94 @@ __device__ __forceinline__ float row_softmax(float x, bool active) {
     return e / s;
 }
 
-// The next q/k column chunk is fetched into registers while the current one is multiplied out (without it every chunk paid a
-// full, un-hidden HBM round trip between two barriers): -3 % at N = 36, -6.5 % at N = 52, -15 % at 64 slices
-// (profiles/r03_gat_experiments.txt, which also lists what did NOT help: a per-head pipeline and LDS-staged edge terms).
 template <int VEC, int MMAX>
-__global__ __launch_bounds__(256) void gat_fused_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                            const float* __restrict__ S, const float* __restrict__ cond,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gat_fused_fwd_kernel(const float* __restrict__ S, const float* __restrict__ cond,
                                                             const float* __restrict__ lbias, const float* __restrict__ geo,
-                                                            int N, int M, int A, int H, int dir, int DC,
+                                                            int N, int M, int A, int H, int dir,
                                                             float* __restrict__ P, float* __restrict__ outT) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int MP = (M + 3) & ~3;
-    const int LDC = DC + 4;
-    float* aff_s = smem;                       // [N*H][MP]
-    float* qs = aff_s + N * H * MP;            // [N][LDC]
-    float* ks = qs + N * LDC;                  // [M][LDC]
+    static_assert(MMAX % 4 == 0 && MMAX <= 64, "neighbour tile");
+    float* aff_s = smem;                       // [NL*H][MMAX] probabilities, columns >= M zero
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long r = blockIdx.x;
     // query-node split (gridDim.y parts per slice, used when there are fewer slices than CUs): this workgroup owns nodes
-    // [n_lo, n_lo + NL) -- their affinities, softmax rows and output rows; keys and values are read whole by every part
+    // [n_lo, n_lo + NL) -- their softmax rows and output rows; the values are read whole by every part
     const int n_per = (N + gridDim.y - 1) / gridDim.y;
     const int n_lo = blockIdx.y * n_per;
     const int NL = min(N - n_lo, n_per);
     if (NL <= 0) return;
-    const int dh = A / H;
-    const float scale = 1.0f / sqrtf((float)dh);
-    const float* qr = q + (r * N + n_lo) * A;
-    const float* kr = k + r * M * A;           // keys exist for the first M (= nongt) nodes only
     const float* Sr = S + r * N * A;
 
-    // ---------------- phase 1: scaled affinities into LDS
-    const int n2 = (NL + 1) >> 1, m2 = (M + 1) >> 1, tiles = n2 * m2;
-    float acc[4][4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[p][j] = 0.f;
-
-    const int dc4 = DC >> 2;
-    constexpr int QV = 4, KV = (MMAX * 16 + 255) / 256;       // float4 per thread per chunk (N <= 64, DC <= 64)
-    f32x4 pq[QV], pk[KV];
-    auto fetch = [&](int c0) {
-#pragma unroll
-        for (int j = 0; j < QV; ++j) {
-            const int i = tid + j * 256;
-            if (i < NL * dc4) pq[j] = *reinterpret_cast<const f32x4*>(&qr[(long long)(i / dc4) * A + c0 + 4 * (i % dc4)]);
-        }
-#pragma unroll
-        for (int j = 0; j < KV; ++j) {
-            const int i = tid + j * 256;
-            if (i < M * dc4) pk[j] = *reinterpret_cast<const f32x4*>(&kr[(long long)(i / dc4) * A + c0 + 4 * (i % dc4)]);
-        }
-    };
-    fetch(0);
-    for (int c0 = 0; c0 < A; c0 += DC) {
-#pragma unroll
-        for (int j = 0; j < QV; ++j) {
-            const int i = tid + j * 256;
-            if (i < NL * dc4) *reinterpret_cast<f32x4*>(&qs[(i / dc4) * LDC + 4 * (i % dc4)]) = pq[j];
-        }
-#pragma unroll
-        for (int j = 0; j < KV; ++j) {
-            const int i = tid + j * 256;
-            if (i < M * dc4) *reinterpret_cast<f32x4*>(&ks[(i / dc4) * LDC + 4 * (i % dc4)]) = pk[j];
-        }
-        __syncthreads();
-        if (c0 + DC < A) fetch(c0 + DC);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int t = tid + p * 256;
-            if (t < tiles) {
-                const int na = 2 * (t / m2), ma = 2 * (t % m2);
-                const int nb = min(na + 1, NL - 1), mb = min(ma + 1, M - 1);
-                const float* qa = qs + na * LDC; const float* qb = qs + nb * LDC;
-                const float* ka = ks + ma * LDC; const float* kb = ks + mb * LDC;
-                for (int d = 0; d < DC; d += 4) {
-                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(qa + d);
-                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(qb + d);
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(ka + d);
-                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(kb + d);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc[p][0] = fmaf(a0[e], b0[e], acc[p][0]);
-                        acc[p][1] = fmaf(a0[e], b1[e], acc[p][1]);
-                        acc[p][2] = fmaf(a1[e], b0[e], acc[p][2]);
-                        acc[p][3] = fmaf(a1[e], b1[e], acc[p][3]);
-                    }
-                }
-            }
-        }
-        if ((c0 + DC) % dh == 0) {             // a head is complete: park it in LDS, reset accumulators
-            const int hd = c0 / dh;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int t = tid + p * 256;
-                if (t < tiles) {
-                    const int na = 2 * (t / m2), ma = 2 * (t % m2);
-                    aff_s[(na * H + hd) * MP + ma] = acc[p][0] * scale;
-                    if (ma + 1 < M) aff_s[(na * H + hd) * MP + ma + 1] = acc[p][1] * scale;
-                    if (na + 1 < NL) {
-                        aff_s[((na + 1) * H + hd) * MP + ma] = acc[p][2] * scale;
-                        if (ma + 1 < M) aff_s[((na + 1) * H + hd) * MP + ma + 1] = acc[p][3] * scale;
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[p][j] = 0.f;
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---------------- phase 2: edge softmax, one (n,h) row per wave pass, neighbour m on lane m
+    // ---------------- edge softmax, one (n,h) row per wave pass, neighbour m on lane m.  Four rows per iteration: their inputs
+    // (adjacency, label bias, affinity, geometry) are all requested before the first softmax is computed -- one exposed memory
+    // round trip per four rows instead of one per row (the loads of a row cannot be hoisted above the P store of the previous one
+    // by the compiler: P is read and written)
     const long long ebase = r * N * N;
-    for (int row = wave; row < NL * H; row += 4) {
-        const int n = n_lo + row / H, hd = row % H;
+    constexpr int RU = 4;
+    for (int row0 = wave; row0 < NL * H; row0 += 4 * RU) {
+        float xin[RU], cin[RU], lbin[RU], gin[RU];
         const bool active = lane < M;
-        float x = 0.f;
-        if (active) {
-            float c, lb;
-            edge_inputs(cond, lbias, ebase, N, n, lane, dir, c, lb);
-            x = aff_s[row * MP + lane];
-            if (geo) x += logf(fmaxf(geo[((r * N + n) * M + lane) * H + hd], GEO_EPS));
-            x = (c > 0.f ? x : NEG_MASK) + lb;
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int row = row0 + 4 * u;
+            const bool ok = active && row < NL * H;
+            const int rr = min(row, NL * H - 1);
+            const int n = n_lo + rr / H, hd = rr % H;
+            const long long pidx = ((r * N + n) * H + hd) * M + min(lane, M - 1);
+            float c = 0.f, lb = 0.f;
+            edge_inputs(cond, lbias, ebase, N, n, min(lane, M - 1), dir, c, lb);
+            cin[u] = c; lbin[u] = lb;
+            xin[u] = P[pidx];                                            // scaled affinity left there by the batched product
+            gin[u] = geo ? geo[((r * N + n) * M + min(lane, M - 1)) * H + hd] : 1.f;
+            (void)ok;
         }
-        const float pv = row_softmax(x, active);
-        if (active) P[((r * N + n) * H + hd) * M + lane] = pv;
-        if (lane < MP) aff_s[row * MP + lane] = active ? pv : 0.f;
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int row = row0 + 4 * u;
+            if (row < NL * H) {                                          // wave-uniform
+                const int n = n_lo + row / H, hd = row % H;
+                float x = xin[u];
+                if (geo) x += logf(fmaxf(gin[u], GEO_EPS));
+                x = (cin[u] > 0.f ? x : NEG_MASK) + lbin[u];
+                const float pv = row_softmax(x, active);
+                if (active) P[((r * N + n) * H + hd) * M + lane] = pv;
+                if (lane < MMAX) aff_s[row * MMAX + lane] = active ? pv : 0.f;
+            }
+        }
     }
     __syncthreads();
 
-    // ---------------- phase 3: neighbour aggregation, thread-owned feature columns
+    // ---------------- neighbour aggregation, thread-owned feature columns
     for (int cb = tid * VEC; cb < A; cb += 256 * VEC) {
         float s[MMAX][VEC];
 #pragma unroll
         for (int m = 0; m < MMAX; ++m) {
-            if (m < M) {
-                if (VEC == 4) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(&Sr[(long long)m * A + cb]);
+            const float* sp = &Sr[(long long)min(m, M - 1) * A + cb];     // clamped row, zeroed below: no branch between the loads
+            if (VEC == 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(sp);
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) s[m][e] = v[e];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) s[m][e] = Sr[(long long)m * A + cb + e];
-                }
+                for (int e = 0; e < VEC; ++e) s[m][e] = m < M ? v[e] : 0.f;
             } else {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) s[m][e] = 0.f;
+                for (int e = 0; e < VEC; ++e) s[m][e] = m < M ? sp[e] : 0.f;
             }
         }
-        for (int row = 0; row < NL * H; ++row) {
+        float* op = outT + (((r * N + n_lo) * H) * (long long)A) + cb;
+        for (int row = 0; row < NL * H; ++row, op += A) {
             float o[VEC];
 #pragma unroll
             for (int e = 0; e < VEC; ++e) o[e] = 0.f;
-            const float* prow = aff_s + row * MP;
+            const float* prow = aff_s + row * MMAX;
+            f32x4 pw[MMAX / 4];
 #pragma unroll
-            for (int m4 = 0; m4 < MMAX; m4 += 4) {
-                if (m4 < MP) {
-                    const f32x4 pw = *reinterpret_cast<const f32x4*>(prow + m4);   // same address in all lanes: broadcast
+            for (int m4 = 0; m4 < MMAX / 4; ++m4) pw[m4] = *reinterpret_cast<const f32x4*>(prow + 4 * m4);   // same address in all lanes: broadcast
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+            for (int m4 = 0; m4 < MMAX / 4; ++m4)
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) o[e] = fmaf(pw[j], s[m4 + j][e], o[e]);
-                }
-            }
-            float* op = outT + (((r * N + n_lo) * H + row) * (long long)A) + cb;
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) o[e] = fmaf(pw[m4][j], s[4 * m4 + j][e], o[e]);
             if (VEC == 4) {
                 f32x4 v = {o[0], o[1], o[2], o[3]};
                 *reinterpret_cast<f32x4*>(op) = v;
@@ -323,12 +252,17 @@ using namespace ekaid;
 #define ST ((hipStream_t)stream)
 
 template <int VEC, int MMAX>
-static int launch_fused(const float* q, const float* k, const float* S, const float* cond, const float* lbias,
-                        const float* geo, int R, int N, int M, int A, int H, int dir, int DC, size_t lds, float* P,
-                        float* outT, hipStream_t st) {
+static int launch_fused(const float* S, const float* cond, const float* lbias, const float* geo, int R, int N, int M, int A, int H,
+                        int dir, float* P, float* outT, hipStream_t st) {
     auto kern = gat_fused_fwd_kernel<VEC, MMAX>;
+    // fewer slices than ~1.5 per CU (the strong-scaling batches): split the query nodes of a slice over up to 8 workgroups
+    static const char* force = getenv("EKAID_GAT_PARTS");       // tuning aid
+    int parts = force ? atoi(force) : (R >= 384 ? 1 : (R >= 192 ? 2 : (R >= 96 ? 4 : 8)));
+    parts = parts < 1 ? 1 : (parts > N ? N : parts);
+    const int n_per = (N + parts - 1) / parts;
+    const size_t lds = sizeof(float) * (size_t)n_per * H * MMAX;
     if (lds > 64 * 1024) {
-        if (func_attr_once(MMAX == 40 ? 48 : 49)) {
+        if (func_attr_once(48 + (MMAX == 40 ? 0 : (MMAX == 56 ? 1 : 2)))) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 (void)hipGetLastError();
                 set_error("gat_fused_fwd: cannot raise dynamic LDS limit to %zu bytes", lds);
@@ -336,12 +270,7 @@ static int launch_fused(const float* q, const float* k, const float* S, const fl
             }
         }
     }
-    // fewer slices than ~1.5 per CU (the strong-scaling batches): split the query nodes of a slice over up to 8 workgroups
-    // (64 slices of 36 nodes: 4 parts 65 us, 8 parts 48 us; 128 slices of 52 nodes: 4 parts 134 us, 6-8 parts 168-185 us)
-    static const char* force = getenv("EKAID_GAT_PARTS");       // tuning aid
-    int parts = force ? atoi(force) : (R >= 384 ? 1 : (R >= 192 ? 2 : (R >= 96 ? 4 : 8)));
-    parts = parts < 1 ? 1 : (parts > N ? N : parts);
-    hipLaunchKernelGGL(kern, dim3(R, parts), dim3(256), lds, st, q, k, S, cond, lbias, geo, N, M, A, H, dir, DC, P, outT);
+    hipLaunchKernelGGL(kern, dim3(R, parts), dim3(256), lds, st, S, cond, lbias, geo, N, M, A, H, dir, P, outT);
     return check_launch("gat_fused_fwd");
 }
 
@@ -353,14 +282,27 @@ extern "C" int ekaid_gat_fused_fwd(const float* q, const float* k, const float* 
         set_error("gat_fused_fwd: unsupported shape N=%d M=%d A=%d H=%d", N, M, A, H);
         return EKAID_ERR_UNSUPPORTED;
     }
+    if ((size_t)N * H * 64 * sizeof(float) > 150 * 1024) { set_error("gat_fused_fwd: too many (node, head) rows for the LDS"); return EKAID_ERR_UNSUPPORTED; }
+    // 1. scaled affinities of every (slice, head) pair into P[r][n][h][m]: one two-level batched product
     const int dh = A / H;
-    int DC = dh < 64 ? dh : 64;
-    while (dh % DC) DC -= 4;
-    const int MP = (M + 3) & ~3;
-    const size_t lds = sizeof(float) * ((size_t)N * H * MP + (size_t)(N + M) * (DC + 4));
-    if (lds > 150 * 1024) { set_error("gat_fused_fwd: LDS need %zu too large", lds); return EKAID_ERR_UNSUPPORTED; }
-    if (M <= 40) return launch_fused<4, 40>(q, k, S, cond, lbias, geo, R, N, M, A, H, dir, DC, lds, P, outT, ST);
-    return launch_fused<2, 64>(q, k, S, cond, lbias, geo, R, N, M, A, H, dir, DC, lds, P, outT, ST);
+    ekaid_gemm_t g;
+    memset(&g, 0, sizeof(g));
+    g.A = q; g.B = k; g.C = P;
+    g.M = N; g.N = M; g.K = dh;
+    g.lda = A; g.ldb = A; g.ldc = H * M;
+    g.transA = 0; g.transB = 1;
+    g.batch1 = R; g.batch2 = H;
+    g.strideA1 = (long long)N * A; g.strideA2 = dh;
+    g.strideB1 = (long long)M * A; g.strideB2 = dh;
+    g.strideC1 = (long long)N * H * M; g.strideC2 = M;
+    g.alpha = 1.0f / sqrtf((float)dh);
+    g.rdiv = 1;
+    const int rc = ekaid_gemm_f32(&g, nullptr, 0, stream);
+    if (rc) return rc;
+    // 2.+3. softmax and aggregation
+    if (M <= 40) return launch_fused<4, 40>(S, cond, lbias, geo, R, N, M, A, H, dir, P, outT, ST);
+    if (M <= 56) return launch_fused<2, 56>(S, cond, lbias, geo, R, N, M, A, H, dir, P, outT, ST);
+    return launch_fused<2, 64>(S, cond, lbias, geo, R, N, M, A, H, dir, P, outT, ST);
 }
 
 static dim3 wave_grid(long long waves) {
