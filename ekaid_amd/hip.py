@@ -144,6 +144,7 @@ SIGNATURES = {
     'ekaid_expand_rows_fwd': [P, P, L, I, I, I, P, F, U64, P],
     'ekaid_expand_rows_bwd': [P, P, L, I, I, I, P, F, U64, P],
     'ekaid_gat_fused_fwd': [P, P, P, P, P, P, I, I, I, I, I, I, P, P, P],
+    'ekaid_gat_dqk': [P, P, P, I, I, I, I, I, F, P, P, P],
     'ekaid_masked_softmax_fwd': [P, P, P, P, I, I, I, I, I, P, P],
     'ekaid_masked_softmax_bwd': [P, P, P, P, I, I, I, I, I, P, P, P, P],
     'ekaid_geom_embed': [P, P, I, I, I, I, P, P],

@@ -1362,6 +1362,9 @@ def geom_embed(bb_dev, M, feat_dim, dim_mat):
     return out
 
 
+_GAT_DQK = os.environ.get('EKAID_GAT_DQK', '1') != '0'      # A/B knob: 0 = dq / dk as two batched products
+
+
 class GatAttentionFn(Function):
     """Neighbour gather + edge softmax + weighted aggregation of GraphSelfAttentionLayer.
     ref: graph_att_layer.py:105-172.  Forward = the fused kernel (impl='fused') or the same math
@@ -1429,13 +1432,18 @@ class GatAttentionFn(Function):
         dgeo = torch.empty_like(geo) if ctx.has_geo else None
         check(L.ekaid_masked_softmax_bwd(ptr(P), ptr(dP), ptr(cond), ptr(geo), R, N, M, H, direction, ptr(daff),
                                          ptr(dlbias), ptr(dgeo), stream()), 'masked_softmax_bwd')
-        # dq[r,:,h] = sc * daff[r,:,h,:] . k[r,:,h]      dk[r,:,h] = sc * daff[r,:,h,:]^T . q[r,:,h]
+        # dq[r,:,h] = sc * daff[r,:,h,:] . k[r,:,h]      dk[r,:,h] = sc * daff[r,:,h,:]^T . q[r,:,h]: one kernel (both are 36-deep
+        # contractions: poor batched products), two batched products outside its envelope
         dq = torch.empty(R, N, A, device=dev, dtype=torch.float32)
-        gemm(daff, k, dq, N, dh, M, H * M, A, A, 0, 0, alpha=sc, batch=(R, H),
-             strides=(N * H * M, M, M * A, dh, N * A, dh))
         dk = torch.empty(R, M, A, device=dev, dtype=torch.float32)
-        gemm(daff, q, dk, M, dh, N, H * M, A, A, 1, 0, alpha=sc, batch=(R, H),
-             strides=(N * H * M, M, N * A, dh, M * A, dh))
+        rc = L.ekaid_gat_dqk(ptr(daff), ptr(q), ptr(k), R, N, M, A, H, sc, ptr(dq), ptr(dk), stream()) if _GAT_DQK else hip.ERR_UNSUPPORTED
+        if rc == hip.ERR_UNSUPPORTED:
+            gemm(daff, k, dq, N, dh, M, H * M, A, A, 0, 0, alpha=sc, batch=(R, H),
+                 strides=(N * H * M, M, M * A, dh, N * A, dh))
+            gemm(daff, q, dk, M, dh, N, H * M, A, A, 1, 0, alpha=sc, batch=(R, H),
+                 strides=(N * H * M, M, N * A, dh, M * A, dh))
+        else:
+            check(rc, 'gat_dqk')
         return dq, dk, dS, None, dlbias, dgeo, None, None, None
 
 

@@ -201,6 +201,13 @@ int ekaid_expand_rows_bwd(const float* dout, const float* mask, long long rows, 
 int ekaid_gat_fused_fwd(const float* q, const float* k, const float* S, const float* cond, const float* lbias,
                         const float* geo, int R, int N, int M, int A, int H, int dir, float* P, float* outT,
                         void* stream);
+/* dq[r][n][h,:] = scale * sum_m daff[r][n][h][m] k[r][m][h,:],  dk[r][m][h,:] = scale * sum_n daff[r][n][h][m] q[r][n][h,:]
+ * (gradients of the scaled affinities q_h . k_h^T; daff from ekaid_masked_softmax_bwd) in one launch.  ERR_UNSUPPORTED outside
+ * N <= 40, M <= N, A % (4 H) == 0, (N + M) * H * 160 bytes of LDS <= 64 KB: the caller composes them from two batched
+ * ekaid_gemm_f32 calls then (faster there).
+ * ref: autograd of graph_att_layer.py:79-108 */
+int ekaid_gat_dqk(const float* daff, const float* q, const float* k, int R, int N, int M, int A, int H, float scale, float* dq,
+                  float* dk, void* stream);
 int ekaid_masked_softmax_fwd(const float* aff, const float* cond, const float* lbias, const float* geo, int R,
                              int N, int M, int H, int dir, float* P, void* stream);
 int ekaid_masked_softmax_bwd(const float* P, const float* dP, const float* cond, const float* geo, int R, int N,

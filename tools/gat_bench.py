@@ -77,7 +77,7 @@ def main():
     bytes_bwd = R * (N * H * A * 4 + 3 * N * A * 4 + N * H * M * 4 + 3 * N * A * 4)
     print('R=%d N=%d M=%d A=%d H=%d' % (R, N, M, A, H))
     print('forward   %8.1f us  %.2f TB/s of %d MB algorithmic' % (fwd, bytes_fwd / fwd / 1e6, bytes_fwd >> 20))
-    print('backward  %8.1f us  %.2f TB/s of %d MB algorithmic (composed: 4 batched GEMMs + softmax backward)' % (
+    print('backward  %8.1f us  %.2f TB/s of %d MB algorithmic (composed: batched GEMMs + softmax backward + the dq/dk kernel)' % (
         bwd, bytes_bwd / bwd / 1e6, bytes_bwd >> 20))
 
 
