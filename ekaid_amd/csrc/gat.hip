@@ -286,9 +286,12 @@ __global__ __launch_bounds__(256) void masked_softmax_bwd_kernel(const float* P,
 // with the same torch expression (mimic_utils.py:195-197) so that no device powf rounding enters the argument.
 __global__ __launch_bounds__(256) void geom_embed_kernel(const double* bb, const float* dim_mat, int R, int N, int M, int fd, float* out) {
     // one thread per (pair, component): the log-geometry value is computed once and fanned out to the fd/8 frequencies
+    extern __shared__ __attribute__((aligned(16))) float tile[];        // [256 items][2 nf]
     const int nf = fd / 8;
     const long long total = (long long)R * N * M * 4;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i0 = (long long)blockIdx.x * 256; i0 < total; i0 += (long long)gridDim.x * 256) {
+        const long long i = i0 + threadIdx.x;
+        if (i < total) {
         long long rest = i;
         const int comp = (int)(rest % 4); rest /= 4;
         const int j = (int)(rest % M); rest /= M;
@@ -315,14 +318,34 @@ __global__ __launch_bounds__(256) void geom_embed_kernel(const double* bb, const
         } else {
             v = log(hi / hj);
         }
-        float* o = out + (((r * N + ii) * M + j) * (long long)fd) + comp * (2 * nf);
+        // item i owns out[i * 2nf .. (i + 1) * 2nf) (fd = 4 * 2nf): the workgroup's 256 items form ONE contiguous block of the output;
+        // staged through LDS so that it leaves as full 16-byte-per-lane rows instead of 2nf scalar stores with a 8nf-byte lane stride
+        float* o = tile + threadIdx.x * (2 * nf);
         for (int t = 0; t < nf; ++t) {
+            // argument in float64 as the reference forms it; reduced to [-pi, pi] in float64 (two-term 2 pi), then ONE float32
+            // sincos: |error| <= 2e-7 (rounding of the reduced argument) + 1 ulp, against 2e-6 allowed
             const double arg = (100.0 * v) / (double)dim_mat[t];
-            double sn, cs;
-            sincos(arg, &sn, &cs);
-            o[t] = (float)sn;
-            o[nf + t] = (float)cs;
+            const double kk = rint(arg * 0.15915494309189535);
+            double red = fma(-kk, 6.283185307179586, arg);
+            red = fma(-kk, 2.4492935982947064e-16, red);
+            float sn, cs;
+            sincosf((float)red, &sn, &cs);
+            o[t] = sn;
+            o[nf + t] = cs;
         }
+        }
+        __syncthreads();
+        {
+            const long long first = i0 * (2 * nf);                          // first output element of this workgroup's block
+            const long long cnt = min((long long)256, total - i0) * (2 * nf);
+            if ((nf & 1) == 0) {
+                for (long long e = 4 * threadIdx.x; e < cnt; e += 1024)
+                    *reinterpret_cast<f32x4*>(out + first + e) = *reinterpret_cast<const f32x4*>(tile + e);
+            } else {
+                for (long long e = threadIdx.x; e < cnt; e += 256) out[first + e] = tile[e];
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -437,6 +460,7 @@ extern "C" int ekaid_geom_embed(const double* bb, const float* dim_mat, int R, i
     long long b = (total + 255) / 256;
     if (b > 8192) b = 8192;
     if (b < 1) b = 1;
-    hipLaunchKernelGGL(geom_embed_kernel, dim3((unsigned)b), dim3(256), 0, ST, bb, dim_mat, R, N, M, feat_dim, out);
+    if (feat_dim > 256) { set_error("geom_embed: feat_dim > 256"); return EKAID_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(geom_embed_kernel, dim3((unsigned)b), dim3(256), 256 * (feat_dim / 4) * sizeof(float), ST, bb, dim_mat, R, N, M, feat_dim, out);
     return check_launch("geom_embed");
 }
