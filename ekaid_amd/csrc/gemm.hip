@@ -231,6 +231,9 @@ __device__ __forceinline__ void write_tiles(const GemmArgs& g, f32x16 (&acc)[TM]
 #ifndef EKAID_SPLIT_PF_SMALL
 #define EKAID_SPLIT_PF_SMALL 1
 #endif
+#ifndef EKAID_SPLIT_PIPE_SMALL
+#define EKAID_SPLIT_PIPE_SMALL false      // software-pipelined K loop for the 64x64 tile (build-time experiment)
+#endif
 #ifndef EKAID_LB_HALF
 #define EKAID_LB_HALF 4
 #endif
@@ -926,7 +929,7 @@ __global__ __launch_bounds__(256, BIG ? EKAID_SPLIT_OCC_BIG : EKAID_SPLIT_OCC_SM
     if ((int)blockIdx.z >= g.splitk) return;
     const int bx = first ? blockIdx.x : blockIdx.x - n0;
     if constexpr (BIG) gemm_split_body<A_KC, B_KC, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG, NP>(g, bx, blockIdx.z);
-    else gemm_split_body<A_KC, B_KC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL, false, NP>(g, bx, blockIdx.z);
+    else gemm_split_body<A_KC, B_KC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL, EKAID_SPLIT_PIPE_SMALL, NP>(g, bx, blockIdx.z);
 }
 
 #ifndef EKAID_GEMM_X2_TU      // (non-template kernels: defined once, in the main translation unit)
@@ -1302,7 +1305,7 @@ template <int NP>
 static int split_dispatch(const GemmArgs& a, int TMN, bool akc, bool bkc, int batch, hipStream_t st) {
 #define EKAID_LAUNCH_SPLIT(AK, BKC) (TMN == 2 ? (big_arm(AK, BKC) == 1 ? launch_split<AK, BKC, 2, 2, 32, 1, false, NP>(a, batch, st) \
                                                   : launch_split<AK, BKC, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG, NP>(a, batch, st)) \
-                                     : TMN == 1 ? launch_split<AK, BKC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL, false, NP>(a, batch, st) \
+                                     : TMN == 1 ? launch_split<AK, BKC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL, EKAID_SPLIT_PIPE_SMALL, NP>(a, batch, st) \
                                      : TMN == 3 ? launch_split<AK, BKC, 2, 1, 32, 1, false, NP>(a, batch, st) : launch_split<AK, BKC, 1, 2, 32, 1, false, NP>(a, batch, st))
     if (akc && bkc) return EKAID_LAUNCH_SPLIT(true, true);
     if (akc && !bkc) return EKAID_LAUNCH_SPLIT(true, false);
