@@ -206,28 +206,26 @@ class ChangeDetector(nn.Module):
         # every tensor with several readers goes through ops.fanout / ops.halves: its gradient is then ONE n-ary sum
         # instead of autograd's zero-fill + copy per slice and pairwise adds
         x = x.reshape(2 * B, N, A).contiguous()
-        x_c, x_g, x_h = ops.fanout(x, 3)
-        bef_d, bef_e, bef_p, aft_d, aft_e, aft_p = ops.halves(x_h, 3)       # bef = x[:B], aft = x[B:], three readers each
+        x_c, x_g, x_d, x_e, x_p = ops.fanout(x, 5)
+        bef_d, aft_d = ops.halves(x_d)                                      # bef = x[:B], aft = x[B:]
         diff = ops.sub(aft_d, bef_d)                                        # (B, N, A)
-        diff_c, diff_g, diff_b, diff_a = ops.fanout(diff, 4)
+        diff_c, diff_g, diff_e = ops.fanout(diff, 3)
         c1d = self.context1(diff_c)                                         # shared by both images: computed once
         g1d = self.gate1(diff_g)
         c2 = self.context2(x_c)                                             # (2B, N, A), bias in the epilogue
         g2 = self.gate2(x_g)
         gated = ops.gate_fuse(c2, g2, c1d, g1d, self.dropout.p, self.training).view(2 * B, N, A)
-        gated_b, gated_a = ops.halves(gated)
 
+        # region attention of BOTH images in one pass over the 2B row-stacked slices (the reference calls it per image,
+        # modules.py:286-299: same weights, row-independent layers): embed([feat | diff | gated]) -> att -> sigmoid, then pooling
         emb_lin, emb_drop = self.embed[0], self.embed[1]
-
-        def region_attention(feat, diff_, gated_feat):
-            e = emb_lin((feat, diff_, gated_feat), ACT_RELU)                # relu(dropout(x)) == dropout(relu(x))
-            e = ops.dropout(e, emb_drop.p, self.training)
-            return self.att(e, ACT_SIGMOID).view(B, N)
-
-        att_b = region_attention(bef_e, diff_b, gated_b)
-        att_a = region_attention(aft_e, diff_a, gated_a)
-        attended_1 = ops.weighted_pool(att_b, bef_p)
-        attended_2 = ops.weighted_pool(att_a, aft_p)
+        e = emb_lin((x_e, ops.repeat2(diff_e), gated), ACT_RELU)            # relu(dropout(x)) == dropout(relu(x))
+        e = ops.dropout(e, emb_drop.p, self.training)
+        att = self.att(e, ACT_SIGMOID).view(2 * B, N)
+        att_p, att_o = ops.fanout(att, 2)                                   # pooling weights / returned attention maps
+        attended = ops.weighted_pool(att_p, x_p)                            # (2B, A)
+        att_b, att_a = ops.halves(att_o)
+        attended_1, attended_2 = ops.halves(attended)
         input_attended = ops.sub(attended_2, attended_1)
         pred = self.fc1(input_attended)
         ops.wn_release()

@@ -806,6 +806,28 @@ def stack2(a, b):
     return torch.cat((a, b), 0)
 
 
+class Repeat2Fn(Function):
+    """x (B, ...) -> [x; x] (2B, ...): the term both images of a pair share, laid out next to their row-stacked features so that a
+    layer runs ONCE over 2B rows instead of once per image.  Backward: the two halves of the gradient summed by one kernel."""
+
+    @staticmethod
+    def forward(ctx, x):
+        require_cuda(x)
+        return torch.cat([x, x], 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        h = g.shape[0] // 2
+        out = torch.empty((h,) + tuple(g.shape[1:]), device=g.device, dtype=g.dtype)
+        _sum_into([g[:h], g[h:]], out)
+        return out
+
+
+def repeat2(x):
+    return Repeat2Fn.apply(x)
+
+
 def halves(x, n=1):
     """(first-half aliases..., second-half aliases...) of a tensor stacked along axis 0; see HalvesFn."""
     assert x.shape[0] % 2 == 0 and x.is_contiguous()
