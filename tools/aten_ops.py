@@ -10,8 +10,8 @@ from torch.profiler import ProfilerActivity, profile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
-from common import build_models  # noqa: E402
+
+from ekaid_amd.formula_init import build_models  # noqa: E402
 from ekaid_amd import hip, ops  # noqa: E402
 from ekaid_amd.config import bench_cfg  # noqa: E402
 from ekaid_amd.dp import FlatAdam  # noqa: E402
