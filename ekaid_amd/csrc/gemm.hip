@@ -1199,7 +1199,8 @@ static void plan(const ekaid_gemm_t* d, int& TMN, int& splitk, int& tiles_m, int
         const int su_k = su ? atoi(su) : 1024;
         if (TMN == 2 && batch == 1 && gemm_mode() >= 1) {
             const long long t128 = (long long)cdiv(d->M, 128) * cdiv(d->N, 128), t64 = (long long)cdiv(d->M, 64) * cdiv(d->N, 64);
-            if (t128 * 4 < 768 * 3 && t64 >= 512 && d->K <= su_k) TMN = 1;
+            if (t128 * 2 < 768 && t64 >= 512 && d->K <= su_k) TMN = 1;     // (under half a wave of 128x128 tiles: at 416 tiles -- 6656 rows, the
+                                                                             // real-data shape -- the big tile wins again: 103-106 vs 111-115 us)
         }
     }
     {
