@@ -399,18 +399,20 @@ def main():
         cd0, sp0 = build_models(cfg, 147, 148, dev, train=False)
         cd0.eval(); sp0.eval()                                       # noqa: E702
 
+        from ekaid_amd.engine import detector_forward
+
         def decode():
-            _, _, outs, _ = forward_loss(cfg, cd0, sp0, b64, T, args.graph)
+            outs = detector_forward(cfg, cd0, b64, args.graph)
             return sp0._sample(outs[3], outs[4], outs[5], None, cfg, sample_max=1)
         with torch.no_grad():
             msd = timed(decode, 10, 2)
             seq, _ = decode()
-            ms_f0 = timed(lambda: forward_loss(cfg, cd0, sp0, b64, T, args.graph), 10, 2)
+            ms_f0 = timed(lambda: detector_forward(cfg, cd0, b64, args.graph), 10, 2)
         nsteps = int((seq != 0).any(0).sum().item())
         del cd0, sp0
         extra['greedy_decode_b64'] = {'ms': round(msd, 3), 'pairs_per_s': round(64 / msd * 1e3, 1), 'decode_steps_run': nsteps,
                                       'ms_per_decode_step': round((msd - ms_f0) / max(nsteps, 1), 4),
-                                      'workload': 'eval forward (teacher-forced pass included, as test_mimic.py:116-122 runs it) + '
+                                      'workload': 'test_mimic.py:109-122: eval detector forward + '
                                                   'greedy _sample (ekaid_speaker_greedy_steps, stop test polled every 8 steps), batch 64, '
                                                   'freshly initialised weights: the end token never comes, all %d steps of the maximum '
                                                   'answer length are decoded' % nsteps}

@@ -43,6 +43,7 @@ def main(argv=None):
     p.add_argument('--data_dir', default='')
     p.add_argument('--split', default='test', choices=['test', 'val', 'train', 'all'])
     p.add_argument('--exp_dir', default=None)
+    p.add_argument('--hip_graph', action='store_true', help='replay the detector forward from a hipGraph per batch shape')
     args = p.parse_args(argv)
     cfg.clear()
     cfg.update(default_cfg())
@@ -86,7 +87,8 @@ def main(argv=None):
     if loader is not None:
         # the reference's loop (test_mimic.py:97-141) over the real split: device feed, detector, greedy decode
         from train_mimic import evaluate
-        predictions, accuracy, total = evaluate(cfg, change_detector, speaker, loader, device, idx_to_word, args.graph)
+        predictions, accuracy, total = evaluate(cfg, change_detector, speaker, loader, device, idx_to_word, args.graph,
+                                                hip_graph=args.hip_graph)
         correct = round(accuracy * total)
     with torch.no_grad():
         for i in range(args.batches if loader is None else 0):

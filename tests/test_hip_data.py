@@ -261,3 +261,26 @@ def test_bench_real_data_line_is_the_only_thing_on_stdout():
     out = json.loads(lines[0])['real_b64']
     assert out['qa_pairs_per_s'] > 0 and out['graphs_captured'] >= 2
     assert out['loader_wait_fraction'] is not None and out['exposed_h2d_ms_per_iteration'] >= 0.0
+
+
+def test_infer_step_replay_equals_eager_forward():
+    """InferStep: the eval-mode detector forward replayed from a hipGraph (captured per input shape) returns exactly what the
+    eager forward returns, for two batch shapes in turn, and keeps returning it on later replays with new inputs."""
+    from ekaid_amd.engine import InferStep, detector_forward
+    from ekaid_amd.synthetic import make_batch
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from common import SMALL, small_models
+    cfg, cd, sp = small_models('all', device='cuda')
+    cd.eval()
+    step = InferStep(cfg, cd, 'all', use_graph=True)
+    for rnd in range(2):
+        for B in (2, 5):
+            shape = dict(SMALL)
+            shape['B'] = B
+            b = {k: v.cuda() for k, v in make_batch(seed=100 + 10 * rnd + B, **shape).items()}
+            with torch.no_grad():
+                want = [t.clone() for t in detector_forward(cfg, cd, b, 'all')]
+            got = step(b)
+            for w, g in zip(want, got):
+                assert torch.equal(w, g)
+    assert len(step._graphs) == 2

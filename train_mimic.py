@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 from ekaid_amd import hip, ops                                            # noqa: E402
 from ekaid_amd.config import cfg, default_cfg, merge_cfg_from_file, merge_into, MIMIC_YAML   # noqa: E402
 from ekaid_amd.dp import FlatAdam, enable_global_question_attention      # noqa: E402
-from ekaid_amd.engine import TrainStep, forward_loss                     # noqa: E402
+from ekaid_amd.engine import TrainStep, detector_forward                 # noqa: E402
 from ekaid_amd.models.dynamic_speaker_change_pos import DynamicSpeaker   # noqa: E402
 from ekaid_amd.models.modules import AddSpatialInfo, ChangeDetector      # noqa: E402
 from ekaid_amd.synthetic import make_batch, slice_batch                  # noqa: E402
@@ -95,17 +95,19 @@ def step_lr(base_lr, gamma, step_size, epoch):
     return base_lr * (gamma ** ((epoch + 1) // step_size))
 
 
-def evaluate(cfg, change_detector, speaker, loader, device, idx_to_word, graph, max_batches=None):
-    """Greedy decode of a split (train_mimic.py:292-362): {pair index: sentence}, exact-match accuracy."""
+def evaluate(cfg, change_detector, speaker, loader, device, idx_to_word, graph, max_batches=None, hip_graph=False):
+    """Greedy decode of a split (train_mimic.py:292-362, test_mimic.py:97-141: detector forward, then ``_sample``): {pair index:
+    sentence}, exact-match accuracy.  ``hip_graph``: the detector forward replayed from a hipGraph per batch shape."""
     from ekaid_amd.datasets.rcc_dataset_pos_mimic import DevicePrefetcher
+    from ekaid_amd.engine import InferStep
     predictions, references, correct, total = {}, {}, 0, 0
     set_mode('eval', [change_detector, speaker])
+    infer = InferStep(cfg, change_detector, graph, cfg.train.setting, use_graph=hip_graph)
     with torch.no_grad():
         for bi, b in enumerate(DevicePrefetcher(loader, device)):
             if max_batches is not None and bi >= max_batches:
                 break
-            T = DynamicSpeaker.count_steps(b['_host_labels'], cfg.model.speaker.seq_length)
-            _, _, outs, _ = forward_loss(cfg, change_detector, speaker, b, T, graph, cfg.train.setting)
+            outs = infer(b)
             seq, _ = speaker._sample(outs[3], outs[4], outs[5], b['labels'], cfg, sample_max=1)
             sents = decode_sequence(idx_to_word, seq)
             gts = decode_sequence(idx_to_word, b['_host_labels'][:, 1:])
@@ -346,7 +348,7 @@ def main(argv=None):
                 else:
                     set_mode('eval', [change_detector, speaker])
                     with torch.no_grad():
-                        _, _, outs, _ = forward_loss(cfg, change_detector, speaker, b, steps, args.graph, args.setting)
+                        outs = detector_forward(cfg, change_detector, b, args.graph, args.setting)
                         seq, _ = speaker._sample(outs[3], outs[4], outs[5], b['labels'], cfg, sample_max=1)
                         pred = decode_sequence(idx_to_word, seq)
                         gts = decode_sequence(idx_to_word, host_labels[:, 1:])
