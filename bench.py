@@ -66,6 +66,8 @@ def parse():
     ap.add_argument('--gemm-shapes', action='store_true', help='print the per-shape GEMM time table to stderr')
     ap.add_argument('--real-only', action='store_true', help='run only the real-data loop (extra.real_b64) and print its JSON: profiling target')
     ap.add_argument('--no-real', action='store_true', help='skip the real-data loop of the extra block')
+    ap.add_argument('--spawn-timeout', type=int, default=1500,
+                    help='--gpus N > 1 started without a launcher: seconds after which the spawned ranks are stopped')
     return ap.parse_args()
 
 
@@ -219,14 +221,77 @@ def timed(fn, steps, warmup):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+def spawn_ranks(n, timeout_s):
+    """``python bench.py --gpus N`` without a launcher: start N fresh child processes of this script, one rank per GPU, and
+    relay rank 0's JSON line.  The parent never touches the GPU (no HIP call before or after the spawn); children are separate
+    processes, not exec replacements.  A child that fails, or the time limit, ends the whole process group."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as s:                  # a free rendezvous port
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    import tempfile
+    procs = []
+    out0 = tempfile.TemporaryFile()             # rank 0's stdout (the JSON line); a file, so a long line can never block the child
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, start_new_session=True))
+
+    def kill_all():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)        # the child's own session: exactly the processes started here
+                except OSError:
+                    pass
+    deadline = time.monotonic() + timeout_s
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+            if rc != 0:
+                print('bench.py: rank %d exited with %d; stopping the other ranks' % (
+                    next(i for i, p in enumerate(procs) if p.poll() not in (None, 0)), rc), file=sys.stderr)
+                break
+            if time.monotonic() > deadline:
+                print('bench.py: ranks still running after %d s; stopping them' % timeout_s, file=sys.stderr)
+                rc = 124
+                break
+            if pending:
+                time.sleep(0.2)
+    finally:
+        kill_all()
+    for p in procs:
+        p.wait()
+    out0.seek(0)
+    out = out0.read().decode()
+    out0.close()
+    if rc == 0:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, args.spawn_timeout))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        raise SystemExit('bench.py --gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run, one rank per GPU '
-                         '(--nproc-per-node = --gpus)' % (args.gpus, world))
+        raise SystemExit('bench.py --gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus N` (it spawns its own ranks) or '
+                         'with torch.distributed.run, one rank per GPU (--nproc-per-node = --gpus)' % (args.gpus, world))
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     local_rank = local_rank % max(torch.cuda.device_count(), 1)      # (several ranks may share a GPU in the gloo plumbing test)
     torch.cuda.set_device(local_rank)
@@ -286,10 +351,19 @@ def main():
 
     comm_fallback = None
     if use_graph and graph_comm == 'captured' and args.graph_comm == 'auto' and world > 1:
-        try:                                   # first call = capture; a failure there is raised on every rank alike
-            step(b, T)
+        # First call = capture.  The ranks AGREE on its outcome before anyone goes on: if one rank alone fell back to eager
+        # collectives while its peers replayed captured ones, the collective sequences would diverge and the run would hang.
+        # (A capture only issues its own collectives on success; TrainStep._capture restores weights / moments / step in a
+        # ``finally``, so a failed attempt leaves every rank at the state it started from.)
+        err = None
+        try:
+            step._graphs[step._key(b, T, None)] = step._capture(b, T, None)
         except Exception as e:                 # noqa: BLE001
-            comm_fallback = '%s: %s' % (type(e).__name__, str(e)[:200])
+            err = '%s: %s' % (type(e).__name__, str(e)[:200])
+        failed = torch.tensor([1 if err else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+        if int(failed.item()):
+            comm_fallback = err or 'capture failed on another rank'
             step.close()
             graph_comm = 'eager'
             step = TrainStep(cfg, cd, sp, opt, args.graph, use_graph=True, comm='eager')

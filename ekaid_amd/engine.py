@@ -1,17 +1,22 @@
 """One training iteration of the difference-VQA path (reference ``train_mimic.py:209-269``) as a reusable object, eager or
 replayed from a captured hipGraph.
 
-Eager: ~1 350 kernel launches issued from Python through ctypes, ~14 ms of host time per step -- invisible at 256 pairs
-per GPU (34 ms of GPU work) but the floor of the strong-scaling points (32 pairs per GPU on 8 GPUs).  The C ABI is
-allocation- and synchronisation-free, so the whole step -- adjacency expansion, detector, decoder, loss,
-backward, Adam -- is captured ONCE per (batch, nodes, decode steps) shape with ``torch.cuda.graph`` (torch's allocator
-and autograd run at capture time only) and replayed with a single launch:
+Eager: ~700 kernel launches per step at 256 pairs (round 3; the decoder and GRU time loops are issued from C,
+csrc/sequence.hip), ~8 ms of host time -- invisible at 256 pairs per GPU (30 ms of GPU work) but the floor of the
+strong-scaling points (32 pairs per GPU on 8 GPUs).  The C ABI is allocation- and synchronisation-free, so the
+whole step -- adjacency expansion, detector, decoder, loss, backward, Adam -- is captured ONCE per (batch, nodes, decode steps,
+scheduled-sampling rate) key with ``torch.cuda.graph`` (torch's allocator and autograd run at capture time only) and replayed
+with a single launch:
   * inputs live in static buffers (one device copy per step);
   * dropout: every site's seed is frozen in the graph, the device-resident epoch word advanced at the head of the graph
     gives every replay fresh masks (include/ekaid_hip.h: ekaid_set_dropout_epoch_ptr);
   * Adam's step counter / learning rate live on the device (ekaid_adam_step_dev);
-  * data parallel: the gradient all-reduce runs eagerly after the replay by default (``comm='eager'``: bucketed RCCL
-    calls + the Adam kernel, ~10 launches); ``comm='captured'`` keeps the overlapped hook-driven all-reduce inside the graph.
+  * data parallel: ``comm='captured'`` (the default of bench.py / train_mimic.py at world > 1) keeps the hook-driven bucketed
+    all-reduce INSIDE the graph, overlapped with the rest of backward exactly as the eager hooks overlap it; ``comm='eager'``
+    issues the bucketed RCCL calls + the Adam kernel after the replay (serialised; the fallback for backends that cannot be
+    captured, e.g. gloo);
+  * scheduled sampling: ``speaker.ss_prob`` is a by-value kernel argument AND selects the decoder path (fused teacher-forced
+    sequence node at 0, step-wise sampling path above), so it is part of the graph key: a rate change recaptures.
 """
 import torch
 
@@ -216,40 +221,55 @@ class TrainStep:
         was_suspended = self.opt.comm_suspended
         self.opt.comm_suspended = True
         try:
-            with torch.cuda.stream(s):
-                for _ in range(self.warmup):    # sizes every workspace, raises kernel attributes, warms the allocator
-                    self._body(static, T, sden)
-                    if self.comm == 'eager' and self.opt.comm_active():
-                        self.opt.step()
+            try:
+                with torch.cuda.stream(s):
+                    for _ in range(self.warmup):    # sizes every workspace, raises kernel attributes, warms the allocator
+                        self._body(static, T, sden)
+                        if self.comm == 'eager' and self.opt.comm_active():
+                            self.opt.step()
+            finally:
+                self.opt.comm_suspended = was_suspended
+            torch.cuda.current_stream(dev).wait_stream(s)
+            torch.cuda.synchronize(dev)
+            ops.set_seed_state(seed_state)          # the capture draws the same site seeds as the first warm-up step
+            g = torch.cuda.CUDAGraph()
+            # thread_local: the RCCL watchdog thread of torch.distributed queries events while this thread captures
+            with torch.cuda.graph(g, pool=self._pool, capture_error_mode='thread_local'):
+                loss, sp_loss = self._body(static, T, sden)
+            if self._pool is None:
+                self._pool = g.pool()
         finally:
-            self.opt.comm_suspended = was_suspended
-        torch.cuda.current_stream(dev).wait_stream(s)
-        torch.cuda.synchronize(dev)
-        ops.set_seed_state(seed_state)          # the capture draws the same site seeds as the first warm-up step
-        g = torch.cuda.CUDAGraph()
-        # thread_local: the RCCL watchdog thread of torch.distributed queries events while this thread captures
-        with torch.cuda.graph(g, pool=self._pool, capture_error_mode='thread_local'):
-            loss, sp_loss = self._body(static, T, sden)
-        if self._pool is None:
-            self._pool = g.pool()
-        self.opt.pflat.copy_(snap_p)
-        if snap_m is not None:
-            self.opt.m.copy_(snap_m)
-            self.opt.v.copy_(snap_v)
-        elif self.opt.m is not None:
-            self.opt.m.zero_()
-            self.opt.v.zero_()
-        self.opt.step_count = snap_step
-        self._epoch.copy_(snap_epoch)
-        self.opt.overlap = overlap
+            # also when the warm-up or the capture raised: the caller may fall back to another launch path and must continue
+            # from the weights, moments, step count and dropout epoch it had (the warm-ups ran a LOCAL Adam)
+            torch.cuda.synchronize(dev)
+            self.opt.pflat.copy_(snap_p)
+            if snap_m is not None:
+                self.opt.m.copy_(snap_m)
+                self.opt.v.copy_(snap_v)
+            elif self.opt.m is not None:
+                self.opt.m.zero_()
+                self.opt.v.zero_()
+            self.opt.step_count = snap_step
+            self._epoch.copy_(snap_epoch)
+            self.opt.overlap = overlap
         return {'graph': g, 'static': static, 'denom': sden, 'loss': loss, 'sp_loss': sp_loss}
+
+    def _key(self, b, T, denom):
+        """What a captured graph froze besides the tensor shapes: the decode-step count, whether the loss denominator is an
+        input, the train/eval mode of both modules and the scheduled-sampling rate (a by-value kernel argument that also
+        selects the decoder path, ``DynamicSpeaker._forward``)."""
+        return (T, denom is not None, bool(self.cd.training), bool(self.sp.training), float(getattr(self.sp, 'ss_prob', 0.0))) + \
+            tuple((k, tuple(b[k].shape), b[k].dtype) for k in INPUT_KEYS)
 
     def __call__(self, b, T, denom=None):
         if not self.use_graph:
             return self._eager(b, T, denom)
-        key = (T, denom is not None) + tuple((k, tuple(b[k].shape), b[k].dtype) for k in INPUT_KEYS)
+        key = self._key(b, T, denom)
         ent = self._graphs.get(key)
         if ent is None:
+            # graphs captured under another mode / scheduled-sampling rate are never replayed again (the rate only rises)
+            for k in [k for k in self._graphs if k[2:5] != key[2:5]]:
+                del self._graphs[k]
             ent = self._capture(b, T, denom)
             self._graphs[key] = ent
         for k in INPUT_KEYS:

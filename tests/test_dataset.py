@@ -179,3 +179,26 @@ def test_compact_batch_is_lossless(tmp_path):
     assert c['masks'].dtype == torch.float32 and c['labels'].shape == (4, 91) and c['d_bb'].dtype == torch.float64
     nbytes = lambda t: sum(v.numel() * v.element_size() for v in t.values())      # noqa: E731
     assert nbytes(c) < 0.5 * nbytes(d)
+
+
+def test_an_evaluation_pass_on_one_rank_does_not_desynchronise_the_shuffle(tmp_path):
+    """Only rank 0 evaluates inside the training loop (train_mimic.py).  Building a loader iterator draws a base seed from torch's
+    default generator, the generator every rank shuffles its next epoch from: train_mimic.evaluate() therefore saves and restores
+    the generator state around its pass.  Pinned here on the loaders alone: the hazard exists (the state moves), and with the
+    guard both ranks still slice the SAME global permutation in the next epoch."""
+    ds = RCCDataset_mimic(make_cfg(tmp_path, 'both', 1), 'train')
+    val = RCCDataset_mimic(make_cfg(tmp_path, 'both', 1), 'test')
+    orders = []
+    for rank in range(2):
+        torch.manual_seed(99)
+        ld = RCCDataLoader(ds, batch_size=4, shuffle=True, rank=rank, world_size=2)
+        first = [b.global_indices for b in ld]                     # epoch 0
+        if rank == 0:                                              # the in-loop evaluation, rank 0 only
+            before = torch.get_rng_state()
+            for _ in RCCDataLoader(val, batch_size=4, shuffle=False):
+                break
+            assert not torch.equal(before, torch.get_rng_state()), 'the hazard this test is about is gone'
+            torch.set_rng_state(before)                            # what evaluate() does in its finally
+        orders.append((first, [b.global_indices for b in ld]))     # epoch 1
+    assert orders[0][0] == orders[1][0] and orders[0][1] == orders[1][1]
+    assert orders[0][0] != orders[0][1]

@@ -153,6 +153,9 @@ def test_resume_on_real_data_continues_the_shuffle(data_dir, tmp_path, where):
     stop = ipe if where == 'epoch_boundary' else ipe + 2
     total = 2 * ipe + 1                                    # into the third epoch
     a = train_mimic.main(common + ['--max_iter', str(total), '--snapshot_interval', '1000', '--exp_dir', str(tmp_path / 'a')])
+    # the uninterrupted run that ALSO snapshots and evaluates at ``stop`` (and at every multiple of it): the in-loop evaluation
+    # builds a loader iterator, which draws from torch's default generator -- evaluate() puts the generator back
+    a_ev = train_mimic.main(common + ['--max_iter', str(total), '--snapshot_interval', str(stop), '--exp_dir', str(tmp_path / 'ae')])
     b1 = train_mimic.main(common + ['--max_iter', str(stop), '--snapshot_interval', str(stop), '--exp_dir', str(tmp_path / 'b')])
     ck = os.path.join(b1['snapshot_dir'], 'checkpoint_%d.pt' % stop)
     b2 = train_mimic.main(common + ['--max_iter', str(total), '--snapshot_interval', '1000', '--exp_dir', str(tmp_path / 'c'),
@@ -161,6 +164,8 @@ def test_resume_on_real_data_continues_the_shuffle(data_dir, tmp_path, where):
     drift = float((_weights(a) - _weights(b2)).abs().max())
     assert drift == 0.0, 'resumed real-data run left the uninterrupted one: max |dw| = %.3e' % drift
     assert a['last']['total_loss'] == b2['last']['total_loss']
+    drift_ev = float((_weights(a_ev) - _weights(b2)).abs().max())
+    assert drift_ev == 0.0, 'a run that evaluates at iteration %d shuffles its later epochs differently: max |dw| = %.3e' % (stop, drift_ev)
 
 
 def test_graph_replay_equals_eager():
@@ -211,6 +216,47 @@ def test_graph_replay_equals_eager():
     # bit-reproducible path: eager == eager exactly, and the replayed graph issues the same kernels on the same data
     assert noise_w == 0.0 and noise_l == 0.0
     assert d_w == 0.0 and d_l == 0.0, 'hipGraph replay differs from the eager steps'
+
+
+def test_graph_key_follows_the_scheduled_sampling_rate(monkeypatch):
+    """``speaker.ss_prob`` is a by-value kernel argument and selects the decoder path (fused teacher-forced node at 0, step-wise
+    sampling above): a hipGraph captured at one rate must not be replayed at another.  The rate is part of the graph
+    key, a change recaptures through the sampling path, and graphs of the old rate are dropped."""
+    from common import build_models
+    from ekaid_amd import hip, ops
+    from ekaid_amd.config import bench_cfg
+    from ekaid_amd.dp import FlatAdam
+    from ekaid_amd.engine import TrainStep
+    from ekaid_amd.synthetic import make_batch
+    cfg = bench_cfg(D=256, seq_length=12)
+    host = make_batch(B=4, N=12, D=256, Lq=8, T=5, seq_length=12, V=148, seed=5)
+    b = {k: v.cuda() for k, v in host.items()}
+    T = 5
+    draws = []
+    real = hip.lib().ekaid_ss_tokens
+    monkeypatch.setattr(hip.lib(), 'ekaid_ss_tokens', lambda *a: (draws.append(a[5]), real(*a))[1], raising=False)
+    cd, sp = build_models(cfg, 147, 148, 'cuda', train=True)
+    opt = FlatAdam([cd, sp], lr=1e-3)
+    ts = TrainStep(cfg, cd, sp, opt, use_graph=True)
+    captures = []
+    cap = ts._capture
+    monkeypatch.setattr(ts, '_capture', lambda *a: (captures.append(sp.ss_prob), cap(*a))[1])
+    try:
+        ops.manual_seed(777)
+        losses = []
+        for rate in (0.0, 0.0, 0.6, 0.6, 0.9):
+            sp.ss_prob = rate
+            n0 = len(draws)
+            losses.append(float(ts(b, T)[0].detach()))
+            assert len(ts._graphs) == 1 and next(iter(ts._graphs))[4] == rate, list(ts._graphs)
+            if rate > 0 and captures.count(rate) == 1 and len(draws) > n0:
+                # the capture ran the sampling path: warm-ups + capture, T - 1 draws each, at the NEW rate
+                assert len(draws) - n0 == (ts.warmup + 1) * (T - 1) and all(abs(d - rate) < 1e-6 for d in draws[n0:])
+        assert captures == [0.0, 0.6, 0.9], captures
+        assert opt.step_count == 5
+        assert len(set(losses)) == 5 and all(l == l and l > 0 for l in losses), losses
+    finally:
+        ts.close()
 
 
 def test_rccl_path_on_one_gpu(tmp_path):

@@ -193,3 +193,19 @@ def test_bench_runs_on_two_ranks(extra, tmp_path):
     c = out['comm']
     assert c['allreduce_bytes'] > 200e6 and c['buckets'] > 1 and c['exposed_comm_ms'] >= 0.0 and c['ms_per_step_without_comm'] > 0
     assert ('hipGraph' in out['config']['launch_path']) == bool(extra)
+
+
+def test_bench_starts_its_own_ranks():
+    """``python bench.py --gpus 2`` with NO launcher around it (the way the driver runs the N = 1 line): the script spawns its two
+    ranks itself -- fresh child processes, the parent never touches the GPU -- and relays rank 0's single JSON line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2', '--warmup', '1',
+           '--no-cpu-baseline', '--no-extra']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1 and r.stdout.strip() == lines[0], r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['value'] > 0 and out['config']['per_gpu_batch'] == 128
+    assert out['comm']['allreduce_bytes'] > 200e6 and out['comm']['exposed_comm_ms'] >= 0.0

@@ -289,3 +289,34 @@ def test_caption_metrics_delegate_to_pycocoevalcap_or_step_aside():
         assert m is not None and 0.0 <= m['Bleu_1'] <= 1.0 and 'CIDEr' in m
     else:
         assert m is None
+
+
+def test_bench_spawner_relays_rank0_and_stops_everything_when_a_rank_fails(tmp_path, monkeypatch):
+    """bench.spawn_ranks (``python bench.py --gpus N`` without a launcher): N child processes with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, rank 0's stdout relayed verbatim, a failing rank ends the run with its exit code and no child is left behind."""
+    import subprocess
+    import sys
+    stub = tmp_path / 'stub.py'
+    stub.write_text(
+        "import os, sys, time\n"
+        "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "assert os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+        "open(os.path.join(os.path.dirname(__file__), 'pid%d' % r), 'w').write(str(os.getpid()))\n"
+        "if '--fail' in sys.argv and r == 1: sys.exit(7)\n"
+        "if '--fail' in sys.argv: time.sleep(600)\n"
+        "print('{\"rank\": %d, \"world\": %d}' % (r, w))\n")
+    drv = tmp_path / 'drv.py'
+    drv.write_text(
+        "import sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "bench.__file__ = %r\n"
+        "sys.exit(bench.spawn_ranks(3, 60))\n" % (ROOT, str(stub)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    ok = subprocess.run([sys.executable, str(drv)], capture_output=True, text=True, timeout=120, env=env)
+    assert ok.returncode == 0 and ok.stdout == '{"rank": 0, "world": 3}\n', (ok.stdout, ok.stderr[-2000:])
+    bad = subprocess.run([sys.executable, str(drv), '--fail'], capture_output=True, text=True, timeout=120, env=env)
+    assert bad.returncode == 7 and bad.stdout == '', (bad.returncode, bad.stdout, bad.stderr[-2000:])
+    for r in (0, 2):                            # the sleeping ranks were stopped, not orphaned
+        pid = int((tmp_path / ('pid%d' % r)).read_text())
+        assert not os.path.exists('/proc/%d' % pid) or open('/proc/%d/stat' % pid).read().split()[2] == 'Z'

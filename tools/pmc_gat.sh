@@ -2,7 +2,8 @@
 # PMC passes over the fused graph-attention forward kernel alone (tools/gat_bench.py --kernel: 35 launches through the C ABI; the
 # counters of the last one).  usage: tools/pmc_gat.sh <outdir> R N M A H      -> <outdir>/summary.json
 out=$1; shift
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+REPO="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+cd /tmp && export TMPDIR=/tmp && cd "$REPO"
 mkdir -p $out
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_RD" \

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Detailed PMC passes over one GEMM shape (tuning aid).  usage: tools/pmc_gemm2.sh <outdir> <nt|nn|tn> M N K
 out=$1; shift
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+REPO="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+cd /tmp && export TMPDIR=/tmp && cd "$REPO"
 mkdir -p $out
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS" \

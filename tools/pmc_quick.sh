@@ -1,7 +1,8 @@
 #!/bin/bash
 # MFMA-busy and clock of one GEMM shape (two PMC passes).  usage: tools/pmc_quick.sh <outdir> <nt|nn|tn> M N K
 out=$1; shift
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+REPO="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+cd /tmp && export TMPDIR=/tmp && cd "$REPO"
 mkdir -p $out
 i=0
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES" "GRBM_GUI_ACTIVE"; do

@@ -3,7 +3,8 @@
 # (a group the hardware cannot collect in one pass makes rocprofv3 abort and hang: every pass runs under timeout)
 # Each counter group is its own rocprofv3 run (kernel-trace + pmc only), as the pool requires.
 out=$1; shift
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+REPO="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+cd /tmp && export TMPDIR=/tmp && cd "$REPO"
 i=0
 first=${PMC_FIRST:-1}
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \

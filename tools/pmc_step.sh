@@ -4,7 +4,8 @@
 #   2. three separate --pmc passes over a short run of the same command (MFMA/SQ group, FETCH_SIZE, WRITE_SIZE)
 # usage: tools/pmc_step.sh <outdir> [bench args...]      (the program itself follows `--`: no env/bash hop)
 out=$1; shift
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+REPO="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+cd /tmp && export TMPDIR=/tmp && cd "$REPO"
 mkdir -p $out
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra "$@" > $out/trace.log 2>&1
 i=0

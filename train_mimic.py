@@ -103,20 +103,28 @@ def evaluate(cfg, change_detector, speaker, loader, device, idx_to_word, graph, 
     predictions, references, correct, total = {}, {}, 0, 0
     set_mode('eval', [change_detector, speaker])
     infer = InferStep(cfg, change_detector, graph, cfg.train.setting, use_graph=hip_graph)
-    with torch.no_grad():
-        for bi, b in enumerate(DevicePrefetcher(loader, device)):
-            if max_batches is not None and bi >= max_batches:
-                break
-            outs = infer(b)
-            seq, _ = speaker._sample(outs[3], outs[4], outs[5], b['labels'], cfg, sample_max=1)
-            sents = decode_sequence(idx_to_word, seq)
-            gts = decode_sequence(idx_to_word, b['_host_labels'][:, 1:])
-            for j, s in enumerate(sents):
-                predictions[str(int(b['pair_index'][j]))] = s
-                references[str(int(b['pair_index'][j]))] = gts[j]
-                correct += int(s == gts[j])
-                total += 1
-    set_mode('train', [change_detector, speaker])
+    # Evaluation must leave torch's default generator where it found it: creating a loader iterator draws a base seed from it
+    # (torch >= 2.x), the training sampler shuffles every epoch from that generator, and only rank 0 evaluates -- without
+    # this the ranks' "global" permutations drift apart after the first in-loop evaluation, and a resumed run (which never
+    # replays the evaluations that preceded its checkpoint) shuffles differently from the uninterrupted one.
+    rng = torch.get_rng_state()
+    try:
+        with torch.no_grad():
+            for bi, b in enumerate(DevicePrefetcher(loader, device)):
+                if max_batches is not None and bi >= max_batches:
+                    break
+                outs = infer(b)
+                seq, _ = speaker._sample(outs[3], outs[4], outs[5], b['labels'], cfg, sample_max=1)
+                sents = decode_sequence(idx_to_word, seq)
+                gts = decode_sequence(idx_to_word, b['_host_labels'][:, 1:])
+                for j, s in enumerate(sents):
+                    predictions[str(int(b['pair_index'][j]))] = s
+                    references[str(int(b['pair_index'][j]))] = gts[j]
+                    correct += int(s == gts[j])
+                    total += 1
+    finally:
+        torch.set_rng_state(rng)
+        set_mode('train', [change_detector, speaker])
     evaluate.last_references = references          # (for the caption metrics; the return value keeps its three fields)
     return predictions, correct / max(total, 1), total
 
@@ -316,9 +324,8 @@ def main(argv=None):
                                   'optimizer_state': optimizer.state_dict(named()), 'iteration': t,
                                   'epoch': epoch + 1 if end_of_epoch else epoch, 'iter_in_epoch': 0 if end_of_epoch else i,
                                   # mid-epoch: the state the epoch's sampler drew its permutation from; on an epoch
-                                  # boundary: the state NOW, from which the next epoch's sampler will draw (nothing between
-                                  # here and the next epoch start consumes torch's generator: evaluation runs without dropout
-                                  # over a sequential sampler)
+                                  # boundary: the state NOW, from which the next epoch's sampler will draw (evaluate() restores
+                                  # the generator it found, so nothing between here and the next epoch start moves it)
                                   'epoch_rng_state': torch.get_rng_state() if end_of_epoch else rng_at_epoch_start,
                                   'dropout_seed_counter': ops.seed_state()[1], 'best': best}
                     save_checkpoint(checkpoint, os.path.join(snapshot_dir, 'checkpoint_%d.pt' % t))
