@@ -32,6 +32,7 @@ constexpr int MAX_DEVICES = 64, ATTR_SLOTS = 64;
 struct DeviceState {
     std::atomic<int> ready{0};
     std::atomic<int> gemm_mode{-1};
+    std::atomic<int> seq_mode{-1};
     std::atomic<const unsigned long long*> epoch{nullptr};
     std::atomic<double*> scratch{nullptr};        // two-stage reduction partials (pointwise.hip), device memory of THIS device
     std::atomic<bool> attr[ATTR_SLOTS];
@@ -62,6 +63,18 @@ int gemm_mode() {
     return m;
 }
 int set_gemm_mode(int mode) { device_state().gemm_mode.store(mode); return EKAID_OK; }
+static int default_seq_mode() {
+    const char* m = getenv("EKAID_SEQ_MODE");        // "stepwise" / "0": the launch-per-product chain; "persistent" / "1": one launch per sequence
+    if (m && (m[0] == 's' || m[0] == '0')) return 0;
+    if (m && (m[0] == 'p' || m[0] == '1')) return 1;
+    return EKAID_SEQ_MODE_DEFAULT;
+}
+int seq_mode() {
+    DeviceState& s = device_state();
+    int m = s.seq_mode.load();
+    if (m < 0) { m = default_seq_mode(); s.seq_mode.store(m); }
+    return m;
+}
 const unsigned long long* dropout_epoch_ptr() { return device_state().epoch.load(std::memory_order_relaxed); }
 double* device_scratch(size_t bytes) {
     // allocated once per device (first use, or ekaid_init), on the calling thread's current device; a second thread racing
@@ -106,6 +119,13 @@ extern "C" int ekaid_dropout_epoch_advance(unsigned long long* epoch_dev, unsign
     hipLaunchKernelGGL(ekaid::epoch_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, epoch_dev, by);
     return ekaid::check_launch("dropout_epoch_advance");
 }
+
+extern "C" int ekaid_set_seq_mode(int mode) {
+    if (mode != 0 && mode != 1) { ekaid::set_error("ekaid_set_seq_mode: 0 (step-wise) or 1 (persistent)"); return EKAID_ERR_ARG; }
+    ekaid::device_state().seq_mode.store(mode);
+    return EKAID_OK;
+}
+extern "C" int ekaid_get_seq_mode(void) { return ekaid::seq_mode(); }
 
 extern "C" int ekaid_version(void) { return EKAID_ABI_VERSION; }
 extern "C" const char* ekaid_last_error(void) { return ekaid::g_err; }

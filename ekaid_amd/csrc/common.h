@@ -21,6 +21,10 @@ struct DeviceState;
 DeviceState& device_state();                       // of the calling thread's current HIP device
 int gemm_mode();                                   // 0 = f32 MFMA, 1 = exact bf16 split (per device)
 int set_gemm_mode(int mode);
+int seq_mode();                                    // 0 = step-wise sequence chains, 1 = persistent sequence kernels where supported (per device)
+#ifndef EKAID_SEQ_MODE_DEFAULT
+#define EKAID_SEQ_MODE_DEFAULT 0
+#endif
 const unsigned long long* dropout_epoch_ptr();     // device word folded into every dropout seed, or NULL
 constexpr size_t EKAID_SCRATCH_BYTES = 2 * 2048 * sizeof(double) + (size_t(1) << 20);    // reduction slots + column-sum partials (pointwise.hip)
 double* device_scratch(size_t bytes);              // per-device reduction scratch (allocated at first use / by ekaid_init), or NULL

@@ -176,11 +176,18 @@ extern "C" int ekaid_gru_seq_bwd(const float* dout, const float* w_hh, const flo
 extern "C" size_t ekaid_speaker_seq_workspace_bytes(const ekaid_speaker_seq_t* d, int backward) {
     if (!spk_args_ok(d, "ekaid_speaker_seq_workspace_bytes")) return 0;
     SpkPlan pl;
-    return spk_plan(d, nullptr, backward != 0, pl) ? pl.bytes : 0;
+    if (!spk_plan(d, nullptr, backward != 0, pl)) return 0;
+    // large enough for either sequence mode (the persistent kernel only needs its seam counters)
+    const size_t pers = backward ? 0 : ekaid_speaker_seq_persistent_workspace_bytes(d);
+    return pl.bytes > pers ? pl.bytes : pers;
 }
 
 extern "C" int ekaid_speaker_seq_fwd(const ekaid_speaker_seq_t* d, void* workspace, size_t workspace_bytes, void* stream) {
     if (!spk_args_ok(d, "ekaid_speaker_seq_fwd")) return EKAID_ERR_ARG;
+    if (seq_mode() == 1) {                  // one persistent launch for the whole sequence where the shape allows it (csrc/persist.hip)
+        const size_t pers = ekaid_speaker_seq_persistent_workspace_bytes(d);
+        if (pers && workspace && workspace_bytes >= pers) return ekaid_speaker_seq_fwd_persistent(d, workspace, workspace_bytes, stream);
+    }
     SpkPlan pl;
     if (!spk_plan(d, workspace, false, pl)) return EKAID_ERR_ARG;
     if (!workspace || workspace_bytes < pl.bytes) { set_error("ekaid_speaker_seq_fwd: workspace too small (%zu < %zu)", workspace_bytes, pl.bytes); return EKAID_ERR_ARG; }

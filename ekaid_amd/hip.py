@@ -172,6 +172,11 @@ SIGNATURES = {
     'ekaid_spk_pos_bwd': [P, I, P, P, I, I, P, P, P, I, F, U64, F, U64, P, P, I, P],
     'ekaid_spk_gate_bwd': [P, P, P, L, P, P],
     'ekaid_ss_tokens': [P, P, I, I, I, F, U64, P, P],
+    'ekaid_speaker_seq_persistent_workspace_bytes': [POINTER(SpeakerSeq)],
+    'ekaid_speaker_seq_fwd_persistent': [POINTER(SpeakerSeq), P, c_size_t, P],
+    'ekaid_speaker_seq_persistent_status_ptr': [P],
+    'ekaid_set_seq_mode': [I],
+    'ekaid_get_seq_mode': [],
     'ekaid_softmax_fwd': [P, P, L, I, I, P],
     'ekaid_softmax_bwd': [P, P, P, L, I, I, P],
     'ekaid_mix3_fwd': [P, P, P, P, I, I, P, P],
@@ -190,7 +195,8 @@ SIGNATURES = {
     'ekaid_adam_step_dev': [P, P, P, P, L, P, P, P, P],
 }
 _RESTYPES = {'ekaid_last_error': c_char_p, 'ekaid_gemm_workspace_bytes': c_size_t, 'ekaid_gru_seq_workspace_bytes': c_size_t,
-             'ekaid_speaker_seq_workspace_bytes': c_size_t, 'ekaid_speaker_greedy_workspace_bytes': c_size_t}
+             'ekaid_speaker_seq_workspace_bytes': c_size_t, 'ekaid_speaker_seq_persistent_workspace_bytes': c_size_t,
+             'ekaid_speaker_seq_persistent_status_ptr': c_void_p, 'ekaid_speaker_greedy_workspace_bytes': c_size_t}
 
 _lib = None
 

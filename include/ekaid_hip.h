@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EKAID_ABI_VERSION 5
+#define EKAID_ABI_VERSION 6
 
 int ekaid_version(void);
 const char* ekaid_last_error(void);        /* thread-local */
@@ -427,6 +427,24 @@ typedef struct ekaid_speaker_seq_bwd {
 size_t ekaid_speaker_seq_workspace_bytes(const ekaid_speaker_seq_t* d, int backward);
 int ekaid_speaker_seq_fwd(const ekaid_speaker_seq_t* d, void* workspace, size_t workspace_bytes, void* stream);
 int ekaid_speaker_seq_bwd(const ekaid_speaker_seq_bwd_t* d, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same forward sequence as ONE persistent launch (csrc/persist.hip): one workgroup per CU stays resident for all T steps, every
+ * product is cut into 16-row x 16-column jobs with the full contraction (exact f32 on v_mfma_f32_16x16x4_f32, no split-K), cell
+ * states stay in LDS, and the five all-to-all dependencies of a step are device-scope counter seams (write-through stores, sc1
+ * loads) instead of kernel boundaries.  Same descriptor, same saved tensors (either forward pairs with either backward); results
+ * agree with ekaid_speaker_seq_fwd to f32 rounding (different summation order), deterministic from run to run.
+ * Supported: R = 512, A = 1024, P = 16, G1 = 2R + A, T <= 96, batch up to what the per-workgroup LDS state allows (256 on a 256-CU
+ * part); anything else -> EKAID_ERR_UNSUPPORTED (workspace_bytes query returns 0).  `workspace` (256-byte aligned) starts with the
+ * seam counters, zeroed by a memset in front of every launch; ekaid_speaker_seq_persistent_status_ptr(workspace) is a DEVICE pointer
+ * to one word: 0 after a good launch, 0x100 + seam if a seam did not open within ~0.5 s and the launch was abandoned.
+ * ekaid_set_seq_mode(1) makes ekaid_speaker_seq_fwd / ekaid_speaker_greedy_steps route supported shapes here (0: step-wise chain;
+ * default from EKAID_SEQ_MODE = stepwise | persistent, see csrc/api.hip).
+ * ref: dynamic_speaker_change_pos.py:94-131 inside :196-222 */
+size_t ekaid_speaker_seq_persistent_workspace_bytes(const ekaid_speaker_seq_t* d);
+int ekaid_speaker_seq_fwd_persistent(const ekaid_speaker_seq_t* d, void* workspace, size_t workspace_bytes, void* stream);
+const unsigned* ekaid_speaker_seq_persistent_status_ptr(const void* workspace);
+int ekaid_set_seq_mode(int mode);
+int ekaid_get_seq_mode(void);
 
 /* Greedy decoding (sample_max = 1, eval mode) of steps t0 .. t1-1 without a host round trip per step: token embedding, word-side
  * gates, the recurrent step, logits, log-softmax and ekaid_greedy_step per step, the chosen tokens feeding the next step on
