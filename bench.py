@@ -277,7 +277,10 @@ def spawn_ranks(n, timeout_s):
     out = out0.read().decode()
     out0.close()
     if rc == 0:
-        sys.stdout.write(out)
+        # stdout carries the ONE JSON line of the contract; anything else a rank's libraries wrote there (gloo announces its
+        # connections on stdout) goes to stderr
+        for ln in out.splitlines():
+            (sys.stdout if ln.startswith('{') else sys.stderr).write(ln + '\n')
         sys.stdout.flush()
     return rc
 

@@ -23,7 +23,7 @@ int gemm_mode();                                   // 0 = f32 MFMA, 1 = exact bf
 int set_gemm_mode(int mode);
 int seq_mode();                                    // 0 = step-wise sequence chains, 1 = persistent sequence kernels where supported (per device)
 #ifndef EKAID_SEQ_MODE_DEFAULT
-#define EKAID_SEQ_MODE_DEFAULT 0
+#define EKAID_SEQ_MODE_DEFAULT 1
 #endif
 const unsigned long long* dropout_epoch_ptr();     // device word folded into every dropout seed, or NULL
 constexpr size_t EKAID_SCRATCH_BYTES = 2 * 2048 * sizeof(double) + (size_t(1) << 20);    // reduction slots + column-sum partials (pointwise.hip)

@@ -6,27 +6,35 @@
 // kernels that sum the slabs.  At 32-256 batch rows every one of them is latency-bound (7-14 us for < 1 us of arithmetic), and
 // the chain is what the real-data loop, greedy decoding and the 8-GPU strong-scaling point spend their time on.  Here one
 // workgroup per CU stays resident for all T steps:
-//   * every product of a step is cut into jobs of 16 batch rows x 16 output columns with the FULL contraction (no split-K, no
-//     slabs: each output element is produced by one workgroup in a fixed order -> deterministic by construction); the four waves
-//     of the workgroup split K, exact f32 arithmetic on v_mfma_f32_16x16x4_f32 (a k-ordered fmaf chain per wave), operands loaded
-//     global -> registers directly in fragment layout (16 bytes per lane, 64 contiguous bytes per row and instruction), the four
-//     partial tiles summed through LDS;
-//   * a workgroup owns the same (column tile, row block) pairs in every step, so LSTM cell states, and the h_lang-side partial
-//     products a later phase of the step needs, never leave its LDS; weights are re-read from L2 each step, prefetched into
-//     registers BEFORE the wait they hide behind;
-//   * the five all-to-all dependencies of a step (h_att/vpos -> row-local module mix and POS chain -> gate-MLP layer 1 -> layer 2 ->
-//     language LSTM -> next step) are device-scope seams instead of kernel boundaries: handed-off activations are stored write-through
-//     (sc1), every storing wave drains (s_waitcnt vmcnt(0)), the workgroup barriers, ONE lane adds to the seam's counter (sharded per
-//     XCD, each shard on a line of its own); consumers poll the eight shards with sc1 loads from one wave, barrier, and then read the
-//     handed-off bytes ONLY with sc1 loads (guide: cdna_hip_programming.md Guideline 16, form R1 / MI355X_MICROARCH.md "Valid forms",
-//     first table row).  Counters count up over the steps of one launch (target = arrivals per step x steps done) and are zeroed by a
-//     memset node in front of every launch; every activation buffer is indexed by the step, so no address is written twice in a
-//     launch.  Spins are bounded: a seam that does not open within ~0.5 s sets the status word and every workgroup leaves.
-// Work that only needs h_lang_{t-1} but is consumed late in the step (the h_lang blocks of the gate MLP and of the language LSTM)
-// runs in the shadow between a seam's arrive and its wait.
+//   * every product of a step is cut into jobs of 16 batch rows x (1, 2 or 4 tiles of) 16 output columns with the FULL contraction
+//     (no split-K, no slabs: each output element is produced by one workgroup in a fixed order -> deterministic by construction);
+//     the four waves of the workgroup split K, exact f32 arithmetic on v_mfma_f32_16x16x4_f32 (a k-ordered fmaf chain per wave),
+//     the partial tiles summed through LDS.  A workgroup owns the same (column tiles, row blocks) in every step: its weight
+//     fragments are fetched once per phase into registers BEFORE the wait they hide behind, LSTM cell states never leave LDS;
+//   * what one phase hands to the next travels in FRAGMENT-MAJOR layout: the activation matrix of a row block is stored as 1-KB
+//     chunks [k / 16][(k % 16) / 4][row][k % 4], exactly the order in which the 64 lanes of a wave hold an MFMA A operand, so every
+//     load instruction of a consumer reads 1 KB contiguous (row-major rows cost 16 half-lines per instruction and ran at a fifth of
+//     the CU's load rate).  The row-major tensors of the saved-tensor contract are written next to it (plain stores, nobody waits);
+//   * the all-to-all volume through the fabric is what bounds a step (every column tile reads all rows): all products that read
+//     h_lang_{t-1} / h_att_{t-1} run in ONE pass over those rows (attention-LSTM gates, POS layer 1, the h_lang blocks of gate-MLP
+//     layer 1 and of the language LSTM); gate-MLP layer 1 is not a product at all -- its [pos_feat | att] input is linear in the
+//     16 POS weights and the 3 module weights of a row, so with F_m = feat_m W_att^T (once per sequence), Wp = W_pp W_p2 and
+//     cp = W_pp b_p2 (once per call) the pre-activation is mw . F + pw . Wp + cp + (h_lang block) + b: 19 multiply-adds per element
+//     instead of a K = 1536 contraction; long contractions run 2 or 4 column tiles per job at large batch (activations read once
+//     per job);
+//   * the five dependencies of a step (h_att/vpos -> row-local module and POS weights -> gate-MLP layer 1 -> layer 2 -> language LSTM
+//     -> next step) are device-scope seams instead of kernel boundaries: handed-off bytes are stored write-through (sc1), every
+//     storing wave drains (s_waitcnt vmcnt(0)), the workgroup barriers, ONE lane adds to the seam's counter (sharded per XCD, each
+//     shard on a line of its own); consumers poll the eight shards with sc1 loads from one wave, barrier, and read the handed-off
+//     bytes ONLY with sc1 loads (cdna_hip_programming.md Guideline 16, form R1 / MI355X_MICROARCH.md "Valid forms", first table row).
+//     Counters count up over the steps of one launch and are zeroed by a memset node in front of every launch.  A hand-off buffer is
+//     rewritten only after a later seam has proven every reader of the previous contents done (h_att is double-buffered: it is read
+//     and rewritten in the same phase).  Spins are bounded: a seam that does not open within ~0.5 s sets the status word and every
+//     workgroup leaves.
 // The saved-tensor contract is that of ekaid_speaker_seq_fwd (include/ekaid_hip.h): either forward pairs with either backward.
 #include "common.h"
 #include "../../include/ekaid_hip.h"
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -35,15 +43,12 @@ namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int NSEAM = 5, SHARDS = 8, LINE = 32;                   // seams per step; counter shards (one per XCD); words per 128-B line
+constexpr int NSEAM = 6, SHARDS = 8, LINE = 32;                   // seams (5 per step + the prologue); counter shards (one per XCD); words per 128-B line
 constexpr int SYNC_WORDS = NSEAM * SHARDS * LINE + LINE;          // + one line for the status word
 constexpr unsigned SPIN_LIMIT = 400000u;                          // polls (~1 us each) before a seam is declared dead
 constexpr int PMAX_T = 96;                                        // steps per launch (seeds travel by value in the kernel arguments)
-#ifndef EKAID_PERSIST_ACQ
-#define EKAID_PERSIST_ACQ 1
-#endif
-constexpr int AUX_SC1 = 16;
-constexpr int AUX_RD = EKAID_PERSIST_ACQ ? 0 : 16;              // loads of handed-off bytes: plain behind an agent-scope acquire, or sc1                                       // buffer cache-policy bit: sc1 (agent-scope write-through / L1 bypass)
+constexpr int MAXJ = 8;                                           // jobs of one phase per workgroup
+constexpr int AUX_SC1 = 16;                                       // buffer cache-policy bit: sc1 (agent-scope write-through / L1 bypass)
 
 __device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u; }      // HW_REG_XCC_ID
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
@@ -59,10 +64,7 @@ __device__ __forceinline__ void bstore4_sc1(const __amdgpu_buffer_rsrc_t r, unsi
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, AUX_SC1);
 }
 __device__ __forceinline__ void store_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float load_sc1(const float* p) {
-    if (EKAID_PERSIST_ACQ) return *p;
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+__device__ __forceinline__ float load_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ---- seams ------------------------------------------------------------------------------------------------------------
 // arrive: every wave has drained its (write-through) stores, the workgroup has met, one lane counts the workgroup in
@@ -96,39 +98,35 @@ __device__ __forceinline__ bool seam_wait(const unsigned* seam, unsigned target,
             __builtin_amdgcn_s_sleep(1);
         }
         if (lane == 0) *ok_lds = good ? 1 : 0;
-        if (EKAID_PERSIST_ACQ) {        // ONE acquire after the match: drops this CU's stale L1 lines (and non-local L2 lines); the wait holds the barrier for it
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
     }
     __syncthreads();
     return *ok_lds != 0;
 }
 
-// ---- 16 x 16 x K tile jobs ----------------------------------------------------------------------------------------------
-// Lane l of a wave holds, for the MFMA's A operand, 4 consecutive k of batch row (l & 15) and, for its B operand, the same 4 k of
-// weight row (= output column) (l & 15); the four 16-lane groups take consecutive 4-k pieces, so one load instruction reads 64
-// contiguous bytes of each of 16 rows.  Block i of a wave is 16 k further on; wave w of the workgroup owns k in [w K/4, (w+1) K/4).
-template <int NB, int AUX>
-__device__ __forceinline__ void load_frag(f32x4 (&v)[NB], const __amdgpu_buffer_rsrc_t r, unsigned off) {
-#pragma unroll
-    for (int i = 0; i < NB; ++i) v[i] = bload4<AUX>(r, off + 64u * i);
-}
-// sum of the four waves' partial tiles; thread tid gets element (row = tid >> 4, col = tid & 15).  `red`: 4 x 320 floats; the
-// caller alternates between two such buffers from job to job (one barrier per job)
-__device__ __forceinline__ float tile_reduce(const f32x4 (&acc)[4], float* red, int wave, int lane, int tid) {
-    const f32x4 c = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+// ---- fragment-major hand-off layout ---------------------------------------------------------------------------------------
+// X (rows x K) of row block rb: chunk (rb, kb) = the 16 rows x 16 k of k-block kb, 1 KB, element (row, k) at float offset
+// ((k % 16) / 4 * 16 + row) * 4 + k % 4 -- lane l = kq * 16 + row of a wave reads its MFMA A-operand piece at byte l * 16.
+__device__ __forceinline__ unsigned fm_chunk(int rb, int kb, int kblocks) { return (unsigned)(rb * kblocks + kb) << 10; }
+
+// 4 waves' partial tiles -> sums.  red: [tile][wave][320 floats]; thread tid gets element (row = tid >> 4, col = tid & 15) of every
+// tile.  One barrier for all NT tiles of a job; the caller alternates between two buffers from job to job.
+template <int NT>
+__device__ __forceinline__ void tiles_reduce(const f32x4 (&part)[NT], float (&v)[NT], float* red, int wave, int lane, int tid) {
     float* mine = red + wave * 320 + (lane >> 4) * 80 + (lane & 15);        // C layout: col = lane & 15, row = 4 (lane >> 4) + r
 #pragma unroll
-    for (int r = 0; r < 4; ++r) mine[r * 16] = c[r];
+    for (int m = 0; m < NT; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[m * 1280 + r * 16] = part[m][r];
+    }
     __syncthreads();
     const int row = tid >> 4, col = tid & 15;
     const float* q = red + (row >> 2) * 80 + (row & 3) * 16 + col;
-    return (q[0] + q[320]) + (q[640] + q[960]);
+#pragma unroll
+    for (int m = 0; m < NT; ++m) v[m] = (q[m * 1280] + q[m * 1280 + 320]) + (q[m * 1280 + 640] + q[m * 1280 + 960]);
 }
 
 struct PFwd {
-    int T, B, G, nrb;
+    int T, B, G, nrb, mtD, mtE;
     float p_lm, p_pos, inv_lm, inv_pos;
     const unsigned long long* ep;
     const float *Wcat, *whh_a, *bhh_a, *w_fc, *b_fc, *b_p1, *w_wp, *b_wp, *w_p2, *b_p2, *w_g1, *b_g1, *w_g2, *b_g2, *wih_l, *bhh_l;
@@ -136,7 +134,10 @@ struct PFwd {
     float *HA, *CA, *HL, *CL, *SA, *SL, *G1D, *MW, *VP, *DP, *PW, *PA, *AT, *GT, *GA;
     unsigned* sync;
     unsigned long long* trace;        // NULL or [G][T][16] stamps (s_memrealtime, 100 MHz)
-    int We, jobs_max, rows_max;
+    // workspace: hand-off buffers (fragment-major unless noted) and the per-call linear maps of gate-MLP layer 1
+    float *HLfm, *HAfm /* [2] */, *G1fm, *GAfm, *MWPW /* [Bp][32] row-major: mw 0..2, pw 16..31 */, *LHP /* [nrb][R/4][256] */;
+    const float *Fm /* [3][B][G1] */, *Wp /* [G1][P] */, *cp /* [G1] */;
+    int We, jobsA, jobsD;
     uint64_t seeds[3 * PMAX_T];
 };
 
@@ -144,22 +145,25 @@ struct PFwd {
 template <int R, int A, int P>
 struct Lds {
     static constexpr int flag = 0;                              // 4
-    static constexpr int red = 4;                               // 2 x 1280
-    static constexpr int hrow = red + 2 * 1280;                 // R   (h_att row of phase B)
+    static constexpr int red = 4;                               // 2 x (4 tiles x 1280)
+    static constexpr int hrow = red + 2 * 5120;                 // R   (h_att row of phase B)
     static constexpr int vrow = hrow + R;                       // R   (vpos row)
     static constexpr int zpart = vrow + R;                      // 8   (module-weight partials: 2 waves x 3)
     static constexpr int pz = zpart + 8;                        // 128 (POS logit partials)
     static constexpr int sz = pz + 128;                         // 64  (POS weights)
     static constexpr int wfc = sz + 64;                         // 3 R
     static constexpr int bsm = wfc + 3 * R;                     // b_fc (4) | b_wp (P) | b_p2 (R)
-    static constexpr int fixed = bsm + 4 + P + R;
-    // then per job slot: g1p 256 | lhp 256 | catt 64 | clang 64; then per row slot: 3 A
-    static constexpr int per_job = 640;
-    static constexpr int per_row = 3 * A;
+    static constexpr int stage = bsm + 4 + P + R;               // MAXJ x 512: [mw | pw] rows of the row blocks of this workgroup's jobs
+    static constexpr int fixed = stage + MAXJ * 512;
+    // then per phase-A job slot: g1p 256 | catt 64 | F slices 3 x 256 ; then per phase-D (job, tile) slot: feature slices 3 x 256;
+    // then per phase-E (job, tile) slot: clang 64
+    static constexpr int per_jobA = 256 + 64 + 768;
+    static constexpr int per_tileD = 768;
+    static constexpr int per_tileE = 64;
 };
 
 struct Ctx {
-    int tid, lane, wave, wg, G, nrb, B, l15, row, col;
+    int tid, lane, wave, wg, G, nrb, B, row, col;
     float* red;
     int par;
     unsigned* status;
@@ -170,211 +174,315 @@ __device__ __forceinline__ void stamp(const Ctx& c, int k) {
     if (c.trace && c.tid == 0) c.trace[k] = __builtin_amdgcn_s_memrealtime();
 }
 
-// x-ring depth of a contraction of NB blocks per wave: at most 16 blocks (~1 us of matrix work) ahead, and a divisor of NB so that
-// the ring keeps its phase from one job to the next
-template <int NB> struct XRing { static constexpr int v = NB <= 16 ? NB : (NB % 16 == 0 ? 16 : (NB % 12 == 0 ? 12 : 8)); };
-
-// One phase of a step for this workgroup: the jobs (column tile tau = wg % tiles, row blocks rb = wg / tiles + n G / tiles) it owns.
-//   * the weight fragments of the tile -- ALL NB blocks of this wave's K quarter, NB0 from the first operand pair, NB1 from the second
-//     -- are requested BEFORE the seam is polled and stay in registers for all jobs of the phase;
-//   * activations stream through a ring of RX blocks that runs ACROSS jobs: as soon as block i of job n has been multiplied, block
-//     i + RX is requested -- of the same job, or of job n + 1 -- so the reduction, the epilogue and the stores of a job overlap the
-//     loads of the next;
-//   * pre(rb, slot) is called before a job's matrix work (issue the loads the epilogue needs), epi(v, pre's value, rb, slot) after the
-//     reduction with the tile element of thread (row = tid >> 4, col = tid & 15); slot = index of the job within the workgroup.
-template <int NB0, int NB1, bool WRES, class Pre, class Epi>
-__device__ __forceinline__ bool run_phase(Ctx& c, int tiles, const __amdgpu_buffer_rsrc_t rw0, unsigned woff0, const __amdgpu_buffer_rsrc_t rw1,
-                                          unsigned woff1, const __amdgpu_buffer_rsrc_t ra0, const __amdgpu_buffer_rsrc_t ra1, unsigned lda_bytes,
-                                          unsigned kw, const unsigned* seam, unsigned target, unsigned code, int stamp_id, Pre pre, Epi epi) {
-    // WRES: all NB weight blocks resident in registers for the phase; otherwise (long contractions under the 256-register budget of
-    // two workgroups per CU) the weights stream through a ring like the activations, one pass per job (from L2)
-    constexpr int NB = NB0 + NB1, RX = XRing<NB>::v, NW = WRES ? NB : RX;
+// One MFMA phase of a step for this workgroup: jobs (tile group tg = wg % tgroups: MT column tiles sharing the activations; row blocks
+// rb = wg / tgroups + n G / tgroups).
+//   * the weight fragments of the MT tiles -- all NB blocks of this wave's K quarter -- are requested BEFORE the seam is polled and stay
+//     in registers for all jobs of the phase; so are the values pre(rb, n) every job's epilogue needs;
+//   * activations stream from the fragment-major buffer through a ring of RX blocks that runs ACROSS jobs: as soon as block i of job n
+//     has been multiplied, block i + RX is requested -- of the same job, or of job n + 1 -- so the reduction, the epilogue and the stores
+//     of a job overlap the loads of the next;
+//   * epi(v[MT], pre value, rb, n) after the reduction, with the tile elements of thread (row = tid >> 4, col = tid & 15).
+template <int NB, int MT, class PreT, class WOff, class Pre, class Epi>
+__device__ __forceinline__ bool run_mt(Ctx& c, int tgroups, const __amdgpu_buffer_rsrc_t rw, WOff woff, const __amdgpu_buffer_rsrc_t rx, int kblocks,
+                                       const unsigned* seam, unsigned target, unsigned code, int stamp_id, Pre pre, Epi epi) {
+    constexpr int RX = MT >= 2 ? 8 : (NB < 16 ? NB : 16), NACC = MT >= 4 ? 1 : 4 / MT;
     static_assert(NB % RX == 0, "ring phase");
-    const int njobs = c.wg < tiles * c.nrb ? (tiles * c.nrb - c.wg + c.G - 1) / c.G : 0;
-    const int rb0 = c.wg / tiles, drb = c.G / tiles;
-    f32x4 w[NW], x[RX];
-    auto wload = [&](int i) { return i < NB0 ? bload4<0>(rw0, woff0 + kw + 64u * i) : bload4<0>(rw1, woff1 + kw + 64u * (i - NB0)); };
+    const int njobs = c.wg < tgroups * c.nrb ? (tgroups * c.nrb - c.wg + c.G - 1) / c.G : 0;
+    const int rb0 = c.wg / tgroups, drb = c.G / tgroups;
+    f32x4 w[MT][NB], x[RX];
+    PreT ev_next;
     if (njobs) {
 #pragma unroll
-        for (int i = 0; i < NW; ++i) w[i] = wload(i);
+        for (int m = 0; m < MT; ++m) {
+            const unsigned wo = woff(m);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) w[m][i] = bload4<0>(rw, wo + 64u * i);
+        }
+        ev_next = pre(rb0, 0);
     }
     if (seam && !seam_wait(seam, target, c.status, c.ok_lds, code)) return false;
     if (stamp_id >= 0) stamp(c, stamp_id);
     if (!njobs) return true;
-#ifdef EKAID_PERSIST_FAKE
-    // EXPERIMENT (wrong results, same byte count): every load instruction of a wave reads 1 KB contiguous
-#define XOFF(rbx) ((unsigned)min((rbx) * 16, c.B - 16) * lda_bytes + (unsigned)(c.wave * (NB * 1024) + c.lane * 16))
-#define XSTEP 1024u
-#else
-#define XOFF(rbx) ((unsigned)min((rbx) * 16 + c.l15, c.B - 1) * lda_bytes + kw)
-#define XSTEP 64u
-#endif
-    unsigned ao = XOFF(rb0);
+    const unsigned lo = (unsigned)c.lane * 16u;
+    unsigned ao = fm_chunk(rb0, c.wave * NB, kblocks) + lo;
 #pragma unroll
-    for (int i = 0; i < RX; ++i) x[i] = i < NB0 ? bload4<AUX_RD>(ra0, ao + XSTEP * i) : bload4<AUX_RD>(ra1, ao + XSTEP * (i - NB0));
+    for (int i = 0; i < RX; ++i) x[i] = bload4<AUX_SC1>(rx, ao + 1024u * i);
+#pragma unroll 1
     for (int n = 0; n < njobs; ++n) {
         const int rb = rb0 + n * drb;
         const bool more = n + 1 < njobs;
-        const unsigned ao2 = XOFF(rb + drb);
-        const auto ev = pre(rb, n);
-        f32x4 acc[4] = {};
+        const unsigned ao2 = fm_chunk(rb + drb, c.wave * NB, kblocks) + lo;
+        const PreT ev = ev_next;
+        if (more) ev_next = pre(rb + drb, n + 1);        // the next job's epilogue operands travel under this job's matrix work
+        f32x4 acc[MT][NACC] = {};
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int sl = i % RX, wl = WRES ? i : sl;
+            const int sl = i % RX;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[sl][e], w[wl][e], acc[e], 0, 0, 0);
-            const int ii = i + RX;
-            if (ii < NB) {
-                x[sl] = ii < NB0 ? bload4<AUX_RD>(ra0, ao + XSTEP * ii) : bload4<AUX_RD>(ra1, ao + XSTEP * (ii - NB0));
-                if (!WRES) w[wl] = wload(ii);
-            } else if (more) {
-                const int i2 = ii - NB;
-                x[sl] = i2 < NB0 ? bload4<AUX_RD>(ra0, ao2 + XSTEP * i2) : bload4<AUX_RD>(ra1, ao2 + XSTEP * (i2 - NB0));
-                if (!WRES) w[wl] = wload(i2);
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[m][e % NACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[sl][e], w[m][i][e], acc[m][e % NACC], 0, 0, 0);
             }
+            const int ii = i + RX;
+            if (ii < NB) x[sl] = bload4<AUX_SC1>(rx, ao + 1024u * ii);
+            else if (more) x[sl] = bload4<AUX_SC1>(rx, ao2 + 1024u * (ii - NB));
         }
         ao = ao2;
-        const float v = tile_reduce(acc, c.red + c.par * 1280, c.wave, c.lane, c.tid);
+        f32x4 part[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            part[m] = acc[m][0];
+#pragma unroll
+            for (int q = 1; q < NACC; ++q) part[m] += acc[m][q];
+        }
+        float v[MT];
+        tiles_reduce<MT>(part, v, c.red + c.par * 5120, c.wave, c.lane, c.tid);
         c.par ^= 1;
         epi(v, ev, rb, n);
     }
     return true;
 }
 
-template <int R, int A, int P>
+struct Pre3 { float a, b, c; };
+struct PreE { float gx[4], lh[4]; };
+
+// gather the values of 4 consecutive lanes (cols 4q .. 4q+3 of a tile row) into the lane with col % 4 == 0
+__device__ __forceinline__ f32x4 gather4(float v) {
+    f32x4 r;
+    r[0] = v; r[1] = __shfl_down(v, 1, 64); r[2] = __shfl_down(v, 2, 64); r[3] = __shfl_down(v, 3, 64);
+    return r;
+}
+
+template <int R, int A, int P, int MTD, int MTE>
 __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PFwd a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using L = Lds<R, A, P>;
     constexpr int G1 = 2 * R + A, NW = 9 * R + G1;
-    constexpr int NBR = R / 64, NBA = A / 64, NBPA = (R + A) / 64, NBG = G1 / 64;      // 16-k blocks per wave of a K-long contraction
+    constexpr int NBR = R / 64, NBA = A / 64, NBG = G1 / 64;   // 16-k blocks per wave of a K-long contraction
+    constexpr int KBR = R / 16, KBA = A / 16, KBG = G1 / 16;    // chunks per row block of the fragment-major buffers
     constexpr int TILES_U = R / 4;                               // gate tiles: 4 hidden units x 4 gates  (128)
     constexpr int TILES_P1 = R / 16, TILES_G1 = G1 / 16, TILES_G2 = A / 16;
+    static_assert(TILES_G1 == TILES_U, "layer-1 tiles and gate tiles share their owner");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
     const int B = a.B, G = a.G, nrb = a.nrb;
     const int l15 = lane & 15, kq4 = (lane >> 4) * 4;
     const int row = tid >> 4, col = tid & 15;                    // element of a reduced tile
     const unsigned shard = xcc_id();
-    unsigned* const status = a.sync + NSEAM * SHARDS * LINE;
-    float* const jobs_lds = lds + L::fixed;
-    float* const rows_lds = jobs_lds + a.jobs_max * L::per_job;
-    Ctx c = {tid, lane, wave, wg, G, nrb, B, l15, row, col, lds + L::red, 0, status, reinterpret_cast<int*>(lds + L::flag), nullptr};
+    unsigned* const status = a.sync + (NSEAM * SHARDS * LINE);
+    float* const jobsA_lds = lds + L::fixed;
+    float* const tilesD_lds = jobsA_lds + a.jobsA * L::per_jobA;
+    float* const tilesE_lds = tilesD_lds + a.jobsD * MTD * L::per_tileD;
+    Ctx c = {tid, lane, wave, wg, G, nrb, B, row, col, lds + L::red, 0, status, reinterpret_cast<int*>(lds + L::flag), nullptr};
+    const long long BR = (long long)B * R;
+    const long long Bp = 16ll * nrb;
 
-    // column tiles of this workgroup (G is a multiple of every tile count: the tile never changes) and, per thread, the tile
-    // element's output column, gate and hidden unit; the biases of those columns stay in registers for the whole sequence
-    const int tU = wg % TILES_U, tP1 = wg % TILES_P1, tG1 = wg % TILES_G1, tG2 = wg % TILES_G2;
-    const int gate = col >> 2, unit = 4 * tU + (col & 3);
-    const int gate_row_l = (l15 >> 2) * R + 4 * tU + (l15 & 3);  // weight row of lane l15 in a gate tile (4 units x 4 gates)
-    const float bA = a.bhh_a[gate * R + unit], bE = a.bhh_l[gate * R + unit], bP1 = a.b_p1[16 * tP1 + col], bG1 = a.b_g1[16 * tG1 + col],
-                bG2 = a.b_g2[16 * tG2 + col];
+    // ---- ownership.  Phase A / C: gate tile tU = wg % 128 (4 hidden units; also layer-1 column tile tU and, for tU < 32, POS tile tU),
+    // row blocks rbA0 + n drbA.  Phase D: tile group tD of MTD layer-2 tiles.  Phase E: tile group tE of MTE gate tiles.
+    const int tU = wg % TILES_U, rbA0 = wg / TILES_U, drbA = G / TILES_U;
+    const int njA = wg < TILES_U * nrb ? (TILES_U * nrb - wg + G - 1) / G : 0;
+    const bool hasP1 = tU < TILES_P1;
+    constexpr int TG_D = TILES_G2 / MTD, TG_E = TILES_U / MTE;
+    const int tD = wg % TG_D, rbD0 = wg / TG_D, drbD = G / TG_D;
+    const int njD = wg < TG_D * nrb ? (TG_D * nrb - wg + G - 1) / G : 0;
+    const int tE = wg % TG_E, rbE0 = wg / TG_E, drbE = G / TG_E;
+    const int njE = wg < TG_E * nrb ? (TG_E * nrb - wg + G - 1) / G : 0;
+    const int gate = col >> 2, ucol = col & 3;
+    const int gate_row_l = (l15 >> 2) * R + (l15 & 3);           // + 4 tile: weight row of lane l15 in a gate tile (4 units x 4 gates)
 
-    // ---- one-time preloads: row-local weights (phase B), feature rows and cell states of the pairs this workgroup owns
+    // ---- one-time preloads
     for (int i = tid; i < 3 * R; i += 256) lds[L::wfc + i] = a.w_fc[i];
     if (tid < 3) lds[L::bsm + tid] = a.b_fc[tid];
     if (tid < P) lds[L::bsm + 4 + tid] = a.b_wp[tid];
     for (int i = tid; i < R; i += 256) lds[L::bsm + 4 + P + i] = a.b_p2[i];
-    {
-        int rs = 0;
-        for (int r = wg; r < B; r += G, ++rs) {
-            float* f = rows_lds + rs * L::per_row;
-            for (int i = tid; i < A; i += 256) {
-                f[i] = a.bef[(long long)r * A + i];
-                f[A + i] = a.diff[(long long)r * A + i];
-                f[2 * A + i] = a.aft[(long long)r * A + i];
-            }
-        }
-        int slot = 0;
-        for (int j = wg; j < TILES_U * nrb; j += G, ++slot) {
-            const int rb = j / TILES_U;
-            if (tid < 64) {
-                const int grow = min(rb * 16 + (tid >> 2), B - 1), u = 4 * tU + (tid & 3);
-                jobs_lds[slot * L::per_job + 512 + tid] = a.CA[(long long)grow * R + u];
-                jobs_lds[slot * L::per_job + 576 + tid] = a.CL[(long long)grow * R + u];
-            }
+    for (int n = 0; n < njA; ++n) {                              // attention-LSTM cell state and the F_m slices of the (tile, row block) pairs
+        const int rb = rbA0 + n * drbA, gr = min(rb * 16 + row, B - 1);
+        float* s = jobsA_lds + n * L::per_jobA;
+        if (tid < 64) s[256 + tid] = a.CA[(long long)min(rb * 16 + (tid >> 2), B - 1) * R + 4 * tU + (tid & 3)];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) s[320 + m * 256 + tid] = a.Fm[((long long)m * B + gr) * G1 + 16 * tU + col];
+    }
+    for (int n = 0; n < njD; ++n) {                              // feature slices of the layer-2 tiles (attended feature = mw . these)
+        const int rb = rbD0 + n * drbD, gr = min(rb * 16 + row, B - 1);
+#pragma unroll
+        for (int m = 0; m < MTD; ++m) {
+            float* s = tilesD_lds + (n * MTD + m) * L::per_tileD;
+            const long long o = (long long)gr * A + 16 * (tD * MTD + m) + col;
+            s[tid] = a.bef[o]; s[256 + tid] = a.diff[o]; s[512 + tid] = a.aft[o];
         }
     }
-    __syncthreads();
+    for (int n = 0; n < njE; ++n) {                              // language-LSTM cell state
+        const int rb = rbE0 + n * drbE;
+#pragma unroll
+        for (int m = 0; m < MTE; ++m)
+            if (tid < 64) tilesE_lds[(n * MTE + m) * L::per_tileE + tid] = a.CL[(long long)min(rb * 16 + (tid >> 2), B - 1) * R + 4 * (tE * MTE + m) + (tid & 3)];
+    }
+    // biases and per-column constants of the owned tiles stay in registers for the whole sequence
+    const float bA = a.bhh_a[gate * R + 4 * tU + ucol], bP1 = hasP1 ? a.b_p1[16 * tU + col] : 0.f;
+    const float bC = a.b_g1[16 * tU + col] + a.cp[16 * tU + col];
+    float wp[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) wp[j] = a.Wp[(long long)(16 * tU + col) * P + j];
+    float bD[MTD], bE[MTE];
+#pragma unroll
+    for (int m = 0; m < MTD; ++m) bD[m] = a.b_g2[16 * (tD * MTD + m) + col];
+#pragma unroll
+    for (int m = 0; m < MTE; ++m) bE[m] = a.bhh_l[gate * R + 4 * (tE * MTE + m) + ucol];
 
-    const long long BR = (long long)B * R;
     const __amdgpu_buffer_rsrc_t rsWcat = make_rsrc(a.Wcat, (long long)NW * R * 4), rsWhh = make_rsrc(a.whh_a, 4ll * R * R * 4),
-                                 rsWg1 = make_rsrc(a.w_g1, (long long)G1 * G1 * 4), rsWg2 = make_rsrc(a.w_g2, (long long)A * G1 * 4),
-                                 rsWil = make_rsrc(a.wih_l, 4ll * R * (a.We + A) * 4);
+                                 rsWg2 = make_rsrc(a.w_g2, (long long)A * G1 * 4), rsWil = make_rsrc(a.wih_l, 4ll * R * (a.We + A) * 4);
+    const __amdgpu_buffer_rsrc_t rsHLfm = make_rsrc(a.HLfm, Bp * R * 4), rsG1fm = make_rsrc(a.G1fm, Bp * G1 * 4), rsGAfm = make_rsrc(a.GAfm, Bp * A * 4),
+                                 rsMWPW = make_rsrc(a.MWPW, Bp * 32 * 4);
     const unsigned kwR = (unsigned)(wave * (R / 4) + kq4) * 4u;          // byte offset of this lane's first k in a K = R contraction
     const unsigned kwA = (unsigned)(wave * (A / 4) + kq4) * 4u;
-    const unsigned kwPA = (unsigned)(wave * ((R + A) / 4) + kq4) * 4u;
     const unsigned kwG = (unsigned)(wave * (G1 / 4) + kq4) * 4u;
     const int ldw_l = a.We + A;
-    auto nopre = [](int, int) { return 0.f; };
+    const unsigned lo = (unsigned)lane * 16u;
+
+    // ---- prologue: the initial states into fragment-major layout (chunk per workgroup pass), then the first seam
+    {
+        const int nchunk = nrb * KBR;
+        const int kq = tid >> 6, rr = (tid >> 2) & 15, e = tid & 3;
+        for (int ch = wg; ch < 2 * nchunk; ch += G) {
+            const int which = ch >= nchunk, cc = ch - which * nchunk, rb = cc / KBR, kb = cc - rb * KBR, gr = rb * 16 + rr;
+            const float* src = which ? a.HA : a.HL;
+            const float v = gr < B ? src[(long long)gr * R + kb * 16 + kq * 4 + e] : 0.f;
+            store_sc1((which ? a.HAfm : a.HLfm) + ((long long)cc << 8) + tid, v);
+        }
+        seam_arrive(a.sync + 5 * SHARDS * LINE, shard);
+        __syncthreads();
+    }
 
     for (int t = 0; t < a.T; ++t) {
-        const float* HLp = a.HL + (long long)t * BR;             // h_lang_{t-1}
-        const float* HAp = a.HA + (long long)t * BR;             // h_att_{t-1}
         float* HAn = a.HA + (long long)(t + 1) * BR;
         float* HLn = a.HL + (long long)(t + 1) * BR;
-        const __amdgpu_buffer_rsrc_t rsHL = make_rsrc(HLp, BR * 4), rsHA = make_rsrc(HAp, BR * 4);
+        float* HAfm_r = a.HAfm + (long long)(t & 1) * Bp * R;          // h_att_{t-1}
+        float* HAfm_w = a.HAfm + (long long)((t + 1) & 1) * Bp * R;    // h_att_t
+        const __amdgpu_buffer_rsrc_t rsHAr = make_rsrc(HAfm_r, Bp * R * 4), rsHAw = make_rsrc(HAfm_w, Bp * R * 4);
         const DropSeed sv = {a.seeds[3 * t], a.ep}, sd = {a.seeds[3 * t + 1], a.ep}, sg = {a.seeds[3 * t + 2], a.ep};
         const unsigned tgt = (unsigned)G * (unsigned)(t + 1);
         c.trace = a.trace ? a.trace + ((long long)wg * a.T + t) * 16 : nullptr;
         stamp(c, 0);
 
-        // =================== phase A (critical part): attention-LSTM gates + cell, POS layer 1 ===================
-        // att gates = [h_lang | h_att] . [W_ih_att[:, E:] | W_hh_att]^T: one contraction over two operand pairs
-        if (!run_phase<NBR, NBR, true>(c, TILES_U, rsWcat, (unsigned)(gate_row_l * R) * 4u, rsWhh, (unsigned)(gate_row_l * R) * 4u, rsHL, rsHA, (unsigned)R * 4u,
-                                 kwR, t > 0 ? a.sync + 4 * SHARDS * LINE : nullptr, (unsigned)G * (unsigned)t, 0x100u + 4, 1,
-                                 [&](int rb, int) { return a.GXA[((long long)t * B + min(rb * 16 + row, B - 1)) * 4 * R + gate * R + unit]; },
-                                 [&](float v, float gx, int rb, int slot) {
-                                     const int grow = rb * 16 + row;
-                                     const float pre = v + gx + bA;
-                                     const float act = gate == 2 ? tanhf(pre) : sigm(pre);
-                                     if (grow < B) a.SA[((long long)t * B + grow) * 4 * R + gate * R + unit] = act;
-                                     const float fg = __shfl_down(act, 4, 64), gg = __shfl_down(act, 8, 64), og = __shfl_down(act, 12, 64);
-                                     if (gate == 0) {
-                                         float* cs = jobs_lds + slot * L::per_job + 512 + row * 4 + (col & 3);
-                                         const float cn = fg * cs[0] + act * gg;
-                                         const float hn = og * tanhf(cn);
-                                         cs[0] = cn;
-                                         if (grow < B) {
-                                             a.CA[(long long)(t + 1) * BR + (long long)grow * R + unit] = cn;
-                                             store_sc1(HAn + (long long)grow * R + unit, hn);
-                                         }
-                                     }
-                                 }))
-            return;
-        stamp(c, 2);
-        // POS layer 1: vpos = dropout(relu(h_lang W_pos1^T + b))
-        run_phase<NBR, 0, true>(c, TILES_P1, rsWcat, (unsigned)((4 * R + 16 * tP1 + l15) * R) * 4u, rsWcat, 0u, rsHL, rsHL, (unsigned)R * 4u, kwR, nullptr, 0u, 0u,
-                          -1, nopre, [&](float v, float, int rb, int) {
-                              const int k = 16 * tP1 + col, grow = rb * 16 + row;
-                              v += bP1;
-                              v = (v > 0.f ? v : 0.f) * dropout_scale(sv, (uint64_t)grow * R + k, a.p_lm, a.inv_lm);
-                              if (grow < B) store_sc1(a.VP + ((long long)t * B + grow) * R + k, v);
-                          });
-        stamp(c, 3);
-        seam_arrive(a.sync + 0 * SHARDS * LINE, shard);
-        stamp(c, 4);
-        // ---- shadow of seam 0: the h_lang block of gate-MLP layer 1, kept in LDS for phase C
-        run_phase<NBR, 0, true>(c, TILES_G1, rsWcat, (unsigned)((5 * R + 16 * tG1 + l15) * R) * 4u, rsWcat, 0u, rsHL, rsHL, (unsigned)R * 4u, kwR, nullptr, 0u, 0u,
-                          -1, nopre, [&](float v, float, int, int slot) { jobs_lds[slot * L::per_job + tid] = v; });
-        stamp(c, 5);
-        if (!seam_wait(a.sync + 0 * SHARDS * LINE, tgt, status, c.ok_lds, 0x100u + 0)) return;
-        stamp(c, 6);
-
-        // =================== phase B: row-local module mix and POS chain ===================
+        // =================== phase A: everything that reads h_lang_{t-1} / h_att_{t-1}, ONE pass over the rows ===================
+        // attention-LSTM gates (+ cell), POS layer 1, the h_lang blocks of gate-MLP layer 1 (kept in LDS for phase C) and of the language-
+        // LSTM gates (handed to the owner of phase E through LHP)
         {
-            float* PAt = a.PA + (long long)t * B * (R + A);
-            float* ATt = a.AT + (long long)t * B * A;
-            const __amdgpu_buffer_rsrc_t rsPA = make_rsrc(PAt, (long long)B * (R + A) * 4), rsAT = make_rsrc(ATt, (long long)B * A * 4);
-            const __amdgpu_buffer_rsrc_t rh = make_rsrc(HAn, BR * 4), rv = make_rsrc(a.VP + (long long)t * BR, BR * 4);
+            f32x4 wAh[NBR], wAa[NBR], w3[NBR], w4[NBR], w2[NBR], x[NBR];
+            float gxa_next = 0.f;
+            auto gxa_of = [&](int rb) { return a.GXA[((long long)t * B + min(rb * 16 + row, B - 1)) * 4 * R + gate * R + 4 * tU + ucol]; };
+            if (njA) {
+                const unsigned woA = (unsigned)((gate_row_l + 4 * tU) * R) * 4u + kwR;
+#pragma unroll
+                for (int i = 0; i < NBR; ++i) {
+                    wAh[i] = bload4<0>(rsWcat, woA + 64u * i);
+                    wAa[i] = bload4<0>(rsWhh, woA + 64u * i);
+                    w3[i] = bload4<0>(rsWcat, (unsigned)((5 * R + 16 * tU + l15) * R) * 4u + kwR + 64u * i);
+                    w4[i] = bload4<0>(rsWcat, (unsigned)((5 * R + G1 + gate_row_l + 4 * tU) * R) * 4u + kwR + 64u * i);
+                    w2[i] = hasP1 ? bload4<0>(rsWcat, (unsigned)((4 * R + 16 * tU + l15) * R) * 4u + kwR + 64u * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                gxa_next = gxa_of(rbA0);
+            }
+            if (!seam_wait(t > 0 ? a.sync + 4 * SHARDS * LINE : a.sync + 5 * SHARDS * LINE, t > 0 ? (unsigned)G * (unsigned)t : (unsigned)G, status,
+                           c.ok_lds, 0x100u + 4))
+                return;
+            stamp(c, 1);
+            if (njA) {
+                unsigned ao = fm_chunk(rbA0, wave * NBR, KBR) + lo;
+#pragma unroll
+                for (int i = 0; i < NBR; ++i) x[i] = bload4<AUX_SC1>(rsHLfm, ao + 1024u * i);
+#pragma unroll 1
+                for (int n = 0; n < njA; ++n) {
+                    {
+                        const int rb = rbA0 + n * drbA;
+                        const bool more = n + 1 < njA;
+                        const unsigned ao2 = fm_chunk(rb + drbA, wave * NBR, KBR) + lo;
+                        const float gxa = gxa_next;
+                        if (more) gxa_next = gxa_of(rb + drbA);
+                        f32x4 accA[2] = {}, acc3 = {}, acc4 = {}, acc2 = {};
+                        // h_lang blocks: four products share them; the ring slot is refilled with the h_att block of the same index
+#pragma unroll
+                        for (int i = 0; i < NBR; ++i) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                accA[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i][e], wAh[i][e], accA[0], 0, 0, 0);
+                                acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i][e], w3[i][e], acc3, 0, 0, 0);
+                                acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i][e], w4[i][e], acc4, 0, 0, 0);
+                                if (hasP1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i][e], w2[i][e], acc2, 0, 0, 0);
+                            }
+                            x[i] = bload4<AUX_SC1>(rsHAr, ao + 1024u * i);
+                        }
+                        // h_att blocks: the attention-LSTM's own recurrence; refilled with the next job's h_lang blocks
+#pragma unroll
+                        for (int i = 0; i < NBR; ++i) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) accA[e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i][e], wAa[i][e], accA[e & 1], 0, 0, 0);
+                            if (more) x[i] = bload4<AUX_SC1>(rsHLfm, ao2 + 1024u * i);
+                        }
+                        ao = ao2;
+                        f32x4 part[4] = {accA[0] + accA[1], acc3, acc4, acc2};
+                        float v[4];
+                        tiles_reduce<4>(part, v, c.red + c.par * 5120, wave, lane, tid);
+                        c.par ^= 1;
+                        const int grow = rb * 16 + row;
+                        float* slot = jobsA_lds + n * L::per_jobA;
+                        // (1) attention-LSTM cell: thread (row, col = gate * 4 + unit)
+                        {
+                            const int unit = 4 * tU + ucol;
+                            const float pre = v[0] + gxa + bA;
+                            const float act = gate == 2 ? tanhf(pre) : sigm(pre);
+                            if (grow < B) a.SA[((long long)t * B + grow) * 4 * R + gate * R + unit] = act;
+                            const float fg = __shfl_down(act, 4, 64), gg = __shfl_down(act, 8, 64), og = __shfl_down(act, 12, 64);
+                            float hn = 0.f;
+                            if (gate == 0) {
+                                float* cs = slot + 256 + row * 4 + ucol;
+                                const float cn = fg * cs[0] + act * gg;
+                                hn = og * tanhf(cn);
+                                cs[0] = cn;
+                                if (grow < B) {
+                                    a.CA[(long long)(t + 1) * BR + (long long)grow * R + unit] = cn;
+                                    HAn[(long long)grow * R + unit] = hn;
+                                }
+                            }
+                            const f32x4 h4 = gather4(hn);           // lanes col 0..3 -> lane col 0: the 4 units of this row, 16 bytes of the hand-off chunk
+                            if (col == 0) bstore4_sc1(rsHAw, fm_chunk(rb, tU >> 2, KBR) + (unsigned)(((tU & 3) * 16 + row) * 16), h4);
+                        }
+                        // (2) h_lang block of gate-MLP layer 1: stays with this workgroup
+                        slot[tid] = v[1];
+                        // (3) h_lang block of the language-LSTM gates: to the owner of the gate tile in phase E (chunk of 256, thread-indexed)
+                        store_sc1(a.LHP + (((long long)rb * TILES_U + tU) << 8) + tid, v[2]);
+                        // (4) POS layer 1: vpos = dropout(relu(. + b))
+                        if (hasP1) {
+                            const int k = 16 * tU + col;
+                            float y = v[3] + bP1;
+                            y = (y > 0.f ? y : 0.f) * dropout_scale(sv, (uint64_t)grow * R + k, a.p_lm, a.inv_lm);
+                            if (grow < B) store_sc1(a.VP + ((long long)t * B + grow) * R + k, y);
+                        }
+                    }
+                }
+            }
+        }
+        stamp(c, 2);
+        seam_arrive(a.sync + 0 * SHARDS * LINE, shard);
+        stamp(c, 3);
+        if (!seam_wait(a.sync + 0 * SHARDS * LINE, tgt, status, c.ok_lds, 0x100u + 0)) return;
+        stamp(c, 4);
+
+        // =================== phase B: row-local module weights and POS weights ===================
+        {
+            const __amdgpu_buffer_rsrc_t rv = make_rsrc(a.VP + (long long)t * BR, BR * 4);
             int rs = 0;
             for (int r = wg; r < B; r += G, ++rs) {
                 if (rs) __syncthreads();
-                if (tid < 128) *reinterpret_cast<f32x4*>(lds + L::hrow + 4 * tid) = bload4<AUX_RD>(rh, (unsigned)(r * R + 4 * tid) * 4u);
-                else *reinterpret_cast<f32x4*>(lds + L::vrow + 4 * (tid - 128)) = bload4<AUX_RD>(rv, (unsigned)(r * R + 4 * (tid - 128)) * 4u);
+                if (tid < 128) *reinterpret_cast<f32x4*>(lds + L::hrow + 4 * tid) =
+                    bload4<AUX_SC1>(rsHAw, fm_chunk(r >> 4, tid >> 2, KBR) + (unsigned)(((tid & 3) * 16 + (r & 15)) * 16));
+                else *reinterpret_cast<f32x4*>(lds + L::vrow + 4 * (tid - 128)) = bload4<AUX_SC1>(rv, (unsigned)(r * R + 4 * (tid - 128)) * 4u);
                 __syncthreads();
                 if (tid < 128) {                                 // module-weight logits: 3 dot products over R
                     float z0 = 0.f, z1 = 0.f, z2 = 0.f;
                     for (int k = tid; k < R; k += 128) {
-                        const float x = lds[L::hrow + k];
-                        z0 += x * lds[L::wfc + k]; z1 += x * lds[L::wfc + R + k]; z2 += x * lds[L::wfc + 2 * R + k];
+                        const float xx = lds[L::hrow + k];
+                        z0 += xx * lds[L::wfc + k]; z1 += xx * lds[L::wfc + R + k]; z2 += xx * lds[L::wfc + 2 * R + k];
                     }
                     z0 = wave_sum(z0); z1 = wave_sum(z1); z2 = wave_sum(z2);
                     if (lane == 0) { lds[L::zpart + wave * 4] = z0; lds[L::zpart + wave * 4 + 1] = z1; lds[L::zpart + wave * 4 + 2] = z2; }
@@ -390,16 +498,16 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
                     lds[L::pz + q] = s;
                 }
                 __syncthreads();
-                float w0 = 0.f, w1 = 0.f, w2 = 0.f;
-                if (tid < 128) {
+                if (tid < 3) {
                     const float z0 = lds[L::zpart] + lds[L::zpart + 4] + lds[L::bsm], z1 = lds[L::zpart + 1] + lds[L::zpart + 5] + lds[L::bsm + 1],
                                 z2 = lds[L::zpart + 2] + lds[L::zpart + 6] + lds[L::bsm + 2];
                     const float mx = fmaxf(z0, fmaxf(z1, z2));
                     const float e0 = __expf(z0 - mx), e1 = __expf(z1 - mx), e2 = __expf(z2 - mx);
                     const float inv = 1.f / (e0 + e1 + e2);
-                    w0 = e0 * inv; w1 = e1 * inv; w2 = e2 * inv;
-                    if (tid == 0) { float* m = a.MW + ((long long)t * B + r) * 3; m[0] = w0; m[1] = w1; m[2] = w2; }
-                } else if (tid < 128 + 16) {                     // (P = 16) dropout, softmax over the classes: 16 lanes
+                    const float wv = (tid == 0 ? e0 : (tid == 1 ? e1 : e2)) * inv;
+                    a.MW[((long long)t * B + r) * 3 + tid] = wv;
+                    store_sc1(a.MWPW + (long long)r * 32 + tid, wv);
+                } else if (tid >= 128 && tid < 128 + 16) {       // (P = 16) dropout, softmax over the classes: 16 lanes
                     const int j = tid - 128;
                     float s = 0.f;
 #pragma unroll
@@ -409,138 +517,255 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
                     float m2 = zz;
 #pragma unroll
                     for (int o = 8; o > 0; o >>= 1) m2 = fmaxf(m2, __shfl_xor(m2, o, 16));
-                    const float e = __expf(zz - m2);
-                    float sum = e;
+                    const float ee = __expf(zz - m2);
+                    float sum = ee;
 #pragma unroll
                     for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
-                    const float pw = e / sum;
+                    const float pw = ee / sum;
                     lds[L::sz + j] = pw;
                     a.PW[((long long)t * B + r) * P + j] = pw;
+                    store_sc1(a.MWPW + (long long)r * 32 + 16 + j, pw);
                 }
-                __syncthreads();
-                if (tid < 128) {                                 // attended feature: A / 128 values per thread, 16-byte pieces
-                    const float* f = rows_lds + rs * L::per_row;
-                    for (int k = 4 * tid; k < A; k += 512) {
-                        const f32x4 v = w0 * *reinterpret_cast<const f32x4*>(f + k) + w1 * *reinterpret_cast<const f32x4*>(f + A + k) +
-                                        w2 * *reinterpret_cast<const f32x4*>(f + 2 * A + k);
-                        bstore4_sc1(rsAT, (unsigned)(r * A + k) * 4u, v);
-                        bstore4_sc1(rsPA, (unsigned)(r * (R + A) + R + k) * 4u, v);
-                    }
-                } else {                                         // pos_feat = w_p2 . pw + b_p2   (w_p2 [R][P]: 64 contiguous bytes per output)
-                    const int q = tid - 128;
-                    for (int k = 4 * q; k < R; k += 512) {
-                        f32x4 s = *reinterpret_cast<const f32x4*>(lds + L::bsm + 4 + P + k);
+            }
+        }
+        stamp(c, 5);
+        seam_arrive(a.sync + 1 * SHARDS * LINE, shard);
+        stamp(c, 6);
+        // ---- shadow of seam 1: pos_feat = w_p2 . pw + b_p2 of the rows just done -- only the saved-tensor contract reads it (PA[:, :R])
+        {
+            int rs = 0;
+            for (int r = wg; r < B; r += G, ++rs) {
+                if (rs == 0 && r + G >= B) {                     // the POS weights of the (single) row are still in LDS
+                    if (tid >= 128) {
+                        const int q = tid - 128;
+                        for (int k = 4 * q; k < R; k += 512) {
+                            f32x4 s = *reinterpret_cast<const f32x4*>(lds + L::bsm + 4 + P + k);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const f32x4* wr = reinterpret_cast<const f32x4*>(a.w_p2 + (long long)(k + e) * P);
+                            for (int e = 0; e < 4; ++e) {
+                                const f32x4* wr = reinterpret_cast<const f32x4*>(a.w_p2 + (long long)(k + e) * P);
 #pragma unroll
-                            for (int j4 = 0; j4 < P / 4; ++j4) {
-                                const f32x4 wv = wr[j4], pv = *reinterpret_cast<const f32x4*>(lds + L::sz + 4 * j4);
-                                s[e] += (wv[0] * pv[0] + wv[1] * pv[1]) + (wv[2] * pv[2] + wv[3] * pv[3]);
+                                for (int j4 = 0; j4 < P / 4; ++j4) {
+                                    const f32x4 wv = wr[j4], pv = *reinterpret_cast<const f32x4*>(lds + L::sz + 4 * j4);
+                                    s[e] += (wv[0] * pv[0] + wv[1] * pv[1]) + (wv[2] * pv[2] + wv[3] * pv[3]);
+                                }
                             }
+                            *reinterpret_cast<f32x4*>(a.PA + ((long long)t * B + r) * (R + A) + k) = s;
                         }
-                        bstore4_sc1(rsPA, (unsigned)(r * (R + A) + k) * 4u, s);
+                    }
+                } else {                                         // several rows per workgroup: from the stored POS weights
+                    for (int k = tid; k < R; k += 256) {
+                        float s = lds[L::bsm + 4 + P + k];
+                        const float* pwr = a.PW + ((long long)t * B + r) * P;
+#pragma unroll
+                        for (int j = 0; j < P; ++j) s += a.w_p2[(long long)k * P + j] * pwr[j];
+                        a.PA[((long long)t * B + r) * (R + A) + k] = s;
                     }
                 }
             }
         }
+        // =================== phase C: gate-MLP layer 1 = mw . F + pw . Wp + (h_lang block) + constants; no contraction ===================
+        if (!seam_wait(a.sync + 1 * SHARDS * LINE, tgt, status, c.ok_lds, 0x100u + 1)) return;
         stamp(c, 7);
-        seam_arrive(a.sync + 1 * SHARDS * LINE, shard);
+        if (njA) {
+            // [mw | pw] of the 16 rows of every owned row block -> LDS (128 x 16 bytes per block), one barrier
+            for (int n = 0; n < njA; ++n)
+                if (tid < 128)
+                    *reinterpret_cast<f32x4*>(lds + L::stage + n * 512 + 4 * tid) =
+                        bload4<AUX_SC1>(rsMWPW, (unsigned)(((rbA0 + n * drbA) * 16 + (tid >> 3)) * 32 + 4 * (tid & 7)) * 4u);
+            __syncthreads();
+            for (int n = 0; n < njA; ++n) {
+                const int rb = rbA0 + n * drbA, grow = rb * 16 + row, nn = 16 * tU + col;
+                const float* slot = jobsA_lds + n * L::per_jobA;
+                const float* mp = lds + L::stage + n * 512 + row * 32;
+                float y = slot[tid] + bC;
+                y += mp[0] * slot[320 + tid] + mp[1] * slot[576 + tid] + mp[2] * slot[832 + tid];
+#pragma unroll
+                for (int j = 0; j < P; ++j) y += mp[16 + j] * wp[j];
+                y = (y > 0.f ? y : 0.f) * dropout_scale(sg, (uint64_t)grow * G1 + nn, a.p_lm, a.inv_lm);
+                if (grow < B) a.G1D[((long long)t * B + grow) * G1 + nn] = y;
+                const f32x4 y4 = gather4(y);
+                if ((col & 3) == 0) bstore4_sc1(rsG1fm, fm_chunk(rb, tU, KBG) + (unsigned)(((col >> 2) * 16 + row) * 16), y4);
+            }
+        }
         stamp(c, 8);
-        // ---- shadow of seam 1: the h_lang block of the language-LSTM gates, kept in LDS for phase E
-        run_phase<NBR, 0, true>(c, TILES_U, rsWcat, (unsigned)((5 * R + G1 + gate_row_l) * R) * 4u, rsWcat, 0u, rsHL, rsHL, (unsigned)R * 4u, kwR, nullptr, 0u, 0u, -1,
-                          nopre, [&](float v, float, int, int slot) { jobs_lds[slot * L::per_job + 256 + tid] = v; });
-        stamp(c, 9);
-        // =================== phase C: gate-MLP layer 1 ===================
-        {
-            const __amdgpu_buffer_rsrc_t rsPA = make_rsrc(a.PA + (long long)t * B * (R + A), (long long)B * (R + A) * 4);
-            if (!run_phase<NBPA, 0, true>(c, TILES_G1, rsWg1, (unsigned)((16 * tG1 + l15) * G1 + R) * 4u, rsWg1, 0u, rsPA, rsPA, (unsigned)(R + A) * 4u, kwPA,
-                                    a.sync + 1 * SHARDS * LINE, tgt, 0x100u + 1, 10, nopre, [&](float v, float, int rb, int slot) {
-                                        const int n = 16 * tG1 + col, grow = rb * 16 + row;
-                                        v += jobs_lds[slot * L::per_job + tid] + bG1;
-                                        v = (v > 0.f ? v : 0.f) * dropout_scale(sg, (uint64_t)grow * G1 + n, a.p_lm, a.inv_lm);
-                                        if (grow < B) store_sc1(a.G1D + ((long long)t * B + grow) * G1 + n, v);
-                                    }))
-                return;
-        }
-        stamp(c, 11);
         seam_arrive(a.sync + 2 * SHARDS * LINE, shard);
-        // =================== phase D: gate-MLP layer 2, gate, gated feature ===================
-        {
-            const __amdgpu_buffer_rsrc_t rsG = make_rsrc(a.G1D + (long long)t * B * G1, (long long)B * G1 * 4);
-            if (!run_phase<NBG, 0, true>(c, TILES_G2, rsWg2, (unsigned)((16 * tG2 + l15) * G1) * 4u, rsWg2, 0u, rsG, rsG, (unsigned)G1 * 4u, kwG,
-                                   a.sync + 2 * SHARDS * LINE, tgt, 0x100u + 2, 12,
-                                   [&](int rb, int) { return load_sc1(a.AT + ((long long)t * B + min(rb * 16 + row, B - 1)) * A + 16 * tG2 + col); },
-                                   [&](float v, float att, int rb, int) {
-                                       const int n = 16 * tG2 + col, grow = rb * 16 + row;
-                                       if (grow < B) {
-                                           const long long o = ((long long)t * B + grow) * A + n;
-                                           const float gte = sigm(v + bG2);
-                                           a.GT[o] = gte;
-                                           store_sc1(a.GA + o, gte * att);
-                                       }
-                                   }))
-                return;
-        }
-        stamp(c, 13);
+        stamp(c, 9);
+        // =================== phase D: gate-MLP layer 2, gate, attended and gated feature ===================
+        if (!run_mt<NBG, MTD, Pre3>(
+                c, TG_D, rsWg2, [&](int m) { return (unsigned)((16 * (tD * MTD + m) + l15) * G1) * 4u + kwG; }, rsG1fm, KBG, a.sync + 2 * SHARDS * LINE, tgt,
+                0x100u + 2, 10,
+                [&](int rb, int) {                               // module weights of this thread's row (handed off at seam 1)
+                    const float* mp = a.MWPW + (long long)(rb * 16 + row) * 32;
+                    return Pre3{load_sc1(mp), load_sc1(mp + 1), load_sc1(mp + 2)};
+                },
+                [&](const float (&v)[MTD], const Pre3& mw, int rb, int n) {
+                    const int grow = rb * 16 + row;
+#pragma unroll
+                    for (int m = 0; m < MTD; ++m) {
+                        const int tau = tD * MTD + m, nn = 16 * tau + col;
+                        const float* f = tilesD_lds + (n * MTD + m) * L::per_tileD;
+                        const float att = mw.a * f[tid] + mw.b * f[256 + tid] + mw.c * f[512 + tid];
+                        const float gte = sigm(v[m] + bD[m]);
+                        const float ga = gte * att;
+                        if (grow < B) {
+                            const long long o = ((long long)t * B + grow) * A + nn;
+                            a.GT[o] = gte;
+                            a.GA[o] = ga;
+                            a.AT[o] = att;
+                            a.PA[((long long)t * B + grow) * (R + A) + R + nn] = att;
+                        }
+                        const f32x4 g4 = gather4(ga);
+                        if ((col & 3) == 0) bstore4_sc1(rsGAfm, fm_chunk(rb, tau, KBA) + (unsigned)(((col >> 2) * 16 + row) * 16), g4);
+                    }
+                }))
+            return;
+        stamp(c, 11);
         seam_arrive(a.sync + 3 * SHARDS * LINE, shard);
+        stamp(c, 12);
         // =================== phase E: language-LSTM gates + cell ===================
-        {
-            const __amdgpu_buffer_rsrc_t rsGA = make_rsrc(a.GA + (long long)t * B * A, (long long)B * A * 4);
-            if (!run_phase<NBA, 0, true>(c, TILES_U, rsWil, (unsigned)(gate_row_l * ldw_l + a.We) * 4u, rsWil, 0u, rsGA, rsGA, (unsigned)A * 4u, kwA,
-                                   a.sync + 3 * SHARDS * LINE, tgt, 0x100u + 3, 14,
-                                   [&](int rb, int) { return a.GXL[((long long)t * B + min(rb * 16 + row, B - 1)) * 4 * R + gate * R + unit]; },
-                                   [&](float v, float gx, int rb, int slot) {
-                                       const int grow = rb * 16 + row;
-                                       const float pre = gx + (jobs_lds[slot * L::per_job + 256 + tid] + v) + bE;
-                                       const float act = gate == 2 ? tanhf(pre) : sigm(pre);
-                                       if (grow < B) a.SL[((long long)t * B + grow) * 4 * R + gate * R + unit] = act;
-                                       const float fg = __shfl_down(act, 4, 64), gg = __shfl_down(act, 8, 64), og = __shfl_down(act, 12, 64);
-                                       if (gate == 0) {
-                                           float* cs = jobs_lds + slot * L::per_job + 576 + row * 4 + (col & 3);
-                                           const float cn = fg * cs[0] + act * gg;
-                                           const float hn = og * tanhf(cn);
-                                           cs[0] = cn;
-                                           if (grow < B) {
-                                               a.CL[(long long)(t + 1) * BR + (long long)grow * R + unit] = cn;
-                                               store_sc1(HLn + (long long)grow * R + unit, hn);
-                                           }
-                                       }
-                                   }))
-                return;
-        }
-        stamp(c, 15);
+        if (!run_mt<NBA, MTE, PreE>(
+                c, TG_E, rsWil, [&](int m) { return (unsigned)((gate_row_l + 4 * (tE * MTE + m)) * ldw_l + a.We) * 4u + kwA; }, rsGAfm, KBA,
+                a.sync + 3 * SHARDS * LINE, tgt, 0x100u + 3, 13,
+                [&](int rb, int) {                               // word-side gates and the h_lang block of phase A (handed off at seam 0)
+                    PreE p;
+                    const int gr = min(rb * 16 + row, B - 1);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        p.gx[m] = m < MTE ? a.GXL[((long long)t * B + gr) * 4 * R + gate * R + 4 * (tE * MTE + m) + ucol] : 0.f;
+                        p.lh[m] = m < MTE ? load_sc1(a.LHP + (((long long)rb * TILES_U + tE * MTE + m) << 8) + tid) : 0.f;
+                    }
+                    return p;
+                },
+                [&](const float (&v)[MTE], const PreE& p, int rb, int n) {
+                    const int grow = rb * 16 + row;
+#pragma unroll
+                    for (int m = 0; m < MTE; ++m) {
+                        const int tau = tE * MTE + m, unit = 4 * tau + ucol;
+                        const float pre = p.gx[m] + (p.lh[m] + v[m]) + bE[m];
+                        const float act = gate == 2 ? tanhf(pre) : sigm(pre);
+                        if (grow < B) a.SL[((long long)t * B + grow) * 4 * R + gate * R + unit] = act;
+                        const float fg = __shfl_down(act, 4, 64), gg = __shfl_down(act, 8, 64), og = __shfl_down(act, 12, 64);
+                        float hn = 0.f;
+                        if (gate == 0) {
+                            float* cs = tilesE_lds + (n * MTE + m) * L::per_tileE + row * 4 + ucol;
+                            const float cn = fg * cs[0] + act * gg;
+                            hn = og * tanhf(cn);
+                            cs[0] = cn;
+                            if (grow < B) {
+                                a.CL[(long long)(t + 1) * BR + (long long)grow * R + unit] = cn;
+                                HLn[(long long)grow * R + unit] = hn;
+                            }
+                        }
+                        const f32x4 h4 = gather4(hn);
+                        if (col == 0) bstore4_sc1(rsHLfm, fm_chunk(rb, tau >> 2, KBR) + (unsigned)(((tau & 3) * 16 + row) * 16), h4);
+                    }
+                }))
+            return;
+        stamp(c, 14);
         seam_arrive(a.sync + 4 * SHARDS * LINE, shard);
+        stamp(c, 15);
     }
 }
 
-constexpr int PR = 512, PA_ = 1024, PP = 16;
+constexpr int PR = 512, PA_ = 1024, PP = 16, PG1 = 2 * PR + PA_;
 
 bool persistent_shape_ok(const ekaid_speaker_seq_t* d) {
-    return d->R == PR && d->A == PA_ && d->P == PP && d->G1 == 2 * PR + PA_ && d->T >= 1 && d->T <= PMAX_T && d->B >= 1 && (d->We % 4) == 0;
+    return d->R == PR && d->A == PA_ && d->P == PP && d->G1 == PG1 && d->T >= 1 && d->T <= PMAX_T && d->B >= 1 && (d->We % 4) == 0;
 }
 
-struct PersistPlan { int G, nrb, jobs_max, rows_max; size_t lds_bytes; };
+struct PersistPlan {
+    int G, nrb, mtD, mtE, jobsA, jobsD, jobsE;
+    size_t lds_bytes;
+    // workspace offsets (bytes)
+    size_t o_hl, o_ha, o_g1, o_ga, o_mwpw, o_lhp, o_fm, o_wp, o_cp, o_gemm, o_trace, total;
+    ekaid_gemm_t gF[3], gWp, gCp;
+    size_t gemm_bytes;
+};
 
-bool persistent_plan(const ekaid_speaker_seq_t* d, PersistPlan& pl) {
+ekaid_gemm_t dense(const float* A, int lda, const float* Bm, int ldb, int transB, float* C, int ldc, int M, int N, int K) {
+    ekaid_gemm_t g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.B = Bm; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.transA = 0; g.transB = transB; g.batch1 = g.batch2 = 1; g.alpha = 1.f; g.rdiv = 1;
+    return g;
+}
+
+bool trace_enabled() {
+    static const bool on = [] { const char* e = getenv("EKAID_PERSIST_TRACE"); return e && e[0] == '1'; }();
+    return on;
+}
+size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+bool persistent_plan(const ekaid_speaker_seq_t* d, void* workspace, PersistPlan& pl) {
     if (!persistent_shape_ok(d)) return false;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
-    // TWO workgroups per CU (each at most half the registers and LDS: both are resident, the second one's matrix work covers the
-    // first one's load waits), and a multiple of the 128 gate tiles so that a workgroup keeps ONE column tile for all its row blocks
-    static const int wg_per_cu = [] { const char* e = getenv("EKAID_PERSIST_WG_PER_CU"); return e && e[0] == '2' ? 2 : 1; }();
-    int G = cus >= 256 ? 256 * wg_per_cu : (cus >= 128 ? 128 * wg_per_cu : 0);
+    // one workgroup per CU, and a multiple of the 128 gate tiles so that a workgroup keeps ONE column tile for all its row blocks
+    const int G = cus >= 256 ? 256 : (cus >= 128 ? 128 : 0);
     if (!G) return false;
     pl.G = G;
     pl.nrb = (d->B + 15) / 16;
-    pl.jobs_max = ((PR / 4) * pl.nrb + G - 1) / G;              // also bounds the 128 layer-1 tiles' slots (G1 / 16 == R / 4)
-    pl.rows_max = (d->B + G - 1) / G;
+    // column tiles per job of the long contractions: activations are read once per job, so wide jobs at large batch (the fabric
+    // volume bounds the step), narrow ones while there are fewer jobs than workgroups
+    static const int force_mt = [] { const char* e = getenv("EKAID_PERSIST_MT"); return e ? atoi(e) : 0; }();
+    // (bounded by the registers the resident weight fragments take: MT x NB blocks of 4 registers; 32 blocks = 128 registers)
+    pl.mtD = 1;
+    pl.mtE = pl.nrb >= 8 ? 2 : 1;
+    if (force_mt == 1) pl.mtD = pl.mtE = 1;
+    auto jobs = [&](int tg) { return (tg * pl.nrb + G - 1) / G; };
+    pl.jobsA = jobs(PR / 4);
+    pl.jobsD = jobs((PA_ / 16) / pl.mtD);
+    pl.jobsE = jobs((PR / 4) / pl.mtE);
+    if (pl.jobsA > MAXJ || pl.jobsD > MAXJ || pl.jobsE > MAXJ || (d->B + G - 1) / G > 4) return false;
     using L = Lds<PR, PA_, PP>;
-    pl.lds_bytes = (size_t)(L::fixed + pl.jobs_max * L::per_job + pl.rows_max * L::per_row) * sizeof(float);
-    return pl.lds_bytes <= 80 * 1024;
+    pl.lds_bytes = (size_t)(L::fixed + pl.jobsA * L::per_jobA + pl.jobsD * pl.mtD * L::per_tileD + pl.jobsE * pl.mtE * L::per_tileE) * sizeof(float);
+    if (pl.lds_bytes > 160 * 1024) return false;
+    const size_t Bp = 16 * (size_t)pl.nrb, f = sizeof(float);
+    size_t o = al256((size_t)SYNC_WORDS * 4);
+    pl.o_hl = o; o += al256(Bp * PR * f);
+    pl.o_ha = o; o += al256(2 * Bp * PR * f);
+    pl.o_g1 = o; o += al256(Bp * PG1 * f);
+    pl.o_ga = o; o += al256(Bp * PA_ * f);
+    pl.o_mwpw = o; o += al256(Bp * 32 * f);
+    pl.o_lhp = o; o += al256(Bp * 4 * PR * f);
+    pl.o_fm = o; o += al256(3 * (size_t)d->B * PG1 * f);
+    pl.o_wp = o; o += al256((size_t)PG1 * PP * f);
+    pl.o_cp = o; o += al256((size_t)PG1 * f);
+    char* ws = (char*)workspace;
+    float* Fm = ws ? (float*)(ws + pl.o_fm) : nullptr;
+    const float* feats[3] = {d->bef, d->diff, d->aft};
+    static const float dummy = 0.f;
+    pl.gemm_bytes = 0;
+    for (int m = 0; m < 3; ++m) {       // F_m = feat_m . W_g1[:, 2R:]^T
+        pl.gF[m] = dense(feats[m] ? feats[m] : &dummy, PA_, d->w_g1 ? d->w_g1 + 2 * PR : &dummy, PG1, 1, Fm ? Fm + (size_t)m * d->B * PG1 : nullptr, PG1, d->B, PG1, PA_);
+        pl.gemm_bytes = std::max(pl.gemm_bytes, ekaid_gemm_workspace_bytes(&pl.gF[m]));
+    }
+    // Wp = W_g1[:, R:2R] . w_p2 (G1 x P), cp = W_g1[:, R:2R] . b_p2 (G1)
+    pl.gWp = dense(d->w_g1 ? d->w_g1 + PR : &dummy, PG1, d->w_p2 ? d->w_p2 : &dummy, PP, 0, ws ? (float*)(ws + pl.o_wp) : nullptr, PP, PG1, PP, PR);
+    pl.gCp = dense(d->w_g1 ? d->w_g1 + PR : &dummy, PG1, d->b_p2 ? d->b_p2 : &dummy, 1, 0, ws ? (float*)(ws + pl.o_cp) : nullptr, 1, PG1, 1, PR);
+    pl.gemm_bytes = std::max(pl.gemm_bytes, std::max(ekaid_gemm_workspace_bytes(&pl.gWp), ekaid_gemm_workspace_bytes(&pl.gCp)));
+    pl.o_gemm = o; o += al256(pl.gemm_bytes);
+    pl.o_trace = o;
+    if (trace_enabled()) o += al256((size_t)G * d->T * 16 * sizeof(unsigned long long));
+    pl.total = o;
+    return true;
+}
+
+template <int MTD, int MTE>
+int launch_fwd(const PFwd& a, const PersistPlan& pl, hipStream_t st, int slot) {
+    auto kern = spk_seq_fwd_persistent_kernel<PR, PA_, PP, MTD, MTE>;
+    if (func_attr_once(slot)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("ekaid_speaker_seq_fwd_persistent: cannot raise the dynamic LDS limit");
+            return EKAID_ERR_LAUNCH;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(pl.G), dim3(256), pl.lds_bytes, st, a);
+    return check_launch("speaker_seq_fwd_persistent");
 }
 
 }  // namespace
@@ -548,36 +773,29 @@ bool persistent_plan(const ekaid_speaker_seq_t* d, PersistPlan& pl) {
 
 using namespace ekaid;
 
-// EKAID_PERSIST_TRACE=1: every workgroup stamps 16 points of every step (s_memrealtime) behind the seam counters (tools/seq_bench.py)
-static bool trace_enabled() {
-    static const bool on = [] { const char* e = getenv("EKAID_PERSIST_TRACE"); return e && e[0] == '1'; }();
-    return on;
-}
-static size_t sync_bytes() { return ((size_t)SYNC_WORDS * 4 + 255) & ~(size_t)255; }
-
 extern "C" size_t ekaid_speaker_seq_persistent_workspace_bytes(const ekaid_speaker_seq_t* d) {
     PersistPlan pl;
-    if (!d || !persistent_plan(d, pl)) return 0;
-    return sync_bytes() + (trace_enabled() ? (size_t)pl.G * d->T * 16 * sizeof(unsigned long long) : 0);
+    if (!d || !persistent_plan(d, nullptr, pl)) return 0;
+    return pl.total;
 }
 
 extern "C" int ekaid_speaker_seq_fwd_persistent(const ekaid_speaker_seq_t* d, void* workspace, size_t workspace_bytes, void* stream) {
     if (!d) { set_error("ekaid_speaker_seq_fwd_persistent: null descriptor"); return EKAID_ERR_ARG; }
     PersistPlan pl;
-    if (!persistent_plan(d, pl)) {
+    if (!persistent_plan(d, workspace, pl)) {
         set_error("ekaid_speaker_seq_fwd_persistent: unsupported shape (R=%d A=%d P=%d G1=%d T=%d B=%d) or device", d->R, d->A, d->P, d->G1, d->T, d->B);
         return EKAID_ERR_UNSUPPORTED;
     }
-    const size_t need = ekaid_speaker_seq_persistent_workspace_bytes(d);
-    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 255)) {
-        set_error("ekaid_speaker_seq_fwd_persistent: workspace too small or misaligned (%zu < %zu)", workspace_bytes, need);
+    if (!workspace || workspace_bytes < pl.total || (reinterpret_cast<uintptr_t>(workspace) & 255)) {
+        set_error("ekaid_speaker_seq_fwd_persistent: workspace too small or misaligned (%zu < %zu)", workspace_bytes, pl.total);
         return EKAID_ERR_ARG;
     }
     if (!d->seeds && (d->p_lm > 0.f || d->p_pos > 0.f)) { set_error("ekaid_speaker_seq_fwd_persistent: dropout without seeds"); return EKAID_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
     PFwd a;
     memset(&a, 0, sizeof(a));
-    a.T = d->T; a.B = d->B; a.G = pl.G; a.nrb = pl.nrb;
+    a.T = d->T; a.B = d->B; a.G = pl.G; a.nrb = pl.nrb; a.mtD = pl.mtD; a.mtE = pl.mtE;
     a.p_lm = d->p_lm; a.p_pos = d->p_pos;
     a.inv_lm = d->p_lm > 0.f ? 1.f / (1.f - d->p_lm) : 1.f;
     a.inv_pos = d->p_pos > 0.f ? 1.f / (1.f - d->p_pos) : 1.f;
@@ -588,26 +806,28 @@ extern "C" int ekaid_speaker_seq_fwd_persistent(const ekaid_speaker_seq_t* d, vo
     a.HA = d->HA; a.CA = d->CA; a.HL = d->HL; a.CL = d->CL; a.SA = d->SA; a.SL = d->SL; a.G1D = d->G1D; a.MW = d->MW; a.VP = d->VP;
     a.DP = d->DP; a.PW = d->PW; a.PA = d->PA; a.AT = d->AT; a.GT = d->GT; a.GA = d->GA;
     a.sync = (unsigned*)workspace;
-    a.trace = trace_enabled() ? reinterpret_cast<unsigned long long*>((char*)workspace + sync_bytes()) : nullptr;
-    a.We = d->We; a.jobs_max = pl.jobs_max; a.rows_max = pl.rows_max;
+    a.trace = trace_enabled() ? reinterpret_cast<unsigned long long*>(ws + pl.o_trace) : nullptr;
+    a.HLfm = (float*)(ws + pl.o_hl); a.HAfm = (float*)(ws + pl.o_ha); a.G1fm = (float*)(ws + pl.o_g1); a.GAfm = (float*)(ws + pl.o_ga);
+    a.MWPW = (float*)(ws + pl.o_mwpw); a.LHP = (float*)(ws + pl.o_lhp);
+    a.Fm = (const float*)(ws + pl.o_fm); a.Wp = (const float*)(ws + pl.o_wp); a.cp = (const float*)(ws + pl.o_cp);
+    a.We = d->We; a.jobsA = pl.jobsA; a.jobsD = pl.jobsD;
     if (d->seeds) memcpy(a.seeds, d->seeds, sizeof(uint64_t) * 3 * d->T);
     const void* ptrs[] = {a.Wcat, a.whh_a, a.bhh_a, a.w_fc, a.b_fc, a.b_p1, a.w_wp, a.b_wp, a.w_p2, a.b_p2, a.w_g1, a.b_g1, a.w_g2, a.b_g2, a.wih_l,
                           a.bhh_l, a.bef, a.diff, a.aft, a.GXA, a.GXL, a.HA, a.CA, a.HL, a.CL, a.SA, a.SL, a.G1D, a.MW, a.VP, a.DP, a.PW, a.PA,
                           a.AT, a.GT, a.GA};
     for (const void* p : ptrs)
         if (!p || (reinterpret_cast<uintptr_t>(p) & 15)) { set_error("ekaid_speaker_seq_fwd_persistent: null or misaligned (16 B) pointer in the descriptor"); return EKAID_ERR_ARG; }
-    auto kern = spk_seq_fwd_persistent_kernel<PR, PA_, PP>;
-    if (func_attr_once(40)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) {
-            (void)hipGetLastError();
-            set_error("ekaid_speaker_seq_fwd_persistent: cannot raise the dynamic LDS limit");
-            return EKAID_ERR_LAUNCH;
-        }
-    }
+    // the linear maps of gate-MLP layer 1 (5 small products in front of the sequence kernel)
+    void* gws = ws + pl.o_gemm;
+    for (int m = 0; m < 3; ++m) { const int rc = ekaid_gemm_f32(&pl.gF[m], gws, pl.gemm_bytes, stream); if (rc) return rc; }
+    { const int rc = ekaid_gemm_f32(&pl.gWp, gws, pl.gemm_bytes, stream); if (rc) return rc; }
+    { const int rc = ekaid_gemm_f32(&pl.gCp, gws, pl.gemm_bytes, stream); if (rc) return rc; }
     // seam counters and the status word start at zero in EVERY launch (a memset node when captured)
-    if (hipMemsetAsync(workspace, 0, sync_bytes(), st) != hipSuccess) { (void)hipGetLastError(); set_error("ekaid_speaker_seq_fwd_persistent: memset failed"); return EKAID_ERR_LAUNCH; }
-    hipLaunchKernelGGL(kern, dim3(pl.G), dim3(256), pl.lds_bytes, st, a);
-    return check_launch("speaker_seq_fwd_persistent");
+    if (hipMemsetAsync(workspace, 0, al256((size_t)SYNC_WORDS * 4), st) != hipSuccess) { (void)hipGetLastError(); set_error("ekaid_speaker_seq_fwd_persistent: memset failed"); return EKAID_ERR_LAUNCH; }
+    if (pl.mtD == 1 && pl.mtE == 1) return launch_fwd<1, 1>(a, pl, st, 40);
+    if (pl.mtD == 1 && pl.mtE == 2) return launch_fwd<1, 2>(a, pl, st, 41);
+    set_error("ekaid_speaker_seq_fwd_persistent: no kernel for tile groups %d / %d", pl.mtD, pl.mtE);
+    return EKAID_ERR_UNSUPPORTED;
 }
 
 /* status word of the last persistent launch on this workspace (device pointer to one unsigned; 0 = fine, 0x100 + seam = a seam

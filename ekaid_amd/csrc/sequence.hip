@@ -186,7 +186,7 @@ extern "C" int ekaid_speaker_seq_fwd(const ekaid_speaker_seq_t* d, void* workspa
     if (!spk_args_ok(d, "ekaid_speaker_seq_fwd")) return EKAID_ERR_ARG;
     if (seq_mode() == 1) {                  // one persistent launch for the whole sequence where the shape allows it (csrc/persist.hip)
         const size_t pers = ekaid_speaker_seq_persistent_workspace_bytes(d);
-        if (pers && workspace && workspace_bytes >= pers) return ekaid_speaker_seq_fwd_persistent(d, workspace, workspace_bytes, stream);
+        if (pers && d->T >= 4 && workspace && workspace_bytes >= pers) return ekaid_speaker_seq_fwd_persistent(d, workspace, workspace_bytes, stream);
     }
     SpkPlan pl;
     if (!spk_plan(d, workspace, false, pl)) return EKAID_ERR_ARG;

@@ -1,0 +1,148 @@
+"""The persistent decoder kernel (csrc/persist.hip: the whole teacher-forced time loop in ONE launch) against the step-wise chain
+(csrc/sequence.hip: 8 launches per decode step) -- the same C-ABI entry, ekaid_speaker_seq_fwd, under ekaid_set_seq_mode(1 / 0).
+
+The two modes compute the same f32 function in different summation orders (full-K 16x16 MFMA jobs vs split-K slabs on the bf16-split
+pipe; gate-MLP layer 1 through its linear maps instead of a K = 1536 product), so they agree to f32 rounding, not bit for bit:
+every saved tensor of the contract is compared at 1e-5 of its scale (measured: <= 1.3e-6).  Dropout masks are a pure function of
+(seed, element index) and must coincide exactly.   ref: dynamic_speaker_change_pos.py:94-131, 196-222."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _sb():
+    import seq_bench
+    from ekaid_amd import hip
+    hip.load()
+    return seq_bench
+
+
+@pytest.mark.parametrize('B,T', [(5, 4), (16, 5), (37, 4), (64, 6), (130, 4), (256, 4)])
+@pytest.mark.parametrize('train', [False, True])
+def test_persistent_forward_equals_the_stepwise_chain(B, T, train):
+    """Every tensor of the saved-tensor contract (states, gate activations, module / POS weights, gate-MLP activations, attended and
+    gated features), ragged batch sizes included (rows past the batch inside the last 16-row block are never stored)."""
+    sb = _sb()
+    pr = sb.problem(B, T, seed=B * 31 + T, train=train)
+    ref, _, _ = sb.run(pr, 0)
+    got, _, status = sb.run(pr, 1)
+    assert status == 0, 'a seam of the persistent launch did not open (status 0x%x)' % status
+    err = sb.compare(ref, got)
+    assert max(err.values()) <= TOL, err
+    if train:       # the same elements were dropped: the masks depend on (seed, index) only
+        for k in ('G1D', 'VP', 'DP'):
+            assert torch.equal(ref[k] == 0, got[k] == 0), 'dropout mask of %s differs between the modes' % k
+
+
+def test_persistent_forward_is_deterministic_and_replayable():
+    """Two launches on the same workspace give the same bits (every output element has one owner and a fixed summation order; the seam
+    counters are re-zeroed by the memset in front of every launch), also when replayed from a captured hipGraph."""
+    import ctypes
+    sb = _sb()
+    from ekaid_amd import hip
+    L = hip.lib()
+    pr = sb.problem(48, 6, seed=3, train=True)
+    a, _, s1 = sb.run(pr, 1)
+    b, _, s2 = sb.run(pr, 1)
+    assert s1 == 0 and s2 == 0
+    for k in sb.OUT_KEYS:
+        assert torch.equal(a[k], b[k]), k
+    # hipGraph: memset node + the five small products + the persistent kernel, replayed three times
+    old = L.ekaid_get_seq_mode()
+    hip.check(L.ekaid_set_seq_mode(1), 'set_seq_mode')
+    try:
+        out = sb.buffers(pr)
+        sq = sb.descriptor(pr, out)
+        need = L.ekaid_speaker_seq_workspace_bytes(ctypes.byref(sq), 0)
+        ws = torch.empty(need, dtype=torch.uint8, device='cuda')
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            hip.check(L.ekaid_speaker_seq_fwd(ctypes.byref(sq), ws.data_ptr(), need, hip.stream()), 'warm-up')
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            hip.check(L.ekaid_speaker_seq_fwd(ctypes.byref(sq), ws.data_ptr(), need, hip.stream()), 'capture')
+        for _ in range(3):
+            for k in ('SA', 'SL', 'G1D', 'GA'):
+                out[k].fill_(float('nan'))
+            g.replay()
+            torch.cuda.synchronize()
+            for k in sb.OUT_KEYS:
+                assert torch.equal(a[k], out[k]), 'replay differs in %s' % k
+    finally:
+        L.ekaid_set_seq_mode(old)
+
+
+def test_unsupported_shapes_keep_the_stepwise_chain():
+    """Mode 1 is "persistent where supported": other widths (the small test configurations) and single steps take the step-wise chain,
+    and the explicit persistent entry refuses them loudly."""
+    import ctypes
+    sb = _sb()
+    from ekaid_amd import hip
+    L = hip.lib()
+    pr = sb.problem(8, 4)
+    out = sb.buffers(pr)
+    sq = sb.descriptor(pr, out)
+    assert L.ekaid_speaker_seq_persistent_workspace_bytes(ctypes.byref(sq)) > 0
+    sq.R = 256
+    assert L.ekaid_speaker_seq_persistent_workspace_bytes(ctypes.byref(sq)) == 0
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device='cuda')
+    assert L.ekaid_speaker_seq_fwd_persistent(ctypes.byref(sq), ws.data_ptr(), ws.numel(), hip.stream()) == hip.ERR_UNSUPPORTED
+    assert 'unsupported shape' in hip.last_error()
+
+
+@pytest.mark.parametrize('train', [False, True])
+def test_decoder_through_the_model_agrees_between_the_sequence_modes(train):
+    """DynamicSpeaker._forward + loss + backward at the production widths under both sequence modes: log-probs, module weights and
+    every parameter gradient (the persistent forward feeds the step-wise backward: same saved tensors)."""
+    from common import build_models
+    from ekaid_amd import hip, ops
+    from ekaid_amd.config import bench_cfg
+    hip.load()
+    L = hip.lib()
+    cfg = bench_cfg(D=256, seq_length=12)
+    cd, sp = build_models(cfg, 147, 148, 'cuda', train=train)
+    g = torch.Generator().manual_seed(11)
+    B, T, A = 24, 7, cfg.model.speaker.input_dim
+    bef, aft, diff = [torch.randn(B, A, generator=g).cuda().requires_grad_(True) for _ in range(3)]
+    seq = torch.zeros(B, 13, dtype=torch.long)
+    seq[:, 0] = 1
+    seq[:, 1:T] = torch.randint(2, 147, (B, T - 1), generator=g)
+    seq = seq.cuda()
+    res = {}
+    old = L.ekaid_get_seq_mode()
+    try:
+        for mode in (0, 1):
+            hip.check(L.ekaid_set_seq_mode(mode), 'set_seq_mode')
+            ops.manual_seed(99)
+            sp.zero_grad()
+            for x in (bef, aft, diff):
+                x.grad = None
+            logp, logpos = sp._forward(bef, aft, diff, seq, num_steps=T)
+            (logp[:, :T].sum() * 1e-2 + logpos[:, :T].sum() * 1e-3).backward()
+            res[mode] = (logp.detach().clone(), torch.stack(sp.module_weights, 1).detach().clone(),
+                         {k: p.grad.detach().clone() for k, p in sp.named_parameters() if p.grad is not None},
+                         [x.grad.detach().clone() for x in (bef, aft, diff)])
+    finally:
+        L.ekaid_set_seq_mode(old)
+
+    def close(x, y, what, tol=2e-5):
+        scale = float(x.abs().max().clamp_min(1e-12))
+        err = float((x - y).abs().max()) / scale
+        assert err <= tol, '%s: %.3e of its scale' % (what, err)
+    close(res[0][0], res[1][0], 'log-probs')
+    close(res[0][1], res[1][1], 'module weights')
+    assert torch.equal(res[0][0].argmax(-1), res[1][0].argmax(-1))
+    assert res[0][2].keys() == res[1][2].keys()
+    for k in res[0][2]:
+        close(res[0][2][k], res[1][2][k], 'grad ' + k, 1e-4)
+    for x, y, n in zip(res[0][3], res[1][3], ('bef', 'aft', 'diff')):
+        close(x, y, 'grad feat_' + n, 1e-4)

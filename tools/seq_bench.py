@@ -97,8 +97,9 @@ def run(pr, mode, iters=0):
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / iters
         if mode == 1 and os.environ.get('EKAID_PERSIST_TRACE') == '1':
-            off = (L.ekaid_speaker_seq_persistent_status_ptr(ws.data_ptr()) - ws.data_ptr() + 128 + 255) // 256 * 256
-            G = (L.ekaid_speaker_seq_persistent_workspace_bytes(ctypes.byref(sq)) - off) // (pr['T'] * 16 * 8)
+            G = 256                                      # one workgroup per CU; the stamps are the last region of the workspace
+            nb = (G * pr['T'] * 128 + 255) // 256 * 256
+            off = L.ekaid_speaker_seq_persistent_workspace_bytes(ctypes.byref(sq)) - nb
             run.trace = ws[off:off + G * pr['T'] * 128].view(torch.int64).view(G, pr['T'], 16).cpu()
         return out, ms, status
     finally:
@@ -133,7 +134,7 @@ def main():
         if tr is not None:
             # per-phase time (us) of the last call: stamps are 100 MHz ticks; spans between consecutive stamps, median over steps,
             # for the slowest / median / fastest workgroup
-            names = ['waitE', 'A1', 'A2', 'arrA', 'A3', 'waitA', 'B', 'arrB', 'A4', 'waitB', 'C', 'waitC', 'D', 'waitD', 'E', 'next']
+            names = ['waitE', 'A', 'arrA', 'waitA', 'B', 'arrB', 'shadow+waitB', 'C', 'arrC', 'waitC', 'D', 'arrD', 'waitD', 'E', 'arrE', 'next']
             idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15]
             d = tr.double()
             spans = torch.zeros(d.shape[0], d.shape[1], 16)
