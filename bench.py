@@ -37,7 +37,26 @@ sys.path.insert(0, ROOT)
 import torch                      # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-FLOP_PER_PAIR_TRAIN = 15.39e9     # algorithmic fwd+bwd work per QA pair (graph=all, N=36, D=2048, T=16)
+
+
+def flop_per_pair(N=36, D=2048, Lq=20, T=16, graph='all', train=True, A=1024, Q=1024, H=4):
+    """Algorithmic work of one QA pair, SURVEY.md section 8(d) (the minimum that reproduces the reference's outputs: last direction only,
+    context1/gate1 once, core.embed hoisted): multiply-adds of img 2NDA, question Lq 3(600 Q + Q^2) + Lq Q^2, per encoder and image
+    N(A+Q)A + 2NA^2 + NHA^2 + (1+H)N^2 A (+ 64 H N^2 for the implicit relation), gating 6NA^2, tail 2N 3A 128, speaker
+    3A 1024 + 14.6 M per decode step.  Training = 3 x forward minus the input gradient of img that nobody needs.
+    (N=36, D=2048, T=16, graph=all: 5.23 GFLOP forward, 15.39 GFLOP training.)"""
+    img = 2.0 * N * D * A
+    question = Lq * 3.0 * (600 * Q + Q * Q) + Lq * Q * Q
+    enc = N * (A + Q) * A + 2.0 * N * A * A + N * H * A * A + (1 + H) * N * N * A
+    encoders = {'semantic': ['s'], 'spatial': ['p'], 'implicit': ['i'], 'i+s': ['i', 's'], 'all': ['s', 'p', 'i']}[graph]
+    graph_mac = 2 * (len(encoders) * enc + (64.0 * H * N * N if 'i' in encoders else 0.0))
+    gating, tail = 6.0 * N * A * A, 2.0 * N * 3 * A * 128
+    speaker = 3.0 * A * 1024 + T * 14.6e6
+    fwd = 2.0 * (img + question + graph_mac + gating + tail + speaker)
+    return 3.0 * fwd - 2.0 * img if train else fwd
+
+
+FLOP_PER_PAIR_TRAIN = flop_per_pair()     # 15.39e9 at the headline shape
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_BF16_MFMA_TFLOPS = 2516.6    # MI355X_MICROARCH.md: dense bf16 MFMA peak (16x the f32-input rate, no sparsity)
 SHAPE = dict(N=36, D=2048, Lq=20, T=16, seq_length=90, V=148)
@@ -161,16 +180,21 @@ def cpu_baseline(cfg, cd, sp, batch_size, graph, budget_s=25.0):
     t_start = time.perf_counter()
     one()                                               # warm-up
     warm = time.perf_counter() - t_start
-    iters, t0 = 0, time.perf_counter()
-    while iters < 1 or (iters < 3 and time.perf_counter() - t0 + warm < budget_s - warm):
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 5 or (len(times) < 8 and time.perf_counter() - t_all + warm < budget_s):
+        t0 = time.perf_counter()
         one()
-        iters += 1
-    dt = (time.perf_counter() - t0) / iters
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    dt = times[len(times) // 2]                          # median iteration
+    iters = len(times)
     return {'value': round(batch_size / dt, 3), 'unit': 'QA-pairs/s', 'cores': cores, 'kind': 'port',
+            'value_best': round(batch_size / times[0], 3), 'value_worst': round(batch_size / times[-1], 3), 'timed_iterations': iters,
             'eval_forward_pairs_per_s': round(batch_size / min(fwd_s), 3), 'parity_vs_hip': parity,
             'parity_vs_hip_bf16x2': parity_x2,
             'sample': 'CPU oracle (PyTorch %s, %d threads = physical cores of this host, %d logical) full train step '
-                      '(forward + backward + torch.optim.Adam) at batch %d: %d timed iterations after 1 warm-up; eval '
+                      '(forward + backward + torch.optim.Adam) at batch %d: %d timed iterations after 1 warm-up, value = the MEDIAN iteration; eval '
                       'forward at batch %d: best of 2; same shapes and weights as the GPU run, dropout off' % (
                           torch.__version__, cores, os.cpu_count() or 0, batch_size, iters, batch_size)}
 
@@ -417,8 +441,9 @@ def main():
         rec = ops.gemm_profile_end()
         ms = sum(r[0] for r in rec)
         fl = sum(r[1] for r in rec)
-        # the dominant kernel: the 128x128-tile instantiations (planner: M >= 512 rows and N >= 128)
-        big = [r for r in rec if r[2][2] >= 512 and r[2][3] >= 128]
+        # the dominant kernel: every launch the planner ran on the 128x128-tile instantiations (ekaid_gemm_plan_query: tile 2) -- the
+        # set rocprofv3 lists as gemm_split_kernel<., ., 2, 2, 32, 1, ., 3, .>
+        big = [r for r in rec if r[2][6] == 2]
         big_ms, big_fl = sum(r[0] for r in big), sum(r[1] for r in big)
         if args.gemm_shapes:
             agg = {}
@@ -427,7 +452,7 @@ def main():
                 a[0] += t_ms
                 a[1] += f
                 a[2] += 1
-            print('%-44s %6s %9s %8s' % ('(tA,tB,M,N,K,batch)', 'calls', 'ms/step', 'TFLOP/s'), file=sys.stderr)
+            print('%-44s %6s %9s %8s' % ('(tA,tB,M,N,K,batch,tile)', 'calls', 'ms/step', 'TFLOP/s'), file=sys.stderr)
             for shape, (t_ms, f, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
                 print('%-44s %6d %9.3f %8.2f' % (shape, n // 2, t_ms / 2, f / (t_ms * 1e-3) / 1e12), file=sys.stderr)
         for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
@@ -439,8 +464,8 @@ def main():
         mult, peak = (6.0, PEAK_BF16_MFMA_TFLOPS) if split else (1.0, PEAK_F32_MFMA_TFLOPS)
         alg_big = big_fl / (big_ms * 1e-3) / 1e12 if big else 0.0
         alg_all = fl / (ms * 1e-3) / 1e12
-        default_shape = args.graph == 'all'
-        path_alg = FLOP_PER_PAIR_TRAIN * per_gpu * args.steps / elapsed / 1e12 if default_shape else None
+        fpp = flop_per_pair(N=SHAPE['N'], D=SHAPE['D'], Lq=SHAPE['Lq'], T=T, graph=args.graph)
+        path_alg = fpp * per_gpu * args.steps / elapsed / 1e12
         roof = {'bound': 'mfma',
                 'kernel': ('ekaid::gemm_split_kernel<.,.,2,2,32,1,.,3> (128x128 tiles; f32 operands split exactly into 3 bf16, '
                            '6 x v_mfma_f32_32x32x16_bf16 per product block, f32 accumulate)') if split else
@@ -454,9 +479,9 @@ def main():
                 'gemm_family': {'launches_per_step': len(rec) // 2, 'ms_per_step': round(ms / 2, 3),
                                 'flop_per_step': fl / 2, 'algorithmic_f32_tflops': round(alg_all, 3),
                                 'frac_of_peak': round(mult * alg_all / peak, 4)},
-                'whole_step': {'algorithmic_f32_tflops_per_gpu': round(path_alg, 3) if path_alg else None,
-                               'frac_of_peak': round(path_alg * mult / peak, 4) if path_alg else None,
-                               'flop_per_pair': FLOP_PER_PAIR_TRAIN if default_shape else None}}
+                'whole_step': {'algorithmic_f32_tflops_per_gpu': round(path_alg, 3), 'frac_of_peak': round(path_alg * mult / peak, 4),
+                               'flop_per_pair': fpp, 'formula': 'bench.flop_per_pair(N=%d, D=%d, Lq=%d, T=%d, graph=%r): SURVEY.md 8(d)' % (
+                                   SHAPE['N'], SHAPE['D'], SHAPE['Lq'], T, args.graph)}}
 
     # ---- extra lines (N = 1): configs[1] forward-only at batch 64, and the T = 90 worst case
     extra = None
@@ -509,12 +534,28 @@ def main():
         b90 = {k: v.to(dev) for k, v in h90.items()}
         T90 = DynamicSpeaker.count_steps(h90['labels'], SHAPE['seq_length'])
         ms90 = timed(lambda: eager(b90, T90), 8, 2)
+        split_now = ops.get_gemm_mode() == ops.GEMM_BF16_SPLIT
+        peak_alg = PEAK_BF16_MFMA_TFLOPS / 6.0 if split_now else PEAK_F32_MFMA_TFLOPS       # algorithmic f32 TFLOP/s the matrix pipe allows
+        f90 = flop_per_pair(N=SHAPE['N'], D=SHAPE['D'], Lq=SHAPE['Lq'], T=T90, graph=args.graph)
+        tf90 = f90 * per_gpu / (ms90 * 1e-3) / 1e12
         extra['train_T90'] = {'ms_per_step': round(ms90, 3), 'pairs_per_s': round(per_gpu / ms90 * 1e3, 1), 'decode_steps': T90,
+                              'roofline': {'bound': 'mfma', 'flop_per_pair': f90, 'algorithmic_f32_tflops': round(tf90, 3),
+                                           'algorithmic_peak_tflops': round(peak_alg, 1), 'frac': round(tf90 / peak_alg, 4)},
                               'workload': 'train step, batch %d, answers of the maximum length (90 decode steps)' % per_gpu}
         del b64, b90
         if not args.no_real:
             step.close()
-            extra['real_b64'] = real_data_loop(args.graph)
+            rd = real_data_loop(args.graph)
+            hist = rd.get('decode_steps_histogram') or {}
+            n_it = sum(hist.values())
+            if n_it and rd.get('ms_per_iteration'):
+                # work of the timed iterations from their decode-step histogram (52 regions, 1024-d features, batch 64)
+                fl = sum(cnt * flop_per_pair(N=52, D=1024, Lq=SHAPE['Lq'], T=int(tk), graph=args.graph) for tk, cnt in hist.items()) / n_it
+                tfr = fl * 64 / (rd['ms_per_iteration'] * 1e-3) / 1e12
+                rd['roofline'] = {'bound': 'mfma', 'flop_per_pair_mean': fl, 'algorithmic_f32_tflops': round(tfr, 3),
+                                  'algorithmic_peak_tflops': round(peak_alg, 1), 'frac': round(tfr / peak_alg, 4),
+                                  'note': 'mean over the histogram of decode steps of the iterations run (not only the timed ones)'}
+            extra['real_b64'] = rd
     if world > 1:
         dist.barrier()
 

@@ -1387,6 +1387,18 @@ extern "C" size_t ekaid_gemm_workspace_bytes(const ekaid_gemm_t* d) {
     return splitk > 1 ? (size_t)splitk * d->M * ((size_t)d->N + (d->a_rowsum ? ASUM_SHARE : 0)) * sizeof(float) : 0;
 }
 
+extern "C" int ekaid_gemm_plan_query(const ekaid_gemm_t* d, int* tile, int* splitk) {
+    if (!d || !tile || !splitk) { set_error("ekaid_gemm_plan_query: null pointer"); return EKAID_ERR_ARG; }
+    *tile = 0; *splitk = 1;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0) return EKAID_OK;
+    int G, NO;
+    if (skinny_tn(d, G, NO)) { *splitk = G; return EKAID_OK; }       // tile 0: the tall-skinny reduction kernels
+    int TMN, sk, kps, tm, tn;
+    plan_full(d, TMN, sk, kps, tm, tn);
+    *tile = TMN; *splitk = sk;
+    return EKAID_OK;
+}
+
 extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t workspace_bytes, void* stream) {
     if (!d || !d->A || !d->B || !d->C) { set_error("ekaid_gemm_f32: null pointer"); return EKAID_ERR_ARG; }
     if (d->M < 0 || d->N < 0 || d->K < 0 || d->batch1 < 1 || d->batch2 < 1) {

@@ -175,6 +175,9 @@ SIGNATURES = {
     'ekaid_speaker_seq_persistent_workspace_bytes': [POINTER(SpeakerSeq)],
     'ekaid_speaker_seq_fwd_persistent': [POINTER(SpeakerSeq), P, c_size_t, P],
     'ekaid_speaker_seq_persistent_status_ptr': [P],
+    'ekaid_speaker_seq_bwd_persistent_workspace_bytes': [POINTER(SpeakerSeq)],
+    'ekaid_speaker_seq_bwd_persistent': [POINTER(SpeakerSeqBwd), P, P, c_size_t, P],
+    'ekaid_gemm_plan_query': [POINTER(GemmDesc), POINTER(c_int), POINTER(c_int)],
     'ekaid_set_seq_mode': [I],
     'ekaid_get_seq_mode': [],
     'ekaid_softmax_fwd': [P, P, L, I, I, P],
@@ -196,7 +199,7 @@ SIGNATURES = {
 }
 _RESTYPES = {'ekaid_last_error': c_char_p, 'ekaid_gemm_workspace_bytes': c_size_t, 'ekaid_gru_seq_workspace_bytes': c_size_t,
              'ekaid_speaker_seq_workspace_bytes': c_size_t, 'ekaid_speaker_seq_persistent_workspace_bytes': c_size_t,
-             'ekaid_speaker_seq_persistent_status_ptr': c_void_p, 'ekaid_speaker_greedy_workspace_bytes': c_size_t}
+             'ekaid_speaker_seq_persistent_status_ptr': c_void_p, 'ekaid_speaker_seq_bwd_persistent_workspace_bytes': c_size_t, 'ekaid_speaker_greedy_workspace_bytes': c_size_t}
 
 _lib = None
 

@@ -206,7 +206,9 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=N
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         nb = batch[0] * batch[1]
-        prof.append((e0, e1, 2.0 * M * N * K * nb, (int(transA), int(transB), M, N, K, nb)))
+        tile, sk = ctypes.c_int(0), ctypes.c_int(1)
+        check(L.ekaid_gemm_plan_query(ctypes.byref(d), ctypes.byref(tile), ctypes.byref(sk)), 'gemm_plan_query')
+        prof.append((e0, e1, 2.0 * M * N * K * nb, (int(transA), int(transB), M, N, K, nb, tile.value)))
     if a_rowsum is not None and not _BIAS_IN_WGRAD:          # A/B knob: the column sums as their own launches
         check(L.ekaid_colsum_acc(d.A, K, M, lda, ptr(a_rowsum), stream()), 'colsum_acc')
 
@@ -257,7 +259,7 @@ def gemm_slabs(A, B, M, N, K, lda, ldb, transA, transB, a_off=0, b_off=0):
     buf = torch.empty(n * M * N, device=A.device, dtype=torch.float32)
     e0 = _prof_begin()
     check(L.ekaid_gemm_slabs(ctypes.byref(d), ptr(buf), buf.numel() * 4, stream()), 'ekaid_gemm_slabs')
-    _prof_end(e0, 2.0 * M * N * K, (int(transA), int(transB), M, N, K, 1))
+    _prof_end(e0, 2.0 * M * N * K, (int(transA), int(transB), M, N, K, 1, 1))
     return SlabSet(buf, n, M, N)
 
 
@@ -278,7 +280,7 @@ def gemm_slabs2(g0, g1):
     check(L.ekaid_gemm_slabs2(ctypes.byref(ds[0]), ptr(bufs[0]), bufs[0].numel() * 4, ctypes.byref(ds[1]), ptr(bufs[1]),
                               bufs[1].numel() * 4, stream()), 'ekaid_gemm_slabs2')
     _prof_end(e0, 2.0 * (g0[2] * g0[3] * g0[4] + g1[2] * g1[3] * g1[4]),
-              (int(g0[7]), int(g0[8]), g0[2], g0[3] + g1[3], g0[4], 2))
+              (int(g0[7]), int(g0[8]), g0[2], g0[3] + g1[3], g0[4], 2, 1))
     return outs[0], outs[1]
 
 
@@ -313,7 +315,8 @@ def gemm_profile_begin():
 
 
 def gemm_profile_end():
-    """Stop collecting; returns [(milliseconds, flops, (transA, transB, M, N, K, batch))] (synchronises)."""
+    """Stop collecting; returns [(milliseconds, flops, (transA, transB, M, N, K, batch, tile))] (synchronises); tile = the kernel
+    instantiation the planner chose (ekaid_gemm_plan_query: 2 = 128x128 tiles, 1 = 64x64, 3 / 4 = 128x64 / 64x128, 0 = tall-skinny)."""
     global _gemm_profile
     rec, _gemm_profile = _gemm_profile, None
     torch.cuda.synchronize()

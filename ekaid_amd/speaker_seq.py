@@ -274,9 +274,20 @@ class SpeakerSeqFn(Function):
             sqb.dHLo, sqb.dDPl = ptr(dHLo), ptr(dDPl)
             sqb.DCAT, sqb.DZFC, sqb.DWP, sqb.DPP, sqb.DZ2 = ptr(DCAT), ptr(DZFC), ptr(DWP), ptr(DPP), ptr(DZ2)
             sqb.d_bef, sqb.d_diff, sqb.d_aft = ptr(d_bef), ptr(d_diff), ptr(d_aft)
-            need = L.ekaid_speaker_seq_workspace_bytes(ctypes.byref(sqb.f), 1)
-            ws = hip.workspace(need, dev)
-            check(L.ekaid_speaker_seq_bwd(ctypes.byref(sqb), ptr(ws), need, stream()), 'speaker_seq_bwd')
+            need_p = L.ekaid_speaker_seq_bwd_persistent_workspace_bytes(ctypes.byref(sqb.f)) if (L.ekaid_get_seq_mode() == 1 and T >= 4) else 0
+            if need_p:
+                # ONE persistent launch for the whole BPTT loop (csrc/persist_bwd.hip).  Its contract leaves two time-batched
+                # pieces to the caller: DPP (read only by the pos2 weight gradient below) and the gate-MLP part of d feat_m
+                dFm = torch.empty(3, B, G1, **f32)
+                ws = hip.workspace(need_p, dev)
+                check(L.ekaid_speaker_seq_bwd_persistent(ctypes.byref(sqb), ptr(dFm), ptr(ws), need_p, stream()), 'speaker_seq_bwd_persistent')
+                _nn(DCAT, oG1, NW, w_g1, R, G1, DPP, 0, R, TB, R, G1)                       # DPP = d gate1x . W_g1[:, R:2R]
+                for m, dfeat in enumerate((d_bef, d_diff, d_aft)):                          # d feat_m += dFm[m] . W_g1[:, 2R:]
+                    _nn(dFm, m * B * G1, G1, w_g1, 2 * R, G1, dfeat, 0, A, B, A, G1, acc=True)
+            else:
+                need = L.ekaid_speaker_seq_workspace_bytes(ctypes.byref(sqb.f), 1)
+                ws = hip.workspace(need, dev)
+                check(L.ekaid_speaker_seq_bwd(ctypes.byref(sqb), ptr(ws), need, stream()), 'speaker_seq_bwd')
         for t in (() if in_c else range(T - 1, -1, -1)):
             o_prev, o_t = t * B * R, (t + 1) * B * R
             ow = t * B * NW

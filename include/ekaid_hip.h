@@ -88,6 +88,9 @@ typedef struct ekaid_gemm {
 
 size_t ekaid_gemm_workspace_bytes(const ekaid_gemm_t* g);
 int ekaid_gemm_f32(const ekaid_gemm_t* g, void* workspace, size_t workspace_bytes, void* stream);
+/* What the planner launches for g (host-side, no launch): *tile = 1 (64x64), 2 (128x128), 3 (128x64), 4 (64x128) or 0 (tall-skinny
+ * reduction kernels), *splitk = K slabs.  For profiles: bench.py attributes every timed launch to the kernel instantiation that ran. */
+int ekaid_gemm_plan_query(const ekaid_gemm_t* g, int* tile, int* splitk);
 
 /* ------------------------------------------------------------------------------------------
  * Raw partial products for consumers that finish the reduction themselves ("slabs").
@@ -445,6 +448,19 @@ int ekaid_speaker_seq_fwd_persistent(const ekaid_speaker_seq_t* d, void* workspa
 const unsigned* ekaid_speaker_seq_persistent_status_ptr(const void* workspace);
 int ekaid_set_seq_mode(int mode);
 int ekaid_get_seq_mode(void);
+
+/* The backward sequence as ONE persistent launch (csrc/persist_bwd.hip), same descriptor and saved tensors as ekaid_speaker_seq_bwd.
+ * Differences in what it returns: (i) DPP is NOT written -- the product d [pos_feat | att] = d gate1x . W_g1[:, R:] is never formed
+ * (what it feeds is linear in the POS / module weights of a row); the caller obtains DPP, which only the pos2 weight gradient needs,
+ * as ONE time-batched product DCAT[:, gate1x block] . W_g1[:, R:2R];  (ii) d_bef / d_diff / d_aft receive only the gradient that
+ * reaches the features through the gating product; the part through gate-MLP layer 1 comes back as
+ * dFm [3][B][G1] = sum_t mw_m[t] * d gate1x[t], and the caller adds dFm[m] . W_g1[:, 2R:] (one product per feature).
+ * `workspace` (256-byte aligned, *_workspace_bytes(&b->f); 0 = unsupported shape) holds the seam counters, transposed weight copies
+ * (made by the call), the hand-off buffers and the linear maps F_m / Wp of the forward.  Status word as for the forward
+ * (ekaid_speaker_seq_persistent_status_ptr; 0x200 + seam).  Supported shapes as ekaid_speaker_seq_fwd_persistent.
+ * ref: autograd of dynamic_speaker_change_pos.py:94-131 inside :196-222 */
+size_t ekaid_speaker_seq_bwd_persistent_workspace_bytes(const ekaid_speaker_seq_t* d);
+int ekaid_speaker_seq_bwd_persistent(const ekaid_speaker_seq_bwd_t* b, float* dFm, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Greedy decoding (sample_max = 1, eval mode) of steps t0 .. t1-1 without a host round trip per step: token embedding, word-side
  * gates, the recurrent step, logits, log-softmax and ekaid_greedy_step per step, the chosen tokens feeding the next step on

@@ -102,7 +102,8 @@ def test_unsupported_shapes_keep_the_stepwise_chain():
 @pytest.mark.parametrize('train', [False, True])
 def test_decoder_through_the_model_agrees_between_the_sequence_modes(train):
     """DynamicSpeaker._forward + loss + backward at the production widths under both sequence modes: log-probs, module weights and
-    every parameter gradient (the persistent forward feeds the step-wise backward: same saved tensors)."""
+    every parameter gradient (mode 1 runs the persistent forward AND the persistent backward; both pair with either counterpart: same
+    saved tensors)."""
     from common import build_models
     from ekaid_amd import hip, ops
     from ekaid_amd.config import bench_cfg
@@ -146,3 +147,22 @@ def test_decoder_through_the_model_agrees_between_the_sequence_modes(train):
         close(res[0][2][k], res[1][2][k], 'grad ' + k, 1e-4)
     for x, y, n in zip(res[0][3], res[1][3], ('bef', 'aft', 'diff')):
         close(x, y, 'grad feat_' + n, 1e-4)
+
+
+@pytest.mark.parametrize('B,T', [(5, 4), (16, 5), (37, 4), (64, 6), (130, 4), (256, 4)])
+@pytest.mark.parametrize('train', [False, True])
+def test_persistent_backward_equals_the_stepwise_chain(B, T, train):
+    """ekaid_speaker_seq_bwd_persistent (one launch for the whole BPTT loop; the d [pos_feat | att] product replaced by its linear
+    maps) + the caller's share of its contract (DPP as one time-batched product, dFm . W_att) against ekaid_speaker_seq_bwd, on the
+    saved tensors of one forward and random upstream gradients: every output of the backward contract."""
+    sb = _sb()
+    pr = sb.problem(B, T, seed=B * 17 + T, train=train)
+    fwd, _, _ = sb.run(pr, 0)
+    ref, _, _ = sb.run_bwd(pr, fwd, 0)
+    got, _, status = sb.run_bwd(pr, fwd, 1)
+    assert status == 0, 'a seam of the persistent backward did not open (status 0x%x)' % status
+    err = sb.compare_bwd(ref, got)
+    assert max(err.values()) <= TOL, err
+    again, _, _ = sb.run_bwd(pr, fwd, 1)
+    for k in ('DCAT', 'DZFC', 'DWP', 'DZ2'):
+        assert torch.equal(got[k], again[k]), 'persistent backward is not deterministic in %s' % k

@@ -117,16 +117,118 @@ def compare(a, b):
     return res
 
 
+BWD_KEYS = ('DCAT', 'DZFC', 'DWP', 'DZ2', 'DPP', 'd_bef', 'd_diff', 'd_aft')
+
+
+def run_bwd(pr, fwd_out, mode, iters=0, seed=7):
+    """Backward over the saved tensors ``fwd_out`` with random upstream gradients.  mode 0: ekaid_speaker_seq_bwd (step-wise chain);
+    1: ekaid_speaker_seq_bwd_persistent + what its contract leaves to the caller (DPP as one time-batched product, the gate-MLP
+    part of the feature gradients from dFm).  Returns (outputs, ms per call, status)."""
+    L = hip.lib()
+    B, T, dev = pr['B'], pr['T'], pr['dev']
+    f32 = dict(device=dev, dtype=torch.float32)
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    dHLo = (torch.randn(T, B, R, generator=g) * 0.1).to(dev)
+    dDPl = (torch.randn(T, B, P, generator=g) * 0.1).to(dev)
+    out = {'DCAT': torch.full((T, B, NW), float('nan'), **f32), 'DZFC': torch.full((T, B, 3), float('nan'), **f32),
+           'DWP': torch.full((T, B, P), float('nan'), **f32), 'DPP': torch.full((T, B, R), float('nan'), **f32),
+           'DZ2': torch.full((T, B, A), float('nan'), **f32)}
+    sqb = hip.SpeakerSeqBwd()
+    sqb.f = descriptor(pr, fwd_out)
+    sqb.dHLo, sqb.dDPl = dHLo.data_ptr(), dDPl.data_ptr()
+    st = hip.stream()
+    w_g1 = pr['w']['w_g1']
+
+    def call(post=True):
+        for k in ('d_bef', 'd_diff', 'd_aft'):
+            out[k] = torch.zeros(B, A, **f32)
+        for k in ('DCAT', 'DZFC', 'DWP', 'DPP', 'DZ2', 'd_bef', 'd_diff', 'd_aft'):
+            setattr(sqb, k, out[k].data_ptr())
+        if mode == 0:
+            hip.check(L.ekaid_speaker_seq_bwd(ctypes.byref(sqb), ws.data_ptr(), need, st), 'speaker_seq_bwd')
+        else:
+            hip.check(L.ekaid_speaker_seq_bwd_persistent(ctypes.byref(sqb), dFm.data_ptr(), ws.data_ptr(), need, st), 'speaker_seq_bwd_persistent')
+            if not post:
+                return
+            # the caller's share: DPP = DCAT[:, gate1x block] . W_g1[:, R:2R]; d feat_m += dFm[m] . W_g1[:, 2R:]
+            out['DPP'] = (out['DCAT'][:, :, 5 * R:5 * R + G1].reshape(T * B, G1) @ w_g1[:, R:2 * R]).view(T, B, R)
+            for m, k in enumerate(('d_bef', 'd_diff', 'd_aft')):
+                out[k] += dFm[m] @ w_g1[:, 2 * R:]
+    if mode == 0:
+        need = L.ekaid_speaker_seq_workspace_bytes(ctypes.byref(sqb.f), 1)
+    else:
+        need = L.ekaid_speaker_seq_bwd_persistent_workspace_bytes(ctypes.byref(sqb.f))
+        assert need > 0, 'persistent backward does not support this shape'
+    ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+    dFm = torch.full((3, B, G1), float('nan'), **f32)
+    call()
+    torch.cuda.synchronize()
+    status = 0
+    if mode == 1:
+        off = L.ekaid_speaker_seq_persistent_status_ptr(ws.data_ptr()) - ws.data_ptr()
+        status = int(ws[off:off + 4].view(torch.int32).item())
+        if os.environ.get('EKAID_PERSIST_TRACE') == '1':
+            nb = (256 * T * 128 + 255) // 256 * 256
+            run_bwd.trace = ws[need - nb:need - nb + 256 * T * 128].view(torch.int64).view(256, T, 16).cpu()
+    ms = None
+    if iters:
+        for _ in range(3):
+            call(False)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            call(False)          # (the caller's four time-batched products are not part of the sequence call: ~0.1 ms per backward)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        call()
+        torch.cuda.synchronize()
+    return out, ms, status
+
+
+def compare_bwd(a, b):
+    res = {}
+    for k in BWD_KEYS:
+        x, y = a[k].double(), b[k].double()
+        res[k] = float((x - y).abs().max() / x.abs().max().clamp_min(1e-30)) if torch.isfinite(y).all() else float('inf')
+    return res
+
+
+def show_trace(tr, B, names):
+    d = tr.double()
+    spans = torch.zeros(d.shape[0], d.shape[1], 16)
+    for k in range(15):
+        spans[:, :, k] = (d[:, :, k + 1] - d[:, :, k]) / 100.0
+    spans[:, :-1, 15] = (d[:, 1:, 0] - d[:, :-1, 15]) / 100.0
+    med = spans[:, 1:-1].median(1).values if d.shape[1] > 2 else spans.mean(1)
+    step_us = ((d[:, -1, 15] - d[:, 0, 0]) / 100.0 / d.shape[1]).median()
+    print('trace B=%d: %.1f us per step; per span: median over workgroups (max)' % (B, float(step_us)), file=sys.stderr)
+    print('  ' + '  '.join('%s %.1f(%.1f)' % (n, float(med[:, k].median()), float(med[:, k].max())) for k, n in enumerate(names)), file=sys.stderr)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, nargs='+', default=[64])
     ap.add_argument('--steps', type=int, default=16)
     ap.add_argument('--train', action='store_true')
     ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--bwd', action='store_true', help='the backward sequence instead of the forward one')
     args = ap.parse_args()
     hip.load()
     for B in args.batch:
         pr = problem(B, args.steps, train=args.train)
+        if args.bwd:
+            fwd, _, _ = run(pr, 0)
+            ref, ms0, _ = run_bwd(pr, fwd, 0, args.iters)
+            got, ms1, status = run_bwd(pr, fwd, 1, args.iters)
+            err = compare_bwd(ref, got)
+            tr = getattr(run_bwd, 'trace', None)
+            if tr is not None:
+                show_trace(tr, B, ['P1', 'arr1', 'wait1', 'P2', 'arr2', 'carryL', 'P3(+wait2)', 'P3', 'arr3', 'wait3', 'P4', 'arr4', 'carryG', 'P5(+wait4)', 'P6', 'next'])
+            print(json.dumps({'bwd': True, 'batch': B, 'steps': args.steps, 'train': args.train, 'status': status,
+                              'stepwise_us_per_step': round(ms0 / args.steps * 1e3, 2), 'persistent_us_per_step': round(ms1 / args.steps * 1e3, 2),
+                              'max_rel_err': round(max(err.values()), 9), 'worst': max(err, key=err.get), 'err': {k: round(v, 9) for k, v in err.items()}}))
+            continue
         ref, ms0, _ = run(pr, 0, args.iters)
         got, ms1, status = run(pr, 1, args.iters)
         err = compare(ref, got)
