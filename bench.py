@@ -199,11 +199,13 @@ def cpu_baseline(cfg, cd, sp, batch_size, graph, budget_s=25.0):
                           torch.__version__, cores, os.cpu_count() or 0, batch_size, iters, batch_size)}
 
 
-def real_data_loop(graph, iters=120, time_from=80):
+def real_data_loop(graph, iters=120, time_from=80, answer_mix='short+90'):
     """BASELINE.json configs[4] on one GPU: train_mimic.py itself (HDF5 reader -> RCCDataLoader -> DevicePrefetcher -> one
-    hipGraph per (shape, decode steps)) on a generated dataset of the REAL shapes -- 52 regions per image, 1024-d ROI features,
-    the yaml's batch 64, ragged answers.  Answer lengths of the generator: uniform 2..40 tokens, every 50th pair 90 tokens (the
-    maximum), so most batches decode 90 steps and the rest 38-40: on real data the decoder, not the detector, sets the step."""
+    hipGraph per (shape, decode steps rounded up to a multiple of 8)) on a generated dataset of the REAL shapes -- 52 regions per image,
+    1024-d ROI features, the yaml's batch 64, ragged answers.  Answer lengths of the generator: 'short+90' = uniform 2..40 tokens,
+    every 50th pair 90 tokens (the maximum), so most batches decode 90 steps and the rest 40; 'uniform' = uniform 2..90 tokens.  On real
+    data the decoder, not the detector, sets the step.  The dataset is large enough that the run stays inside one epoch (160 iterations:
+    the real training set has thousands per epoch; an epoch boundary restarts the loader thread and costs one batch assembly)."""
     import shutil
     import tempfile
     import train_mimic
@@ -211,7 +213,7 @@ def real_data_loop(graph, iters=120, time_from=80):
     d = tempfile.mkdtemp(prefix='ekaid_real_')
     try:
         t0 = time.perf_counter()
-        make_dataset(d, n_images=512, n_pairs=3200, nodes=52, D=1024)
+        make_dataset(d, n_images=512, n_pairs=12800, nodes=52, D=1024, answer_mix=answer_mix)
         gen_s = time.perf_counter() - t0
         with contextlib.redirect_stdout(sys.stderr):        # stdout carries the ONE JSON line of the contract, nothing else
             out = train_mimic.main(['--data_dir', d, '--graph', graph, '--hip_graph', '--max_iter', str(iters), '--time_from', str(time_from),
@@ -221,17 +223,19 @@ def real_data_loop(graph, iters=120, time_from=80):
     tm = out['timing'] or {}
     step_ms = tm.get('ms_per_iteration', 0.0)
     return {'workload': 'BASELINE.json configs[4] on one GPU: train_mimic.py --hip_graph on a generated dataset in the reference layout '
-                        '(52 regions x 2 images, 1024-d ROI features, batch 64, answers uniform 2..40 tokens, every 50th pair 90 tokens), '
-                        'reader + prefetcher + one hipGraph per (shape, decode steps); %d timed iterations after %d' % (
-                            tm.get('iterations', 0), time_from),
+                        '(52 regions x 2 images, 1024-d ROI features, batch 64, answers %s), reader + prefetcher + one hipGraph per (shape, '
+                        'decode steps rounded up to a multiple of %d); %d timed iterations after %d, %d iterations per epoch' % (
+                            'uniform 2..40 tokens, every 50th pair 90 tokens' if answer_mix == 'short+90' else 'uniform 2..90 tokens',
+                            out.get('t_round', 1), tm.get('iterations', 0), time_from, out.get('iters_per_epoch', 0)),
             'qa_pairs_per_s': round(tm.get('qa_pairs_per_s', 0.0), 1), 'ms_per_iteration': round(step_ms, 3),
             'loader_wait_ms_per_iteration': round(tm.get('loader_wait_ms_per_iteration', 0.0), 3),
             'loader_wait_fraction': round(tm.get('loader_wait_ms_per_iteration', 0.0) / step_ms, 4) if step_ms else None,
             'batch_assembly_ms': round(tm.get('batch_assembly_ms', 0.0), 3), 'staging_ms': round(tm.get('staging_ms', 0.0), 3),
             'h2d_ms_per_batch': round(tm.get('h2d_ms_per_batch', 0.0), 3), 'h2d_bytes_per_batch': tm.get('h2d_bytes_per_batch'),
             'exposed_h2d_ms_per_iteration': round(tm.get('exposed_h2d_ms_per_iteration', 0.0), 3),
-            'graphs_captured': out['graphs_captured'], 'decode_steps_histogram': tm.get('decode_steps_histogram'),
-            'dataset_generation_s': round(gen_s, 2)}
+            'graphs_captured': out['graphs_captured'], 'graph_capture_s': round(out.get('graph_capture_s', 0.0), 3),
+            'graph_pool_bytes': out.get('graph_pool_bytes'), 'decode_steps_histogram': tm.get('decode_steps_histogram'),
+            'decode_steps_run_histogram': out.get('decode_steps_run_histogram'), 'dataset_generation_s': round(gen_s, 2)}
 
 
 def timed(fn, steps, warmup):
@@ -546,7 +550,7 @@ def main():
         if not args.no_real:
             step.close()
             rd = real_data_loop(args.graph)
-            hist = rd.get('decode_steps_histogram') or {}
+            hist = rd.get('decode_steps_run_histogram') or rd.get('decode_steps_histogram') or {}
             n_it = sum(hist.values())
             if n_it and rd.get('ms_per_iteration'):
                 # work of the timed iterations from their decode-step histogram (52 regions, 1024-d features, batch 64)
@@ -556,6 +560,11 @@ def main():
                                   'algorithmic_peak_tflops': round(peak_alg, 1), 'frac': round(tfr / peak_alg, 4),
                                   'note': 'mean over the histogram of decode steps of the iterations run (not only the timed ones)'}
             extra['real_b64'] = rd
+            # robustness on a realistic answer-length mix (uniform 2..90): how many graphs, how long their capture, how much memory
+            ru = real_data_loop(args.graph, iters=300, time_from=200, answer_mix='uniform')
+            extra['real_b64_uniform_lengths'] = {k: ru[k] for k in ('workload', 'qa_pairs_per_s', 'ms_per_iteration', 'loader_wait_fraction',
+                                                                    'graphs_captured', 'graph_capture_s', 'graph_pool_bytes',
+                                                                    'decode_steps_histogram', 'decode_steps_run_histogram')}
     if world > 1:
         dist.barrier()
 

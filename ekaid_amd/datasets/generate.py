@@ -24,7 +24,9 @@ from .. import h5lite
 from ..synthetic import _REV
 
 
-def make_dataset(out_dir, n_images=96, n_pairs=400, nodes=52, D=1024, V=148, seed=0, chunk_rows=100, max_answer=40):
+def make_dataset(out_dir, n_images=96, n_pairs=400, nodes=52, D=1024, V=148, seed=0, chunk_rows=100, max_answer=40, answer_mix='short+90'):
+    """``answer_mix``: 'short+90' = answers uniform 2..max_answer tokens, every 50th pair the 90-token maximum (most 64-pair batches then
+    decode 90 steps, the rest ~max_answer); 'uniform' = uniform 2..90 tokens, nothing forced."""
     os.makedirs(out_dir, exist_ok=True)
     rng = np.random.default_rng([seed, 77])
     feats = np.maximum(rng.standard_normal((n_images, nodes, D), dtype=np.float32), 0.0)
@@ -58,7 +60,10 @@ def make_dataset(out_dir, n_images=96, n_pairs=400, nodes=52, D=1024, V=148, see
     for i in range(n_pairs):
         ql = int(rng.integers(3, 13))
         q[i, :ql] = rng.integers(2, V, ql)
-        al = int(rng.integers(2, max_answer + 1)) if i % 50 else 90
+        if answer_mix == 'uniform':
+            al = int(rng.integers(2, 91))
+        else:
+            al = int(rng.integers(2, max_answer + 1)) if i % 50 else 90
         a[i, 0] = 1
         a[i, 1:al] = rng.integers(2, V, al - 1)
         pos[i, :al] = rng.integers(1, 16, al)
@@ -95,5 +100,6 @@ if __name__ == '__main__':
     ap.add_argument('--nodes', type=int, default=52)
     ap.add_argument('--dim', type=int, default=1024)
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--answer_mix', choices=['short+90', 'uniform'], default='short+90')
     a = ap.parse_args()
-    print(make_dataset(a.out, a.images, a.pairs, a.nodes, a.dim, seed=a.seed))
+    print(make_dataset(a.out, a.images, a.pairs, a.nodes, a.dim, seed=a.seed, answer_mix=a.answer_mix))

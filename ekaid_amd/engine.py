@@ -118,12 +118,20 @@ class TrainStep:
     With ``use_graph`` do not keep loss tensors of EARLIER eager steps of the same modules alive across the first call
     of a new shape (they pin autograd nodes to the eager stream; see ``_capture``)."""
 
-    def __init__(self, cfg, cd, sp, opt, graph='all', setting='mode2', use_graph=False, comm='eager', warmup=2):
+    def __init__(self, cfg, cd, sp, opt, graph='all', setting='mode2', use_graph=False, comm='eager', warmup=2, t_round=1):
         if comm not in ('eager', 'captured'):
             raise ValueError("comm must be 'eager' or 'captured'")
         self.cfg, self.cd, self.sp, self.opt = cfg, cd, sp, opt
         self.graph, self.setting = graph, setting
         self.use_graph, self.comm, self.warmup = use_graph, comm, warmup
+        # Ragged answers give every batch its own number of decode steps and every (shape, steps) pair its own captured graph -- up to
+        # seq_length - 1 of them on real data.  ``t_round`` > 1 runs the decoder for the step count rounded UP to a multiple of it
+        # (capped at seq_length): the extra steps read padding tokens, their log-prob rows meet an all-zero loss mask (the criterion
+        # multiplies by masks[:, 1:]), so loss and gradients are those of the exact step count up to the summation order of the
+        # time-batched products (K = steps x batch rows grows by zero rows), and the number of graphs drops by that factor.
+        self.t_round = max(int(t_round), 1)
+        self.capture_s = 0.0
+        self.graph_pool_bytes = 0
         self._graphs = {}
         self._pool = None
         self._epoch = None
@@ -261,7 +269,13 @@ class TrainStep:
         return (T, denom is not None, bool(self.cd.training), bool(self.sp.training), float(getattr(self.sp, 'ss_prob', 0.0))) + \
             tuple((k, tuple(b[k].shape), b[k].dtype) for k in INPUT_KEYS)
 
+    def rounded_steps(self, T):
+        if self.t_round <= 1:
+            return T
+        return min(int(self.cfg.model.speaker.seq_length), -(-int(T) // self.t_round) * self.t_round)
+
     def __call__(self, b, T, denom=None):
+        T = self.rounded_steps(T)
         if not self.use_graph:
             return self._eager(b, T, denom)
         key = self._key(b, T, denom)
@@ -270,7 +284,13 @@ class TrainStep:
             # graphs captured under another mode / scheduled-sampling rate are never replayed again (the rate only rises)
             for k in [k for k in self._graphs if k[2:5] != key[2:5]]:
                 del self._graphs[k]
+            import time
+            torch.cuda.synchronize()
+            t0, m0 = time.perf_counter(), torch.cuda.memory_allocated()
             ent = self._capture(b, T, denom)
+            torch.cuda.synchronize()
+            self.capture_s += time.perf_counter() - t0
+            self.graph_pool_bytes += max(torch.cuda.memory_allocated() - m0, 0)
             self._graphs[key] = ent
         for k in INPUT_KEYS:
             ent['static'][k].copy_(b[k], non_blocking=True)

@@ -13,6 +13,7 @@ stays in the time loop.  All activations are stored time-major (T, B, .) so that
 for every t" is a contiguous slice of the (T+1, B, R) state buffer.
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -20,6 +21,8 @@ from torch.autograd import Function
 from . import hip, ops
 from .hip import ACT_NONE, ACT_RELU, ACT_SIGMOID, check, ptr, stream
 from .ops import gemm
+
+PERSISTENT_BWD_MIN_STEPS = int(os.environ.get('EKAID_SEQ_BWD_MIN_STEPS', '32'))
 
 PARAM_NAMES = ('embed.0.weight', 'core.embed.0.weight', 'core.embed.0.bias',
                'core.module_att_lstm.weight_ih', 'core.module_att_lstm.weight_hh',
@@ -274,7 +277,9 @@ class SpeakerSeqFn(Function):
             sqb.dHLo, sqb.dDPl = ptr(dHLo), ptr(dDPl)
             sqb.DCAT, sqb.DZFC, sqb.DWP, sqb.DPP, sqb.DZ2 = ptr(DCAT), ptr(DZFC), ptr(DWP), ptr(DPP), ptr(DZ2)
             sqb.d_bef, sqb.d_diff, sqb.d_aft = ptr(d_bef), ptr(d_diff), ptr(d_aft)
-            need_p = L.ekaid_speaker_seq_bwd_persistent_workspace_bytes(ctypes.byref(sqb.f)) if (L.ekaid_get_seq_mode() == 1 and T >= 4) else 0
+            # (same-box A/B, profiles/r04_ab_seq_mode.txt: the persistent backward pays 4 weight transposes + 4 small products in front and 4
+            # time-batched products behind; it wins from ~32 decode steps on -- the real-data answers -- and is level below)
+            need_p = L.ekaid_speaker_seq_bwd_persistent_workspace_bytes(ctypes.byref(sqb.f)) if (L.ekaid_get_seq_mode() == 1 and T >= PERSISTENT_BWD_MIN_STEPS) else 0
             if need_p:
                 # ONE persistent launch for the whole BPTT loop (csrc/persist_bwd.hip).  Its contract leaves two time-batched
                 # pieces to the caller: DPP (read only by the pos2 weight gradient below) and the gate-MLP part of d feat_m

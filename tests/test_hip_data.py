@@ -218,6 +218,44 @@ def test_graph_replay_equals_eager():
     assert d_w == 0.0 and d_l == 0.0, 'hipGraph replay differs from the eager steps'
 
 
+def test_decode_steps_rounded_up_leave_loss_and_gradients_unchanged():
+    """TrainStep(t_round=8): the decoder runs 8 steps for a batch whose answers need 5 (fewer captured graphs on ragged data).  The three
+    extra steps read padding tokens and their log-prob rows meet an all-zero loss mask, so the loss and every gradient are those of the
+    exact step count -- up to the summation order of the time-batched products, whose contraction grows by zero rows (hence 1e-5 of
+    each tensor's scale, not bit equality)."""
+    from common import build_models
+    from ekaid_amd import ops
+    from ekaid_amd.config import bench_cfg
+    from ekaid_amd.dp import FlatAdam
+    from ekaid_amd.engine import TrainStep, forward_loss
+    from ekaid_amd.synthetic import make_batch
+    cfg = bench_cfg(D=256, seq_length=12)
+    host = make_batch(B=6, N=12, D=256, Lq=8, T=5, seq_length=12, V=148, seed=9)
+    b = {k: v.cuda() for k, v in host.items()}
+    cd, sp = build_models(cfg, 147, 148, 'cuda', train=False)          # eval mode: no dropout, so the two runs are comparable
+    ts = TrainStep(cfg, cd, sp, FlatAdam([cd, sp], lr=1e-3), t_round=8)
+    assert ts.rounded_steps(5) == 8 and ts.rounded_steps(11) == 12 and ts.rounded_steps(8) == 8
+    assert TrainStep(cfg, cd, sp, ts.opt).rounded_steps(5) == 5
+    res = []
+    for T in (5, ts.rounded_steps(5)):
+        ops.manual_seed(5)
+        for m in (cd, sp):
+            m.zero_grad()
+        loss = forward_loss(cfg, cd, sp, b, T)[0]
+        loss.backward()
+        res.append((float(loss.detach()), {k: p.grad.detach().clone() for m in (cd, sp) for k, p in m.named_parameters() if p.grad is not None}))
+    (l5, g5), (l8, g8) = res
+    assert l5 == pytest.approx(l8, rel=2e-6), (l5, l8)
+    assert g5.keys() == g8.keys() and len(g5) > 40
+    gmax = max(float(v.abs().max()) for v in g5.values())
+    # (parameters whose true gradient is zero -- key bias under a softmax, W2 bias under the batch softmax -- carry rounding noise only)
+    live = [k for k in g5 if float(g5[k].abs().max()) > 1e-6 * gmax]
+    assert len(live) > 40
+    worst = max(float((g5[k] - g8[k]).abs().max()) / float(g5[k].abs().max()) for k in live)
+    print('decode steps 5 vs 8 (3 masked): loss %.7f / %.7f, worst gradient deviation %.2e of the tensor scale' % (l5, l8, worst))
+    assert worst <= 1e-5, worst
+
+
 def test_graph_key_follows_the_scheduled_sampling_rate(monkeypatch):
     """``speaker.ss_prob`` is a by-value kernel argument and selects the decoder path (fused teacher-forced node at 0, step-wise
     sampling above): a hipGraph captured at one rate must not be replayed at another.  The rate is part of the graph

@@ -61,15 +61,15 @@ def test_persistent_forward_is_deterministic_and_replayable():
     try:
         out = sb.buffers(pr)
         sq = sb.descriptor(pr, out)
-        need = L.ekaid_speaker_seq_workspace_bytes(ctypes.byref(sq), 0)
+        need = L.ekaid_speaker_seq_persistent_workspace_bytes(ctypes.byref(sq))
         ws = torch.empty(need, dtype=torch.uint8, device='cuda')
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
-            hip.check(L.ekaid_speaker_seq_fwd(ctypes.byref(sq), ws.data_ptr(), need, hip.stream()), 'warm-up')
+            hip.check(L.ekaid_speaker_seq_fwd_persistent(ctypes.byref(sq), ws.data_ptr(), need, hip.stream()), 'warm-up')
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            hip.check(L.ekaid_speaker_seq_fwd(ctypes.byref(sq), ws.data_ptr(), need, hip.stream()), 'capture')
+            hip.check(L.ekaid_speaker_seq_fwd_persistent(ctypes.byref(sq), ws.data_ptr(), need, hip.stream()), 'capture')
         for _ in range(3):
             for k in ('SA', 'SL', 'G1D', 'GA'):
                 out[k].fill_(float('nan'))
@@ -100,19 +100,20 @@ def test_unsupported_shapes_keep_the_stepwise_chain():
 
 
 @pytest.mark.parametrize('train', [False, True])
-def test_decoder_through_the_model_agrees_between_the_sequence_modes(train):
+def test_decoder_through_the_model_agrees_between_the_sequence_modes(train, monkeypatch):
     """DynamicSpeaker._forward + loss + backward at the production widths under both sequence modes: log-probs, module weights and
     every parameter gradient (mode 1 runs the persistent forward AND the persistent backward; both pair with either counterpart: same
     saved tensors)."""
     from common import build_models
-    from ekaid_amd import hip, ops
+    from ekaid_amd import hip, ops, speaker_seq
     from ekaid_amd.config import bench_cfg
     hip.load()
     L = hip.lib()
+    monkeypatch.setattr(speaker_seq, 'PERSISTENT_BWD_MIN_STEPS', 4)      # (the default keeps short sequences on the step-wise backward)
     cfg = bench_cfg(D=256, seq_length=12)
     cd, sp = build_models(cfg, 147, 148, 'cuda', train=train)
     g = torch.Generator().manual_seed(11)
-    B, T, A = 24, 7, cfg.model.speaker.input_dim
+    B, T, A = 24, 9, cfg.model.speaker.input_dim
     bef, aft, diff = [torch.randn(B, A, generator=g).cuda().requires_grad_(True) for _ in range(3)]
     seq = torch.zeros(B, 13, dtype=torch.long)
     seq[:, 0] = 1

@@ -84,6 +84,9 @@ def parse(argv=None):
     p.add_argument('--exp_dir', default=None)
     p.add_argument('--quiet', action='store_true')
     p.add_argument('--no_final_snapshot', action='store_true', help='benchmark aid: no checkpoint / evaluation at max_iter')
+    p.add_argument('--t_round', type=int, default=None,
+                   help='decode steps rounded up to a multiple of this (extra steps are fully masked); default 8 with --hip_graph (fewer '
+                        'captured graphs on ragged answers), 1 otherwise')
     p.add_argument('--time_from', type=int, default=None,
                    help='benchmark aid: time the loop from this iteration on (QA-pairs/s, loader wait, exposed host->device copy)')
     return p.parse_args(argv)
@@ -222,7 +225,9 @@ def main(argv=None):
         raise SystemExit('only the configured optimiser (adam, utils.py:96-99) is implemented')
     optimizer = FlatAdam([change_detector, speaker], lr=o.lr, betas=(o.alpha, o.beta), eps=o.epsilon)
     graph_comm = args.graph_comm if args.graph_comm != 'auto' else ('captured' if world > 1 else 'eager')
-    step = TrainStep(cfg, change_detector, speaker, optimizer, args.graph, args.setting, use_graph=args.hip_graph, comm=graph_comm)
+    t_round = args.t_round if args.t_round is not None else (8 if args.hip_graph else 1)
+    step = TrainStep(cfg, change_detector, speaker, optimizer, args.graph, args.setting, use_graph=args.hip_graph, comm=graph_comm,
+                     t_round=t_round)
     shape = dict(N=args.nodes, D=D, Lq=20, T=args.answer_steps, seq_length=cfg.model.speaker.seq_length, V=V)
 
     def named():
@@ -259,7 +264,7 @@ def main(argv=None):
     set_mode('train', [change_detector, speaker])
     loss_avg = AverageMeter()
     last = {}
-    prefetchers, timing, t_clock, steps_hist = [], None, None, {}
+    prefetchers, timing, t_clock, steps_hist, run_hist = [], None, None, {}, {}
 
     def stop_clock():
         torch.cuda.synchronize()
@@ -300,6 +305,7 @@ def main(argv=None):
                 t_clock = (time.perf_counter(), t, [pf.stats() for pf in prefetchers])
             steps = DynamicSpeaker.count_steps(host_labels, shape['seq_length'])
             steps_hist[steps] = steps_hist.get(steps, 0) + 1
+            run_hist[step.rounded_steps(steps)] = run_hist.get(step.rounded_steps(steps), 0) + 1
             denom = None
             if world > 1 and msum is not None:
                 denom = torch.tensor([msum / world], dtype=torch.float32, device=device)
@@ -371,7 +377,9 @@ def main(argv=None):
         dist.destroy_process_group()
     return {'iteration': t, 'epoch': epoch, 'lr': optimizer.lr, 'last': last, 'snapshot_dir': snapshot_dir,
             'change_detector': change_detector, 'speaker': speaker, 'optimizer': optimizer,
-            'graphs_captured': graphs_captured, 'timing': timing, 'iters_per_epoch': iters_per_epoch}
+            'graphs_captured': graphs_captured, 'graph_capture_s': step.capture_s, 'graph_pool_bytes': step.graph_pool_bytes,
+            'decode_steps_run_histogram': dict(sorted(run_hist.items())), 't_round': step.t_round,
+            'timing': timing, 'iters_per_epoch': iters_per_epoch}
 
 
 if __name__ == '__main__':
