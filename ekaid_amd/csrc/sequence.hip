@@ -6,6 +6,7 @@
 // ref: language_model.py:106-115 (nn.GRU), dynamic_speaker_change_pos.py:94-131,196-222 (DynamicCore inside _forward).
 #include "common.h"
 #include "../../include/ekaid_hip.h"
+#include <cstdlib>
 #include <cstring>
 
 namespace ekaid {
@@ -133,12 +134,20 @@ using namespace ekaid;
 extern "C" size_t ekaid_gru_seq_workspace_bytes(int B, int T, int H, int backward) {
     if (B < 1 || T < 1 || H < 1) return 0;
     GruPlan pl;
-    return gru_plan(B, T, H, nullptr, nullptr, backward != 0, pl) ? pl.bytes : 0;
+    if (!gru_plan(B, T, H, nullptr, nullptr, backward != 0, pl)) return 0;
+    const size_t pers = ekaid_gru_seq_persistent_workspace_bytes(B, T, H, backward);      // either form fits
+    return pl.bytes > pers ? pl.bytes : pers;
 }
 
 extern "C" int ekaid_gru_seq_fwd(const float* gi, const float* w_hh, const float* b_hh, int B, int T, int H, float* hall, float* save,
                                  void* workspace, size_t workspace_bytes, void* stream) {
     if (!gi || !w_hh || !b_hh || !hall || !save || B < 1 || T < 1 || H < 1) { set_error("ekaid_gru_seq_fwd: bad arguments"); return EKAID_ERR_ARG; }
+    // one persistent launch where the shape allows it AND it measured faster (csrc/persist_gru.hip; tools/gru_bench.py, same box:
+    // 12.6 -> 10.7 us per step at 32 rows, 13.8 -> 10.2 at 64, 16.3 -> 14.6 at 128, level at 256)
+    if (seq_mode() == 1 && T >= 4 && B <= 128) {
+        const size_t pers = ekaid_gru_seq_persistent_workspace_bytes(B, T, H, 0);
+        if (pers && workspace && workspace_bytes >= pers) return ekaid_gru_seq_fwd_persistent(gi, w_hh, b_hh, B, T, H, hall, save, workspace, workspace_bytes, stream);
+    }
     GruPlan pl;
     if (!gru_plan(B, T, H, w_hh, workspace, false, pl)) return EKAID_ERR_ARG;
     if (!workspace || workspace_bytes < pl.bytes) { set_error("ekaid_gru_seq_fwd: workspace too small (%zu < %zu)", workspace_bytes, pl.bytes); return EKAID_ERR_ARG; }
@@ -156,6 +165,14 @@ extern "C" int ekaid_gru_seq_fwd(const float* gi, const float* w_hh, const float
 extern "C" int ekaid_gru_seq_bwd(const float* dout, const float* w_hh, const float* hall, const float* save, int B, int T, int H,
                                  float* dgi, float* dgh, void* workspace, size_t workspace_bytes, void* stream) {
     if (!dout || !w_hh || !hall || !save || !dgi || !dgh || B < 1 || T < 1 || H < 1) { set_error("ekaid_gru_seq_bwd: bad arguments"); return EKAID_ERR_ARG; }
+    // the persistent backward is NOT routed by default: one seam + a K = 3H carry job + the element-wise cell backward per step measured
+    // 14.5-14.8 us against 11.9-12.8 us for the two small launches of the step-wise chain at 32-64 rows, 37 against 22-24 at 256
+    // (tools/gru_bench.py); EKAID_GRU_BWD=persistent selects it (tests call the entry directly)
+    static const bool gru_bwd_persistent = [] { const char* e = getenv("EKAID_GRU_BWD"); return e && e[0] == 'p'; }();
+    if (seq_mode() == 1 && T >= 4 && gru_bwd_persistent) {
+        const size_t pers = ekaid_gru_seq_persistent_workspace_bytes(B, T, H, 1);
+        if (pers && workspace && workspace_bytes >= pers) return ekaid_gru_seq_bwd_persistent(dout, w_hh, hall, save, B, T, H, dgi, dgh, workspace, workspace_bytes, stream);
+    }
     GruPlan pl;
     if (!gru_plan(B, T, H, w_hh, workspace, true, pl)) return EKAID_ERR_ARG;
     if (!workspace || workspace_bytes < pl.bytes) { set_error("ekaid_gru_seq_bwd: workspace too small (%zu < %zu)", workspace_bytes, pl.bytes); return EKAID_ERR_ARG; }

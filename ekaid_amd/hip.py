@@ -120,6 +120,9 @@ SIGNATURES = {
     'ekaid_gru_seq_workspace_bytes': [I, I, I, I],
     'ekaid_gru_seq_fwd': [P, P, P, I, I, I, P, P, P, c_size_t, P],
     'ekaid_gru_seq_bwd': [P, P, P, P, I, I, I, P, P, P, c_size_t, P],
+    'ekaid_gru_seq_fwd_persistent': [P, P, P, I, I, I, P, P, P, c_size_t, P],
+    'ekaid_gru_seq_bwd_persistent': [P, P, P, P, I, I, I, P, P, P, c_size_t, P],
+    'ekaid_gru_seq_persistent_workspace_bytes': [I, I, I, I],
     'ekaid_speaker_seq_workspace_bytes': [POINTER(SpeakerSeq), I],
     'ekaid_speaker_seq_fwd': [POINTER(SpeakerSeq), P, c_size_t, P],
     'ekaid_speaker_seq_bwd': [POINTER(SpeakerSeqBwd), P, c_size_t, P],
@@ -197,7 +200,7 @@ SIGNATURES = {
     'ekaid_adam_step': [P, P, P, P, L, F, F, F, F, I, F, P],
     'ekaid_adam_step_dev': [P, P, P, P, L, P, P, P, P],
 }
-_RESTYPES = {'ekaid_last_error': c_char_p, 'ekaid_gemm_workspace_bytes': c_size_t, 'ekaid_gru_seq_workspace_bytes': c_size_t,
+_RESTYPES = {'ekaid_last_error': c_char_p, 'ekaid_gemm_workspace_bytes': c_size_t, 'ekaid_gru_seq_workspace_bytes': c_size_t, 'ekaid_gru_seq_persistent_workspace_bytes': c_size_t,
              'ekaid_speaker_seq_workspace_bytes': c_size_t, 'ekaid_speaker_seq_persistent_workspace_bytes': c_size_t,
              'ekaid_speaker_seq_persistent_status_ptr': c_void_p, 'ekaid_speaker_seq_bwd_persistent_workspace_bytes': c_size_t, 'ekaid_speaker_greedy_workspace_bytes': c_size_t}
 

@@ -400,6 +400,15 @@ int ekaid_gru_seq_fwd(const float* gi, const float* w_hh, const float* b_hh, int
                       void* workspace, size_t workspace_bytes, void* stream);
 int ekaid_gru_seq_bwd(const float* dout, const float* w_hh, const float* hall, const float* save, int B, int T, int H, float* dgi,
                       float* dgh, void* workspace, size_t workspace_bytes, void* stream);
+/* The same two sequences as ONE persistent launch each (csrc/persist_gru.hip; H = 1024 only, otherwise EKAID_ERR_UNSUPPORTED and a
+ * workspace query of 0): one seam + one 16 x 16 MFMA job per step instead of two launches.  Same arguments and results (to f32
+ * rounding; deterministic).  ekaid_gru_seq_fwd / _bwd route here under ekaid_set_seq_mode(1) when the shape is supported;
+ * ekaid_gru_seq_workspace_bytes covers either form. */
+size_t ekaid_gru_seq_persistent_workspace_bytes(int B, int T, int H, int backward);
+int ekaid_gru_seq_fwd_persistent(const float* gi, const float* w_hh, const float* b_hh, int B, int T, int H, float* hall, float* save,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+int ekaid_gru_seq_bwd_persistent(const float* dout, const float* w_hh, const float* hall, const float* save, int B, int T, int H,
+                                 float* dgi, float* dgh, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Teacher-forced answer decoder, the recurrent part of DynamicSpeaker._forward (ref: dynamic_speaker_change_pos.py:94-131,
  * 196-222): per step module-attention LSTM -> module weights + attended feature -> POS chain -> gate MLP -> language LSTM;

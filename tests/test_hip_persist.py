@@ -167,3 +167,61 @@ def test_persistent_backward_equals_the_stepwise_chain(B, T, train):
     again, _, _ = sb.run_bwd(pr, fwd, 1)
     for k in ('DCAT', 'DZFC', 'DWP', 'DZ2'):
         assert torch.equal(got[k], again[k]), 'persistent backward is not deterministic in %s' % k
+
+
+@pytest.mark.parametrize('B,T', [(5, 4), (32, 20), (64, 20), (200, 6), (256, 20)])
+def test_persistent_gru_equals_the_stepwise_chain(B, T):
+    """ekaid_gru_seq_fwd_persistent / _bwd_persistent (one launch per direction, one seam per step) against the step-wise chain
+    (ekaid_gru_seq_fwd / _bwd under ekaid_set_seq_mode(0)): states, saved gate activations, both gradient outputs; bit-identical
+    relaunch.   ref: language_model.py:106-115 (nn.GRU, gate order r, z, n)."""
+    from ekaid_amd import hip
+    hip.load()
+    L = hip.lib()
+    H = 1024
+    g = torch.Generator().manual_seed(B * 7 + T)
+    f32 = dict(device='cuda', dtype=torch.float32)
+    gi = (torch.randn(B, T, 3 * H, generator=g) * 0.7).cuda()
+    w_hh = (torch.randn(3 * H, H, generator=g) * H ** -0.5).cuda()
+    b_hh = (torch.randn(3 * H, generator=g) * 0.1).cuda()
+    h0 = (torch.randn(B, H, generator=g) * 0.3).cuda()
+    dout = (torch.randn(B, T, H, generator=g) * 0.1).cuda()
+    st = hip.stream()
+
+    def run(persistent):
+        hall = torch.full((T + 1, B, H), float('nan'), **f32)
+        hall[0] = h0
+        save = torch.full((T, B, 4 * H), float('nan'), **f32)
+        dgi = torch.full((B, T, 3 * H), float('nan'), **f32)
+        dgh = torch.full((T, B, 3 * H), float('nan'), **f32)
+        if persistent:
+            nf, nb = L.ekaid_gru_seq_persistent_workspace_bytes(B, T, H, 0), L.ekaid_gru_seq_persistent_workspace_bytes(B, T, H, 1)
+            assert nf > 0 and nb > 0
+            ws = torch.empty(max(nf, nb), dtype=torch.uint8, device='cuda')
+            hip.check(L.ekaid_gru_seq_fwd_persistent(gi.data_ptr(), w_hh.data_ptr(), b_hh.data_ptr(), B, T, H, hall.data_ptr(), save.data_ptr(),
+                                                     ws.data_ptr(), nf, st), 'gru_seq_fwd_persistent')
+            hip.check(L.ekaid_gru_seq_bwd_persistent(dout.data_ptr(), w_hh.data_ptr(), hall.data_ptr(), save.data_ptr(), B, T, H, dgi.data_ptr(),
+                                                     dgh.data_ptr(), ws.data_ptr(), nb, st), 'gru_seq_bwd_persistent')
+            torch.cuda.synchronize()
+            off = L.ekaid_speaker_seq_persistent_status_ptr(ws.data_ptr()) - ws.data_ptr()
+            assert int(ws[off:off + 4].view(torch.int32).item()) == 0
+        else:
+            old = L.ekaid_get_seq_mode()
+            hip.check(L.ekaid_set_seq_mode(0), 'set_seq_mode')
+            try:
+                nf, nb = L.ekaid_gru_seq_workspace_bytes(B, T, H, 0), L.ekaid_gru_seq_workspace_bytes(B, T, H, 1)
+                ws = torch.empty(max(nf, nb, 256), dtype=torch.uint8, device='cuda')
+                hip.check(L.ekaid_gru_seq_fwd(gi.data_ptr(), w_hh.data_ptr(), b_hh.data_ptr(), B, T, H, hall.data_ptr(), save.data_ptr(),
+                                              ws.data_ptr(), nf, st), 'gru_seq_fwd')
+                hip.check(L.ekaid_gru_seq_bwd(dout.data_ptr(), w_hh.data_ptr(), hall.data_ptr(), save.data_ptr(), B, T, H, dgi.data_ptr(),
+                                              dgh.data_ptr(), ws.data_ptr(), nb, st), 'gru_seq_bwd')
+            finally:
+                L.ekaid_set_seq_mode(old)
+        torch.cuda.synchronize()
+        return {'hall': hall, 'save': save, 'dgi': dgi, 'dgh': dgh}
+    ref, got, again = run(False), run(True), run(True)
+    for k in ref:
+        x, y = ref[k].double(), got[k].double()
+        assert torch.isfinite(y).all(), k
+        err = float((x - y).abs().max() / x.abs().max())
+        assert err <= TOL, '%s: %.3e' % (k, err)
+        assert torch.equal(got[k], again[k]), 'persistent GRU is not deterministic in %s' % k
