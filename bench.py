@@ -343,6 +343,10 @@ def main():
     from ekaid_amd.synthetic import make_batch, slice_batch
     hip.load()
     hip.check(hip.lib().ekaid_init(local_rank), 'ekaid_init')
+    if world > max(torch.cuda.device_count(), 1):
+        # several ranks on one GPU (the single-GPU plumbing tests): two processes' persistent sequence kernels cannot both have all
+        # their workgroups resident, their seams would time out -- the launch-per-product chains have no such requirement
+        hip.check(hip.lib().ekaid_set_seq_mode(0), 'set_seq_mode')
     if args.real_only:
         print(json.dumps({'real_b64': real_data_loop(args.graph)}))
         return
@@ -417,6 +421,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_val = float(loss.item())
+    hip.seq_status_check()
     # host-side cost of issuing one step (GPU idle at the start, no synchronisation inside): the lower bound the
     # launch path puts on the step time -- for the mode that was timed and for the eager launch path
     torch.cuda.synchronize()

@@ -34,7 +34,8 @@ struct DeviceState {
     std::atomic<int> gemm_mode{-1};
     std::atomic<int> seq_mode{-1};
     std::atomic<const unsigned long long*> epoch{nullptr};
-    std::atomic<double*> scratch{nullptr};        // two-stage reduction partials (pointwise.hip), device memory of THIS device
+    std::atomic<double*> scratch{nullptr};
+    std::atomic<unsigned*> seq_status{nullptr};   // device word the persistent sequence kernels set when a seam times out (sticky)        // two-stage reduction partials (pointwise.hip), device memory of THIS device
     std::atomic<bool> attr[ATTR_SLOTS];
 };
 static DeviceState g_dev[MAX_DEVICES];
@@ -87,6 +88,15 @@ double* device_scratch(size_t bytes) {
     if (!s.scratch.compare_exchange_strong(expected, p)) { (void)hipFree(p); p = expected; }
     return p;
 }
+unsigned* seq_status_ptr() {
+    DeviceState& s = device_state();
+    unsigned* p = s.seq_status.load();
+    if (p) return p;
+    if (hipMalloc(&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    unsigned* expected = nullptr;
+    if (!s.seq_status.compare_exchange_strong(expected, p)) { (void)hipFree(p); p = expected; }
+    return p;
+}
 bool func_attr_once(int slot) {
     if (slot < 0 || slot >= ATTR_SLOTS) return true;
     bool expected = false;
@@ -126,6 +136,24 @@ extern "C" int ekaid_set_seq_mode(int mode) {
     return EKAID_OK;
 }
 extern "C" int ekaid_get_seq_mode(void) { return ekaid::seq_mode(); }
+
+extern "C" int ekaid_seq_status_read(unsigned* host_value, void* stream) {
+    if (!host_value) { ekaid::set_error("ekaid_seq_status_read: null pointer"); return EKAID_ERR_ARG; }
+    unsigned* p = ekaid::seq_status_ptr();
+    if (!p) { ekaid::set_error("ekaid_seq_status_read: no status word"); return EKAID_ERR_LAUNCH; }
+    if (hipMemcpyAsync(host_value, p, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+        (void)hipGetLastError();
+        ekaid::set_error("ekaid_seq_status_read: copy failed");
+        return EKAID_ERR_LAUNCH;
+    }
+    return EKAID_OK;
+}
+extern "C" int ekaid_seq_status_clear(void* stream) {
+    unsigned* p = ekaid::seq_status_ptr();
+    if (!p || hipMemsetAsync(p, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess) { (void)hipGetLastError(); ekaid::set_error("ekaid_seq_status_clear failed"); return EKAID_ERR_LAUNCH; }
+    return EKAID_OK;
+}
 
 extern "C" int ekaid_version(void) { return EKAID_ABI_VERSION; }
 extern "C" const char* ekaid_last_error(void) { return ekaid::g_err; }

@@ -46,6 +46,7 @@ struct PFwd {
     const float *bef, *diff, *aft, *GXA, *GXL;
     float *HA, *CA, *HL, *CL, *SA, *SL, *G1D, *MW, *VP, *DP, *PW, *PA, *AT, *GT, *GA;
     unsigned* sync;
+    unsigned* status;                 // per-device sticky word: non-zero = a seam timed out (api.hip: seq_status_ptr)
     unsigned long long* trace;        // NULL or [G][T][16] stamps (s_memrealtime, 100 MHz)
     // workspace: hand-off buffers (fragment-major unless noted) and the per-call linear maps of gate-MLP layer 1
     float *HLfm, *HAfm /* [2] */, *G1fm, *GAfm, *MWPW /* [Bp][32] row-major: mw 0..2, pw 16..31 */, *LHP /* [nrb][R/4][256] */;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
     const int l15 = lane & 15, kq4 = (lane >> 4) * 4;
     const int row = tid >> 4, col = tid & 15;                    // element of a reduced tile
     const unsigned shard = xcc_id();
-    unsigned* const status = a.sync + (NSEAM * SHARDS * LINE);
+    unsigned* const status = a.status;
     float* const jobsA_lds = lds + L::fixed;
     float* const tilesD_lds = jobsA_lds + a.jobsA * L::per_jobA;
     float* const tilesE_lds = tilesD_lds + a.jobsD * MTD * L::per_tileD;
@@ -616,6 +617,8 @@ extern "C" int ekaid_speaker_seq_fwd_persistent(const ekaid_speaker_seq_t* d, vo
     a.HA = d->HA; a.CA = d->CA; a.HL = d->HL; a.CL = d->CL; a.SA = d->SA; a.SL = d->SL; a.G1D = d->G1D; a.MW = d->MW; a.VP = d->VP;
     a.DP = d->DP; a.PW = d->PW; a.PA = d->PA; a.AT = d->AT; a.GT = d->GT; a.GA = d->GA;
     a.sync = (unsigned*)workspace;
+    a.status = seq_status_ptr();
+    if (!a.status) { set_error("persistent sequence kernel: cannot allocate the status word"); return EKAID_ERR_LAUNCH; }
     a.trace = persist_trace_enabled() ? reinterpret_cast<unsigned long long*>(ws + pl.o_trace) : nullptr;
     a.HLfm = (float*)(ws + pl.o_hl); a.HAfm = (float*)(ws + pl.o_ha); a.G1fm = (float*)(ws + pl.o_g1); a.GAfm = (float*)(ws + pl.o_ga);
     a.MWPW = (float*)(ws + pl.o_mwpw); a.LHP = (float*)(ws + pl.o_lhp);
@@ -640,8 +643,10 @@ extern "C" int ekaid_speaker_seq_fwd_persistent(const ekaid_speaker_seq_t* d, vo
     return EKAID_ERR_UNSUPPORTED;
 }
 
-/* status word of the last persistent launch on this workspace (device pointer to one unsigned; 0 = fine, 0x100 + seam = a seam
- * did not open in time and the launch was abandoned) */
+/* device pointer to the per-device status word of the persistent sequence kernels: 0 = every launch so far was fine; 0x100 / 0x200 /
+ * 0x300 + seam = a seam of a decoder forward / backward / GRU launch did not open in time and that launch (and, the word being sticky,
+ * every later one) was abandoned.  (The argument is ignored: kept for callers of ABI 6 drafts.) */
 extern "C" const unsigned* ekaid_speaker_seq_persistent_status_ptr(const void* workspace) {
-    return workspace ? reinterpret_cast<const unsigned*>(workspace) + NSEAM * SHARDS * LINE : nullptr;
+    (void)workspace;
+    return seq_status_ptr();
 }

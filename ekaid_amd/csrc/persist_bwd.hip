@@ -42,6 +42,7 @@ struct PBwd {
     float *DCAT, *DZFC, *DWP, *DZ2, *d_bef, *d_diff, *d_aft, *dFm;
     float *DGLfm, *DZ2fm, *DG1fm, *DP1fm, *DGAfm, *PART1 /* [nrb][G1/16][16][20] */, *PARTG /* [nrb][A/16][16][4] */, *DZ /* [Bp][4] */;
     unsigned* sync;
+    unsigned* status;                 // per-device sticky word: non-zero = a seam timed out (api.hip: seq_status_ptr)
     unsigned long long* trace;
     int jobsU, jobs2, jobs3;
     uint64_t seeds[3 * PMAX_T];
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256, 1) void spk_seq_bwd_persistent_kernel(const PB
     const int l15 = lane & 15, kq4 = (lane >> 4) * 4;
     const int row = tid >> 4, col = tid & 15;
     const unsigned shard = xcc_id();
-    unsigned* const status = a.sync + (NSEAM * SHARDS * LINE);
+    unsigned* const status = a.status;
     float* const slotsU = lds + L_fixed;                         // per job: dhl_acc | dha_acc | dc_l | dc_a   (4 x 256)
     float* const slots2 = slotsU + a.jobsU * 1024;               // per job: feat_m slices (3 x 256) | d feat_m accumulators (3 x 256)
     float* const slots3 = slots2 + a.jobs2 * 1536;               // per job: F_m slices (3 x 256) | dF_m accumulators (3 x 256)
@@ -472,6 +473,8 @@ extern "C" int ekaid_speaker_seq_bwd_persistent(const ekaid_speaker_seq_bwd_t* b
     a.DGLfm = (float*)(ws + pl.o_dgl); a.DZ2fm = (float*)(ws + pl.o_dz2); a.DG1fm = (float*)(ws + pl.o_dg1); a.DP1fm = (float*)(ws + pl.o_dp1);
     a.DGAfm = (float*)(ws + pl.o_dga); a.PART1 = (float*)(ws + pl.o_p1); a.PARTG = (float*)(ws + pl.o_pg); a.DZ = (float*)(ws + pl.o_dz);
     a.sync = (unsigned*)workspace;
+    a.status = seq_status_ptr();
+    if (!a.status) { set_error("persistent sequence kernel: cannot allocate the status word"); return EKAID_ERR_LAUNCH; }
     a.trace = persist_trace_enabled() ? reinterpret_cast<unsigned long long*>(ws + pl.o_trace) : nullptr;
     a.jobsU = pl.jobsU; a.jobs2 = pl.jobs2; a.jobs3 = pl.jobs3;
     if (d->seeds) memcpy(a.seeds, d->seeds, sizeof(uint64_t) * 3 * d->T);

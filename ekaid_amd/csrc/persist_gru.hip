@@ -23,6 +23,7 @@ struct PGru {
     float *dgi, *dgh;                    // backward: [B][T][3H], [T][B][3H]
     float *Hfm /* fwd: [2][Bp][H] */, *Dfm /* bwd: [2][Bp][3H] */;
     unsigned* sync;
+    unsigned* status;                 // per-device sticky word: non-zero = a seam timed out (api.hip: seq_status_ptr)
 };
 
 struct Pre3g { float r, z, n; };
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256, 1) void gru_seq_fwd_persistent_kernel(const PG
     const int B = a.B, G = a.G, nrb = a.nrb, T = a.T;
     const int l15 = lane & 15, kq4 = (lane >> 4) * 4, row = tid >> 4, col = tid & 15;
     const unsigned shard = xcc_id();
-    unsigned* const status = a.sync + NSEAM * SHARDS * LINE;
+    unsigned* const status = a.status;
     Ctx c = {tid, lane, wave, wg, G, nrb, B, row, col, lds + L_red, 0, status, reinterpret_cast<int*>(lds), nullptr};
     float* const hstate = lds + L_fixed;                        // per job: h_{t-1} of the owned (row, unit) elements
     const long long Bp = 16ll * nrb, BH = (long long)B * H;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256, 1) void gru_seq_bwd_persistent_kernel(const PG
     const int B = a.B, G = a.G, nrb = a.nrb, T = a.T;
     const int l15 = lane & 15, kq4 = (lane >> 4) * 4, row = tid >> 4, col = tid & 15;
     const unsigned shard = xcc_id();
-    unsigned* const status = a.sync + NSEAM * SHARDS * LINE;
+    unsigned* const status = a.status;
     Ctx c = {tid, lane, wave, wg, G, nrb, B, row, col, lds + L_red, 0, status, reinterpret_cast<int*>(lds), nullptr};
     float* const st = lds + L_fixed;                            // per job: carry (d gh_{t+1} . W_hh) | direct term z * d of step t+1
     const long long Bp = 16ll * nrb, BH = (long long)B * H;
@@ -217,6 +218,8 @@ extern "C" int ekaid_gru_seq_fwd_persistent(const float* gi, const float* w_hh, 
     a.gi = gi; a.w = w_hh; a.b_hh = b_hh; a.hall = hall; a.save = save;
     a.Hfm = (float*)((char*)workspace + pl.o_hfm);
     a.sync = (unsigned*)workspace;
+    a.status = seq_status_ptr();
+    if (!a.status) { set_error("persistent sequence kernel: cannot allocate the status word"); return EKAID_ERR_LAUNCH; }
     if (hipMemsetAsync(workspace, 0, al256((size_t)SYNC_WORDS * 4), st) != hipSuccess) { (void)hipGetLastError(); set_error("ekaid_gru_seq_fwd_persistent: memset failed"); return EKAID_ERR_LAUNCH; }
     return launch_gru(gru_seq_fwd_persistent_kernel<GH>, a, pl, st, 45, "gru_seq_fwd_persistent");
 }
@@ -239,6 +242,8 @@ extern "C" int ekaid_gru_seq_bwd_persistent(const float* dout, const float* w_hh
     a.dout = dout; a.dgi = dgi; a.dgh = dgh;
     a.Dfm = (float*)(ws + pl.o_dfm);
     a.sync = (unsigned*)workspace;
+    a.status = seq_status_ptr();
+    if (!a.status) { set_error("persistent sequence kernel: cannot allocate the status word"); return EKAID_ERR_LAUNCH; }
     const int rc = ekaid_transpose(w_hh, 3 * GH, GH, GH, (float*)(ws + pl.o_wt), 3 * GH, stream);      // W_hh^T [H][3H]
     if (rc) return rc;
     if (hipMemsetAsync(workspace, 0, al256((size_t)SYNC_WORDS * 4), st) != hipSuccess) { (void)hipGetLastError(); set_error("ekaid_gru_seq_bwd_persistent: memset failed"); return EKAID_ERR_LAUNCH; }

@@ -6,7 +6,7 @@ there is no CPU or ATen fallback behind it.
 """
 import ctypes
 import os
-from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_longlong, c_size_t,
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_longlong, c_size_t, c_uint,
                     c_uint64, c_void_p)
 
 import torch
@@ -181,6 +181,8 @@ SIGNATURES = {
     'ekaid_speaker_seq_bwd_persistent_workspace_bytes': [POINTER(SpeakerSeq)],
     'ekaid_speaker_seq_bwd_persistent': [POINTER(SpeakerSeqBwd), P, P, c_size_t, P],
     'ekaid_gemm_plan_query': [POINTER(GemmDesc), POINTER(c_int), POINTER(c_int)],
+    'ekaid_seq_status_read': [POINTER(c_uint), P],
+    'ekaid_seq_status_clear': [P],
     'ekaid_set_seq_mode': [I],
     'ekaid_get_seq_mode': [],
     'ekaid_softmax_fwd': [P, P, L, I, I, P],
@@ -251,6 +253,17 @@ def check(rc, what=''):
     _calls += 1
     if rc != 0:
         raise EkaidError('%s failed (rc=%d): %s' % (what or 'ekaid call', rc, last_error()))
+
+
+def seq_status_check(what='persistent sequence kernel'):
+    """Raise if a persistent sequence kernel (csrc/persist*.hip) abandoned a launch since the last clear: a seam timed out -- typically
+    because not all of its workgroups were resident (another process sharing the GPU).  Synchronises the current stream."""
+    v = c_uint(0)
+    check(lib().ekaid_seq_status_read(ctypes.byref(v), stream()), 'seq_status_read')
+    if v.value:
+        lib().ekaid_seq_status_clear(stream())
+        raise EkaidError('%s: a seam did not open in time (status 0x%x): the launch was abandoned and its outputs are invalid. Is another '
+                         'process using this GPU? (EKAID_SEQ_MODE=stepwise selects the launch-per-product chains)' % (what, v.value))
 
 
 def ptr(t):

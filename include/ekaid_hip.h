@@ -447,14 +447,20 @@ int ekaid_speaker_seq_bwd(const ekaid_speaker_seq_bwd_t* d, void* workspace, siz
  * agree with ekaid_speaker_seq_fwd to f32 rounding (different summation order), deterministic from run to run.
  * Supported: R = 512, A = 1024, P = 16, G1 = 2R + A, T <= 96, batch up to what the per-workgroup LDS state allows (256 on a 256-CU
  * part); anything else -> EKAID_ERR_UNSUPPORTED (workspace_bytes query returns 0).  `workspace` (256-byte aligned) starts with the
- * seam counters, zeroed by a memset in front of every launch; ekaid_speaker_seq_persistent_status_ptr(workspace) is a DEVICE pointer
- * to one word: 0 after a good launch, 0x100 + seam if a seam did not open within ~0.5 s and the launch was abandoned.
+ * seam counters, zeroed by a memset in front of every launch; ekaid_speaker_seq_persistent_status_ptr() is a DEVICE pointer to the
+ * per-device status word (0 = fine; see ekaid_seq_status_read).
  * ekaid_set_seq_mode(1) makes ekaid_speaker_seq_fwd / ekaid_speaker_greedy_steps route supported shapes here (0: step-wise chain;
  * default from EKAID_SEQ_MODE = stepwise | persistent, see csrc/api.hip).
  * ref: dynamic_speaker_change_pos.py:94-131 inside :196-222 */
 size_t ekaid_speaker_seq_persistent_workspace_bytes(const ekaid_speaker_seq_t* d);
 int ekaid_speaker_seq_fwd_persistent(const ekaid_speaker_seq_t* d, void* workspace, size_t workspace_bytes, void* stream);
 const unsigned* ekaid_speaker_seq_persistent_status_ptr(const void* workspace);
+/* The persistent sequence kernels never hang: a seam that does not open within ~0.5 s (e.g. because another process' kernels keep some
+ * of the CUs, so that not all workgroups of the launch are resident) sets a per-device, STICKY status word and every workgroup leaves;
+ * the outputs of that launch are garbage.  ekaid_seq_status_read copies the word to the host (synchronises `stream`): 0 = fine;
+ * callers check it where they synchronise anyway (ekaid_amd: at log intervals, at the end of a run, in the tests). */
+int ekaid_seq_status_read(unsigned* host_value, void* stream);
+int ekaid_seq_status_clear(void* stream);
 int ekaid_set_seq_mode(int mode);
 int ekaid_get_seq_mode(void);
 

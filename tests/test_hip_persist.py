@@ -202,8 +202,7 @@ def test_persistent_gru_equals_the_stepwise_chain(B, T):
             hip.check(L.ekaid_gru_seq_bwd_persistent(dout.data_ptr(), w_hh.data_ptr(), hall.data_ptr(), save.data_ptr(), B, T, H, dgi.data_ptr(),
                                                      dgh.data_ptr(), ws.data_ptr(), nb, st), 'gru_seq_bwd_persistent')
             torch.cuda.synchronize()
-            off = L.ekaid_speaker_seq_persistent_status_ptr(ws.data_ptr()) - ws.data_ptr()
-            assert int(ws[off:off + 4].view(torch.int32).item()) == 0
+            hip.seq_status_check('persistent GRU')
         else:
             old = L.ekaid_get_seq_mode()
             hip.check(L.ekaid_set_seq_mode(0), 'set_seq_mode')

@@ -43,6 +43,15 @@ def problem(B, T, seed=0, train=False, dev='cuda'):
     return {'B': B, 'T': T, 'w': w, 'init': init, 'seeds': seeds, 'p': (0.5, 0.5) if train else (0.0, 0.0), 'dev': dev}
 
 
+def seq_status():
+    """The per-device status word of the persistent kernels (0 = fine), cleared after reading."""
+    v = ctypes.c_uint(0)
+    hip.check(hip.lib().ekaid_seq_status_read(ctypes.byref(v), hip.stream()), 'seq_status_read')
+    if v.value:
+        hip.lib().ekaid_seq_status_clear(hip.stream())
+    return v.value
+
+
 def buffers(pr):
     B, T, dev = pr['B'], pr['T'], pr['dev']
     f32 = dict(device=dev, dtype=torch.float32)
@@ -86,8 +95,7 @@ def run(pr, mode, iters=0):
         torch.cuda.synchronize()
         status = 0
         if mode == 1:
-            off = L.ekaid_speaker_seq_persistent_status_ptr(ws.data_ptr()) - ws.data_ptr()
-            status = int(ws[off:off + 4].view(torch.int32).item())
+            status = seq_status()
         ms = None
         if iters:
             for _ in range(3):
@@ -168,8 +176,7 @@ def run_bwd(pr, fwd_out, mode, iters=0, seed=7):
     torch.cuda.synchronize()
     status = 0
     if mode == 1:
-        off = L.ekaid_speaker_seq_persistent_status_ptr(ws.data_ptr()) - ws.data_ptr()
-        status = int(ws[off:off + 4].view(torch.int32).item())
+        status = seq_status()
         if os.environ.get('EKAID_PERSIST_TRACE') == '1':
             nb = (256 * T * 128 + 255) // 256 * 256
             run_bwd.trace = ws[need - nb:need - nb + 256 * T * 128].view(torch.int64).view(256, T, 16).cpu()

@@ -170,6 +170,8 @@ def main(argv=None):
         own_pg = True
     hip.load()
     hip.check(hip.lib().ekaid_init(local_rank), 'ekaid_init')
+    if world > max(torch.cuda.device_count(), 1):      # ranks sharing a GPU: no persistent sequence kernels (they need every CU at once)
+        hip.check(hip.lib().ekaid_set_seq_mode(0), 'set_seq_mode')
     random.seed(args.seed)
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)          # identical default initialisation and sample order on every rank
@@ -315,6 +317,7 @@ def main(argv=None):
             if t_clock is not None and timing is None and t == cfg.train.max_iter:
                 timing = stop_clock()           # before the final snapshot / evaluation
             if t % cfg.train.log_interval == 0 or t == cfg.train.max_iter:
+                hip.seq_status_check()          # (synchronises, like the loss read below) a persistent kernel never hangs, it reports
                 val = float(loss.item())
                 loss_avg.update(val, 2 * per_gpu)
                 last = {'speaker_loss': float(speaker_loss.item()), 'total_loss': val, 'avg_total_loss': loss_avg.avg}
