@@ -11,7 +11,7 @@ namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int NSEAM = 6, SHARDS = 8, LINE = 32;                   // seams (5 per step + the prologue); counter shards (one per XCD); words per 128-B line
+constexpr int NSEAM = 8, SHARDS = 8, LINE = 32;                   // seams (5 per step, the prologue, 2 of greedy decoding); counter shards (one per XCD); words per 128-B line
 constexpr int SYNC_WORDS = NSEAM * SHARDS * LINE + LINE;          // + one line for the status word
 constexpr unsigned SPIN_LIMIT = 400000u;                          // polls (~1 us each) before a seam is declared dead
 constexpr int PMAX_T = 96;                                        // steps per launch (seeds travel by value in the kernel arguments)

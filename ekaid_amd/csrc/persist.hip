@@ -52,6 +52,11 @@ struct PFwd {
     float *HLfm, *HAfm /* [2] */, *G1fm, *GAfm, *MWPW /* [Bp][32] row-major: mw 0..2, pw 16..31 */, *LHP /* [nrb][R/4][256] */;
     const float *Fm /* [3][B][G1] */, *Wp /* [G1][P] */, *cp /* [G1] */;
     int We, jobsA, jobsD;
+    // greedy decoding (template flag GREEDY): the step loop additionally forms the logits, picks the tokens and feeds them back
+    int V, seq_len, t_base;
+    const float *emb, *bih_l, *w_lo, *b_lo;
+    long long* it; int* unfinished; long long* seq; float* seq_logp; int* n_unfinished;
+    float *XTfm /* [Bp][512]: relu(emb[token]) padded with zeros, fragment-major */, *LOG /* [Bp][160] logits, row-major */;
     uint64_t seeds[3 * PMAX_T];
 };
 
@@ -73,13 +78,13 @@ struct Lds {
     // then per phase-E (job, tile) slot: clang 64
     static constexpr int per_jobA = 256 + 64 + 768;
     static constexpr int per_tileD = 768;
-    static constexpr int per_tileE = 64;
+    static constexpr int per_tileE = 64 + 256;                  // language-LSTM cell state | (greedy) word-side gates of the tile
 };
 
 struct Pre3 { float a, b, c; };
 struct PreE { float gx[4], lh[4]; };
 
-template <int R, int A, int P, int MTD, int MTE>
+template <int R, int A, int P, int MTD, int MTE, bool GREEDY>
 __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PFwd a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using L = Lds<R, A, P>;
@@ -153,6 +158,9 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
     for (int m = 0; m < MTD; ++m) bD[m] = a.b_g2[16 * (tD * MTD + m) + col];
 #pragma unroll
     for (int m = 0; m < MTE; ++m) bE[m] = a.bhh_l[gate * R + 4 * (tE * MTE + m) + ucol];
+    float bIh[MTE];
+#pragma unroll
+    for (int m = 0; m < MTE; ++m) bIh[m] = GREEDY ? a.bih_l[gate * R + 4 * (tE * MTE + m) + ucol] : 0.f;
 
     const __amdgpu_buffer_rsrc_t rsWcat = make_rsrc(a.Wcat, (long long)NW * R * 4), rsWhh = make_rsrc(a.whh_a, 4ll * R * R * 4),
                                  rsWg2 = make_rsrc(a.w_g2, (long long)A * G1 * 4), rsWil = make_rsrc(a.wih_l, 4ll * R * (a.We + A) * 4);
@@ -174,9 +182,25 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
             const float v = gr < B ? src[(long long)gr * R + kb * 16 + kq * 4 + e] : 0.f;
             store_sc1((which ? a.HAfm : a.HLfm) + ((long long)cc << 8) + tid, v);
         }
+        if (GREEDY) {                                            // word input of the first step: relu(emb[token]) of the tokens handed in
+            const __amdgpu_buffer_rsrc_t rsXT = make_rsrc(a.XTfm, Bp * 512 * 4);
+            for (int r = wg; r < B; r += G) {
+                if (tid < 128) {
+                    const long long tok = a.it[r];
+                    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+                    if (4 * tid < a.We) {
+                        x = *reinterpret_cast<const f32x4*>(a.emb + tok * a.We + 4 * tid);
+#pragma unroll
+                        for (int e2 = 0; e2 < 4; ++e2) x[e2] = x[e2] > 0.f ? x[e2] : 0.f;
+                    }
+                    bstore4_sc1(rsXT, fm_chunk(r >> 4, tid >> 2, 32) + (unsigned)(((tid & 3) * 16 + (r & 15)) * 16), x);
+                }
+            }
+        }
         seam_arrive(a.sync + 5 * SHARDS * LINE, shard);
         __syncthreads();
     }
+    const __amdgpu_buffer_rsrc_t rsXTfm = make_rsrc(a.XTfm, Bp * 512 * 4), rsWlo = make_rsrc(a.w_lo, (long long)(GREEDY ? a.V : 1) * R * 4);
 
     for (int t = 0; t < a.T; ++t) {
         float* HAn = a.HA + (long long)(t + 1) * BR;
@@ -186,6 +210,7 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
         const __amdgpu_buffer_rsrc_t rsHAr = make_rsrc(HAfm_r, Bp * R * 4), rsHAw = make_rsrc(HAfm_w, Bp * R * 4);
         const DropSeed sv = {a.seeds[3 * t], a.ep}, sd = {a.seeds[3 * t + 1], a.ep}, sg = {a.seeds[3 * t + 2], a.ep};
         const unsigned tgt = (unsigned)G * (unsigned)(t + 1);
+        const int ts = GREEDY ? 0 : t;                            // greedy decoding: the activation buffers are ONE step large
         c.trace = a.trace ? a.trace + ((long long)wg * a.T + t) * 16 : nullptr;
         stamp(c, 0);
 
@@ -195,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
         {
             f32x4 wAh[NBR], wAa[NBR], w3[NBR], w4[NBR], w2[NBR], x[NBR];
             float gxa_next = 0.f;
-            auto gxa_of = [&](int rb) { return a.GXA[((long long)t * B + min(rb * 16 + row, B - 1)) * 4 * R + gate * R + 4 * tU + ucol]; };
+            auto gxa_of = [&](int rb) { return a.GXA[((long long)ts * B + min(rb * 16 + row, B - 1)) * 4 * R + gate * R + 4 * tU + ucol]; };
             if (njA) {
                 const unsigned woA = (unsigned)((gate_row_l + 4 * tU) * R) * 4u + kwR;
 #pragma unroll
@@ -256,7 +281,7 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
                             const int unit = 4 * tU + ucol;
                             const float pre = v[0] + gxa + bA;
                             const float act = gate == 2 ? tanhf(pre) : sigm(pre);
-                            if (grow < B) a.SA[((long long)t * B + grow) * 4 * R + gate * R + unit] = act;
+                            if (grow < B) a.SA[((long long)ts * B + grow) * 4 * R + gate * R + unit] = act;
                             const float fg = __shfl_down(act, 4, 64), gg = __shfl_down(act, 8, 64), og = __shfl_down(act, 12, 64);
                             float hn = 0.f;
                             if (gate == 0) {
@@ -281,7 +306,7 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
                             const int k = 16 * tU + col;
                             float y = v[3] + bP1;
                             y = (y > 0.f ? y : 0.f) * dropout_scale(sv, (uint64_t)grow * R + k, a.p_lm, a.inv_lm);
-                            if (grow < B) store_sc1(a.VP + ((long long)t * B + grow) * R + k, y);
+                            if (grow < B) store_sc1(a.VP + ((long long)ts * B + grow) * R + k, y);
                         }
                     }
                 }
@@ -295,7 +320,7 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
 
         // =================== phase B: row-local module weights and POS weights ===================
         {
-            const __amdgpu_buffer_rsrc_t rv = make_rsrc(a.VP + (long long)t * BR, BR * 4);
+            const __amdgpu_buffer_rsrc_t rv = make_rsrc(a.VP + (long long)ts * BR, BR * 4);
             int rs = 0;
             for (int r = wg; r < B; r += G, ++rs) {
                 if (rs) __syncthreads();
@@ -338,7 +363,7 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
 #pragma unroll
                     for (int cc = 0; cc < 8; ++cc) s += lds[L::pz + j * 8 + cc];
                     const float zz = (s + lds[L::bsm + 4 + j]) * dropout_scale(sd, (uint64_t)r * P + j, a.p_pos, a.inv_pos);
-                    a.DP[((long long)t * B + r) * P + j] = zz;
+                    a.DP[((long long)ts * B + r) * P + j] = zz;
                     float m2 = zz;
 #pragma unroll
                     for (int o = 8; o > 0; o >>= 1) m2 = fmaxf(m2, __shfl_xor(m2, o, 16));
@@ -348,7 +373,7 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
                     for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
                     const float pw = ee / sum;
                     lds[L::sz + j] = pw;
-                    a.PW[((long long)t * B + r) * P + j] = pw;
+                    a.PW[((long long)ts * B + r) * P + j] = pw;
                     store_sc1(a.MWPW + (long long)r * 32 + 16 + j, pw);
                 }
             }
@@ -374,16 +399,16 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
                                     s[e] += (wv[0] * pv[0] + wv[1] * pv[1]) + (wv[2] * pv[2] + wv[3] * pv[3]);
                                 }
                             }
-                            *reinterpret_cast<f32x4*>(a.PA + ((long long)t * B + r) * (R + A) + k) = s;
+                            *reinterpret_cast<f32x4*>(a.PA + ((long long)ts * B + r) * (R + A) + k) = s;
                         }
                     }
                 } else {                                         // several rows per workgroup: from the stored POS weights
                     for (int k = tid; k < R; k += 256) {
                         float s = lds[L::bsm + 4 + P + k];
-                        const float* pwr = a.PW + ((long long)t * B + r) * P;
+                        const float* pwr = a.PW + ((long long)ts * B + r) * P;
 #pragma unroll
                         for (int j = 0; j < P; ++j) s += a.w_p2[(long long)k * P + j] * pwr[j];
-                        a.PA[((long long)t * B + r) * (R + A) + k] = s;
+                        a.PA[((long long)ts * B + r) * (R + A) + k] = s;
                     }
                 }
             }
@@ -407,7 +432,7 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
 #pragma unroll
                 for (int j = 0; j < P; ++j) y += mp[16 + j] * wp[j];
                 y = (y > 0.f ? y : 0.f) * dropout_scale(sg, (uint64_t)grow * G1 + nn, a.p_lm, a.inv_lm);
-                if (grow < B) a.G1D[((long long)t * B + grow) * G1 + nn] = y;
+                if (grow < B) a.G1D[((long long)ts * B + grow) * G1 + nn] = y;
                 const f32x4 y4 = gather4(y);
                 if ((col & 3) == 0) bstore4_sc1(rsG1fm, fm_chunk(rb, tU, KBG) + (unsigned)(((col >> 2) * 16 + row) * 16), y4);
             }
@@ -433,11 +458,11 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
                         const float gte = sigm(v[m] + bD[m]);
                         const float ga = gte * att;
                         if (grow < B) {
-                            const long long o = ((long long)t * B + grow) * A + nn;
+                            const long long o = ((long long)ts * B + grow) * A + nn;
                             a.GT[o] = gte;
                             a.GA[o] = ga;
                             a.AT[o] = att;
-                            a.PA[((long long)t * B + grow) * (R + A) + R + nn] = att;
+                            a.PA[((long long)ts * B + grow) * (R + A) + R + nn] = att;
                         }
                         const f32x4 g4 = gather4(ga);
                         if ((col & 3) == 0) bstore4_sc1(rsGAfm, fm_chunk(rb, tau, KBA) + (unsigned)(((col >> 2) * 16 + row) * 16), g4);
@@ -447,6 +472,21 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
         stamp(c, 11);
         seam_arrive(a.sync + 3 * SHARDS * LINE, shard);
         stamp(c, 12);
+        if (GREEDY) {
+            // word-side gates of the language LSTM, relu(emb[token]) . W_ih[:, :We]^T (K = We padded with zero activations to 512), by the
+            // owners of phase E, kept in LDS; the tokens were fed back behind seam 7 of the previous step (prologue: seam 5)
+            if (!run_mt<NBR, MTE, PreE>(
+                    c, TG_E, [&](int m, int i) { return bload4<0>(rsWil, (unsigned)((gate_row_l + 4 * (tE * MTE + m)) * ldw_l) * 4u + kwR + 64u * i); }, rsXTfm, 32,
+                    t > 0 ? a.sync + 7 * SHARDS * LINE : nullptr, (unsigned)G * (unsigned)t, 0x100u + 7, -1, [&](int, int) { return PreE{}; },
+                    [&](const float (&v)[MTE], const PreE&, int, int n) {
+#pragma unroll
+                        for (int m = 0; m < MTE; ++m) tilesE_lds[(n * MTE + m) * L::per_tileE + 64 + tid] = v[m];
+                    }))
+                return;
+            // every row had stopped at the previous step: the launch ends here (each workgroup reads the same final count behind seam 7,
+            // which every workgroup has just waited for; the half step run so far wrote only states nobody reads)
+            if (t > 0 && __hip_atomic_load(a.n_unfinished + a.t_base + t - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+        }
         // =================== phase E: language-LSTM gates + cell ===================
         if (!run_mt<NBA, MTE, PreE>(
                 c, TG_E, [&](int m, int i) { return bload4<0>(rsWil, (unsigned)((gate_row_l + 4 * (tE * MTE + m)) * ldw_l + a.We) * 4u + kwA + 64u * i); }, rsGAfm, KBA,
@@ -456,7 +496,7 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
                     const int gr = min(rb * 16 + row, B - 1);
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
-                        p.gx[m] = m < MTE ? a.GXL[((long long)t * B + gr) * 4 * R + gate * R + 4 * (tE * MTE + m) + ucol] : 0.f;
+                        p.gx[m] = (m < MTE && !GREEDY) ? a.GXL[((long long)t * B + gr) * 4 * R + gate * R + 4 * (tE * MTE + m) + ucol] : 0.f;
                         p.lh[m] = m < MTE ? load_sc1(a.LHP + (((long long)rb * TILES_U + tE * MTE + m) << 8) + tid) : 0.f;
                     }
                     return p;
@@ -466,9 +506,10 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
 #pragma unroll
                     for (int m = 0; m < MTE; ++m) {
                         const int tau = tE * MTE + m, unit = 4 * tau + ucol;
-                        const float pre = p.gx[m] + (p.lh[m] + v[m]) + bE[m];
+                        const float gxw = GREEDY ? tilesE_lds[(n * MTE + m) * L::per_tileE + 64 + tid] + bIh[m] : p.gx[m];
+                        const float pre = gxw + (p.lh[m] + v[m]) + bE[m];
                         const float act = gate == 2 ? tanhf(pre) : sigm(pre);
-                        if (grow < B) a.SL[((long long)t * B + grow) * 4 * R + gate * R + unit] = act;
+                        if (grow < B) a.SL[((long long)ts * B + grow) * 4 * R + gate * R + unit] = act;
                         const float fg = __shfl_down(act, 4, 64), gg = __shfl_down(act, 8, 64), og = __shfl_down(act, 12, 64);
                         float hn = 0.f;
                         if (gate == 0) {
@@ -489,6 +530,78 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
         stamp(c, 14);
         seam_arrive(a.sync + 4 * SHARDS * LINE, shard);
         stamp(c, 15);
+        if (GREEDY) {
+            // ---- logits = h_lang_t . W_logit^T + b (V columns = ceil(V / 16) tiles in 16 tile slots), eval mode: no output dropout
+            const int tL = wg % 16, vcol = 16 * tL + col;
+            const float blo = vcol < a.V ? a.b_lo[vcol] : 0.f;
+            if (!run_mt<NBR, 1, PreE>(
+                    c, 16, [&](int, int i) { return bload4<0>(rsWlo, (unsigned)(min(16 * tL + l15, a.V - 1) * R) * 4u + kwR + 64u * i); }, rsHLfm, KBR,
+                    a.sync + 4 * SHARDS * LINE, tgt, 0x100u + 4, -1, [&](int, int) { return PreE{}; },
+                    [&](const float (&v)[1], const PreE&, int rb, int) {
+                        const int grow = rb * 16 + row;
+                        if (grow < B && vcol < a.V) store_sc1(a.LOG + (long long)grow * 160 + vcol, v[0] + blo);
+                    }))
+                return;
+            seam_arrive(a.sync + 6 * SHARDS * LINE, shard);
+            if (!seam_wait(a.sync + 6 * SHARDS * LINE, tgt, status, c.ok_lds, 0x100u + 6)) return;
+            // ---- row-local: log-softmax, arg-max (lowest index on ties, token 0 forbidden at the first step), stop flags, next token
+            const int ta = a.t_base + t;
+            for (int r = wg; r < B; r += G) {
+                if (tid < 64) {
+                    float x[3], mx = -INFINITY;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const int v = lane + 64 * q;
+                        x[q] = v < a.V ? load_sc1(a.LOG + (long long)r * 160 + v) : -INFINITY;
+                        mx = fmaxf(mx, x[q]);
+                    }
+                    mx = wave_max(mx);
+                    float sm = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) sm += lane + 64 * q < a.V ? expf(x[q] - mx) : 0.f;
+                    sm = wave_sum(sm);
+                    const float ls = logf(sm);
+                    float best = -INFINITY;
+                    int arg = a.V;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const int v = lane + 64 * q;
+                        float lp = v < a.V ? (x[q] - mx) - ls : -INFINITY;
+                        if (ta == 0 && v == 0) lp = -INFINITY;
+                        if (lp > best) { best = lp; arg = v; }
+                    }
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) {
+                        const float ob = __shfl_xor(best, off, 64);
+                        const int oa = __shfl_xor(arg, off, 64);
+                        if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+                    }
+                    if (lane == 0) {
+                        const int un = ta == 0 ? (arg > 0) : (a.unfinished[r] && arg > 0);
+                        a.unfinished[r] = un;
+                        const long long tok = un ? arg : 0;
+                        a.it[r] = tok;
+                        a.seq[(long long)r * a.seq_len + ta] = tok;
+                        a.seq_logp[(long long)r * a.seq_len + ta] = best;
+                        if (un) atomicAdd(a.n_unfinished + ta, 1);
+                        reinterpret_cast<int*>(lds + L::zpart)[0] = (int)tok;
+                    }
+                }
+                __syncthreads();
+                if (tid < 128) {                                 // relu(emb[token]) -> the word input of the next step, fragment-major
+                    const long long tok = reinterpret_cast<const int*>(lds + L::zpart)[0];
+                    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+                    if (4 * tid < a.We) {
+                        x = *reinterpret_cast<const f32x4*>(a.emb + tok * a.We + 4 * tid);
+#pragma unroll
+                        for (int e2 = 0; e2 < 4; ++e2) x[e2] = x[e2] > 0.f ? x[e2] : 0.f;
+                    }
+                    bstore4_sc1(rsXTfm, fm_chunk(r >> 4, tid >> 2, 32) + (unsigned)(((tid & 3) * 16 + (r & 15)) * 16), x);
+                }
+                __syncthreads();
+            }
+            seam_arrive(a.sync + 7 * SHARDS * LINE, shard);
+        }
     }
 }
 
@@ -565,9 +678,9 @@ bool persistent_plan(const ekaid_speaker_seq_t* d, void* workspace, PersistPlan&
     return true;
 }
 
-template <int MTD, int MTE>
+template <int MTD, int MTE, bool GREEDY = false>
 int launch_fwd(const PFwd& a, const PersistPlan& pl, hipStream_t st, int slot) {
-    auto kern = spk_seq_fwd_persistent_kernel<PR, PA_, PP, MTD, MTE>;
+    auto kern = spk_seq_fwd_persistent_kernel<PR, PA_, PP, MTD, MTE, GREEDY>;
     if (func_attr_once(slot)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             (void)hipGetLastError();
@@ -590,18 +703,23 @@ extern "C" size_t ekaid_speaker_seq_persistent_workspace_bytes(const ekaid_speak
     return pl.total;
 }
 
-extern "C" int ekaid_speaker_seq_fwd_persistent(const ekaid_speaker_seq_t* d, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!d) { set_error("ekaid_speaker_seq_fwd_persistent: null descriptor"); return EKAID_ERR_ARG; }
+namespace ekaid {
+namespace {
+// builds the kernel arguments, runs the prologue products and launches; `gq` != NULL: greedy decoding of steps [t0, t0 + d->T)
+int launch_persistent_fwd(const ekaid_speaker_seq_t* d, const ekaid_speaker_greedy_t* gq, int t0, void* workspace, size_t workspace_bytes, void* stream,
+                          const char* who) {
     PersistPlan pl;
     if (!persistent_plan(d, workspace, pl)) {
-        set_error("ekaid_speaker_seq_fwd_persistent: unsupported shape (R=%d A=%d P=%d G1=%d T=%d B=%d) or device", d->R, d->A, d->P, d->G1, d->T, d->B);
+        set_error("%s: unsupported shape (R=%d A=%d P=%d G1=%d T=%d B=%d) or device", who, d->R, d->A, d->P, d->G1, d->T, d->B);
         return EKAID_ERR_UNSUPPORTED;
     }
-    if (!workspace || workspace_bytes < pl.total || (reinterpret_cast<uintptr_t>(workspace) & 255)) {
-        set_error("ekaid_speaker_seq_fwd_persistent: workspace too small or misaligned (%zu < %zu)", workspace_bytes, pl.total);
+    const size_t Bp = 16 * (size_t)pl.nrb;
+    const size_t o_xt = pl.total, o_log = o_xt + al256(Bp * 512 * sizeof(float)), total = gq ? o_log + al256(Bp * 160 * sizeof(float)) : pl.total;
+    if (!workspace || workspace_bytes < total || (reinterpret_cast<uintptr_t>(workspace) & 255)) {
+        set_error("%s: workspace too small or misaligned (%zu < %zu)", who, workspace_bytes, total);
         return EKAID_ERR_ARG;
     }
-    if (!d->seeds && (d->p_lm > 0.f || d->p_pos > 0.f)) { set_error("ekaid_speaker_seq_fwd_persistent: dropout without seeds"); return EKAID_ERR_ARG; }
+    if (!d->seeds && (d->p_lm > 0.f || d->p_pos > 0.f)) { set_error("%s: dropout without seeds", who); return EKAID_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
     PFwd a;
@@ -618,29 +736,79 @@ extern "C" int ekaid_speaker_seq_fwd_persistent(const ekaid_speaker_seq_t* d, vo
     a.DP = d->DP; a.PW = d->PW; a.PA = d->PA; a.AT = d->AT; a.GT = d->GT; a.GA = d->GA;
     a.sync = (unsigned*)workspace;
     a.status = seq_status_ptr();
-    if (!a.status) { set_error("persistent sequence kernel: cannot allocate the status word"); return EKAID_ERR_LAUNCH; }
+    if (!a.status) { set_error("%s: cannot allocate the status word", who); return EKAID_ERR_LAUNCH; }
     a.trace = persist_trace_enabled() ? reinterpret_cast<unsigned long long*>(ws + pl.o_trace) : nullptr;
     a.HLfm = (float*)(ws + pl.o_hl); a.HAfm = (float*)(ws + pl.o_ha); a.G1fm = (float*)(ws + pl.o_g1); a.GAfm = (float*)(ws + pl.o_ga);
     a.MWPW = (float*)(ws + pl.o_mwpw); a.LHP = (float*)(ws + pl.o_lhp);
     a.Fm = (const float*)(ws + pl.o_fm); a.Wp = (const float*)(ws + pl.o_wp); a.cp = (const float*)(ws + pl.o_cp);
     a.We = d->We; a.jobsA = pl.jobsA; a.jobsD = pl.jobsD;
     if (d->seeds) memcpy(a.seeds, d->seeds, sizeof(uint64_t) * 3 * d->T);
+    if (gq) {
+        a.V = gq->V; a.seq_len = gq->seq_len; a.t_base = t0;
+        a.emb = gq->emb; a.bih_l = gq->bih_l; a.w_lo = gq->w_lo; a.b_lo = gq->b_lo;
+        a.it = (long long*)gq->it; a.unfinished = gq->unfinished; a.seq = (long long*)gq->seq; a.seq_logp = gq->seq_logp; a.n_unfinished = gq->n_unfinished;
+        a.XTfm = (float*)(ws + o_xt); a.LOG = (float*)(ws + o_log);
+    }
     const void* ptrs[] = {a.Wcat, a.whh_a, a.bhh_a, a.w_fc, a.b_fc, a.b_p1, a.w_wp, a.b_wp, a.w_p2, a.b_p2, a.w_g1, a.b_g1, a.w_g2, a.b_g2, a.wih_l,
-                          a.bhh_l, a.bef, a.diff, a.aft, a.GXA, a.GXL, a.HA, a.CA, a.HL, a.CL, a.SA, a.SL, a.G1D, a.MW, a.VP, a.DP, a.PW, a.PA,
-                          a.AT, a.GT, a.GA};
+                          a.bhh_l, a.bef, a.diff, a.aft, a.GXA, gq ? (const void*)a.GXA : (const void*)a.GXL, a.HA, a.CA, a.HL, a.CL, a.SA, a.SL, a.G1D, a.VP,
+                          a.DP, a.PW, a.PA, a.AT, a.GT, a.GA};
     for (const void* p : ptrs)
-        if (!p || (reinterpret_cast<uintptr_t>(p) & 15)) { set_error("ekaid_speaker_seq_fwd_persistent: null or misaligned (16 B) pointer in the descriptor"); return EKAID_ERR_ARG; }
+        if (!p || (reinterpret_cast<uintptr_t>(p) & 15)) { set_error("%s: null or misaligned (16 B) pointer in the descriptor", who); return EKAID_ERR_ARG; }
+    if (!a.MW || (reinterpret_cast<uintptr_t>(a.MW) & 3)) { set_error("%s: null or misaligned module-weight buffer", who); return EKAID_ERR_ARG; }
     // the linear maps of gate-MLP layer 1 (5 small products in front of the sequence kernel)
     void* gws = ws + pl.o_gemm;
     for (int m = 0; m < 3; ++m) { const int rc = ekaid_gemm_f32(&pl.gF[m], gws, pl.gemm_bytes, stream); if (rc) return rc; }
     { const int rc = ekaid_gemm_f32(&pl.gWp, gws, pl.gemm_bytes, stream); if (rc) return rc; }
     { const int rc = ekaid_gemm_f32(&pl.gCp, gws, pl.gemm_bytes, stream); if (rc) return rc; }
-    // seam counters and the status word start at zero in EVERY launch (a memset node when captured)
-    if (hipMemsetAsync(workspace, 0, al256((size_t)SYNC_WORDS * 4), st) != hipSuccess) { (void)hipGetLastError(); set_error("ekaid_speaker_seq_fwd_persistent: memset failed"); return EKAID_ERR_LAUNCH; }
-    if (pl.mtD == 1 && pl.mtE == 1) return launch_fwd<1, 1>(a, pl, st, 40);
-    if (pl.mtD == 1 && pl.mtE == 2) return launch_fwd<1, 2>(a, pl, st, 41);
-    set_error("ekaid_speaker_seq_fwd_persistent: no kernel for tile groups %d / %d", pl.mtD, pl.mtE);
+    // seam counters start at zero in EVERY launch (a memset node when captured)
+    if (hipMemsetAsync(workspace, 0, al256((size_t)SYNC_WORDS * 4), st) != hipSuccess) { (void)hipGetLastError(); set_error("%s: memset failed", who); return EKAID_ERR_LAUNCH; }
+    if (gq) {
+        if (pl.mtD == 1 && pl.mtE == 1) return launch_fwd<1, 1, true>(a, pl, st, 47);
+        if (pl.mtD == 1 && pl.mtE == 2) return launch_fwd<1, 2, true>(a, pl, st, 43);
+    } else {
+        if (pl.mtD == 1 && pl.mtE == 1) return launch_fwd<1, 1>(a, pl, st, 40);
+        if (pl.mtD == 1 && pl.mtE == 2) return launch_fwd<1, 2>(a, pl, st, 41);
+    }
+    set_error("%s: no kernel for tile groups %d / %d", who, pl.mtD, pl.mtE);
     return EKAID_ERR_UNSUPPORTED;
+}
+}  // namespace
+}  // namespace ekaid
+
+extern "C" int ekaid_speaker_seq_fwd_persistent(const ekaid_speaker_seq_t* d, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!d) { set_error("ekaid_speaker_seq_fwd_persistent: null descriptor"); return EKAID_ERR_ARG; }
+    return launch_persistent_fwd(d, nullptr, 0, workspace, workspace_bytes, stream, "ekaid_speaker_seq_fwd_persistent");
+}
+
+/* Greedy decoding of steps [t0, t1) in ONE persistent launch: the forward kernel with three more stations per step -- the word-side
+ * gates of the language LSTM from the fed-back tokens, the logits, and a row-local station (log-softmax, arg-max with lowest-index
+ * ties, token 0 forbidden at step 0, stop flags, seq / seq_logprobs, next token).  Same descriptor and results as
+ * ekaid_speaker_greedy_steps (token ids identical unless two log-probs tie within f32 rounding). */
+extern "C" size_t ekaid_speaker_greedy_persistent_workspace_bytes(const ekaid_speaker_greedy_t* q, int steps) {
+    if (!q || steps < 1 || q->V < 1 || q->V > 160 || q->f.We > 512) return 0;
+    ekaid_speaker_seq_t d = q->f;
+    d.T = steps;
+    PersistPlan pl;
+    if (!persistent_plan(&d, nullptr, pl)) return 0;
+    const size_t Bp = 16 * (size_t)pl.nrb;
+    return pl.total + al256(Bp * 512 * sizeof(float)) + al256(Bp * 160 * sizeof(float));
+}
+
+extern "C" int ekaid_speaker_greedy_steps_persistent(const ekaid_speaker_greedy_t* q, int t0, int t1, void* workspace, size_t workspace_bytes,
+                                                     void* stream) {
+    if (!q || t0 < 0 || t1 <= t0 || t1 > q->f.T || q->seq_len < t1 || !q->emb || !q->bih_l || !q->w_lo || !q->b_lo || !q->it || !q->unfinished ||
+        !q->seq || !q->seq_logp || !q->n_unfinished || q->V < 1 || q->V > 160 || q->f.We > 512) {
+        set_error("ekaid_speaker_greedy_steps_persistent: bad arguments");
+        return EKAID_ERR_ARG;
+    }
+    if (q->f.p_lm != 0.f || q->f.p_pos != 0.f) { set_error("ekaid_speaker_greedy_steps_persistent: eval mode only"); return EKAID_ERR_UNSUPPORTED; }
+    ekaid_speaker_seq_t d = q->f;
+    const size_t BR = (size_t)d.B * d.R;
+    d.T = t1 - t0;
+    d.seeds = nullptr;
+    d.HA = q->f.HA + t0 * BR; d.CA = q->f.CA + t0 * BR; d.HL = q->f.HL + t0 * BR; d.CL = q->f.CL + t0 * BR;
+    d.MW = q->f.MW + (size_t)t0 * d.B * 3;
+    return launch_persistent_fwd(&d, q, t0, workspace, workspace_bytes, stream, "ekaid_speaker_greedy_steps_persistent");
 }
 
 /* device pointer to the per-device status word of the persistent sequence kernels: 0 = every launch so far was fine; 0x100 / 0x200 /

@@ -345,6 +345,7 @@ extern "C" int ekaid_speaker_seq_bwd(const ekaid_speaker_seq_bwd_t* b, void* wor
 // n_unfinished every few steps (the reference tests "all finished" every step, dynamic_speaker_change_pos.py:354).
 namespace ekaid {
 namespace {
+constexpr int PERSISTENT_GREEDY_MAX_STEPS = 96;
 struct GreedyPlan { ekaid_gemm_t gxl, lo; float *ws_gxl, *ws_lo; void* ws_seq; size_t seq_bytes, bytes; };
 
 ekaid_gemm_t dense_nt(const float* A, int lda, const float* W, int ldw, float* C, int M, int N, int K, const float* bias) {
@@ -377,7 +378,9 @@ bool greedy_plan(const ekaid_speaker_greedy_t* q, void* ws, GreedyPlan& pl) {
 extern "C" size_t ekaid_speaker_greedy_workspace_bytes(const ekaid_speaker_greedy_t* q) {
     if (!q || !spk_args_ok(&q->f, "ekaid_speaker_greedy_workspace_bytes") || q->V < 1) return 0;
     GreedyPlan pl;
-    return greedy_plan(q, nullptr, pl) ? pl.bytes : 0;
+    if (!greedy_plan(q, nullptr, pl)) return 0;
+    const size_t pers = ekaid_speaker_greedy_persistent_workspace_bytes(q, q->f.T < PERSISTENT_GREEDY_MAX_STEPS ? q->f.T : PERSISTENT_GREEDY_MAX_STEPS);
+    return pl.bytes > pers ? pl.bytes : pers;
 }
 
 extern "C" int ekaid_speaker_greedy_steps(const ekaid_speaker_greedy_t* q, int t0, int t1, void* workspace, size_t workspace_bytes,
@@ -389,6 +392,10 @@ extern "C" int ekaid_speaker_greedy_steps(const ekaid_speaker_greedy_t* q, int t
         !q->logp || !q->it || !q->unfinished || !q->seq || !q->seq_logp || !q->n_unfinished || !d->GXL || !d->GXA) {
         set_error("ekaid_speaker_greedy_steps: bad arguments (steps [%d, %d) of %d)", t0, t1, d->T);
         return EKAID_ERR_ARG;
+    }
+    if (seq_mode() == 1 && t1 - t0 >= 4) {      // the whole range as ONE persistent launch where the shape allows it (csrc/persist.hip)
+        const size_t pers = ekaid_speaker_greedy_persistent_workspace_bytes(q, t1 - t0);
+        if (pers && workspace && workspace_bytes >= pers) return ekaid_speaker_greedy_steps_persistent(q, t0, t1, workspace, workspace_bytes, stream);
     }
     GreedyPlan pl;
     if (!greedy_plan(q, workspace, pl)) return EKAID_ERR_ARG;

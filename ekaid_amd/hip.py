@@ -128,6 +128,8 @@ SIGNATURES = {
     'ekaid_speaker_seq_bwd': [POINTER(SpeakerSeqBwd), P, c_size_t, P],
     'ekaid_speaker_greedy_workspace_bytes': [POINTER(SpeakerGreedy)],
     'ekaid_speaker_greedy_steps': [POINTER(SpeakerGreedy), I, I, P, c_size_t, P],
+    'ekaid_speaker_greedy_steps_persistent': [POINTER(SpeakerGreedy), I, I, P, c_size_t, P],
+    'ekaid_speaker_greedy_persistent_workspace_bytes': [POINTER(SpeakerGreedy), I],
     'ekaid_spk_step_a_fwd': [POINTER(SpkStepAFwd), P],
     'ekaid_spk_step_a_bwd': [POINTER(SpkStepABwd), P],
     'ekaid_wn_scale_fwd': [P, P, L, P, P, P],
@@ -204,7 +206,7 @@ SIGNATURES = {
 }
 _RESTYPES = {'ekaid_last_error': c_char_p, 'ekaid_gemm_workspace_bytes': c_size_t, 'ekaid_gru_seq_workspace_bytes': c_size_t, 'ekaid_gru_seq_persistent_workspace_bytes': c_size_t,
              'ekaid_speaker_seq_workspace_bytes': c_size_t, 'ekaid_speaker_seq_persistent_workspace_bytes': c_size_t,
-             'ekaid_speaker_seq_persistent_status_ptr': c_void_p, 'ekaid_speaker_seq_bwd_persistent_workspace_bytes': c_size_t, 'ekaid_speaker_greedy_workspace_bytes': c_size_t}
+             'ekaid_speaker_seq_persistent_status_ptr': c_void_p, 'ekaid_speaker_seq_bwd_persistent_workspace_bytes': c_size_t, 'ekaid_speaker_greedy_workspace_bytes': c_size_t, 'ekaid_speaker_greedy_persistent_workspace_bytes': c_size_t}
 
 _lib = None
 

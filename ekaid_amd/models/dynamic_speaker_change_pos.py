@@ -112,7 +112,8 @@ class DynamicSpeaker(CaptionModel):
         self.logit = Linear(self.rnn_size, self.vocab_size)
         self.module_weights = []
         self.fused_sequence = True      # _forward as one BPTT node; False = step-by-step through autograd
-        self.greedy_poll = 8            # greedy _sample: host checks "all finished" every this many steps
+        self.greedy_poll = 8            # step-by-step greedy _sample: host checks "all finished" every this many steps
+        self.greedy_poll_fused = None   # fused greedy _sample: steps per C-ABI call (None: speaker_seq.greedy_decode chooses)
 
     def init_hidden(self, batch_size):
         """((h_att, h_lang), (c_att, c_lang)); indexable like the reference's stacked (2, B, rnn) tensors."""
@@ -210,10 +211,10 @@ class DynamicSpeaker(CaptionModel):
         embed_pre = self.core.embed_pre(feat_bef, feat_aft, feat_diff)
         it = feat_bef.new_zeros(batch_size, dtype=torch.long) + 2          # <bos> hard-coded as id 2 (:311)
         if sample_max and not decoding_constraint and not self.training and self.fused_sequence:
-            # greedy path (test_mimic.py:119-122), eval mode: ``greedy_poll`` decode steps per C-ABI call
+            # greedy path (test_mimic.py:119-122), eval mode: ``greedy_poll_fused`` decode steps per C-ABI call
             # (ekaid_speaker_greedy_steps: the chosen tokens feed the next step on the device), one host read per call
             from ..speaker_seq import greedy_decode
-            seq, seq_logprobs, self.module_weights = greedy_decode(self, feat_bef, feat_aft, feat_diff, self.greedy_poll)
+            seq, seq_logprobs, self.module_weights = greedy_decode(self, feat_bef, feat_aft, feat_diff, self.greedy_poll_fused)
             return seq, seq_logprobs
         if sample_max and not decoding_constraint:
             # the same loop step by step (train mode / under autograd / fused_sequence off): argmax / stop-flag bookkeeping in one

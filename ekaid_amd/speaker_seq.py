@@ -399,9 +399,11 @@ def speaker_sequence(speaker, feat_bef, feat_aft, feat_diff, tok_tb):
 
 
 @torch.no_grad()
-def greedy_decode(speaker, feat_bef, feat_aft, feat_diff, poll=8):
+def greedy_decode(speaker, feat_bef, feat_aft, feat_diff, poll=None):
     """Greedy ``_sample`` (eval mode) through ``ekaid_speaker_greedy_steps``: ``poll`` decode steps per C-ABI call, the chosen
-    tokens feed the next step on the device, the host reads the "still running" counters once per call.  Returns
+    tokens feed the next step on the device, the host reads the "still running" counters once per call.  ``poll=None``: the whole
+    sequence in ONE call where the persistent kernel takes it (it ends by itself at the step after which every row has stopped),
+    8 steps per call on the step-wise chain.  Returns
     (seq, seq_logprobs, module weights per step run), seq zeroed after the step at which every sample had finished -- what the
     reference's loop leaves behind (dynamic_speaker_change_pos.py:309-357, test_mimic.py:119-122)."""
     sd = dict(speaker.named_parameters())
@@ -444,6 +446,8 @@ def greedy_decode(speaker, feat_bef, feat_aft, feat_diff, poll=8):
     g.seq, g.seq_logp, g.seq_len, g.n_unfinished = ptr(seq), ptr(seq_logp), Tm, ptr(counts)
     need = L.ekaid_speaker_greedy_workspace_bytes(ctypes.byref(g))
     ws = hip.workspace(need, dev)
+    if poll is None:
+        poll = Tm if (L.ekaid_get_seq_mode() == 1 and L.ekaid_speaker_greedy_persistent_workspace_bytes(ctypes.byref(g), Tm)) else 8
     steps_run = Tm
     for t0 in range(0, Tm, poll):
         t1 = min(Tm, t0 + poll)

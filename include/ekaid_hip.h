@@ -499,6 +499,12 @@ typedef struct ekaid_speaker_greedy {
 } ekaid_speaker_greedy_t;
 size_t ekaid_speaker_greedy_workspace_bytes(const ekaid_speaker_greedy_t* g);
 int ekaid_speaker_greedy_steps(const ekaid_speaker_greedy_t* g, int t0, int t1, void* workspace, size_t workspace_bytes, void* stream);
+/* The same range of steps as ONE persistent launch (csrc/persist.hip: the forward sequence kernel with three more stations per step:
+ * word-side gates from the fed-back tokens, logits, row-local log-softmax / arg-max / stop flags).  Production widths only (workspace
+ * query 0 otherwise); ekaid_speaker_greedy_steps routes ranges of >= 4 steps here under ekaid_set_seq_mode(1), and
+ * ekaid_speaker_greedy_workspace_bytes covers either form. */
+size_t ekaid_speaker_greedy_persistent_workspace_bytes(const ekaid_speaker_greedy_t* g, int steps);
+int ekaid_speaker_greedy_steps_persistent(const ekaid_speaker_greedy_t* g, int t0, int t1, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Scheduled sampling, one decode step for the whole batch: it[b] = teacher[b * ld_teacher] with probability 1 - ss_prob, else a
  * draw from exp(logp_prev[b][:]) (counter-based uniforms from `seed`; the reference draws with torch.multinomial: same

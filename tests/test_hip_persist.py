@@ -150,6 +150,44 @@ def test_decoder_through_the_model_agrees_between_the_sequence_modes(train, monk
         close(x, y, 'grad feat_' + n, 1e-4)
 
 
+@pytest.mark.parametrize('B,poll,bias0', [(7, 8, 0.5), (64, 8, 0.5), (64, None, 0.5), (150, 5, 0.5), (256, None, 0.5), (64, None, 60.0), (20, None, 6.0)])
+def test_greedy_decoding_agrees_between_the_sequence_modes(B, poll, bias0):
+    """speaker_seq.greedy_decode at the production widths: ranges of decode steps as ONE persistent launch (tokens, stop flags and the
+    next word's embedding stay on the device between steps) against the step-wise chain: identical token ids and stop positions,
+    log-probs and module weights <= 1e-5, the step-wise tail of a range shorter than 4 steps (poll = 5 over 12 steps) in between, and
+    the default (poll = None): the whole sequence in one launch that ends by itself once every row has stopped."""
+    from common import build_models
+    from ekaid_amd import hip, speaker_seq
+    from ekaid_amd.config import bench_cfg
+    hip.load()
+    L = hip.lib()
+    cfg = bench_cfg(D=256, seq_length=12)
+    cd, sp = build_models(cfg, 147, 148, 'cuda', train=False)
+    g = torch.Generator().manual_seed(5 + B)
+    A = cfg.model.speaker.input_dim
+    bef, aft, diff = [torch.randn(B, A, generator=g).cuda() for _ in range(3)]
+    with torch.no_grad():                                                  # random-init logits are nearly flat: spread them so that rows stop at
+        sp.logit.weight.mul_(8.0)                                          # different steps and ties within rounding do not decide the ids
+        sp.logit.bias[0] += bias0                                          # (60: every row stops at step 1, the launch ends by itself at step 2)
+    res = {}
+    old = L.ekaid_get_seq_mode()
+    try:
+        for mode in (0, 1):
+            hip.check(L.ekaid_set_seq_mode(mode), 'set_seq_mode')
+            seq, lp, mw = speaker_seq.greedy_decode(sp, bef, aft, diff, poll=poll)
+            torch.cuda.synchronize()
+            hip.seq_status_check('greedy decode')
+            res[mode] = (seq.clone(), lp.clone(), torch.stack(mw, 1).clone())
+    finally:
+        L.ekaid_set_seq_mode(old)
+    assert torch.equal(res[0][0], res[1][0])
+    assert res[0][2].shape == res[1][2].shape
+    if bias0 > 50:
+        assert res[1][2].shape[1] == 2 and int((res[1][0] != 0).sum()) == B
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-5 * max(1.0, float(res[0][1].abs().max()))
+    assert float((res[0][2] - res[1][2]).abs().max()) <= 1e-5
+
+
 @pytest.mark.parametrize('B,T', [(5, 4), (16, 5), (37, 4), (64, 6), (130, 4), (256, 4)])
 @pytest.mark.parametrize('train', [False, True])
 def test_persistent_backward_equals_the_stepwise_chain(B, T, train):
