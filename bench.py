@@ -524,7 +524,8 @@ def main():
         extra['greedy_decode_b64'] = {'ms': round(msd, 3), 'pairs_per_s': round(64 / msd * 1e3, 1), 'decode_steps_run': nsteps,
                                       'ms_per_decode_step': round((msd - ms_f0) / max(nsteps, 1), 4),
                                       'workload': 'test_mimic.py:109-122: eval detector forward + '
-                                                  'greedy _sample (ekaid_speaker_greedy_steps, stop test polled every 8 steps), batch 64, '
+                                                  'greedy _sample (ekaid_speaker_greedy_steps: one persistent launch for the whole answer under the default sequence mode, '
+                                                 'ending by itself once every row has stopped; 8 steps per call on the step-wise chain), batch 64, '
                                                   'freshly initialised weights: the end token never comes, all %d steps of the maximum '
                                                   'answer length are decoded' % nsteps}
         # opt-in reduced-precision GEMM arithmetic (two bf16 terms per operand, three products): the same train step, NOT the
