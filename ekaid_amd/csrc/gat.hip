@@ -284,7 +284,8 @@ __global__ __launch_bounds__(256) void masked_softmax_bwd_kernel(const float* P,
 // ref: utils/mimic_utils.py:152-208.  out[r][i][j][c*(fd/4) + s*(fd/8) + t], c = component (dx,dy,dw,dh),
 // s = 0 sin / 1 cos, t = frequency index; dim_mat[t] = 1000^(8t/fd) is the reference's float32 table, built on the host
 // with the same torch expression (mimic_utils.py:195-197) so that no device powf rounding enters the argument.
-__global__ __launch_bounds__(256) void geom_embed_kernel(const double* bb, const float* dim_mat, int R, int N, int M, int fd, float* out) {
+__global__ __launch_bounds__(256) void geom_embed_kernel(const double* bb, const float* dim_mat, int R, int N, int M, int fd, float* out,
+                                                         float p, float inv_keep, DropSeed seed) {
     // one thread per (pair, component): the log-geometry value is computed once and fanned out to the fd/8 frequencies
     extern __shared__ __attribute__((aligned(16))) float tile[];        // [256 items][2 nf]
     const int nf = fd / 8;
@@ -338,11 +339,18 @@ __global__ __launch_bounds__(256) void geom_embed_kernel(const double* bb, const
         {
             const long long first = i0 * (2 * nf);                          // first output element of this workgroup's block
             const long long cnt = min((long long)256, total - i0) * (2 * nf);
+            // p > 0: the input dropout of the layer that reads the embedding (graph_att_layer.py:121, fc.py:36-37), mask index = flat index
             if ((nf & 1) == 0) {
-                for (long long e = 4 * threadIdx.x; e < cnt; e += 1024)
-                    *reinterpret_cast<f32x4*>(out + first + e) = *reinterpret_cast<const f32x4*>(tile + e);
+                for (long long e = 4 * threadIdx.x; e < cnt; e += 1024) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(tile + e);
+                    if (p > 0.f) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] *= dropout_scale(seed, (uint64_t)(first + e + c), p, inv_keep);
+                    }
+                    *reinterpret_cast<f32x4*>(out + first + e) = v;
+                }
             } else {
-                for (long long e = threadIdx.x; e < cnt; e += 256) out[first + e] = tile[e];
+                for (long long e = threadIdx.x; e < cnt; e += 256) out[first + e] = tile[e] * dropout_scale(seed, (uint64_t)(first + e), p, inv_keep);
             }
         }
         __syncthreads();
@@ -455,12 +463,18 @@ extern "C" int ekaid_masked_softmax_bwd(const float* P, const float* dP, const f
     return check_launch("masked_softmax_bwd");
 }
 extern "C" int ekaid_geom_embed(const double* bb, const float* dim_mat, int R, int N, int M, int feat_dim, float* out, void* stream) {
+    return ekaid_geom_embed_dropout(bb, dim_mat, R, N, M, feat_dim, out, 0.f, 0, stream);
+}
+extern "C" int ekaid_geom_embed_dropout(const double* bb, const float* dim_mat, int R, int N, int M, int feat_dim, float* out, float p,
+                                        uint64_t seed, void* stream) {
     if (feat_dim % 8) { set_error("geom_embed: feat_dim %% 8 != 0"); return EKAID_ERR_ARG; }
+    if (!(p >= 0.f && p < 1.f)) { set_error("geom_embed: dropout probability outside [0, 1)"); return EKAID_ERR_ARG; }
     const long long total = (long long)R * N * M * 4;
     long long b = (total + 255) / 256;
     if (b > 8192) b = 8192;
     if (b < 1) b = 1;
     if (feat_dim > 256) { set_error("geom_embed: feat_dim > 256"); return EKAID_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(geom_embed_kernel, dim3((unsigned)b), dim3(256), 256 * (feat_dim / 4) * sizeof(float), ST, bb, dim_mat, R, N, M, feat_dim, out);
+    hipLaunchKernelGGL(geom_embed_kernel, dim3((unsigned)b), dim3(256), 256 * (feat_dim / 4) * sizeof(float), ST, bb, dim_mat, R, N, M, feat_dim, out,
+                       p, p > 0.f ? 1.f / (1.f - p) : 1.f, DropSeed{seed, dropout_epoch_ptr()});
     return check_launch("geom_embed");
 }

@@ -38,6 +38,8 @@ class GemmDesc(Structure):
         ('act', c_int),
         ('drop_p', c_float), ('drop_seed', c_uint64),
         ('a_rowsum', c_void_p),
+        ('post', c_void_p), ('ldpost', c_int),
+        ('drop_out', c_void_p * 2), ('drop_out_p', c_float * 2), ('drop_out_seed', c_uint64 * 2),
     ]
 
 
@@ -153,6 +155,7 @@ SIGNATURES = {
     'ekaid_masked_softmax_fwd': [P, P, P, P, I, I, I, I, I, P, P],
     'ekaid_masked_softmax_bwd': [P, P, P, P, I, I, I, I, I, P, P, P, P],
     'ekaid_geom_embed': [P, P, I, I, I, I, P, P],
+    'ekaid_geom_embed_dropout': [P, P, I, I, I, I, P, F, U64, P],
     'ekaid_residual_relu2_fwd': [P, P, P, L, F, U64, P],
     'ekaid_residual_relu2_bwd': [P, P, P, L, F, U64, P],
     'ekaid_gate_fuse_fwd': [P, P, P, P, P, L, L, F, U64, U64, P],

@@ -117,9 +117,11 @@ class ChangeDetector(nn.Module):
         self._dim_mat = None
 
     # ------------------------------------------------------------------ geometry
-    def position_emb(self, bb):
+    def position_emb(self, bb, reader=None):
         """(R, N, 4) float64 boxes (host or device) -> (R, N, M, pos_emb_dim) float32 on the device.
-        ref: modules.py:162-166 -> mimic_utils.py:152-208 (float64 math, cast at graph_att_layer.py:115)."""
+        ref: modules.py:162-166 -> mimic_utils.py:152-208 (float64 math, cast at graph_att_layer.py:115).
+        ``reader``: the implicit relation encoder when it is the embedding's only reader -- in training its pair_pos_fc1 input dropout
+        is applied as the embedding is written (one pass over 170 MB at 256 pairs instead of three)."""
         dev = self.img.weight.device
         if self._dim_mat is None or self._dim_mat.device != dev:
             feat_range = torch.arange(0, self.pos_emb_dim / 8)
@@ -129,7 +131,10 @@ class ChangeDetector(nn.Module):
         # re-reads the (nongt, N) block as (N, nongt) (graph_att_layer.py:117-126); ekaid_geom_embed reproduces that
         # re-indexing (no shipped configuration reaches it: nongt_dim = 52 >= regions per image)
         M = min(self.nongt_dim, bb.shape[1])
-        return ops.geom_embed(bb, M, self.pos_emb_dim, self._dim_mat)
+        p = 0.0
+        if reader is not None and reader.training and reader.num_steps == 1 and not reader.implicit_relation.compute_dead_directions:
+            p = float(reader.implicit_relation.neighbor_net[-1].pair_pos_fc1.input_dropout())
+        return ops.geom_embed(bb, M, self.pos_emb_dim, self._dim_mat, p)
 
     def _wn_layers(self, setting, graph):
         """(weight_v, weight_g) of the weight-normed layers a forward call with this setting / graph runs: the encoders
@@ -188,7 +193,7 @@ class ChangeDetector(nn.Module):
             if graph == 'spatial' or graph == 'all' or graph == 'i+s':
                 x, _ = self.spatial_relation.forward(x, ops.stack2(d_adj_matrix, q_adj_matrix), qs.pop())
             if graph == 'implicit' or graph == 'all' or graph == 'i+s':
-                pos = self.position_emb(ops.stack2(d_bb, q_bb))
+                pos = self.position_emb(ops.stack2(d_bb, q_bb), self.imp_relation)
                 x, _ = self.imp_relation.forward(x, pos, qs.pop())
             if graph == 'all':
                 # Q-A: input_bef1/2/3 are one tensor -> cs*x + cp*x + (1-cs-cp)*x   (modules.py:234-235)

@@ -23,12 +23,13 @@ def q_expand_v_cat(q, v, mask=True, p=0.0, training=False, lazy=False):
         keep = ops.rowsum(v, as_mask=True).view(-1)
     else:
         keep = torch.ones(R * N, device=v.device, dtype=torch.float32)
+    v2 = ops.pass_slot(v, v.reshape(R * N, A))          # (v may be a fan-out alias: its reader is the FCNet that takes v2)
     if training and p > 0:      # the consumer FCNet's input dropout, fused into the expansion kernel
-        return v.reshape(R * N, A), PreDropped(ops.expand_rows(q, keep, N, p, True))
+        return v2, PreDropped(ops.expand_rows(q, keep, N, p, True))
     if lazy and not torch.is_grad_enabled():
         # inference: nothing is expanded; the consumer FCNet takes q . Wq^T once per sample (fc.RowBroadcast)
-        return v.reshape(R * N, A), RowBroadcast(q, keep, N)
-    return v.reshape(R * N, A), ops.expand_rows(q, keep, N)
+        return v2, RowBroadcast(q, keep, N)
+    return v2, ops.expand_rows(q, keep, N)
 
 
 class ImplicitRelationEncoder(nn.Module):

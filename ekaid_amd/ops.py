@@ -170,9 +170,11 @@ def seq_in_c():
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=None,
          accumulate=False, bias=None, R=None, ldr=0, rdiv=1, rowmask=None, act=ACT_NONE,
-         batch=(1, 1), strides=(0, 0, 0, 0, 0, 0), a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_seed=0, a_rowsum=None):
-    """C = act(alpha * op(A) op(B) [+C] [+bias] [+R]) on raw device buffers (element offsets a_off..); ``a_rowsum`` (transA only):
-    a_rowsum[m] += sum_k op(A)[m][k], the bias gradient riding on a weight-gradient product."""
+         batch=(1, 1), strides=(0, 0, 0, 0, 0, 0), a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_seed=0, a_rowsum=None,
+         post=None, ldpost=0, drop_out=()):
+    """C = dropout(act(alpha * op(A) op(B) [+C] [+bias] [+R])) [+post] on raw device buffers (element offsets a_off..); ``a_rowsum``
+    (transA only): a_rowsum[m] += sum_k op(A)[m][k], the bias gradient riding on a weight-gradient product; ``drop_out``: up to two
+    (buffer, p, seed) -- dropped copies of the finished C written by the same epilogue."""
     d = GemmDesc()
     d.A = A.data_ptr() + 4 * a_off
     d.B = B.data_ptr() + 4 * b_off
@@ -194,6 +196,12 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=N
     d.drop_p = drop_p
     d.drop_seed = drop_seed
     d.a_rowsum = ptr(a_rowsum) if _BIAS_IN_WGRAD else None
+    d.post = ptr(post)
+    d.ldpost = ldpost
+    for i, (buf, pk, sk) in enumerate(drop_out):
+        d.drop_out[i] = buf.data_ptr() + 4 * c_off
+        d.drop_out_p[i] = pk
+        d.drop_out_seed[i] = sk
     L = hip.lib()
     need = L.ekaid_gemm_workspace_bytes(ctypes.byref(d))
     ws = hip.workspace(need, C.device) if need else None
@@ -361,29 +369,41 @@ class LinearFn(Function):
         xs2, lds = zip(*[_rows2d(x) for x in xs])
         xs2, lds = list(xs2), list(lds)
         seeds = [0] * len(xs2)
+        copies = ()
+        if isinstance(drops, LinearOpts):
+            drops, copies = drops.drops, drops.copies
         if drops is not None:
             for i, pd in enumerate(drops):
                 if pd > 0.0:
-                    x = xs2[i] if lds[i] == xs2[i].shape[1] else xs2[i].contiguous()    # mask index = flat index
-                    xd = torch.empty_like(x)
-                    seeds[i] = next_seed()
-                    check(hip.lib().ekaid_dropout(ptr(x), ptr(xd), x.numel(), float(pd), seeds[i], stream()), 'dropout')
+                    pre = getattr(xs[i], '_ekaid_predrop', None)
+                    if pre is not None and pre[0] == float(pd) and pre[2].numel() == xs2[i].numel():
+                        seeds[i], xd = pre[1], pre[2].view(xs2[i].shape)       # the producer's epilogue wrote the dropped input
+                    else:
+                        x = xs2[i] if lds[i] == xs2[i].shape[1] else xs2[i].contiguous()    # mask index = flat index
+                        xd = torch.empty_like(x)
+                        seeds[i] = next_seed()
+                        check(hip.lib().ekaid_dropout(ptr(x), ptr(xd), x.numel(), float(pd), seeds[i], stream()), 'dropout')
                     xs2[i], lds[i] = xd, xd.shape[1]
         ctx.drops, ctx.seeds = drops, seeds
+        ctx.slots = [slot_of(x) for x in xs]
         M = xs2[0].shape[0]
         assert sum(x.shape[1] for x in xs2) == Ktot, 'input widths do not add up to in_features'
         y = torch.empty(M, N, device=W.device, dtype=torch.float32)
         Wt = weight_transposed(W) if _use_transposed(M) else None
+        # input dropouts of the layers that read y, written by the epilogue of the last product: (p, seed, dropped copy) each
+        emitted = [(float(pc), next_seed(), torch.empty_like(y)) for pc in copies]
+        _emitted_copies[:] = emitted
         off = 0
         for i, (x, ld) in enumerate(zip(xs2, lds)):
             last = i == len(xs2) - 1
             K = x.shape[1]
+            extra = [(c, pc, sc) for pc, sc, c in emitted] if last else ()
             if Wt is not None:      # B = W^T [K][N]: n-contiguous staging (512-byte row segments), the faster variant
                 gemm(x, Wt, y, M, N, K, ld, N, N, 0, 0, alpha_dev=scale, accumulate=i > 0,
-                     bias=b if last else None, act=act if last else ACT_NONE, b_off=off * N)
+                     bias=b if last else None, act=act if last else ACT_NONE, b_off=off * N, drop_out=extra)
             else:
                 gemm(x, W, y, M, N, K, ld, Ktot, N, 0, 1, alpha_dev=scale, accumulate=i > 0,
-                     bias=b if last else None, act=act if last else ACT_NONE, b_off=off)
+                     bias=b if last else None, act=act if last else ACT_NONE, b_off=off, drop_out=extra)
             off += K
         ctx.act = act
         ctx.has_b = b is not None
@@ -418,9 +438,13 @@ class LinearFn(Function):
             if need[5 + i]:
                 dx = torch.empty(M, K, device=W.device, dtype=torch.float32)
                 pd = ctx.drops[i] if ctx.drops is not None else 0.0
+                slot = ctx.slots[i]
+                post = None                          # another reader's gradient of the same tensor joins behind the dropout (GradSlot)
+                if slot is not None and slot.lent is not None and slot.lent.numel() == dx.numel():
+                    post, slot.lent = slot.lent, None
                 gemm(dz, W, dx, M, K, N, N, Ktot, K, 0, 0, alpha_dev=scale, b_off=off,
-                     drop_p=float(pd), drop_seed=ctx.seeds[i])          # input-dropout backward in the epilogue
-                dxs.append(dx.view(*ctx.lead[i], K))
+                     drop_p=float(pd), drop_seed=ctx.seeds[i], post=post, ldpost=K)          # input-dropout backward in the epilogue
+                dxs.append(lend_grad(slot, dx.view(*ctx.lead[i], K)))
             else:
                 dxs.append(None)
             off += K
@@ -508,6 +532,18 @@ class WNLinearFn(Function):
     @staticmethod
     def backward(ctx, dy):
         return LinearFn.backward(ctx, dy)
+
+
+class LinearOpts:
+    """``drops`` argument of LinearFn / WNLinearFn when the layer also emits dropped copies of its output: ``drops`` = the
+    per-input dropout probabilities (or None), ``copies`` = one probability per copy."""
+    __slots__ = ('drops', 'copies')
+
+    def __init__(self, drops, copies):
+        self.drops, self.copies = drops, tuple(copies)
+
+
+_emitted_copies = []        # side channel LinearFn.forward -> wn_linear: the (p, seed, buffer) triples of the call that just ran
 
 
 def linear(xs, W, b=None, scale=None, act=ACT_NONE, drops=None):
@@ -631,12 +667,28 @@ def wn_linear_rowbcast(x, q, mask, group, v, g, b=None, act=ACT_NONE):
     return y.view(*x.shape[:-1], N)
 
 
-def wn_linear(xs, v, g, b=None, act=ACT_NONE, drops=None):
+def wn_linear(xs, v, g, b=None, act=ACT_NONE, drops=None, copies=()):
+    """``copies``: dropout probabilities of the layers that will read the output -- their dropped inputs come out of this layer's
+    epilogue (``out._ekaid_copies`` = [(p, seed, buffer)]; see ``predropped``) instead of one dropout pass per reader."""
     if isinstance(xs, torch.Tensor):
         xs = (xs,)
     if drops is not None and not any(d > 0.0 for d in drops):
         drops = None
-    return WNLinearFn.apply(v, b, g, act, drops, *xs)
+    copies = tuple(float(c) for c in copies if c > 0.0)
+    if not copies:
+        return WNLinearFn.apply(v, b, g, act, drops, *xs)
+    out = WNLinearFn.apply(v, b, g, act, LinearOpts(drops, copies), *xs)
+    out._ekaid_copies = list(_emitted_copies)
+    del _emitted_copies[:]
+    return out
+
+
+def predropped(alias, copy):
+    """Mark ``alias`` (a tensor about to enter an FCNet with input dropout) as already dropped: ``copy`` = (p, seed, buffer) from
+    the producer's ``_ekaid_copies``.  The reader uses the buffer as data and (p, seed) for its backward."""
+    if copy is not None:
+        alias._ekaid_predrop = copy
+    return alias
 
 
 # --------------------------------------------------------------------------- #
@@ -745,32 +797,74 @@ def _sum_into(grads, out):
         check(hip.lib().ekaid_sum_n(arr, len(part), ptr(out), out.numel(), stream()), 'sum_n')
 
 
+class GradSlot:
+    """The gradient of a tensor with several readers, handed from reader to reader during backward instead of being summed by a
+    kernel at the end.  Every alias ``fanout`` returns carries the slot of its tensor (``_ekaid_slot``) and goes to ONE reader.  A
+    reader whose backward knows slots either LENDS its gradient (``lend_grad``: the slot keeps a reference, the reader returns None
+    to autograd) or FOLDS what is lent into its own product (the input-gradient GEMM of a linear layer adds it behind its dropout
+    epilogue: ``ekaid_gemm_t.post``) and lends the result.  Lent tensors are only ever read.  ``FanoutFn.backward`` collects what is
+    still lent next to the gradients that arrived the ordinary way, so any mix of readers stays correct."""
+    __slots__ = ('lent',)
+
+    def __init__(self):
+        self.lent = None
+
+
+def slot_of(x):
+    return getattr(x, '_ekaid_slot', None)
+
+
+def pass_slot(src, dst):
+    """``dst`` is a reshaped view of the fan-out alias ``src`` and goes to src's reader in its place."""
+    slot = slot_of(src)
+    if slot is not None:
+        dst._ekaid_slot = slot
+    return dst
+
+
+def lend_grad(slot, g):
+    """What a reader's backward returns for an input that came out of ``fanout``: None when the gradient now waits in the slot."""
+    if slot is None or g is None or slot.lent is not None or not g.is_contiguous():
+        return g
+    slot.lent = g
+    return None
+
+
 class FanoutFn(Function):
-    """x -> n aliases of x, one per consumer.  Backward: the n incoming gradients are summed by ONE kernel (autograd would
-    accumulate them pairwise: n-1 ATen adds, each re-reading the running sum).  ref: every tensor of the path with more
-    than one reader, e.g. the encoder output feeding context2 / gate2 / attention / pooling (modules.py:266-303)."""
+    """x -> n aliases of x, one per consumer.  Backward: gradients handed over through the GradSlot arrive already summed; the
+    others are summed by ONE kernel (autograd would accumulate them pairwise: n-1 ATen adds, each re-reading the running sum).
+    ref: every tensor of the path with more than one reader, e.g. the encoder output feeding context2 / gate2 / attention /
+    pooling (modules.py:266-303)."""
 
     @staticmethod
-    def forward(ctx, x, n):
+    def forward(ctx, x, n, slot):
         ctx.set_materialize_grads(False)
+        ctx.slot, ctx.shape = slot, tuple(x.shape)
         return tuple(x.view(x.shape) for _ in range(n))
 
     @staticmethod
     def backward(ctx, *grads):
         gs = [g for g in grads if g is not None]
+        if ctx.slot.lent is not None:
+            gs.append(ctx.slot.lent.view(ctx.shape))
+            ctx.slot.lent = None
         if not gs:
-            return None, None
+            return None, None, None
         if len(gs) == 1:
-            return gs[0], None
+            return gs[0], None, None
         out = torch.empty(gs[0].shape, device=gs[0].device, dtype=gs[0].dtype)
         _sum_into(gs, out)
-        return out, None
+        return out, None, None
 
 
 def fanout(x, n):
     if n <= 1 or not x.requires_grad:
         return (x,) * n
-    return FanoutFn.apply(x, n)
+    slot = GradSlot()
+    outs = FanoutFn.apply(x, n, slot)
+    for o in outs:
+        o._ekaid_slot = slot
+    return outs
 
 
 class HalvesFn(Function):
@@ -950,6 +1044,7 @@ class ResidualRelu2Fn(Function):
         check(hip.lib().ekaid_residual_relu2_fwd(ptr(v), ptr(o), ptr(out), v.numel(), p, seed, stream()),
               'residual_relu2_fwd')
         ctx.p, ctx.seed = p, seed
+        ctx.slot_v = slot_of(v)
         ctx.save_for_backward(o)
         return out
 
@@ -960,7 +1055,7 @@ class ResidualRelu2Fn(Function):
         do = torch.empty_like(d)
         check(hip.lib().ekaid_residual_relu2_bwd(ptr(o), ptr(d), ptr(do), d.numel(), ctx.p, ctx.seed, stream()),
               'residual_relu2_bwd')
-        return d, do, None, None
+        return lend_grad(ctx.slot_v, d), do, None, None
 
 
 def residual_relu2(v, o, p, training):
@@ -1376,14 +1471,20 @@ def layer_norm(x, gamma, beta, eps):
 # --------------------------------------------------------------------------- #
 # graph attention core
 # --------------------------------------------------------------------------- #
-def geom_embed(bb_dev, M, feat_dim, dim_mat):
-    """float64 boxes (R,N,4) on the device -> float32 pair embedding (R,N,M,feat_dim); no gradient."""
+def geom_embed(bb_dev, M, feat_dim, dim_mat, p=0.0):
+    """float64 boxes (R,N,4) on the device -> float32 pair embedding (R,N,M,feat_dim); no gradient.  ``p`` > 0: the input dropout
+    of the ONE layer that reads it, applied as it is written (``out._ekaid_dropped`` = p tells the reader)."""
     require_cuda(bb_dev, dim_mat)
     assert bb_dev.dtype == torch.float64
     bb_dev = _c(bb_dev)
     R, N, _ = bb_dev.shape
     out = torch.empty(R, N, M, feat_dim, device=bb_dev.device, dtype=torch.float32)
-    check(hip.lib().ekaid_geom_embed(bb_dev.data_ptr(), ptr(dim_mat), R, N, M, feat_dim, ptr(out), stream()), 'geom_embed')
+    if p > 0.0:
+        check(hip.lib().ekaid_geom_embed_dropout(bb_dev.data_ptr(), ptr(dim_mat), R, N, M, feat_dim, ptr(out), float(p), next_seed(),
+                                                 stream()), 'geom_embed_dropout')
+        out._ekaid_dropped = float(p)
+    else:
+        check(hip.lib().ekaid_geom_embed(bb_dev.data_ptr(), ptr(dim_mat), R, N, M, feat_dim, ptr(out), stream()), 'geom_embed')
     return out
 
 
@@ -1399,6 +1500,7 @@ class GatAttentionFn(Function):
     @staticmethod
     def forward(ctx, q, k, S, cond, lbias, geo, H, direction, impl):
         require_cuda(q, k, S, cond, lbias)
+        ctx.slot_S = slot_of(S)
         q, k, S, cond, lbias = _c(q), _c(k), _c(S), _c(cond), _c(lbias)
         geo = _c(geo) if geo is not None else None
         R, N, A = q.shape
@@ -1469,7 +1571,7 @@ class GatAttentionFn(Function):
                  strides=(N * H * M, M, N * A, dh, M * A, dh))
         else:
             check(rc, 'gat_dqk')
-        return dq, dk, dS, None, dlbias, dgeo, None, None, None
+        return dq, dk, lend_grad(ctx.slot_S, dS), None, dlbias, dgeo, None, None, None
 
 
 def gat_attention(q, k, S, cond, lbias, geo, H, direction, impl='fused'):

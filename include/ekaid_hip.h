@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EKAID_ABI_VERSION 6
+#define EKAID_ABI_VERSION 7
 
 int ekaid_version(void);
 const char* ekaid_last_error(void);        /* thread-local */
@@ -54,7 +54,7 @@ int ekaid_dropout_epoch_advance(unsigned long long* epoch_dev, unsigned long lon
 
 /* ------------------------------------------------------------------------------------------
  * Dense contraction on the fp32 matrix cores.
- *   C = dropout( act( alpha * alpha_dev[0] * op(A).op(B)  [+ C]  [+ bias[n]]  [+ rowmask[m] * R[m / rdiv][n]] ) )
+ *   C = dropout( act( alpha * alpha_dev[0] * op(A).op(B)  [+ C]  [+ bias[n]]  [+ rowmask[m] * R[m / rdiv][n]] ) )  [+ post[m][n]]
  * transA=0: A is [M][K]; transA=1: A is [K][M].  transB=1: B is [N][K]; transB=0: B is [K][N].
  * Two batch dimensions (batch1 x batch2) with element strides; batch index z -> (z / batch2, z % batch2).
  * ref: every nn.Linear / FCNet / matmul on the path -- modules.py:195-196,278-303,
@@ -84,6 +84,14 @@ typedef struct ekaid_gemm {
     float* a_rowsum;        /* optional, needs transA: a_rowsum[m] += sum_k op(A)[m][k] (f32, fixed order).  The bias gradient of a
                                linear layer rides on its weight-gradient product dW = dY^T X this way (A = dY): dY is not read a
                                second time by a column-sum kernel.  ekaid_gemm_f32 only; counted by ekaid_gemm_workspace_bytes. */
+    const float* post;      /* optional (one batch): C = dropout(act(...)) + post[m * ldpost + n] -- a gradient of the same tensor that joins
+                               this input-gradient product behind its dropout, instead of an n-ary sum kernel afterwards */
+    int ldpost;
+    float* drop_out[2];     /* optional (one batch): dropped copies of the finished C, drop_out[k][m * ldc + n] = C[m][n] * keep(drop_out_seed[k],
+                               m * N + n) / (1 - drop_out_p[k]): the input dropouts (fc.py:36-37) of the layers that read C, emitted by C's
+                               producer instead of one dropout pass per reader */
+    float drop_out_p[2];
+    uint64_t drop_out_seed[2];
 } ekaid_gemm_t;
 
 size_t ekaid_gemm_workspace_bytes(const ekaid_gemm_t* g);
@@ -220,6 +228,10 @@ int ekaid_masked_softmax_bwd(const float* P, const float* dP, const float* cond,
  * ref: utils/mimic_utils.py:152-208, modules.py:162-166.  bb is a DEVICE pointer to [R][N][4] doubles;
  * dim_mat a device array of feat_dim/8 floats = 1000^(8t/feat_dim) (the reference's float32 table). */
 int ekaid_geom_embed(const double* bb, const float* dim_mat, int R, int N, int M, int feat_dim, float* out, void* stream);
+/* The same with the input dropout of the embedding's reader (pair_pos_fc1: graph_att_layer.py:121, fc.py:36-37) applied as the
+ * embedding is written: out *= keep(seed, flat index) / (1 - p).  The embedding has no gradient, so nothing else changes. */
+int ekaid_geom_embed_dropout(const double* bb, const float* dim_mat, int R, int N, int M, int feat_dim, float* out, float p,
+                             uint64_t seed, void* stream);
 
 /* v_new = v + relu(dropout(2*o))       ref: graph_att.py:98-104 (quirk Q-B) + relation_encoder.py:80-81,128-129 (Q-A)
  * bwd: do = dvnew * 2 * keep/(1-p) * [o*keep > 0]   (dv = dvnew) */

@@ -921,6 +921,82 @@ def test_fanout_sums_bias_slots_and_batched_step_dropout():
     assert all(t.data_ptr() % 16 == 0 for t in z)
 
 
+@pytest.mark.parametrize('M,N,K', [(100, 70, 33), (1152, 1024, 1024), (256, 512, 4096), (64, 1024, 2304)])
+def test_gemm_epilogue_post_add_and_dropped_copies(M, N, K, gemm_arith):
+    """ekaid_gemm_t.post (a gradient that joins behind the dropout) and .drop_out (dropped copies of the finished C for the
+    layers that read it) against the separate kernels they replace: bit-identical (same product, same mask function); tiles
+    stored directly and split-K shapes finished by the reduce kernel."""
+    from ekaid_amd import hip, ops
+    L = hip.lib()
+    A, W = rnd(M, K, seed=1).to(DEV), rnd(N, K, seed=2).to(DEV)
+    post, bias = rnd(M, N, seed=3).to(DEV), rnd(N, seed=4).to(DEV)
+    plain = torch.empty(M, N, device=DEV)
+    ops.gemm(A, W, plain, M, N, K, K, K, N, 0, 1, bias=bias)
+    # post: C = dropout(product) + post
+    c = torch.empty(M, N, device=DEV)
+    ops.gemm(A, W, c, M, N, K, K, K, N, 0, 1, bias=bias, drop_p=0.3, drop_seed=77, post=post, ldpost=N)
+    d = torch.empty(M, N, device=DEV)
+    hip.check(L.ekaid_dropout(hip.ptr(plain), hip.ptr(d), plain.numel(), 0.3, 77, hip.stream()), 'dropout')
+    assert torch.equal(c, d + post)
+    # dropped copies: one and two, different probabilities and seeds; C itself stays undropped
+    for specs in ([(0.2, 5)], [(0.2, 5), (0.5, 6)]):
+        copies = [(torch.empty(M, N, device=DEV), pk, sk) for pk, sk in specs]
+        c2 = torch.empty(M, N, device=DEV)
+        ops.gemm(A, W, c2, M, N, K, K, K, N, 0, 1, bias=bias, drop_out=copies)
+        assert torch.equal(c2, plain)
+        for buf, pk, sk in copies:
+            want = torch.empty(M, N, device=DEV)
+            hip.check(L.ekaid_dropout(hip.ptr(plain), hip.ptr(want), plain.numel(), pk, sk, hip.stream()), 'dropout')
+            assert torch.equal(buf, want) and abs(float((buf == 0).float().mean()) - pk) < 0.05
+
+
+def test_fanout_gradients_handed_from_reader_to_reader():
+    """ops.GradSlot: readers of a fan-out tensor that know slots (linear layers with input dropout, the residual of
+    residual_relu2, the value operand of the attention core) pass ONE running gradient along instead of leaving n tensors to a sum
+    kernel; any mix with ordinary readers gives the same gradient as the unfused graph."""
+    from ekaid_amd import hip, ops
+    from ekaid_amd.models.fc import FCNet
+    torch.manual_seed(0)
+    R, N, A = 6, 9, 64
+    x0 = rnd(R, N, A, seed=1).to(DEV)
+    fq, fk = FCNet([A, A], None, 0.2).to(DEV), FCNet([A, A], None, 0.2).to(DEV)
+    fq.train(); fk.train()
+    wq, wk, wo = rnd(R * N, A, seed=2).to(DEV), rnd(R * N, A, seed=3).to(DEV), rnd(R, N, A, seed=4).to(DEV)
+    o = rnd(R, N, A, seed=5).to(DEV)
+
+    def run(slots):
+        x = x0.clone().requires_grad_(True)
+        ops.manual_seed(123)
+        if slots:
+            a, b, c, d = ops.fanout(x, 4)
+        else:
+            a = b = c = d = x
+        y = (fq(a.view(R * N, A)) * wq).sum() + (fk(ops.pass_slot(b, b.view(R * N, A))) * wk).sum()
+        y = y + (ops.residual_relu2(c, o, 0.0, True) * wo).sum() + (d * d).sum()          # d: an ordinary reader
+        g, = torch.autograd.grad(y, x)
+        return g, None
+
+    g_plain, _ = run(False)
+    g_slots, _ = run(True)
+    check(g_slots, g_plain, 2e-6, 'gradient through the slot hand-over')
+    # the slot-aware readers alone: nothing is left to sum
+    x = x0.clone().requires_grad_(True)
+    a, b, c = ops.fanout(x, 3)
+    slot = ops.slot_of(a)
+    y = (fq(ops.pass_slot(a, a.view(R * N, A))) * wq).sum() + (fk(ops.pass_slot(b, b.view(R * N, A))) * wk).sum()
+    y = y + (ops.residual_relu2(c, o, 0.0, True) * wo).sum()
+    import ekaid_amd.ops as O
+    seen = []
+    real = O._sum_into
+    O._sum_into = lambda grads, out: (seen.append(len(grads)), real(grads, out))[1]
+    try:
+        g, = torch.autograd.grad(y, x)
+    finally:
+        O._sum_into = real
+    assert not seen, 'a sum kernel still ran: %r' % (seen,)
+    assert slot.lent is None and g.shape == x.shape and float(g.abs().sum()) > 0
+
+
 # --------------------------------------------------------------------------- slabs: GEMMs whose consumers reduce
 @pytest.mark.parametrize('mode,M,N,K', [('nt', 32, 6656, 512), ('nt', 256, 2048, 1536), ('nn', 32, 512, 6656), ('nn', 7, 100, 50),
                                         ('nt', 2, 64, 31), ('nn', 256, 1024, 2048), ('nt', 600, 256, 512)])
