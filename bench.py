@@ -230,6 +230,7 @@ def real_data_loop(graph, iters=120, time_from=80, answer_mix='short+90'):
             'qa_pairs_per_s': round(tm.get('qa_pairs_per_s', 0.0), 1), 'ms_per_iteration': round(step_ms, 3),
             'loader_wait_ms_per_iteration': round(tm.get('loader_wait_ms_per_iteration', 0.0), 3),
             'loader_wait_fraction': round(tm.get('loader_wait_ms_per_iteration', 0.0) / step_ms, 4) if step_ms else None,
+            'host_waits_for_device_ms_per_iteration': round(tm.get('host_waits_for_device_ms_per_iteration', 0.0), 3),
             'batch_assembly_ms': round(tm.get('batch_assembly_ms', 0.0), 3), 'staging_ms': round(tm.get('staging_ms', 0.0), 3),
             'h2d_ms_per_batch': round(tm.get('h2d_ms_per_batch', 0.0), 3), 'h2d_bytes_per_batch': tm.get('h2d_bytes_per_batch'),
             'exposed_h2d_ms_per_iteration': round(tm.get('exposed_h2d_ms_per_iteration', 0.0), 3),

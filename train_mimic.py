@@ -271,12 +271,13 @@ def main(argv=None):
     def stop_clock():
         torch.cuda.synchronize()
         dt, n_it = time.perf_counter() - t_clock[0], t - t_clock[1]
-        keys = ('h2d_ms', 'stall_ms', 'loader_wait_s', 'batches', 'h2d_bytes', 'produce_s', 'stage_s')
+        keys = ('h2d_ms', 'stall_ms', 'loader_wait_s', 'batches', 'h2d_bytes', 'produce_s', 'stage_s', 'gpu_wait_s')
         before = {k: sum(d[k] for d in t_clock[2]) for k in keys}
         after = {k: sum(pf.stats()[k] for pf in prefetchers) for k in keys}
         nb = max(after['batches'] - before['batches'], 1)
         return {'iterations': n_it, 'ms_per_iteration': dt / n_it * 1e3, 'qa_pairs_per_s': global_bs * n_it / dt,
                 'loader_wait_ms_per_iteration': (after['loader_wait_s'] - before['loader_wait_s']) / nb * 1e3,
+                'host_waits_for_device_ms_per_iteration': (after['gpu_wait_s'] - before['gpu_wait_s']) / nb * 1e3,
                 'batch_assembly_ms': (after['produce_s'] - before['produce_s']) / nb * 1e3,
                 'staging_ms': (after['stage_s'] - before['stage_s']) / nb * 1e3,
                 'h2d_ms_per_batch': (after['h2d_ms'] - before['h2d_ms']) / nb,
