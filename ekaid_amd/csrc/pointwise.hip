@@ -233,6 +233,33 @@ __global__ __launch_bounds__(256) void sum_n_tail_kernel(SumArgs a, float* out, 
 __global__ __launch_bounds__(256) void axpby_kernel(const float* x, const float* y, float* out, long long n, float a, float b) {
     GS_LOOP(i, n) out[i] = y ? a * x[i] + b * y[i] : a * x[i];
 }
+// (a*x + b*x) + c*x in that order: what two axpby launches wrote (quirk Q-A, SelfMix3Fn)
+__global__ __launch_bounds__(256) void self_mix3_kernel(const float* x, float* out, long long n, float a, float b, float c) {
+    GS_LOOP(i, n) {
+        const float v = x[i];
+        const float t = a * v + b * v;
+        out[i] = 1.0f * t + c * v;
+    }
+}
+// zero-row mask of x (rowsum_kernel's summation order) and a dropped copy of x in one pass: the question-expansion mask and the
+// input dropout of the FCNet that reads x next (relation_encoder.py:19-29, fc.py:36-37)
+__global__ __launch_bounds__(256) void rowmask_dropout_kernel(const float* x, long long rows, int cols, float* mask, float* y, float p,
+                                                              float inv_keep, DropSeed seed) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long r = wave0; r < rows; r += nwaves) {
+        const float* q = x + r * cols;
+        float s = 0.f;
+        for (int c = lane; c < cols; c += 64) {
+            const float v = q[c];
+            s += v;
+            y[r * cols + c] = v * dropout_scale(seed, (uint64_t)(r * cols + c), p, inv_keep);
+        }
+        s = wave_sum(s);
+        if (lane == 0) mask[r] = s != 0.f ? 1.f : 0.f;
+    }
+}
 __global__ __launch_bounds__(256) void mul_kernel(const float* x, const float* y, float* out, long long n) {
     GS_LOOP(i, n) out[i] = x[i] * y[i];
 }
@@ -840,6 +867,15 @@ extern "C" int ekaid_dropout(const float* x, float* y, long long n, float p, uin
 extern "C" int ekaid_axpby(const float* x, const float* y, float* out, long long n, float a, float b, void* stream) {
     hipLaunchKernelGGL(axpby_kernel, grid1d(n), dim3(256), 0, ST, x, y, out, n, a, b);
     return check_launch("axpby");
+}
+extern "C" int ekaid_self_mix3(const float* x, float* out, long long n, float a, float b, float c, void* stream) {
+    hipLaunchKernelGGL(self_mix3_kernel, grid1d(n), dim3(256), 0, ST, x, out, n, a, b, c);
+    return check_launch("self_mix3");
+}
+extern "C" int ekaid_rowmask_dropout(const float* x, long long rows, int cols, float* mask, float* y, float p, uint64_t seed, void* stream) {
+    if (!(p >= 0.f && p < 1.f) || cols < 1) { set_error("rowmask_dropout: bad arguments"); return EKAID_ERR_ARG; }
+    hipLaunchKernelGGL(rowmask_dropout_kernel, grid1d(rows * 64), dim3(256), 0, ST, x, rows, cols, mask, y, p, INVK(p), DS(seed));
+    return check_launch("rowmask_dropout");
 }
 extern "C" int ekaid_mul(const float* x, const float* y, float* out, long long n, void* stream) {
     hipLaunchKernelGGL(mul_kernel, grid1d(n), dim3(256), 0, ST, x, y, out, n);

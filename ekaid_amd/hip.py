@@ -148,6 +148,8 @@ SIGNATURES = {
     'ekaid_axpby': [P, P, P, L, F, F, P],
     'ekaid_mul': [P, P, P, L, P],
     'ekaid_rowsum': [P, L, I, P, I, P],
+    'ekaid_rowmask_dropout': [P, L, I, P, P, F, U64, P],
+    'ekaid_self_mix3': [P, P, L, F, F, F, P],
     'ekaid_expand_rows_fwd': [P, P, L, I, I, I, P, F, U64, P],
     'ekaid_expand_rows_bwd': [P, P, L, I, I, I, P, F, U64, P],
     'ekaid_gat_fused_fwd': [P, P, P, P, P, P, I, I, I, I, I, I, P, P, P],

@@ -19,11 +19,15 @@ def q_expand_v_cat(q, v, mask=True, p=0.0, training=False, lazy=False):
     on nodes whose feature row sums to exactly 0.  ``q`` may hold fewer rows than R (R = 2B image
     slices share the B question vectors)."""
     R, N, A = v.shape
-    if mask:
+    v2 = ops.pass_slot(v, v.reshape(R * N, A))          # (v may be a fan-out alias: its reader is the FCNet that takes v2)
+    if mask and training and p > 0 and v.is_contiguous():
+        # one pass over v: the zero-row mask and the dropped copy the consumer FCNet multiplies (its input dropout)
+        keep, seed, vd = ops.rowmask_dropout(v, p)
+        ops.predropped(v2, (float(p), seed, vd))
+    elif mask:
         keep = ops.rowsum(v, as_mask=True).view(-1)
     else:
         keep = torch.ones(R * N, device=v.device, dtype=torch.float32)
-    v2 = ops.pass_slot(v, v.reshape(R * N, A))          # (v may be a fan-out alias: its reader is the FCNet that takes v2)
     if training and p > 0:      # the consumer FCNet's input dropout, fused into the expansion kernel
         return v2, PreDropped(ops.expand_rows(q, keep, N, p, True))
     if lazy and not torch.is_grad_enabled():

@@ -752,17 +752,15 @@ class AxpbyFn(Function):
 
 class SelfMix3Fn(Function):
     """a*x + b*x + c*x evaluated in that order (quirk Q-A: the reference's three "parallel" encoder outputs are one tensor,
-    modules.py:234-235): two launches forward, two backward, no fan-out adds."""
+    modules.py:234-235): one launch forward, one backward, no fan-out adds."""
 
     @staticmethod
     def forward(ctx, x, a, b, c):
         require_cuda(x)
         x = _c(x)
         L = hip.lib()
-        t = torch.empty_like(x)
-        check(L.ekaid_axpby(ptr(x), ptr(x), ptr(t), x.numel(), a, b, stream()), 'axpby')
         out = torch.empty_like(x)
-        check(L.ekaid_axpby(ptr(t), ptr(x), ptr(out), x.numel(), 1.0, c, stream()), 'axpby')
+        check(L.ekaid_self_mix3(ptr(x), ptr(out), x.numel(), a, b, c, stream()), 'self_mix3')
         ctx.abc = (a, b, c)
         return out
 
@@ -771,10 +769,8 @@ class SelfMix3Fn(Function):
         a, b, c = ctx.abc
         d = _c(d)
         L = hip.lib()
-        t = torch.empty_like(d)
-        check(L.ekaid_axpby(ptr(d), ptr(d), ptr(t), d.numel(), a, b, stream()), 'axpby')
         dx = torch.empty_like(d)
-        check(L.ekaid_axpby(ptr(t), ptr(d), ptr(dx), d.numel(), 1.0, c, stream()), 'axpby')
+        check(L.ekaid_self_mix3(ptr(d), ptr(dx), d.numel(), a, b, c, stream()), 'self_mix3')
         return dx, None, None, None
 
 
@@ -998,6 +994,20 @@ def rowsum(x, as_mask=False):
     out = torch.empty(x.shape[:-1], device=x.device, dtype=torch.float32)
     check(hip.lib().ekaid_rowsum(ptr(x), rows, x.shape[-1], ptr(out), int(as_mask), stream()), 'rowsum')
     return out
+
+
+def rowmask_dropout(x, p):
+    """(zero-row mask of x [rows], seed, dropout(x)) in one pass over x (no gradient: the dropped copy is DATA for a linear layer
+    that takes x itself as its autograd input, see ``predropped``)."""
+    require_cuda(x)
+    xc = _c(x.detach())
+    cols = xc.shape[-1]
+    rows = xc.numel() // cols
+    mask = torch.empty(rows, device=x.device, dtype=torch.float32)
+    xd = torch.empty(rows, cols, device=x.device, dtype=torch.float32)
+    seed = next_seed()
+    check(hip.lib().ekaid_rowmask_dropout(ptr(xc), rows, cols, ptr(mask), ptr(xd), float(p), seed, stream()), 'rowmask_dropout')
+    return mask, seed, xd
 
 
 class ExpandRowsFn(Function):

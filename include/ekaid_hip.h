@@ -192,6 +192,11 @@ int ekaid_mul(const float* x, const float* y, float* out, long long n, void* str
 /* rowsum over the last dim: out[r] = sum_c x[r][c];  mask variant: out[r] = (sum != 0)
  * ref: graph_att.py:89 (condensed adjacency), relation_encoder.py:24-27 (zero-row test) */
 int ekaid_rowsum(const float* x, long long rows, int cols, float* out, int as_nonzero_mask, void* stream);
+/* mask[r] = (sum of row r != 0) exactly as ekaid_rowsum(..., 1) forms it, and y = dropout(x) (mask index = flat index), one pass:
+ * the zero-row mask of q_expand_v_cat (relation_encoder.py:19-29) and the input dropout of the FCNet that reads x (fc.py:36-37). */
+int ekaid_rowmask_dropout(const float* x, long long rows, int cols, float* mask, float* y, float p, uint64_t seed, void* stream);
+/* out = (a*x + b*x) + c*x, evaluated in that order (the reference's three "parallel" encoder outputs are one tensor: modules.py:234-235). */
+int ekaid_self_mix3(const float* x, float* out, long long n, float a, float b, float c, void* stream);
 /* out[r][c] = mask[r] * q[(r / group) % qrows][c]     ref: relation_encoder.py:19-29 (q_expand_v_cat, q half;
  * qrows = batch size lets the main and the reference image share one question matrix)
  * bwd: dq[j][c] = sum over rows r with (r / group) % qrows == j of mask[r] * dout[r][c] */

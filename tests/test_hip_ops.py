@@ -950,6 +950,28 @@ def test_gemm_epilogue_post_add_and_dropped_copies(M, N, K, gemm_arith):
             assert torch.equal(buf, want) and abs(float((buf == 0).float().mean()) - pk) < 0.05
 
 
+def test_rowmask_dropout_and_self_mix3_equal_the_launches_they_replace():
+    from ekaid_amd import hip, ops
+    L = hip.lib()
+    x = rnd(300, 1024, seed=1).to(DEV)
+    x[7] = 0.0
+    x[100, :] = 0.0
+    x[11, :2] = torch.tensor([1.0, -1.0], device=DEV)
+    x[11, 2:] = 0.0                                     # sums to exactly zero without being a zero row: masked, as in the reference
+    keep, seed, xd = ops.rowmask_dropout(x, 0.2)
+    assert torch.equal(keep, ops.rowsum(x, as_mask=True).view(-1)) and float(keep[7]) == 0.0 and float(keep[11]) == 0.0
+    want = torch.empty_like(x)
+    hip.check(L.ekaid_dropout(hip.ptr(x), hip.ptr(want), x.numel(), 0.2, seed, hip.stream()), 'dropout')
+    assert torch.equal(xd, want)
+    y = torch.empty(1000 * 37 + 3, device=DEV)
+    src = rnd(1000 * 37 + 3, seed=2).to(DEV)
+    hip.check(L.ekaid_self_mix3(hip.ptr(src), hip.ptr(y), src.numel(), 0.3, 0.5, 0.2, hip.stream()), 'self_mix3')
+    t, y2 = torch.empty_like(src), torch.empty_like(src)
+    hip.check(L.ekaid_axpby(hip.ptr(src), hip.ptr(src), hip.ptr(t), src.numel(), 0.3, 0.5, hip.stream()), 'axpby')
+    hip.check(L.ekaid_axpby(hip.ptr(t), hip.ptr(src), hip.ptr(y2), src.numel(), 1.0, 0.2, hip.stream()), 'axpby')
+    check(y, y2, 1.5e-7, 'self_mix3 vs two axpby launches')
+
+
 def test_fanout_gradients_handed_from_reader_to_reader():
     """ops.GradSlot: readers of a fan-out tensor that know slots (linear layers with input dropout, the residual of
     residual_relu2, the value operand of the attention core) pass ONE running gradient along instead of leaving n tensors to a sum
