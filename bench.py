@@ -85,9 +85,16 @@ def parse():
     ap.add_argument('--gemm-shapes', action='store_true', help='print the per-shape GEMM time table to stderr')
     ap.add_argument('--real-only', action='store_true', help='run only the real-data loop (extra.real_b64) and print its JSON: profiling target')
     ap.add_argument('--no-real', action='store_true', help='skip the real-data loop of the extra block')
+    ap.add_argument('--nodes', type=int, default=None, help='tuning aid: regions per image instead of 36 (the line then names a different workload)')
+    ap.add_argument('--feat-dim', type=int, default=None, help='tuning aid: ROI feature width instead of 2048')
+    ap.add_argument('--decode-steps', type=int, default=None, help='tuning aid: answer length (decode steps) instead of 16')
     ap.add_argument('--spawn-timeout', type=int, default=1500,
                     help='--gpus N > 1 started without a launcher: seconds after which the spawned ranks are stopped')
-    return ap.parse_args()
+    args = ap.parse_args()
+    for key, val in (('N', args.nodes), ('D', args.feat_dim), ('T', args.decode_steps)):
+        if val is not None:
+            SHAPE[key] = val
+    return args
 
 
 def train_step(cfg, cd, sp, opt, b, T, graph, marks=None):
@@ -624,9 +631,10 @@ def main():
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f32', 'gemm_arithmetic': 'bf16x3-exact-split (6 MFMA products, f32 accumulate)' if ops.get_gemm_mode() == ops.GEMM_BF16_SPLIT else 'f32-mfma',
             'data': 'synthetic',
-            'config': {'workload': '%s: synthetic 36-region x 2-image graphs, 2048-d ROI features, 20-token questions, 16 decode '
+            'config': {'workload': '%s: synthetic %d-region x 2-image graphs, %d-d ROI features, 20-token questions, %d decode '
                                    'steps, graph=%s, train step (fwd+bwd+all-reduce+Adam), dropout %s' % (
-                                       workload, args.graph, 'off' if args.eval else 'on'),
+                                       workload if (SHAPE['N'], SHAPE['D'], SHAPE['T']) == (36, 2048, 16) else 'tuning run (NOT a BASELINE.json configuration)',
+                                       SHAPE['N'], SHAPE['D'], SHAPE['T'], args.graph, 'off' if args.eval else 'on'),
                        'global_batch': global_batch, 'per_gpu_batch': per_gpu,
                        'parallelism': 'dp%d' % world, 'question_attention': 'global-batch' if args.global_qc else 'local-batch',
                        'launch_path': ('hipGraph replay, all-reduce %s' % graph_comm) if use_graph else 'eager launches',

@@ -202,6 +202,86 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
     }
     const __amdgpu_buffer_rsrc_t rsXTfm = make_rsrc(a.XTfm, Bp * 512 * 4), rsWlo = make_rsrc(a.w_lo, (long long)(GREEDY ? a.V : 1) * R * 4);
 
+    // ---- greedy decoding: the two stations that turn h_lang_t into the next token.  They run INSIDE step t + 1 -- the logits between the
+    // arrival at seam 0 and its wait, the row-local part between the arrival at seam 1 and its wait -- so neither adds a seam to the chain
+    // of the step (h_lang_t stays in its hand-off buffer until phase E of step t + 1); the last step's run after the loop.
+    auto logits_station = [&](const unsigned* seam4, unsigned target4) -> bool {
+        // logits = h_lang . W_logit^T + b (V columns = ceil(V / 16) tiles in 16 tile slots), eval mode: no output dropout
+        const int tL = wg % 16, vcol = 16 * tL + col;
+        const float blo = vcol < a.V ? a.b_lo[vcol] : 0.f;
+        if (!run_mt<NBR, 1, PreE>(
+                c, 16, [&](int, int i) { return bload4<0>(rsWlo, (unsigned)(min(16 * tL + l15, a.V - 1) * R) * 4u + kwR + 64u * i); }, rsHLfm, KBR,
+                seam4, target4, 0x100u + 4, -1, [&](int, int) { return PreE{}; },
+                [&](const float (&v)[1], const PreE&, int rb, int) {
+                    const int grow = rb * 16 + row;
+                    if (grow < B && vcol < a.V) store_sc1(a.LOG + (long long)grow * 160 + vcol, v[0] + blo);
+                }))
+            return false;
+        seam_arrive(a.sync + 6 * SHARDS * LINE, shard);
+        return true;
+    };
+    auto rows_station = [&](int tp, unsigned target6) -> bool {
+        if (wg >= B) return true;                                // (one row per workgroup and pass; the others have nothing to wait for)
+        if (!seam_wait(a.sync + 6 * SHARDS * LINE, target6, status, c.ok_lds, 0x100u + 6)) return false;
+        // row-local: log-softmax, arg-max (lowest index on ties, token 0 forbidden at the first step), stop flags, next token
+        const int ta = a.t_base + tp;
+        for (int r = wg; r < B; r += G) {
+            if (tid < 64) {
+                float x[3], mx = -INFINITY;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int v = lane + 64 * q;
+                    x[q] = v < a.V ? load_sc1(a.LOG + (long long)r * 160 + v) : -INFINITY;
+                    mx = fmaxf(mx, x[q]);
+                }
+                mx = wave_max(mx);
+                float sm = 0.f;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) sm += lane + 64 * q < a.V ? expf(x[q] - mx) : 0.f;
+                sm = wave_sum(sm);
+                const float ls = logf(sm);
+                float best = -INFINITY;
+                int arg = a.V;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int v = lane + 64 * q;
+                    float lp = v < a.V ? (x[q] - mx) - ls : -INFINITY;
+                    if (ta == 0 && v == 0) lp = -INFINITY;
+                    if (lp > best) { best = lp; arg = v; }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float ob = __shfl_xor(best, off, 64);
+                    const int oa = __shfl_xor(arg, off, 64);
+                    if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+                }
+                if (lane == 0) {
+                    const int un = ta == 0 ? (arg > 0) : (a.unfinished[r] && arg > 0);
+                    a.unfinished[r] = un;
+                    const long long tok = un ? arg : 0;
+                    a.it[r] = tok;
+                    a.seq[(long long)r * a.seq_len + ta] = tok;
+                    a.seq_logp[(long long)r * a.seq_len + ta] = best;
+                    if (un) atomicAdd(a.n_unfinished + ta, 1);
+                    reinterpret_cast<int*>(lds + L::zpart)[0] = (int)tok;
+                }
+            }
+            __syncthreads();
+            if (tid < 128) {                                 // relu(emb[token]) -> the word input of the next step, fragment-major
+                const long long tok = reinterpret_cast<const int*>(lds + L::zpart)[0];
+                f32x4 x = {0.f, 0.f, 0.f, 0.f};
+                if (4 * tid < a.We) {
+                    x = *reinterpret_cast<const f32x4*>(a.emb + tok * a.We + 4 * tid);
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) x[e2] = x[e2] > 0.f ? x[e2] : 0.f;
+                }
+                bstore4_sc1(rsXTfm, fm_chunk(r >> 4, tid >> 2, 32) + (unsigned)(((tid & 3) * 16 + (r & 15)) * 16), x);
+            }
+            __syncthreads();
+        }
+        return true;
+    };
+
     for (int t = 0; t < a.T; ++t) {
         float* HAn = a.HA + (long long)(t + 1) * BR;
         float* HLn = a.HL + (long long)(t + 1) * BR;
@@ -314,6 +394,9 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
         }
         stamp(c, 2);
         seam_arrive(a.sync + 0 * SHARDS * LINE, shard);
+        if (GREEDY && t > 0) {                                   // logits of step t - 1 (every workgroup has waited for seam 4 of that step above)
+            if (!logits_station(nullptr, 0u)) return;
+        }
         stamp(c, 3);
         if (!seam_wait(a.sync + 0 * SHARDS * LINE, tgt, status, c.ok_lds, 0x100u + 0)) return;
         stamp(c, 4);
@@ -380,6 +463,10 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
         }
         stamp(c, 5);
         seam_arrive(a.sync + 1 * SHARDS * LINE, shard);
+        if (GREEDY && t > 0) {                                   // tokens of step t - 1 -> the word input phase E of this step reads behind seam 7
+            if (!rows_station(t - 1, (unsigned)G * (unsigned)t)) return;
+            seam_arrive(a.sync + 7 * SHARDS * LINE, shard);
+        }
         stamp(c, 6);
         // ---- shadow of seam 1: pos_feat = w_p2 . pw + b_p2 of the rows just done -- only the saved-tensor contract reads it (PA[:, :R])
         {
@@ -530,78 +617,10 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
         stamp(c, 14);
         seam_arrive(a.sync + 4 * SHARDS * LINE, shard);
         stamp(c, 15);
-        if (GREEDY) {
-            // ---- logits = h_lang_t . W_logit^T + b (V columns = ceil(V / 16) tiles in 16 tile slots), eval mode: no output dropout
-            const int tL = wg % 16, vcol = 16 * tL + col;
-            const float blo = vcol < a.V ? a.b_lo[vcol] : 0.f;
-            if (!run_mt<NBR, 1, PreE>(
-                    c, 16, [&](int, int i) { return bload4<0>(rsWlo, (unsigned)(min(16 * tL + l15, a.V - 1) * R) * 4u + kwR + 64u * i); }, rsHLfm, KBR,
-                    a.sync + 4 * SHARDS * LINE, tgt, 0x100u + 4, -1, [&](int, int) { return PreE{}; },
-                    [&](const float (&v)[1], const PreE&, int rb, int) {
-                        const int grow = rb * 16 + row;
-                        if (grow < B && vcol < a.V) store_sc1(a.LOG + (long long)grow * 160 + vcol, v[0] + blo);
-                    }))
-                return;
-            seam_arrive(a.sync + 6 * SHARDS * LINE, shard);
-            if (!seam_wait(a.sync + 6 * SHARDS * LINE, tgt, status, c.ok_lds, 0x100u + 6)) return;
-            // ---- row-local: log-softmax, arg-max (lowest index on ties, token 0 forbidden at the first step), stop flags, next token
-            const int ta = a.t_base + t;
-            for (int r = wg; r < B; r += G) {
-                if (tid < 64) {
-                    float x[3], mx = -INFINITY;
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const int v = lane + 64 * q;
-                        x[q] = v < a.V ? load_sc1(a.LOG + (long long)r * 160 + v) : -INFINITY;
-                        mx = fmaxf(mx, x[q]);
-                    }
-                    mx = wave_max(mx);
-                    float sm = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) sm += lane + 64 * q < a.V ? expf(x[q] - mx) : 0.f;
-                    sm = wave_sum(sm);
-                    const float ls = logf(sm);
-                    float best = -INFINITY;
-                    int arg = a.V;
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const int v = lane + 64 * q;
-                        float lp = v < a.V ? (x[q] - mx) - ls : -INFINITY;
-                        if (ta == 0 && v == 0) lp = -INFINITY;
-                        if (lp > best) { best = lp; arg = v; }
-                    }
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) {
-                        const float ob = __shfl_xor(best, off, 64);
-                        const int oa = __shfl_xor(arg, off, 64);
-                        if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
-                    }
-                    if (lane == 0) {
-                        const int un = ta == 0 ? (arg > 0) : (a.unfinished[r] && arg > 0);
-                        a.unfinished[r] = un;
-                        const long long tok = un ? arg : 0;
-                        a.it[r] = tok;
-                        a.seq[(long long)r * a.seq_len + ta] = tok;
-                        a.seq_logp[(long long)r * a.seq_len + ta] = best;
-                        if (un) atomicAdd(a.n_unfinished + ta, 1);
-                        reinterpret_cast<int*>(lds + L::zpart)[0] = (int)tok;
-                    }
-                }
-                __syncthreads();
-                if (tid < 128) {                                 // relu(emb[token]) -> the word input of the next step, fragment-major
-                    const long long tok = reinterpret_cast<const int*>(lds + L::zpart)[0];
-                    f32x4 x = {0.f, 0.f, 0.f, 0.f};
-                    if (4 * tid < a.We) {
-                        x = *reinterpret_cast<const f32x4*>(a.emb + tok * a.We + 4 * tid);
-#pragma unroll
-                        for (int e2 = 0; e2 < 4; ++e2) x[e2] = x[e2] > 0.f ? x[e2] : 0.f;
-                    }
-                    bstore4_sc1(rsXTfm, fm_chunk(r >> 4, tid >> 2, 32) + (unsigned)(((tid & 3) * 16 + (r & 15)) * 16), x);
-                }
-                __syncthreads();
-            }
-            seam_arrive(a.sync + 7 * SHARDS * LINE, shard);
-        }
+    }
+    if (GREEDY) {                                                // the last step's token
+        if (!logits_station(a.sync + 4 * SHARDS * LINE, (unsigned)G * (unsigned)a.T)) return;
+        if (!rows_station(a.T - 1, (unsigned)G * (unsigned)a.T)) return;
     }
 }
 
