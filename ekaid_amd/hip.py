@@ -39,7 +39,6 @@ class GemmDesc(Structure):
         ('drop_p', c_float), ('drop_seed', c_uint64),
         ('a_rowsum', c_void_p),
         ('post', c_void_p), ('ldpost', c_int),
-        ('drop_out', c_void_p * 2), ('drop_out_p', c_float * 2), ('drop_out_seed', c_uint64 * 2),
     ]
 
 

@@ -60,10 +60,10 @@ class WNLinear(nn.Module):
         self.weight_v = nn.Parameter(lin.weight.detach().clone())
         self.in_features, self.out_features = in_dim, out_dim
 
-    def forward(self, xs, act=ACT_NONE, drops=None, copies=()):
+    def forward(self, xs, act=ACT_NONE, drops=None):
         """``drops``: per-input dropout probabilities applied to the inputs inside the linear node (the FCNet's
-        Dropout layer; its backward then rides in the dgrad GEMM epilogue).  ``copies``: see ``ops.wn_linear``."""
-        return ops.wn_linear(xs, self.weight_v, self.weight_g, self.bias, act, drops, copies)
+        Dropout layer; its backward then rides in the dgrad GEMM epilogue)."""
+        return ops.wn_linear(xs, self.weight_v, self.weight_g, self.bias, act, drops)
 
     def extra_repr(self):
         return 'in_features=%d, out_features=%d, bias=%s' % (self.in_features, self.out_features,
@@ -87,12 +87,9 @@ class FCNet(nn.Module):
         self.main = nn.Sequential(*layers)
         self.act = _ACT_CODE[act]
 
-    def forward(self, x, copies=()):
-        """``x``: tensor or tuple of tensors (feature-axis concatenation).  ``copies``: input-dropout probabilities of the FCNets
-        that will read the output (training): the last layer's epilogue writes their dropped inputs (``ops.wn_linear``)."""
+    def forward(self, x):
+        """``x``: tensor or tuple of tensors (feature-axis concatenation)."""
         pending = 0.0                                        # dropout of the layer input, applied inside the linear node
-        n_lin = sum(isinstance(m, WNLinear) for m in self.main)
-        i_lin = 0
         if isinstance(x, (tuple, list)) and any(isinstance(t, RowBroadcast) for t in x):
             lin = [m for m in self.main if isinstance(m, WNLinear)]
             if (len(x) == 2 and isinstance(x[1], RowBroadcast) and len(lin) == 1 and not torch.is_grad_enabled()
@@ -110,8 +107,7 @@ class FCNet(nn.Module):
                     pending = 0.0
                 drops = tuple(0.0 if isinstance(t, PreDropped) else pending for t in xs)
                 xs = tuple(t.tensor if isinstance(t, PreDropped) else t for t in xs)
-                i_lin += 1
-                x = layer(xs if len(xs) > 1 else xs[0], self.act, drops, copies if (i_lin == n_lin and self.training) else ())
+                x = layer(xs if len(xs) > 1 else xs[0], self.act, drops)
                 pending = 0.0
         return x
 

@@ -56,18 +56,13 @@ class GAttNet(nn.Module):
         elif self.pos_emb_dim < 0 and pos_emb is not None:
             raise ValueError("position embedding is NOT None with pos_emb_dim < 0")
         R, N = adj_matrix.shape[0], adj_matrix.shape[1]
-        dirs = range(self.dir_num) if self.compute_dead_directions else [self.dir_num - 1]
-        # training: the input dropouts of the surviving direction's query / key layers come out of the self_weights epilogue
-        net = self.neighbor_net[dirs[-1]]
-        copies = (net.query.input_dropout(), net.key.input_dropout()) if (self.training and len(dirs) == 1 and N <= net.nongt_dim) else ()
-        sf = self.self_weights(v_feat, copies)
-        self_feat = sf.view(R, N, self.out_feat_dim)
-        dropped = getattr(sf, '_ekaid_copies', None)
+        self_feat = self.self_weights(v_feat).view(R, N, self.out_feat_dim)
         cond, lbias = self.edge_terms(adj_matrix)
         aff = [None] * self.dir_num
         output = None
+        dirs = range(self.dir_num) if self.compute_dead_directions else [self.dir_num - 1]
         for d in dirs:
-            output, aff[d] = self.neighbor_net[d].forward(self_feat, cond, pos_emb, lbias, direction=d, dropped=dropped)
+            output, aff[d] = self.neighbor_net[d].forward(self_feat, cond, pos_emb, lbias, direction=d)
         if residual is None:
             residual = torch.zeros_like(output)
         out = ops.residual_relu2(residual, output, self.dropout.p, self.training)

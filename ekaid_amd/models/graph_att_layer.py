@@ -37,22 +37,17 @@ class GraphSelfAttentionLayer(nn.Module):
         self.linear_out_2 = Linear(self.fc_dim * feat_dim, self.dim[2])
         self.attention_impl = 'fused'        # 'fused' | 'gemm' (same math composed from batched GEMMs)
 
-    def forward(self, roi_feat, adj_matrix, position_embedding, label_biases_att, direction=0, dropped=None):
+    def forward(self, roi_feat, adj_matrix, position_embedding, label_biases_att, direction=0):
         """
         roi_feat: [R, N, feat_dim]; adj_matrix / label_biases_att: [R, N, N] in the ORIGINAL orientation
         (``direction=1`` makes the kernel read them transposed, which is what graph_att.py:76,88 feeds
         to neighbor_net[1]); position_embedding: [R, N, M, pos_emb_dim] or None.
-        ``dropped``: None, or the dropped copies of roi_feat its producer wrote for the query and the key layer
-        (``ops.wn_linear(copies=...)``: [(p, seed, buffer)] * 2; all N rows are keys).
         Returns (output [R, N, feat_dim], softmax [R, N, heads, M]).
         """
         R, N, A = roi_feat.shape
         M = self.nongt_dim if self.nongt_dim < N else N
         feat_q, feat_k, feat_s = ops.fanout(roi_feat, 3)          # three readers: query, key, aggregated values
         key_feat = feat_k if M == N else feat_k[:, :M].contiguous()
-        if dropped is not None and len(dropped) == 2 and M == N and feat_q is not key_feat:
-            ops.predropped(feat_q, dropped[0])
-            ops.predropped(key_feat, dropped[1])
         q_data = self.query(feat_q).view(R, N, A)
         k_data = self.key(key_feat).view(R, M, A)
         geo = None

@@ -171,10 +171,9 @@ def seq_in_c():
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=None,
          accumulate=False, bias=None, R=None, ldr=0, rdiv=1, rowmask=None, act=ACT_NONE,
          batch=(1, 1), strides=(0, 0, 0, 0, 0, 0), a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_seed=0, a_rowsum=None,
-         post=None, ldpost=0, drop_out=()):
+         post=None, ldpost=0):
     """C = dropout(act(alpha * op(A) op(B) [+C] [+bias] [+R])) [+post] on raw device buffers (element offsets a_off..); ``a_rowsum``
-    (transA only): a_rowsum[m] += sum_k op(A)[m][k], the bias gradient riding on a weight-gradient product; ``drop_out``: up to two
-    (buffer, p, seed) -- dropped copies of the finished C written by the same epilogue."""
+    (transA only): a_rowsum[m] += sum_k op(A)[m][k], the bias gradient riding on a weight-gradient product."""
     d = GemmDesc()
     d.A = A.data_ptr() + 4 * a_off
     d.B = B.data_ptr() + 4 * b_off
@@ -198,10 +197,6 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=N
     d.a_rowsum = ptr(a_rowsum) if _BIAS_IN_WGRAD else None
     d.post = ptr(post)
     d.ldpost = ldpost
-    for i, (buf, pk, sk) in enumerate(drop_out):
-        d.drop_out[i] = buf.data_ptr() + 4 * c_off
-        d.drop_out_p[i] = pk
-        d.drop_out_seed[i] = sk
     L = hip.lib()
     need = L.ekaid_gemm_workspace_bytes(ctypes.byref(d))
     ws = hip.workspace(need, C.device) if need else None
@@ -369,9 +364,6 @@ class LinearFn(Function):
         xs2, lds = zip(*[_rows2d(x) for x in xs])
         xs2, lds = list(xs2), list(lds)
         seeds = [0] * len(xs2)
-        copies = ()
-        if isinstance(drops, LinearOpts):
-            drops, copies = drops.drops, drops.copies
         if drops is not None:
             for i, pd in enumerate(drops):
                 if pd > 0.0:
@@ -390,20 +382,16 @@ class LinearFn(Function):
         assert sum(x.shape[1] for x in xs2) == Ktot, 'input widths do not add up to in_features'
         y = torch.empty(M, N, device=W.device, dtype=torch.float32)
         Wt = weight_transposed(W) if _use_transposed(M) else None
-        # input dropouts of the layers that read y, written by the epilogue of the last product: (p, seed, dropped copy) each
-        emitted = [(float(pc), next_seed(), torch.empty_like(y)) for pc in copies]
-        _emitted_copies[:] = emitted
         off = 0
         for i, (x, ld) in enumerate(zip(xs2, lds)):
             last = i == len(xs2) - 1
             K = x.shape[1]
-            extra = [(c, pc, sc) for pc, sc, c in emitted] if last else ()
             if Wt is not None:      # B = W^T [K][N]: n-contiguous staging (512-byte row segments), the faster variant
                 gemm(x, Wt, y, M, N, K, ld, N, N, 0, 0, alpha_dev=scale, accumulate=i > 0,
-                     bias=b if last else None, act=act if last else ACT_NONE, b_off=off * N, drop_out=extra)
+                     bias=b if last else None, act=act if last else ACT_NONE, b_off=off * N)
             else:
                 gemm(x, W, y, M, N, K, ld, Ktot, N, 0, 1, alpha_dev=scale, accumulate=i > 0,
-                     bias=b if last else None, act=act if last else ACT_NONE, b_off=off, drop_out=extra)
+                     bias=b if last else None, act=act if last else ACT_NONE, b_off=off)
             off += K
         ctx.act = act
         ctx.has_b = b is not None
@@ -534,18 +522,6 @@ class WNLinearFn(Function):
         return LinearFn.backward(ctx, dy)
 
 
-class LinearOpts:
-    """``drops`` argument of LinearFn / WNLinearFn when the layer also emits dropped copies of its output: ``drops`` = the
-    per-input dropout probabilities (or None), ``copies`` = one probability per copy."""
-    __slots__ = ('drops', 'copies')
-
-    def __init__(self, drops, copies):
-        self.drops, self.copies = drops, tuple(copies)
-
-
-_emitted_copies = []        # side channel LinearFn.forward -> wn_linear: the (p, seed, buffer) triples of the call that just ran
-
-
 def linear(xs, W, b=None, scale=None, act=ACT_NONE, drops=None):
     if isinstance(xs, torch.Tensor):
         xs = (xs,)
@@ -667,25 +643,18 @@ def wn_linear_rowbcast(x, q, mask, group, v, g, b=None, act=ACT_NONE):
     return y.view(*x.shape[:-1], N)
 
 
-def wn_linear(xs, v, g, b=None, act=ACT_NONE, drops=None, copies=()):
-    """``copies``: dropout probabilities of the layers that will read the output -- their dropped inputs come out of this layer's
-    epilogue (``out._ekaid_copies`` = [(p, seed, buffer)]; see ``predropped``) instead of one dropout pass per reader."""
+def wn_linear(xs, v, g, b=None, act=ACT_NONE, drops=None):
     if isinstance(xs, torch.Tensor):
         xs = (xs,)
     if drops is not None and not any(d > 0.0 for d in drops):
         drops = None
-    copies = tuple(float(c) for c in copies if c > 0.0)
-    if not copies:
-        return WNLinearFn.apply(v, b, g, act, drops, *xs)
-    out = WNLinearFn.apply(v, b, g, act, LinearOpts(drops, copies), *xs)
-    out._ekaid_copies = list(_emitted_copies)
-    del _emitted_copies[:]
-    return out
+    return WNLinearFn.apply(v, b, g, act, drops, *xs)
 
 
 def predropped(alias, copy):
     """Mark ``alias`` (a tensor about to enter an FCNet with input dropout) as already dropped: ``copy`` = (p, seed, buffer) from
-    the producer's ``_ekaid_copies``.  The reader uses the buffer as data and (p, seed) for its backward."""
+    the kernel that made the dropped copy on its way (``rowmask_dropout``).  The reader uses the buffer as data and (p, seed) for its
+    backward."""
     if copy is not None:
         alias._ekaid_predrop = copy
     return alias

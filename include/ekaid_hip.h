@@ -87,11 +87,6 @@ typedef struct ekaid_gemm {
     const float* post;      /* optional (one batch): C = dropout(act(...)) + post[m * ldpost + n] -- a gradient of the same tensor that joins
                                this input-gradient product behind its dropout, instead of an n-ary sum kernel afterwards */
     int ldpost;
-    float* drop_out[2];     /* optional (one batch): dropped copies of the finished C, drop_out[k][m * ldc + n] = C[m][n] * keep(drop_out_seed[k],
-                               m * N + n) / (1 - drop_out_p[k]): the input dropouts (fc.py:36-37) of the layers that read C, emitted by C's
-                               producer instead of one dropout pass per reader */
-    float drop_out_p[2];
-    uint64_t drop_out_seed[2];
 } ekaid_gemm_t;
 
 size_t ekaid_gemm_workspace_bytes(const ekaid_gemm_t* g);

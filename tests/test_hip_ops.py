@@ -922,10 +922,10 @@ def test_fanout_sums_bias_slots_and_batched_step_dropout():
 
 
 @pytest.mark.parametrize('M,N,K', [(100, 70, 33), (1152, 1024, 1024), (256, 512, 4096), (64, 1024, 2304)])
-def test_gemm_epilogue_post_add_and_dropped_copies(M, N, K, gemm_arith):
-    """ekaid_gemm_t.post (a gradient that joins behind the dropout) and .drop_out (dropped copies of the finished C for the
-    layers that read it) against the separate kernels they replace: bit-identical (same product, same mask function); tiles
-    stored directly and split-K shapes finished by the reduce kernel."""
+def test_gemm_epilogue_post_add(M, N, K, gemm_arith):
+    """ekaid_gemm_t.post (a gradient that joins the product behind its dropout) against the separate kernels it replaces: bit-identical
+    (same product, same mask function); tiles stored directly, edge tiles, and split-K shapes finished by the reduce kernel; with an
+    accumulating product (old C and post both fetched ahead of the stores)."""
     from ekaid_amd import hip, ops
     L = hip.lib()
     A, W = rnd(M, K, seed=1).to(DEV), rnd(N, K, seed=2).to(DEV)
@@ -938,16 +938,13 @@ def test_gemm_epilogue_post_add_and_dropped_copies(M, N, K, gemm_arith):
     d = torch.empty(M, N, device=DEV)
     hip.check(L.ekaid_dropout(hip.ptr(plain), hip.ptr(d), plain.numel(), 0.3, 77, hip.stream()), 'dropout')
     assert torch.equal(c, d + post)
-    # dropped copies: one and two, different probabilities and seeds; C itself stays undropped
-    for specs in ([(0.2, 5)], [(0.2, 5), (0.5, 6)]):
-        copies = [(torch.empty(M, N, device=DEV), pk, sk) for pk, sk in specs]
-        c2 = torch.empty(M, N, device=DEV)
-        ops.gemm(A, W, c2, M, N, K, K, K, N, 0, 1, bias=bias, drop_out=copies)
-        assert torch.equal(c2, plain)
-        for buf, pk, sk in copies:
-            want = torch.empty(M, N, device=DEV)
-            hip.check(L.ekaid_dropout(hip.ptr(plain), hip.ptr(want), plain.numel(), pk, sk, hip.stream()), 'dropout')
-            assert torch.equal(buf, want) and abs(float((buf == 0).float().mean()) - pk) < 0.05
+    # accumulate (old C added before the dropout) together with post
+    c0 = rnd(M, N, seed=5).to(DEV)
+    c3 = c0.clone()
+    ops.gemm(A, W, c3, M, N, K, K, K, N, 0, 1, accumulate=True, post=post, ldpost=N)
+    plain2 = torch.empty(M, N, device=DEV)
+    ops.gemm(A, W, plain2, M, N, K, K, K, N, 0, 1)
+    check(c3, (plain2 + c0) + post, 1e-6, 'accumulate + post')
 
 
 def test_rowmask_dropout_and_self_mix3_equal_the_launches_they_replace():
