@@ -61,17 +61,24 @@ struct Epi {
 // elements BEFORE the first store of the group: a load issued between two stores cannot be moved above the earlier one (C and post may
 // alias as far as the compiler knows), and an epilogue of 64 load -> add -> store round trips per lane costs more than the n-ary sum
 // kernel the post operand replaces (measured: +37 us per launch at 18432 x 1024)
-__device__ __forceinline__ float epilogue(float acc, float cold, float postv, int m, int n, const Epi& e, float alpha) {
-    float v = acc * alpha;
-    if (e.beta) v += cold;
-    if (e.bias) v += e.bias[n];
+// The same holds for every other operand: `pre` = bias[n] + rowmask[m] * R[m / rdiv][n] and `seed` = the dropout seed with the epoch word
+// folded in (a device word under hipGraph replay) are formed by the callers ahead of the stores as well (epi_pre / epi_seed).
+__device__ __forceinline__ float epi_pre(const Epi& e, int m, int n) {
+    float p = e.bias ? e.bias[n] : 0.f;
     if (e.R) {
         float r = e.R[(long long)(m / e.rdiv) * e.ldr + n];
         if (e.rowmask) r *= e.rowmask[m];
-        v += r;
+        p += r;
     }
+    return p;
+}
+__device__ __forceinline__ uint64_t epi_seed(const Epi& e) { return e.drop_p > 0.f ? drop_seed_value(DropSeed{e.drop_seed, e.drop_epoch}) : 0ull; }
+__device__ __forceinline__ float epilogue(float acc, float cold, float pre, float postv, uint64_t seed, int m, int n, const Epi& e, float alpha) {
+    float v = acc * alpha;
+    if (e.beta) v += cold;
+    v += pre;
     v = act_apply(v, e.act);
-    if (e.drop_p > 0.f) v *= dropout_scale(DropSeed{e.drop_seed, e.drop_epoch}, (uint64_t)m * e.n_cols + n, e.drop_p, e.drop_inv);
+    if (e.drop_p > 0.f) v *= dropout_scale(seed, (uint64_t)m * e.n_cols + n, e.drop_p, e.drop_inv);
     return v + postv;
 }
 
@@ -190,6 +197,7 @@ __device__ __forceinline__ void write_tiles(const GemmArgs& g, f32x16 (&acc)[TM]
         ldc = g.ldc;
     }
     const float alpha = g.e.alpha_dev ? g.e.alpha * g.e.alpha_dev[0] : g.e.alpha;
+    const uint64_t seed = slab ? 0ull : epi_seed(g.e);
     const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N);
     auto store_tiles = [&](auto checked) {
         constexpr bool CHECK = decltype(checked)::value;
@@ -201,22 +209,24 @@ __device__ __forceinline__ void write_tiles(const GemmArgs& g, f32x16 (&acc)[TM]
                 if (CHECK && n >= g.N) continue;
                 const int mb = m0 + wm + 32 * i + 4 * h;
                 float* cp0 = C + (long long)mb * ldc + n;
-                float cold[16], postv[16];                       // the 16 old-C / post elements of this lane, all requested before the first store
-                const bool has_cold = !slab && g.e.beta, has_post = !slab && g.e.post;
+                float cold[16], postv[16], pre[16];              // the operands of this lane's 16 elements, all requested before the first store
+                const bool has_cold = !slab && g.e.beta, has_post = !slab && g.e.post, has_res = !slab && g.e.R;
                 const float* pp0 = has_post ? g.e.post + (long long)mb * g.e.ldpost + n : nullptr;
+                const float bias = (!slab && g.e.bias) ? g.e.bias[n] : 0.f;
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
                     const int dm = (t & 3) + 8 * (t >> 2);
                     const bool ok = !CHECK || mb + dm < g.M;
                     cold[t] = (has_cold && ok) ? cp0[(long long)dm * ldc] : 0.f;
                     postv[t] = (has_post && ok) ? pp0[(long long)dm * g.e.ldpost] : 0.f;
+                    pre[t] = (has_res && ok) ? epi_pre(g.e, mb + dm, n) : bias;
                 }
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
                     const int dm = (t & 3) + 8 * (t >> 2);
                     if (CHECK && mb + dm >= g.M) continue;
                     float* cp = cp0 + (long long)dm * ldc;
-                    *cp = slab ? acc[i][jj][t] : epilogue(acc[i][jj][t], cold[t], postv[t], mb + dm, n, g.e, alpha);
+                    *cp = slab ? acc[i][jj][t] : epilogue(acc[i][jj][t], cold[t], pre[t], postv[t], seed, mb + dm, n, g.e, alpha);
                 }
             }
     };
@@ -1075,7 +1085,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, flo
         for (int k = 0; k < splitk; ++k) s += ws[(long long)k * total + i];
         float* cp = C + (long long)m * ldc + n;
         const float cold = e.beta ? *cp : 0.f;
-        *cp = epilogue(s, cold, e.post ? e.post[(long long)m * e.ldpost + n] : 0.f, m, n, e, alpha);
+        *cp = epilogue(s, cold, epi_pre(e, m, n), e.post ? e.post[(long long)m * e.ldpost + n] : 0.f, epi_seed(e), m, n, e, alpha);
     }
 }
 
@@ -1111,8 +1121,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __r
         if ((e.ldpost & 3) == 0 && (reinterpret_cast<uintptr_t>(e.post) & 15) == 0) pv = *reinterpret_cast<const f32x4*>(pp);
         else { pv[0] = pp[0]; pv[1] = pp[1]; pv[2] = pp[2]; pv[3] = pp[3]; }
     }
+    const uint64_t seed = epi_seed(e);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) o[c] = epilogue(s[c], cold[c], pv[c], m, n + c, e, alpha);
+    for (int c = 0; c < 4; ++c) o[c] = epilogue(s[c], cold[c], epi_pre(e, m, n + c), pv[c], seed, m, n + c, e, alpha);
     *cp = o;
 }
 
