@@ -51,7 +51,7 @@ struct PFwd {
     // workspace: hand-off buffers (fragment-major unless noted) and the per-call linear maps of gate-MLP layer 1
     float *HLfm, *HAfm /* [2] */, *G1fm, *GAfm, *MWPW /* [Bp][32] row-major: mw 0..2, pw 16..31 */, *LHP /* [nrb][R/4][256] */;
     const float *Fm /* [3][B][G1] */, *Wp /* [G1][P] */, *cp /* [G1] */;
-    int We, jobsA, jobsD;
+    int We, jobsA, jobsD, jobsE, wp_lds;
     // greedy decoding (template flag GREEDY): the step loop additionally forms the logits, picks the tokens and feeds them back
     int V, seq_len, t_base;
     const float *emb, *bih_l, *w_lo, *b_lo;
@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
     float* const jobsA_lds = lds + L::fixed;
     float* const tilesD_lds = jobsA_lds + a.jobsA * L::per_jobA;
     float* const tilesE_lds = tilesD_lds + a.jobsD * MTD * L::per_tileD;
+    float* const wwp_lds = tilesE_lds + a.jobsE * MTE * L::per_tileE;     // (a.wp_lds) weight_pos, rows padded to R + 4 floats
     Ctx c = {tid, lane, wave, wg, G, nrb, B, row, col, lds + L::red, 0, status, reinterpret_cast<int*>(lds + L::flag), nullptr};
     const long long BR = (long long)B * R;
     const long long Bp = 16ll * nrb;
@@ -125,6 +126,8 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
     if (tid < 3) lds[L::bsm + tid] = a.b_fc[tid];
     if (tid < P) lds[L::bsm + 4 + tid] = a.b_wp[tid];
     for (int i = tid; i < R; i += 256) lds[L::bsm + 4 + P + i] = a.b_p2[i];
+    if (a.wp_lds && wg < B)                                       // (only the workgroups that own a batch row read it)
+        for (int i = tid; i < P * R; i += 256) wwp_lds[(i / R) * (R + 4) + i % R] = a.w_wp[i];
     for (int n = 0; n < njA; ++n) {                              // attention-LSTM cell state and the F_m slices of the (tile, row block) pairs
         const int rb = rbA0 + n * drbA, gr = min(rb * 16 + row, B - 1);
         float* s = jobsA_lds + n * L::per_jobA;
@@ -421,12 +424,23 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
                     if (lane == 0) { lds[L::zpart + wave * 4] = z0; lds[L::zpart + wave * 4 + 1] = z1; lds[L::zpart + wave * 4 + 2] = z2; }
                 } else {                                         // POS logits: thread (j = q >> 3, c = q & 7) sums the k with (k / 4) % 8 == c
                     const int q = tid - 128, j = q >> 3, cq = q & 7;
-                    const f32x4* wr = reinterpret_cast<const f32x4*>(a.w_wp + j * R) + cq;
+                    // weight_pos row j from LDS when it fits (from L2 it is 16 dependent-latency loads per thread and row: 2.8 of the
+                    // phase's 6.3 us), same order of operations either way
                     float s = 0.f;
+                    if (a.wp_lds) {
+                        const float* wl = wwp_lds + j * (R + 4) + 4 * cq;
 #pragma unroll 4
-                    for (int i = 0; i < R / 32; ++i) {
-                        const f32x4 wv = wr[8 * i], xv = *reinterpret_cast<const f32x4*>(lds + L::vrow + 4 * (cq + 8 * i));
-                        s += (wv[0] * xv[0] + wv[1] * xv[1]) + (wv[2] * xv[2] + wv[3] * xv[3]);
+                        for (int i = 0; i < R / 32; ++i) {
+                            const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + 32 * i), xv = *reinterpret_cast<const f32x4*>(lds + L::vrow + 4 * (cq + 8 * i));
+                            s += (wv[0] * xv[0] + wv[1] * xv[1]) + (wv[2] * xv[2] + wv[3] * xv[3]);
+                        }
+                    } else {
+                        const f32x4* wr = reinterpret_cast<const f32x4*>(a.w_wp + j * R) + cq;
+#pragma unroll 4
+                        for (int i = 0; i < R / 32; ++i) {
+                            const f32x4 wv = wr[8 * i], xv = *reinterpret_cast<const f32x4*>(lds + L::vrow + 4 * (cq + 8 * i));
+                            s += (wv[0] * xv[0] + wv[1] * xv[1]) + (wv[2] * xv[2] + wv[3] * xv[3]);
+                        }
                     }
                     lds[L::pz + q] = s;
                 }
@@ -631,7 +645,7 @@ bool persistent_shape_ok(const ekaid_speaker_seq_t* d) {
 }
 
 struct PersistPlan {
-    int G, nrb, mtD, mtE, jobsA, jobsD, jobsE;
+    int G, nrb, mtD, mtE, jobsA, jobsD, jobsE, wp_lds;
     size_t lds_bytes;
     // workspace offsets (bytes)
     size_t o_hl, o_ha, o_g1, o_ga, o_mwpw, o_lhp, o_fm, o_wp, o_cp, o_gemm, o_trace, total;
@@ -666,6 +680,8 @@ bool persistent_plan(const ekaid_speaker_seq_t* d, void* workspace, PersistPlan&
     using L = Lds<PR, PA_, PP>;
     pl.lds_bytes = (size_t)(L::fixed + pl.jobsA * L::per_jobA + pl.jobsD * pl.mtD * L::per_tileD + pl.jobsE * pl.mtE * L::per_tileE) * sizeof(float);
     if (pl.lds_bytes > 160 * 1024) return false;
+    pl.wp_lds = pl.lds_bytes + (size_t)PP * (PR + 4) * sizeof(float) <= 160 * 1024;      // weight_pos next to the job slots when it fits
+    if (pl.wp_lds) pl.lds_bytes += (size_t)PP * (PR + 4) * sizeof(float);
     const size_t Bp = 16 * (size_t)pl.nrb, f = sizeof(float);
     size_t o = al256((size_t)SYNC_WORDS * 4);
     pl.o_hl = o; o += al256(Bp * PR * f);
@@ -760,7 +776,7 @@ int launch_persistent_fwd(const ekaid_speaker_seq_t* d, const ekaid_speaker_gree
     a.HLfm = (float*)(ws + pl.o_hl); a.HAfm = (float*)(ws + pl.o_ha); a.G1fm = (float*)(ws + pl.o_g1); a.GAfm = (float*)(ws + pl.o_ga);
     a.MWPW = (float*)(ws + pl.o_mwpw); a.LHP = (float*)(ws + pl.o_lhp);
     a.Fm = (const float*)(ws + pl.o_fm); a.Wp = (const float*)(ws + pl.o_wp); a.cp = (const float*)(ws + pl.o_cp);
-    a.We = d->We; a.jobsA = pl.jobsA; a.jobsD = pl.jobsD;
+    a.We = d->We; a.jobsA = pl.jobsA; a.jobsD = pl.jobsD; a.jobsE = pl.jobsE; a.wp_lds = pl.wp_lds;
     if (d->seeds) memcpy(a.seeds, d->seeds, sizeof(uint64_t) * 3 * d->T);
     if (gq) {
         a.V = gq->V; a.seq_len = gq->seq_len; a.t_base = t0;
