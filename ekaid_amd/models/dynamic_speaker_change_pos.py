@@ -236,7 +236,38 @@ class DynamicSpeaker(CaptionModel):
                         seq_logprobs[:, first + 1:] = 0
                         break
             return seq, seq_logprobs
-        raise NotImplementedError(
-            'DynamicSpeaker._sample: only greedy decoding (sample_max=1, no decoding constraint) is on the EKAID path -- it is '
-            'what test_mimic.py:119-122 and train_mimic.py:330 call; the multinomial / constrained branch of the reference '
-            '(dynamic_speaker_change_pos.py:309-357) is not reproduced')
+        # the remaining branches of the reference loop (:320-357), step by step through get_logprobs_state (HIP kernels); the token
+        # bookkeeping is a handful of device-side tensor ops per step, the "all finished" test is polled like above:
+        #   * multinomial sampling (sample_max == 0) with cfg.model.speaker.temperature (:336-343),
+        #   * the decoding constraint (never repeat the word sampled at t - 1, :324-327), for either way of choosing.
+        # The random stream is torch's device generator, so the draws differ from the reference's CPU draws by construction.
+        temperature = float(sp.get('temperature', 1.0))
+        unfinished = None
+        for t in range(self.seq_length):
+            logprobs, state, _ = self.get_logprobs_state(it, feat_bef, feat_aft, feat_diff, state, embed_pre)
+            lp = logprobs.detach().clone()
+            if t == 0:
+                lp[:, 0] = float('-inf')                                   # never sample NULL first (:318-322)
+            if decoding_constraint and t > 0:
+                lp.scatter_(1, seq[:, t - 1:t], float('-inf'))
+            if sample_max:
+                sample_logprobs, it = torch.max(lp, 1)
+            else:
+                # exp(logprobs / temperature) as in the reference, shifted by the row maximum first: the same distribution once
+                # multinomial normalises it, but no row underflows to all zeros at a small temperature
+                shifted = lp - lp.max(1, keepdim=True).values
+                prob_prev = torch.exp(shifted) if temperature == 1.0 else torch.exp(shifted / temperature)
+                it = torch.multinomial(prob_prev, 1)
+                sample_logprobs = lp.gather(1, it).view(-1)                # the log-prob of the sampled word, not tempered (:342)
+                it = it.view(-1)
+            it = it.long()
+            # the reference leaves the loop at the first step after which nobody is running (:354-356); polled here, so the steps in
+            # between are blanked by a device-side flag: (everything had stopped before this step) -> nothing is recorded
+            running = None if t == 0 else (unfinished.sum() > 0)
+            unfinished = (it > 0) if t == 0 else unfinished * (it > 0)
+            it = it * unfinished.type_as(it)
+            seq[:, t] = it
+            seq_logprobs[:, t] = sample_logprobs.view(-1) if running is None else sample_logprobs.view(-1) * running.to(sample_logprobs.dtype)
+            if ((t + 1) % self.greedy_poll == 0 or t == self.seq_length - 1) and int(unfinished.sum()) == 0:
+                break
+        return seq, seq_logprobs

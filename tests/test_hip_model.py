@@ -186,6 +186,48 @@ def test_greedy_decode_sequence_call_equals_the_step_by_step_loop():
     close(res[True][2][:, :n], res[False][2][:, :n], 1e-5, 'module weights per decode step')
 
 
+def test_sampling_branches_of_sample_follow_the_reference_loop():
+    """The non-greedy branches of DynamicSpeaker._sample (dynamic_speaker_change_pos.py:320-357): multinomial sampling with a
+    temperature, and the decoding constraint.  The random stream is the device generator (draws differ from the reference's by
+    construction), so the checks are the loop's invariants: at a vanishing temperature the draws are the greedy ids; NULL is never
+    drawn first; the recorded log-prob is the untempered log-prob of the drawn word; rows stay 0 after their first 0; under the
+    constraint no word repeats its predecessor; everything after the step at which all rows had stopped is blank."""
+    import copy
+    cfg, cd, sp = small_models('all', device=DEV)
+    with torch.no_grad():
+        _, _, outs, _, _ = hip_step(cfg, cd, sp, make_batch(**SMALL), 'mode2', 'all')
+        greedy, greedy_lp = sp._sample(outs[3], outs[4], outs[5], None, cfg, sample_max=1)
+        cold = copy.deepcopy(cfg)
+        cold.model.speaker['temperature'] = 1e-3
+        torch.manual_seed(3)
+        seq, lp = sp._sample(outs[3], outs[4], outs[5], None, cold, sample_max=0)
+        assert torch.equal(seq, greedy)
+        close(lp, greedy_lp, 1e-5, 'log-probs of the drawn words at a vanishing temperature')
+        hot = copy.deepcopy(cfg)
+        hot.model.speaker['temperature'] = 2.0
+        hot.model.speaker['decoding_contraint'] = 1
+        torch.manual_seed(4)
+        seq2, lp2 = sp._sample(outs[3], outs[4], outs[5], None, hot, sample_max=0)
+        torch.manual_seed(4)
+        seq3, _ = sp._sample(outs[3], outs[4], outs[5], None, hot, sample_max=0)
+        assert torch.equal(seq2, seq3), 'same seed, same draws'
+        assert not torch.equal(seq2, greedy) and int((seq2[:, 0] == 0).sum()) == 0
+        s2 = seq2.cpu()
+        alive = torch.ones(s2.shape[0], dtype=torch.bool)
+        for t in range(s2.shape[1]):
+            assert bool((s2[~alive, t] == 0).all()), 'a stopped row stays stopped'
+            if t > 0:
+                rep = alive & (s2[:, t] == s2[:, t - 1]) & (s2[:, t] > 0)
+                assert not bool(rep.any()), 'the constraint forbids repeating the previous word'
+            alive = alive & (s2[:, t] > 0)
+        assert bool((lp2 <= 0).all()) and bool(torch.isfinite(lp2).all())
+        con = copy.deepcopy(cfg)
+        con.model.speaker['decoding_contraint'] = 1
+        seq4, _ = sp._sample(outs[3], outs[4], outs[5], None, con, sample_max=1)          # constrained arg-max
+        s4 = seq4.cpu()
+        assert not bool(((s4[:, 1:] == s4[:, :-1]) & (s4[:, 1:] > 0)).any())
+
+
 def test_fused_adam_two_steps_match_reference():
     from ekaid_amd.dp import FlatAdam
     g = load_golden('f5_adam')
