@@ -25,7 +25,7 @@ def _sb():
     return seq_bench
 
 
-@pytest.mark.parametrize('B,T', [(5, 4), (16, 5), (37, 4), (64, 6), (130, 4), (256, 4)])
+@pytest.mark.parametrize('B,T', [(5, 4), (16, 5), (37, 4), (64, 6), (130, 4), (256, 4), (64, 90), (1, 96)])
 @pytest.mark.parametrize('train', [False, True])
 def test_persistent_forward_equals_the_stepwise_chain(B, T, train):
     """Every tensor of the saved-tensor contract (states, gate activations, module / POS weights, gate-MLP activations, attended and
@@ -188,7 +188,7 @@ def test_greedy_decoding_agrees_between_the_sequence_modes(B, poll, bias0):
     assert float((res[0][2] - res[1][2]).abs().max()) <= 1e-5
 
 
-@pytest.mark.parametrize('B,T', [(5, 4), (16, 5), (37, 4), (64, 6), (130, 4), (256, 4)])
+@pytest.mark.parametrize('B,T', [(5, 4), (16, 5), (37, 4), (64, 6), (130, 4), (256, 4), (64, 90), (1, 96)])
 @pytest.mark.parametrize('train', [False, True])
 def test_persistent_backward_equals_the_stepwise_chain(B, T, train):
     """ekaid_speaker_seq_bwd_persistent (one launch for the whole BPTT loop; the d [pos_feat | att] product replaced by its linear
