@@ -202,12 +202,9 @@ extern "C" size_t ekaid_speaker_seq_workspace_bytes(const ekaid_speaker_seq_t* d
 extern "C" int ekaid_speaker_seq_fwd(const ekaid_speaker_seq_t* d, void* workspace, size_t workspace_bytes, void* stream) {
     if (!spk_args_ok(d, "ekaid_speaker_seq_fwd")) return EKAID_ERR_ARG;
     if (seq_mode() == 1) {                  // one persistent launch for the whole sequence where the shape allows it (csrc/persist.hip); short
-                                            // sequences do not amortise its prologue (5 small products, the layout conversion of the initial states):
-                                            // from 8 steps up to 128 rows (per step 38-59 us against 57-82), from 24 steps above (87 against 101;
-                                            // same box at 256 rows x 16 steps: 28.09 ms persistent, 28.01 step-wise)
+                                            // sequences do not amortise its prologue (5 small products, the layout conversion of the initial states)
         const size_t pers = ekaid_speaker_seq_persistent_workspace_bytes(d);
-        if (pers && d->T >= (d->B > 128 ? 24 : 8) && workspace && workspace_bytes >= pers)
-            return ekaid_speaker_seq_fwd_persistent(d, workspace, workspace_bytes, stream);
+        if (pers && d->T >= 8 && workspace && workspace_bytes >= pers) return ekaid_speaker_seq_fwd_persistent(d, workspace, workspace_bytes, stream);
     }
     SpkPlan pl;
     if (!spk_plan(d, workspace, false, pl)) return EKAID_ERR_ARG;
