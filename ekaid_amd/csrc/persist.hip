@@ -205,9 +205,11 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
     }
     const __amdgpu_buffer_rsrc_t rsXTfm = make_rsrc(a.XTfm, Bp * 512 * 4), rsWlo = make_rsrc(a.w_lo, (long long)(GREEDY ? a.V : 1) * R * 4);
 
-    // ---- greedy decoding: the two stations that turn h_lang_t into the next token.  They run INSIDE step t + 1 -- the logits between the
-    // arrival at seam 0 and its wait, the row-local part between the arrival at seam 1 and its wait -- so neither adds a seam to the chain
-    // of the step (h_lang_t stays in its hand-off buffer until phase E of step t + 1); the last step's run after the loop.
+    // ---- greedy decoding: the two stations that turn h_lang_t into the next token.  They run INSIDE step t + 1 and ride on its seams:
+    // the logits between the arrival at seam 0 and its wait (h_lang_t stays in its hand-off buffer until phase E of step t + 1; every
+    // workgroup has waited for it at the top of phase A); the row-local part behind the wait of seam 1 -- a workgroup arrives there after
+    // its logits, so seam 1 also proves every logit stored; the word input of phase E behind the wait of seam 2, for the same reason.  No
+    // seam of their own; the last step's run after the loop, with one.
     auto logits_station = [&](const unsigned* seam4, unsigned target4) -> bool {
         // logits = h_lang . W_logit^T + b (V columns = ceil(V / 16) tiles in 16 tile slots), eval mode: no output dropout
         const int tL = wg % 16, vcol = 16 * tL + col;
@@ -220,12 +222,10 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
                     if (grow < B && vcol < a.V) store_sc1(a.LOG + (long long)grow * 160 + vcol, v[0] + blo);
                 }))
             return false;
-        seam_arrive(a.sync + 6 * SHARDS * LINE, shard);
         return true;
     };
-    auto rows_station = [&](int tp, unsigned target6) -> bool {
-        if (wg >= B) return true;                                // (one row per workgroup and pass; the others have nothing to wait for)
-        if (!seam_wait(a.sync + 6 * SHARDS * LINE, target6, status, c.ok_lds, 0x100u + 6)) return false;
+    auto rows_station = [&](int tp) -> bool {
+        if (wg >= B) return true;                                // (one row per workgroup and pass)
         // row-local: log-softmax, arg-max (lowest index on ties, token 0 forbidden at the first step), stop flags, next token
         const int ta = a.t_base + tp;
         for (int r = wg; r < B; r += G) {
@@ -477,10 +477,6 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
         }
         stamp(c, 5);
         seam_arrive(a.sync + 1 * SHARDS * LINE, shard);
-        if (GREEDY && t > 0) {                                   // tokens of step t - 1 -> the word input phase E of this step reads behind seam 7
-            if (!rows_station(t - 1, (unsigned)G * (unsigned)t)) return;
-            seam_arrive(a.sync + 7 * SHARDS * LINE, shard);
-        }
         stamp(c, 6);
         // ---- shadow of seam 1: pos_feat = w_p2 . pw + b_p2 of the rows just done -- only the saved-tensor contract reads it (PA[:, :R])
         {
@@ -517,6 +513,9 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
         // =================== phase C: gate-MLP layer 1 = mw . F + pw . Wp + (h_lang block) + constants; no contraction ===================
         if (!seam_wait(a.sync + 1 * SHARDS * LINE, tgt, status, c.ok_lds, 0x100u + 1)) return;
         stamp(c, 7);
+        if (GREEDY && t > 0) {                                   // tokens of step t - 1 -> the word input phase E of this step reads behind seam 2
+            if (!rows_station(t - 1)) return;
+        }
         if (njA) {
             // [mw | pw] of the 16 rows of every owned row block -> LDS (128 x 16 bytes per block), one barrier
             for (int n = 0; n < njA; ++n)
@@ -575,17 +574,17 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
         stamp(c, 12);
         if (GREEDY) {
             // word-side gates of the language LSTM, relu(emb[token]) . W_ih[:, :We]^T (K = We padded with zero activations to 512), by the
-            // owners of phase E, kept in LDS; the tokens were fed back behind seam 7 of the previous step (prologue: seam 5)
+            // owners of phase E, kept in LDS; the tokens were stored before their writers arrived at seam 2 (prologue: seam 5)
             if (!run_mt<NBR, MTE, PreE>(
                     c, TG_E, [&](int m, int i) { return bload4<0>(rsWil, (unsigned)((gate_row_l + 4 * (tE * MTE + m)) * ldw_l) * 4u + kwR + 64u * i); }, rsXTfm, 32,
-                    t > 0 ? a.sync + 7 * SHARDS * LINE : nullptr, (unsigned)G * (unsigned)t, 0x100u + 7, -1, [&](int, int) { return PreE{}; },
+                    nullptr, 0u, 0x100u + 7, -1, [&](int, int) { return PreE{}; },
                     [&](const float (&v)[MTE], const PreE&, int, int n) {
 #pragma unroll
                         for (int m = 0; m < MTE; ++m) tilesE_lds[(n * MTE + m) * L::per_tileE + 64 + tid] = v[m];
                     }))
                 return;
-            // every row had stopped at the previous step: the launch ends here (each workgroup reads the same final count behind seam 7,
-            // which every workgroup has just waited for; the half step run so far wrote only states nobody reads)
+            // every row had stopped at the previous step: the launch ends here (each workgroup reads the same final count behind seam 2,
+            // which every workgroup has waited for in front of phase D; the half step run so far wrote only states nobody reads)
             if (t > 0 && __hip_atomic_load(a.n_unfinished + a.t_base + t - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
         }
         // =================== phase E: language-LSTM gates + cell ===================
@@ -634,7 +633,9 @@ __global__ __launch_bounds__(256, 1) void spk_seq_fwd_persistent_kernel(const PF
     }
     if (GREEDY) {                                                // the last step's token
         if (!logits_station(a.sync + 4 * SHARDS * LINE, (unsigned)G * (unsigned)a.T)) return;
-        if (!rows_station(a.T - 1, (unsigned)G * (unsigned)a.T)) return;
+        seam_arrive(a.sync + 6 * SHARDS * LINE, shard);
+        if (!seam_wait(a.sync + 6 * SHARDS * LINE, (unsigned)G, status, c.ok_lds, 0x100u + 6)) return;
+        if (!rows_station(a.T - 1)) return;
     }
 }
 
