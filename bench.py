@@ -283,6 +283,11 @@ def spawn_ranks(n, timeout_s):
                     os.killpg(p.pid, signal.SIGKILL)        # the child's own session: exactly the processes started here
                 except OSError:
                     pass
+    def on_signal(signum, _frame):              # a SIGTERM / SIGHUP to the parent (harness timeout) raises no exception by itself: the
+        kill_all()                              # ranks sit in their own sessions and would be orphaned holding the GPUs
+        os._exit(128 + signum)
+    for sig in (signal.SIGTERM, signal.SIGHUP, signal.SIGINT):
+        signal.signal(sig, on_signal)
     deadline = time.monotonic() + timeout_s
     rc = 0
     try:

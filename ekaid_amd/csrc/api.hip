@@ -115,7 +115,7 @@ extern "C" int ekaid_init(int device_id) {
         return EKAID_ERR_ARG;
     }
     (void)ekaid::device_state();
-    const bool ok = ekaid::device_scratch(ekaid::EKAID_SCRATCH_BYTES) != nullptr;
+    const bool ok = ekaid::device_scratch(ekaid::EKAID_SCRATCH_BYTES) != nullptr && ekaid::seq_status_ptr() != nullptr;
     (void)hipSetDevice(cur);
     if (!ok) { ekaid::set_error("ekaid_init: cannot allocate the reduction scratch on device %d", device_id); return EKAID_ERR_LAUNCH; }
     return EKAID_OK;

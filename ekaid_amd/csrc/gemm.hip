@@ -1436,6 +1436,10 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     }
     if (d->transA && d->transB) { set_error("ekaid_gemm_f32: transA && transB unsupported"); return EKAID_ERR_UNSUPPORTED; }
     if (d->rdiv < 1 && d->R) { set_error("ekaid_gemm_f32: rdiv must be >= 1"); return EKAID_ERR_ARG; }
+    if (d->post && (d->batch1 * d->batch2 != 1 || d->ldpost < d->N)) {      // `post` is indexed m * ldpost + n: it has no batch strides
+        set_error("ekaid_gemm_f32: post needs one batch and ldpost >= N (batch %dx%d, ldpost %d, N %d)", d->batch1, d->batch2, d->ldpost, d->N);
+        return EKAID_ERR_ARG;
+    }
     if (d->M == 0 || d->N == 0) return EKAID_OK;
     hipStream_t st = (hipStream_t)stream;
     {

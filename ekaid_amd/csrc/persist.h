@@ -3,6 +3,8 @@
 #pragma once
 #include "common.h"
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 
@@ -17,6 +19,37 @@ constexpr unsigned SPIN_LIMIT = 400000u;                          // polls (~1 u
 constexpr int PMAX_T = 96;                                        // steps per launch (seeds travel by value in the kernel arguments)
 constexpr int MAXJ = 8;                                           // jobs of one phase per workgroup
 constexpr int AUX_SC1 = 16;                                       // buffer cache-policy bit: sc1 (agent-scope write-through / L1 bypass)
+
+// The workgroups of a persistent kernel wait for each other at the seams, so ALL of them must be resident at once.  Checked when a
+// launch is PLANNED (not assumed): the runtime's occupancy of this kernel with this much dynamic LDS, times the CUs of the device, must
+// cover the grid, and no CU mask may be in force (the CU-count attribute still reports the whole chip under a mask).  `false` sends
+// the caller to the launch-per-product chain (csrc/sequence.hip).  What this cannot see -- another process on the same GPU, a resident
+// collective kernel stalled on a late peer -- is caught at run time: bounded spins, the sticky status word, and the Adam kernel that
+// refuses the update of a faulted step (pointwise.hip: adam_prep_kernel).
+inline bool grid_fits(const void* kern, int slot, int G, int cus, size_t lds_bytes) {
+    static const bool masked = getenv("HSA_CU_MASK") != nullptr || getenv("ROC_GLOBAL_CU_MASK") != nullptr;
+    if (masked) return false;
+    if (func_attr_once(slot)) {
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); return false; }
+    }
+    struct Ent { const void* k; size_t lds; int dev; int per_cu; };
+    static Ent cache[16];
+    static std::atomic<int> n_cache{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int n = n_cache.load(std::memory_order_acquire);
+    for (int i = 0; i < n && i < 16; ++i)
+        if (cache[i].k == kern && cache[i].lds == lds_bytes && cache[i].dev == dev) return (long long)cache[i].per_cu * cus >= G;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds_bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+    static std::mutex mu;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        const int m = n_cache.load(std::memory_order_relaxed);
+        if (m < 16) { cache[m] = Ent{kern, lds_bytes, dev, per_cu}; n_cache.store(m + 1, std::memory_order_release); }
+    }
+    return (long long)per_cu * cus >= G;
+}
 
 __device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u; }      // HW_REG_XCC_ID
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }

@@ -646,7 +646,7 @@ bool persistent_shape_ok(const ekaid_speaker_seq_t* d) {
 }
 
 struct PersistPlan {
-    int G, nrb, mtD, mtE, jobsA, jobsD, jobsE, wp_lds;
+    int G, nrb, mtD, mtE, jobsA, jobsD, jobsE, wp_lds, cus;
     size_t lds_bytes;
     // workspace offsets (bytes)
     size_t o_hl, o_ha, o_g1, o_ga, o_mwpw, o_lhp, o_fm, o_wp, o_cp, o_gemm, o_trace, total;
@@ -683,6 +683,12 @@ bool persistent_plan(const ekaid_speaker_seq_t* d, void* workspace, PersistPlan&
     if (pl.lds_bytes > 160 * 1024) return false;
     pl.wp_lds = pl.lds_bytes + (size_t)PP * (PR + 4) * sizeof(float) <= 160 * 1024;      // weight_pos next to the job slots when it fits
     if (pl.wp_lds) pl.lds_bytes += (size_t)PP * (PR + 4) * sizeof(float);
+    {   // every workgroup resident at once? (the teacher-forced instantiation of this tile grouping; the greedy one is checked by its caller)
+        const void* kern = pl.mtE == 2 ? reinterpret_cast<const void*>(spk_seq_fwd_persistent_kernel<PR, PA_, PP, 1, 2, false>)
+                                       : reinterpret_cast<const void*>(spk_seq_fwd_persistent_kernel<PR, PA_, PP, 1, 1, false>);
+        if (!grid_fits(kern, pl.mtE == 2 ? 41 : 40, G, cus, pl.lds_bytes)) return false;
+        pl.cus = cus;
+    }
     const size_t Bp = 16 * (size_t)pl.nrb, f = sizeof(float);
     size_t o = al256((size_t)SYNC_WORDS * 4);
     pl.o_hl = o; o += al256(Bp * PR * f);
@@ -826,6 +832,11 @@ extern "C" size_t ekaid_speaker_greedy_persistent_workspace_bytes(const ekaid_sp
     d.T = steps;
     PersistPlan pl;
     if (!persistent_plan(&d, nullptr, pl)) return 0;
+    {
+        const void* kern = pl.mtE == 2 ? reinterpret_cast<const void*>(spk_seq_fwd_persistent_kernel<PR, PA_, PP, 1, 2, true>)
+                                       : reinterpret_cast<const void*>(spk_seq_fwd_persistent_kernel<PR, PA_, PP, 1, 1, true>);
+        if (!grid_fits(kern, pl.mtE == 2 ? 43 : 47, pl.G, pl.cus, pl.lds_bytes)) return 0;
+    }
     const size_t Bp = 16 * (size_t)pl.nrb;
     return pl.total + al256(Bp * 512 * sizeof(float)) + al256(Bp * 160 * sizeof(float));
 }

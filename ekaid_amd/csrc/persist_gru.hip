@@ -170,6 +170,8 @@ bool gru_persistent_plan(int B, int T, int H, bool backward, GruPlanP& pl) {
     pl.jobs = ((GH / 16) * pl.nrb + G - 1) / G;
     if (pl.jobs > MAXJ * 2) return false;
     pl.lds_bytes = (size_t)(4 + 2 * 5120 + pl.jobs * (backward ? 512 : 256)) * sizeof(float);
+    if (!grid_fits(backward ? reinterpret_cast<const void*>(gru_seq_bwd_persistent_kernel<GH>) : reinterpret_cast<const void*>(gru_seq_fwd_persistent_kernel<GH>),
+                   backward ? 46 : 45, G, cus, pl.lds_bytes)) return false;
     const size_t Bp = 16 * (size_t)pl.nrb, f = sizeof(float);
     size_t o = al256((size_t)SYNC_WORDS * 4);
     pl.o_hfm = o; if (!backward) o += al256(2 * Bp * GH * f);

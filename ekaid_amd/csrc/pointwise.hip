@@ -711,7 +711,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
 // Adam whose step counter and hyper-parameters live on the DEVICE (graph-capturable: a captured launch of the by-value
 // form would freeze the bias correction and the learning rate).  state[0] = step (incremented here, as a float-exact
 // integer < 2^24 steps... stored as int), hyper = {lr, beta1, beta2, eps, grad_scale}.
-__global__ void adam_prep_kernel(int* step, const float* hyper, float* derived) {
+// A persistent sequence kernel that abandoned its launch (csrc/persist*.hip: a seam timed out) leaves garbage gradients behind.
+// The update is then SKIPPED on the device -- step counter, moments and weights untouched -- when the local status word is set or
+// when `fault` (a flag every rank adds into the all-reduced gradient buffer, ekaid_seq_fault_flag) is non-zero on any rank.
+__global__ void adam_prep_kernel(int* step, const float* hyper, float* derived, const unsigned* status, const float* fault) {
+    if ((status && status[0] != 0u) || (fault && fault[0] != 0.f)) { derived[2] = 1.f; return; }
+    derived[2] = 0.f;
     const int t = step[0] + 1;
     step[0] = t;
     const double b1 = hyper[1], b2 = hyper[2];
@@ -720,6 +725,7 @@ __global__ void adam_prep_kernel(int* step, const float* hyper, float* derived) 
 }
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* p, const float* g, float* m, float* v, long long n, const float* hyper,
                                                        const float* derived) {
+    if (derived[2] != 0.f) return;            // (uniform over the grid: the whole update is skipped)
     const float lr_bc1 = derived[0], inv_sqrt_bc2 = derived[1], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], gscale = hyper[4];
     GS_LOOP(i, n) {
         const float gr = g[i] * gscale;
@@ -1031,10 +1037,18 @@ extern "C" int ekaid_adam_step(float* p, const float* g, float* m, float* v, lon
                        (float)(1.0 / sqrt(bc2)), grad_scale);
     return check_launch("adam_step");
 }
+__global__ void seq_fault_flag_kernel(const unsigned* status, float* flag) { flag[0] = status[0] != 0u ? 1.f : 0.f; }
+extern "C" int ekaid_seq_fault_flag(float* flag, void* stream) {
+    if (!flag) { set_error("ekaid_seq_fault_flag: null pointer"); return EKAID_ERR_ARG; }
+    const unsigned* status = seq_status_ptr();
+    if (!status) { set_error("ekaid_seq_fault_flag: no status word (call ekaid_init first)"); return EKAID_ERR_LAUNCH; }
+    hipLaunchKernelGGL(seq_fault_flag_kernel, dim3(1), dim3(1), 0, ST, status, flag);
+    return check_launch("seq_fault_flag");
+}
 extern "C" int ekaid_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* hyper_dev, int* step_dev,
-                                   float* derived_dev, void* stream) {
+                                   float* derived_dev, const float* fault_flag, void* stream) {
     if (!hyper_dev || !step_dev || !derived_dev) { set_error("adam_step_dev: null state pointer"); return EKAID_ERR_ARG; }
-    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, ST, step_dev, hyper_dev, derived_dev);
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, ST, step_dev, hyper_dev, derived_dev, (const unsigned*)seq_status_ptr(), fault_flag);
     hipLaunchKernelGGL(adam_dev_kernel, grid1d(n), dim3(256), 0, ST, p, g, m, v, n, hyper_dev, (const float*)derived_dev);
     return check_launch("adam_step_dev");
 }

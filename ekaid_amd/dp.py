@@ -101,7 +101,11 @@ class GradBuckets:
             total += (n + 7) // 8 * 8                    # every tensor starts on an 8-element group (32-byte aligned)
         self.total = total
         self.pflat = torch.zeros(total, device=dev, dtype=dt)
-        self.gflat = torch.zeros(total, device=dev, dtype=dt)
+        # one more 8-element group behind the gradients: element `total` is the FAULT FLAG of the step -- each rank writes 1.0 there if
+        # one of its persistent sequence kernels abandoned its launch (ekaid_seq_fault_flag, just before the last bucket goes out), the
+        # flag travels inside the last bucket's all-reduce, and the Adam kernel of EVERY rank skips the update when the sum is non-zero
+        self._gstore = torch.zeros(total + 8, device=dev, dtype=dt)
+        self.gflat = self._gstore[:total]
         self.live, self.offsets = live, offs
         self._offset_of = {id(p): o for p, o in zip(live, offs)}
         self._gbase = self.gflat.data_ptr()
@@ -120,7 +124,7 @@ class GradBuckets:
             cur_bytes += p.numel() * 4
             last = i == len(live) - 1
             if cur_bytes >= self.bucket_bytes or last:
-                end = total if last else offs[i + 1]
+                end = total + 8 if last else offs[i + 1]         # (the last bucket carries the fault flag group)
                 self.buckets.append((start, end, len(members)))
                 for m in members:
                     self._bucket_of[id(m)] = len(self.buckets) - 1
@@ -161,7 +165,7 @@ class GradBuckets:
     # ------------------------------------------------------------------ per-step API
     def zero_grad(self):
         if self.built:
-            self.gflat.zero_()
+            self._gstore.zero_()
             if self.gflat.is_cuda:
                 # gradients are WRITTEN into their flat slots by the backward kernels and adopted by autograd as p.grad
                 # (ops.grad_out); a parameter that receives none this step keeps the zeros of its slot
@@ -185,7 +189,11 @@ class GradBuckets:
         self._next = max(self._next, b + 1)
         if self.launch_log is not None:
             self.launch_log.append((b, hip.calls_issued()))
-        self.handles.append(dist.all_reduce(self.gflat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if b == len(self.buckets) - 1 and self._gstore.is_cuda:
+            # every persistent launch of this step lies behind us (forward; the decoder's BPTT kernel opens backward, the GRU's closes it
+            # before its weights -- members of this last bucket -- have their gradients): this rank's verdict joins the reduction
+            hip.check(hip.lib().ekaid_seq_fault_flag(self._gstore.data_ptr() + 4 * self.total, hip.stream()), 'seq_fault_flag')
+        self.handles.append(dist.all_reduce(self._gstore[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Make every bucket's reduced SUM visible to the current stream (call after backward)."""
@@ -226,7 +234,7 @@ class FlatAdam(GradBuckets):
             self._hyper = torch.tensor([self._lr, self.betas[0], self.betas[1], self.eps, 1.0 / self.world],
                                        dtype=torch.float32, device=dev)
             self._step_dev = torch.tensor([self._step_host], dtype=torch.int32, device=dev)
-            self._derived = torch.zeros(2, dtype=torch.float32, device=dev)
+            self._derived = torch.zeros(4, dtype=torch.float32, device=dev)
         return self._hyper, self._step_dev, self._derived
 
     @property
@@ -271,7 +279,8 @@ class FlatAdam(GradBuckets):
             self.v = torch.zeros_like(self.pflat)
         hyper, step, derived = self._device_state()
         hip.check(hip.lib().ekaid_adam_step_dev(hip.ptr(self.pflat), hip.ptr(self.gflat), hip.ptr(self.m), hip.ptr(self.v),
-                                                self.total, hip.ptr(hyper), hip.ptr(step), hip.ptr(derived), hip.stream()),
+                                                self.total, hip.ptr(hyper), hip.ptr(step), hip.ptr(derived),
+                                                self._gstore.data_ptr() + 4 * self.total, hip.stream()),
                   'adam_step_dev')
 
     # ------------------------------------------------------------------ checkpointing (SURVEY f-4)

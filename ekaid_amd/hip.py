@@ -206,7 +206,8 @@ SIGNATURES = {
     'ekaid_transpose': [P, I, I, I, P, I, P],
     'ekaid_nonfinite_count': [P, L, P, P],
     'ekaid_adam_step': [P, P, P, P, L, F, F, F, F, I, F, P],
-    'ekaid_adam_step_dev': [P, P, P, P, L, P, P, P, P],
+    'ekaid_adam_step_dev': [P, P, P, P, L, P, P, P, P, P],
+    'ekaid_seq_fault_flag': [P, P],
 }
 _RESTYPES = {'ekaid_last_error': c_char_p, 'ekaid_gemm_workspace_bytes': c_size_t, 'ekaid_gru_seq_workspace_bytes': c_size_t, 'ekaid_gru_seq_persistent_workspace_bytes': c_size_t,
              'ekaid_speaker_seq_workspace_bytes': c_size_t, 'ekaid_speaker_seq_persistent_workspace_bytes': c_size_t,
@@ -270,6 +271,15 @@ def seq_status_check(what='persistent sequence kernel'):
         lib().ekaid_seq_status_clear(stream())
         raise EkaidError('%s: a seam did not open in time (status 0x%x): the launch was abandoned and its outputs are invalid. Is another '
                          'process using this GPU? (EKAID_SEQ_MODE=stepwise selects the launch-per-product chains)' % (what, v.value))
+
+
+def seq_status_take():
+    """The status word of the persistent sequence kernels (0 = fine), cleared if it was set.  Synchronises the current stream."""
+    v = c_uint(0)
+    check(lib().ekaid_seq_status_read(ctypes.byref(v), stream()), 'seq_status_read')
+    if v.value:
+        check(lib().ekaid_seq_status_clear(stream()), 'seq_status_clear')
+    return int(v.value)
 
 
 def ptr(t):

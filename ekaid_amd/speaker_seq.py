@@ -446,17 +446,35 @@ def greedy_decode(speaker, feat_bef, feat_aft, feat_diff, poll=None):
     g.seq, g.seq_logp, g.seq_len, g.n_unfinished = ptr(seq), ptr(seq_logp), Tm, ptr(counts)
     need = L.ekaid_speaker_greedy_workspace_bytes(ctypes.byref(g))
     ws = hip.workspace(need, dev)
-    if poll is None:
-        poll = Tm if (L.ekaid_get_seq_mode() == 1 and L.ekaid_speaker_greedy_persistent_workspace_bytes(ctypes.byref(g), Tm)) else 8
-    steps_run = Tm
-    for t0 in range(0, Tm, poll):
-        t1 = min(Tm, t0 + poll)
-        check(L.ekaid_speaker_greedy_steps(ctypes.byref(g), t0, t1, ptr(ws), need, stream()), 'speaker_greedy_steps')
-        done = (counts[:t1] == 0).nonzero()
-        if done.numel():                                                 # everything had finished at step `first`
-            first = int(done[0])
-            seq[:, first + 1:] = 0
-            seq_logp[:, first + 1:] = 0
-            steps_run = first + 1
-            break
+    def run(poll):
+        if poll is None:
+            poll = Tm if (L.ekaid_get_seq_mode() == 1 and L.ekaid_speaker_greedy_persistent_workspace_bytes(ctypes.byref(g), Tm)) else 8
+        steps_run = Tm
+        for t0 in range(0, Tm, poll):
+            t1 = min(Tm, t0 + poll)
+            check(L.ekaid_speaker_greedy_steps(ctypes.byref(g), t0, t1, ptr(ws), need, stream()), 'speaker_greedy_steps')
+            done = (counts[:t1] == 0).nonzero()
+            if done.numel():                                                 # everything had finished at step `first`
+                first = int(done[0])
+                seq[:, first + 1:] = 0
+                seq_logp[:, first + 1:] = 0
+                steps_run = first + 1
+                break
+        return steps_run
+    persistent = L.ekaid_get_seq_mode() == 1
+    steps_run = run(poll)
+    if persistent:
+        # The host has just synchronised for `done`.  A persistent launch that abandoned itself (a seam timed out: not all of its
+        # workgroups were resident) leaves `counts` at zero, which reads as "every answer ended at step 0" -- one-token garbage.  Read the
+        # status word here; on a fault clear it, move this device to the launch-per-product chain for good and decode again.
+        st = hip.seq_status_take()
+        if st:
+            import warnings
+            warnings.warn('greedy_decode: a persistent sequence kernel abandoned its launch (status 0x%x); this device now uses the '
+                          'step-wise chain (ekaid_set_seq_mode(0)) and the answers are decoded again' % st, RuntimeWarning)
+            check(L.ekaid_set_seq_mode(0), 'set_seq_mode')
+            for tns in (HA, CA, HL, CL, MW, seq, seq_logp, counts, unfinished):
+                tns.zero_()
+            it.fill_(2)
+            steps_run = run(8)
     return seq, seq_logp, list(MW[:steps_run].unbind(0))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EKAID_ABI_VERSION 7
+#define EKAID_ABI_VERSION 8
 
 int ekaid_version(void);
 const char* ekaid_last_error(void);        /* thread-local */
@@ -591,9 +591,17 @@ int ekaid_adam_step(float* p, const float* g, float* m, float* v, long long n, f
                     float eps, int step, float grad_scale, void* stream);
 /* The same update with the step counter and the hyper-parameters in DEVICE memory, for hipGraph capture (a captured
  * by-value launch would freeze the bias correction and the learning-rate schedule): step_dev[0] is incremented by the
- * call, hyper_dev = {lr, beta1, beta2, eps, grad_scale}, derived_dev = 2 floats of scratch. */
+ * call, hyper_dev = {lr, beta1, beta2, eps, grad_scale}, derived_dev = 4 floats of scratch.
+ * Fault guard (ABI 8): the update is skipped ON THE DEVICE -- step counter, moments and weights untouched -- when the per-device
+ * status word of the persistent sequence kernels is set (a seam timed out: that step's gradients are garbage) or when
+ * fault_flag (nullable) holds a non-zero value: the slot behind the flat gradient buffer into which every rank writes its own
+ * status with ekaid_seq_fault_flag before the last bucket's all-reduce, so that ALL ranks skip a step one rank could not finish.
+ * The host still raises where it reads the status word (ekaid_seq_status_read); nothing is applied in between. */
 int ekaid_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* hyper_dev, int* step_dev,
-                        float* derived_dev, void* stream);
+                        float* derived_dev, const float* fault_flag, void* stream);
+/* flag[0] = 1.0f if the status word of the persistent sequence kernels is set on this device, else 0.0f (one tiny launch,
+ * graph-capturable).  No reference counterpart: the reference has neither persistent kernels nor data parallelism. */
+int ekaid_seq_fault_flag(float* flag, void* stream);
 
 #ifdef __cplusplus
 }

@@ -161,8 +161,11 @@ def implicit_encoder(P, prefix, v, pos_emb, q, cfg):
 # a3-a5  models/language_model.py
 # --------------------------------------------------------------------------- #
 def word_embedding(P, tokens):                                       # :48-53
-    return torch.cat([F.embedding(tokens, P['w_emb.emb.weight']),
-                      F.embedding(tokens, P['w_emb.emb_.weight'])], dim=2)
+    # :26-28  nn.Embedding(ntoken + 1, emb_dim, padding_idx=ntoken): the LAST row is the padding row -- looked up like any other, but it
+    # never receives a gradient (ntoken = 147 is a real word id in the vocabulary, SURVEY.md section 0: its row stays as initialised)
+    pad = P['w_emb.emb.weight'].shape[0] - 1
+    return torch.cat([F.embedding(tokens, P['w_emb.emb.weight'], padding_idx=pad),
+                      F.embedding(tokens, P['w_emb.emb_.weight'], padding_idx=pad)], dim=2)
 
 
 def gru_forward_all(P, x):                                           # :106-115 (nn.GRU, h0=0)

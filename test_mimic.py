@@ -83,6 +83,7 @@ def main(argv=None):
     os.makedirs(out_dir, exist_ok=True)
     D = cfg.model.change_detector.feat_dim - 2
     predictions, correct, total = {}, 0, 0
+    sequences, sequence_logprobs = [], []
     t0 = time.time()
     if loader is not None:
         # the reference's loop (test_mimic.py:97-141) over the real split: device feed, detector, greedy decode
@@ -100,7 +101,9 @@ def main(argv=None):
                    (('d_adj', 'spatial'), ('q_adj', 'spatial'), ('d_sem', 'semantic'), ('q_sem', 'semantic'))]
             outs = change_detector(b['input_1'], b['input_2'], adj[0], adj[1], adj[2], adj[3], b['d_bb'], b['q_bb'],
                                    b['question'], setting=cfg.train.setting, graph=args.graph)
-            seq, _ = speaker._sample(outs[3], outs[4], outs[5], b['labels'], cfg, sample_max=1)
+            seq, seq_lp = speaker._sample(outs[3], outs[4], outs[5], b['labels'], cfg, sample_max=1)
+            sequences.append(seq.cpu())
+            sequence_logprobs.append(seq_lp.cpu())
             sents = decode_sequence(idx_to_word, seq)
             gts = decode_sequence(idx_to_word, b['labels'][:, 1:])
             for j, s in enumerate(sents):
@@ -119,7 +122,8 @@ def main(argv=None):
         metrics = caption_metrics(predictions, getattr(_ev, 'last_references', {}))        # test_mimic.py:143-152, when pycocoevalcap exists
         if metrics:
             print(', '.join('%s %.4f' % kv for kv in metrics.items()))
-    return {'results_file': path, 'accuracy': correct / max(total, 1), 'n': total, 'predictions': predictions, 'metrics': metrics}
+    return {'results_file': path, 'accuracy': correct / max(total, 1), 'n': total, 'predictions': predictions, 'metrics': metrics,
+            'sequences': sequences, 'sequence_logprobs': sequence_logprobs}
 
 
 if __name__ == '__main__':

@@ -28,3 +28,21 @@ def to_device(batch, device):
     for k, v in batch.items():
         out[k] = v if k in ('d_bb', 'q_bb') else v.to(device)
     return out
+
+
+def real_shape_case():
+    """(cfg, batch) of the real-data-shape parity case: Medical-Diff-VQA shapes (52 regions x 1024-d; config.yaml widths shrunk only
+    in att_dim to keep the CPU runs fast), ragged answer lengths (per-sample masks), an undetected region (all-zero ROI row ->
+    question masked out only if the projected row sums to zero, relation_encoder.py:23-27) and a fully isolated node."""
+    cfg = small_cfg(graph='all', D=1024, att_dim=128, heads=4, qdim=64, seq_length=12)
+    batch = make_batch(B=3, N=52, D=1024, Lq=9, T=7, seq_length=12, V=31, seed=5)
+    batch['input_1'][0, 5] = 0                               # undetected region
+    batch['labels'][1, 4:] = 0                               # shorter answers
+    batch['labels'][2, 6:] = 0
+    batch['masks'] = torch.zeros_like(batch['masks'])
+    for b in range(3):
+        n = int((batch['labels'][b] != 0).sum()) + 1
+        batch['masks'][b, :n] = 1
+    batch['d_adj'][0, 7, :] = 0
+    batch['d_adj'][0, :, 7] = 0                              # isolated node in the spatial graph
+    return cfg, batch

@@ -77,3 +77,78 @@ def negligible_grad_names(names_json, ref_rows, atol_frac=1e-6):
     names = json.loads(str(names_json))
     floor = atol_frac * float(np.median(ref_rows[:, 0]))
     return [k for i, k in enumerate(names) if ref_rows[i][0] <= floor]
+
+
+# --------------------------------------------------------------------------- #
+# whole-tensor sketches: a compact fixture that still sees EVERY element
+# --------------------------------------------------------------------------- #
+SK_CHUNKS, SK_PROJ = 16, 4
+
+
+def _signs(n, salt):
+    """n pseudo-random +-1 values from integer hashing only (murmur3 finaliser of i * 0x9E3779B1 + salt): exact and portable."""
+    m = np.uint64(0xFFFFFFFF)
+    x = (np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B1) + np.uint64(salt & 0xFFFFFFFF)) & m
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x85EBCA6B)) & m
+    x ^= x >> np.uint64(13)
+    x = (x * np.uint64(0xC2B2AE35)) & m
+    x ^= x >> np.uint64(16)
+    return np.where((x >> np.uint64(31)) & np.uint64(1), 1.0, -1.0)
+
+
+def tensor_sketch(t):
+    """float64 [SK_CHUNKS, 1 + SK_PROJ]: the flat tensor cut into SK_CHUNKS contiguous chunks; per chunk its l2 norm and SK_PROJ
+    random-sign projections.  An error vector e moves a chunk's projection by a N(0, |e_chunk|^2) amount, so any wrong slice of any
+    size shows up in the chunk that holds it (10-number summaries only see the sampled positions and the global norm)."""
+    x = t.detach().double().reshape(-1).cpu().numpy()
+    n = x.size
+    out = np.zeros((SK_CHUNKS, 1 + SK_PROJ))
+    bounds = [(c * n) // SK_CHUNKS for c in range(SK_CHUNKS + 1)]
+    for c in range(SK_CHUNKS):
+        seg = x[bounds[c]:bounds[c + 1]]
+        if seg.size == 0:
+            continue
+        out[c, 0] = np.sqrt(np.dot(seg, seg))
+        for j in range(SK_PROJ):
+            out[c, 1 + j] = np.dot(seg, _signs(seg.size, 7919 * (c * SK_PROJ + j) + 104729))
+    return out
+
+
+def sketch_named(named):
+    names, rows = [], []
+    for k, v in named:
+        if v is None:
+            continue
+        names.append(k)
+        rows.append(tensor_sketch(v))
+    return json.dumps(names), np.stack(rows)
+
+
+def assert_sketch_close(names_json, ref_sk, named, tol, what=''):
+    """Every tensor of ``named`` against its reference sketch: per chunk, every projection within tol * max(chunk norm, tensor norm /
+    sqrt(chunks)) -- a bound on the l2 error of each chunk relative to the chunk itself, floored at the tensor's typical chunk.
+    Tensors whose reference norm is below 1e-6 of the median (exact-zero gradients) only need to be equally negligible."""
+    names = json.loads(str(names_json))
+    got = dict(named)
+    norms = np.sqrt((ref_sk[:, :, 0] ** 2).sum(1))
+    floor = 1e-6 * float(np.median(norms))
+    bad, worst = [], (None, 0.0)
+    for i, k in enumerate(names):
+        assert k in got and got[k] is not None, '%s: missing tensor %s' % (what, k)
+        sk = tensor_sketch(got[k])
+        if norms[i] <= floor:
+            if np.sqrt((sk[:, 0] ** 2).sum()) > 100 * floor:
+                bad.append((k, float(np.sqrt((sk[:, 0] ** 2).sum())), 0.0))
+            continue
+        scale = np.maximum(ref_sk[i][:, 0], norms[i] / np.sqrt(SK_CHUNKS))[:, None]
+        err = float((np.abs(sk[:, 1:] - ref_sk[i][:, 1:]) / scale).max())
+        nerr = float((np.abs(sk[:, 0] - ref_sk[i][:, 0]) / scale[:, 0]).max())
+        e = max(err, nerr)
+        if e > worst[1]:
+            worst = (k, e)
+        if e > tol:
+            bad.append((k, err, nerr))
+    assert not bad, '%s: %d tensors off (name, projection err, chunk-norm err): %s' % (what, len(bad), bad[:6])
+    extra = [k for k, v in got.items() if v is not None and k not in names]
+    return extra, worst

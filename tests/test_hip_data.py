@@ -368,3 +368,37 @@ def test_infer_step_replay_equals_eager_forward():
             for w, g in zip(want, got):
                 assert torch.equal(w, g)
     assert len(step._graphs) == 2
+
+
+def test_checkpoint_written_by_the_reference_runs_through_test_mimic(tmp_path):
+    """tests/golden/ref_checkpoint_small.pt.xz was written by the REFERENCE's own code (its modules, its ``save_checkpoint``, its
+    ``utils.attr_dict.AttrDict`` as ``model_cfg``: tests/golden/make_ref_checkpoint.py replays train_mimic.py:281-290).  The product's
+    ``test_mimic.py -p`` loads it unchanged and decodes the answers the reference's own evaluation loop (test_mimic.py:97-124,
+    greedy ``_sample``) decoded from it: token ids identical, their log-probs within 1e-3.  ref: utils/utils.py:11-23."""
+    import lzma
+    import yaml
+    import test_mimic
+    from ekaid_amd.utils.utils import load_checkpoint
+    gold = np.load(os.path.join(ROOT, 'tests', 'golden', 'ref_checkpoint_small_golden.npz'))
+    ck_path = str(tmp_path / 'checkpoint_0.pt')
+    with lzma.open(os.path.join(ROOT, 'tests', 'golden', 'ref_checkpoint_small.pt.xz'), 'rb') as f, open(ck_path, 'wb') as g:
+        g.write(f.read())
+    raw = open(ck_path, 'rb').read()
+    assert b'utils.attr_dict' in raw and b'ekaid_amd' not in raw, 'the file must be the reference\'s own pickle'
+    ck = load_checkpoint(ck_path)
+    assert set(ck) == {'change_detector_state', 'speaker_state', 'model_cfg'}
+
+    def plain(d):
+        return {k: plain(v) for k, v in d.items()} if isinstance(d, dict) else d
+    cfg_path = str(tmp_path / 'cfg.yaml')
+    with open(cfg_path, 'w') as f:
+        yaml.safe_dump(plain(ck['model_cfg']), f)            # the run's yaml: what `--cfg` points at in the reference too
+    nb = sum(1 for k in gold.files if k.startswith('seq_') and not k.startswith('seq_logp'))
+    res = test_mimic.main(['-p', ck_path, '--cfg', cfg_path, '--synthetic', '--batches', str(nb), '--nodes', '8',
+                           '--exp_dir', str(tmp_path), '--graph', 'all'])
+    assert len(res['sequences']) == nb
+    for i in range(nb):
+        want, want_lp = gold['seq_%d' % i], gold['seq_logp_%d' % i]
+        got, got_lp = res['sequences'][i].numpy(), res['sequence_logprobs'][i].numpy()
+        assert np.array_equal(got, want), 'greedy ids differ from the reference\'s in batch %d' % i
+        assert np.abs(got_lp - want_lp).max() <= 1e-3 * max(np.abs(want_lp).max(), 1.0)

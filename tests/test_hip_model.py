@@ -8,10 +8,10 @@ import numpy as np
 import pytest
 import torch
 
-from common import FULL, SMALL, build_models, oracle_params, small_models, to_device
+from common import FULL, SMALL, build_models, oracle_params, real_shape_case, small_models, to_device
 from ekaid_amd.config import bench_cfg, small_cfg
 from ekaid_amd.synthetic import make_batch
-from golden_util import assert_summary_close, load_golden, negligible_grad_names, tensor_summary
+from golden_util import assert_sketch_close, assert_summary_close, load_golden, negligible_grad_names, tensor_summary
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -311,6 +311,50 @@ def test_config2_batch64_forward_against_cpu_oracle():
     close(loss, loss_o, 1e-4, 'loss')
 
 
+def test_batch256_forward_at_the_metric_batch_size_vs_reference_and_oracle():
+    """The metric's own batch: 256 pairs, BASELINE.json configs[2] shapes, T = 16, full-width model, eval forward through the HIP path.
+    Quirk Q-C (language_model.py:149) makes every question vector depend on the batch size itself, so B = 256 is not B = 64 four
+    times.  (1) against the REFERENCE run at B = 256 (tests/golden/f9_b256.npz, made by importing it: make_b256_golden.py): loss,
+    question vectors, arg-max answers of all 256 x 16 positions identical, log-probs <= 1e-3 relative, whole-tensor sketches;
+    (2) against the CPU oracle on the full (256, 16, 148) log-prob tensor, element-wise."""
+    from golden_util import tensor_sketch
+    from oracle import ekaid_oracle as O
+    g = load_golden('f9_b256')
+    cfg = bench_cfg()
+    cd, sp = build_models(cfg, 147, 148, DEV)
+    batch = make_batch(B=256, **FULL)
+    with torch.no_grad():
+        q = cd.encode_question(batch['question'].to(DEV))
+        loss, _, outs, logp, _ = hip_step(cfg, cd, sp, batch, 'mode2', 'all')
+    lp = logp[:, :16].cpu()
+    rows = [0, 85, 170, 255]
+    close(loss, g['loss'], 1e-4, 'loss')
+    close(q[:4], g['q_rows'], 1e-4, 'question vectors (Q-C at B = 256)')
+    close(lp[rows], g['logp_rows'], LOGIT_TOL, 'logp rows')
+    close(outs[5][rows], g['feat_diff_rows'], 1e-4, 'feat_diff rows')
+    close(outs[1][rows], g['att_bef_rows'], 1e-4, 'att_bef rows')
+    am = lp.argmax(-1)
+    assert np.array_equal(am.numpy(), g['argmax'].astype(np.int64)), 'arg-max answers differ from the reference at B = 256'
+    tgt = batch['labels'][:, 1:17]
+    got_am, got_lb = lp.gather(-1, am[..., None])[..., 0], lp.gather(-1, tgt[..., None])[..., 0]
+    close(got_am, g['logp_argmax'], LOGIT_TOL, 'logp at arg-max')
+    close(got_lb, g['logp_label'], LOGIT_TOL, 'logp at label')
+    ew = np.abs(got_lb.numpy() - g['logp_label']) / np.maximum(np.abs(g['logp_label']), 1e-2)
+    assert ew.max() <= LOGIT_TOL, 'label log-probs element-wise rel %.3e' % ew.max()
+    for name, t in (('q', q), ('logp', lp), ('feat_diff', outs[5])):
+        sk, ref = tensor_sketch(t), g[name + '_sketch']
+        scale = np.maximum(ref[:, :1], np.sqrt((ref[:, 0] ** 2).sum() / len(ref)))
+        assert (np.abs(sk - ref) / scale).max() <= 1e-3, name + ' sketch vs reference'
+    with torch.no_grad():
+        _, res = O.train_loss(oracle_params(cd), oracle_params(sp), cfg, batch, 'mode2', 'all')
+    want = res['logp'][:, :16]
+    e = close(lp, want, LOGIT_TOL, 'logp B=256 vs oracle')
+    ew, frac = elementwise_rel(lp, want, 1e-2)
+    print('B=256 logp vs CPU oracle: rel-to-max %.3e, element-wise rel %.3e (over the %.1f %% of entries with |logp| >= 1e-2)' % (e, ew, 100 * frac))
+    assert ew <= LOGIT_TOL
+    assert torch.equal(am, want.argmax(-1))
+
+
 def test_train_mode_dropout_path_runs_and_is_seed_reproducible():
     from ekaid_amd import ops
     cfg, cd, sp = small_models('all', device=DEV)
@@ -446,7 +490,39 @@ def test_full_size_batch256_size_independent_properties():
         assert (p.grad is None) == dead, 'gradient liveness of %s' % k
 
 
-def _oracle_vs_hip(cfg, cd, sp, batch, graph='all', tol_grad=1e-3, check=('img.weight', 'context1.weight', 'q_emb.rnn.weight_hh_l0')):
+def _all_gradients_elementwise(cd, sp, Pcd, Psp, tol, what):
+    """EVERY live parameter's gradient, element by element, against the oracle's: max |hip - oracle| <= tol * max |oracle| per tensor
+    (a wrong gradient in any slice of any tensor fails, not just one that a sampled position happens to hit).  A parameter whose
+    true gradient is exactly zero (key bias under a softmax, W2 bias under the batch softmax, the implicit label bias: noise around
+    0 on both sides) only has to be equally negligible; dead / frozen parameters must have no gradient on either side."""
+    rows, bad = [], []
+    for tag, mod, P in (('cd.', cd, Pcd), ('sp.', sp, Psp)):
+        for k, p in mod.named_parameters():
+            go = P[k].grad
+            if go is None or float(go.abs().max()) == 0.0:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, '%s: gradient on %s%s, none in the oracle' % (what, tag, k)
+                continue
+            assert p.grad is not None, '%s: no gradient on live parameter %s%s' % (what, tag, k)
+            rows.append((tag + k, p.grad.detach().double().cpu(), go.detach().double()))
+    assert len(rows) > 40, 'too few live parameters compared (%d)' % len(rows)
+    med = float(np.median([float(go.norm()) / np.sqrt(go.numel()) for _, _, go in rows]))
+    worst = (None, 0.0)
+    for name, g, go in rows:
+        scale = float(go.abs().max())
+        if float(go.norm()) / np.sqrt(go.numel()) <= 1e-6 * med:         # exact-zero gradient: equally negligible
+            if float(g.abs().max()) > 100e-6 * med:
+                bad.append((name, float(g.abs().max()), 0.0))
+            continue
+        err = float((g - go).abs().max()) / scale
+        if err > worst[1]:
+            worst = (name, err)
+        if err > tol:
+            bad.append((name, err, scale))
+    print('%s: %d live gradients element-wise vs oracle, worst %s %.3e' % (what, len(rows), worst[0], worst[1]))
+    assert not bad, '%s: %d gradients off element-wise (name, err / max, max): %s' % (what, len(bad), bad[:8])
+
+
+def _oracle_vs_hip(cfg, cd, sp, batch, graph='all', tol_grad=1e-3, what='oracle vs hip'):
     from oracle import ekaid_oracle as O
     loss, sp_loss, outs, logp, logpos = hip_step(cfg, cd, sp, batch, 'mode2', graph)
     loss.backward()
@@ -459,29 +535,33 @@ def _oracle_vs_hip(cfg, cd, sp, batch, graph='all', tol_grad=1e-3, check=('img.w
     assert torch.equal(logp[:, :T].argmax(-1).cpu(), res['logp'][:, :T].argmax(-1))
     for i, k in enumerate(('pred', 'att_bef', 'att_aft', 'feat_bef', 'feat_aft', 'feat_diff')):
         close(outs[i], res['outs'][i], 1e-4, k)
-    for k in check:
-        close(dict(cd.named_parameters())[k].grad, Pcd[k].grad, tol_grad, 'grad ' + k)
-    for k in ('logit.weight', 'core.lang_lstm.weight_hh', 'embed.0.weight'):
-        close(dict(sp.named_parameters())[k].grad, Psp[k].grad, tol_grad, 'grad sp.' + k)
+    _all_gradients_elementwise(cd, sp, Pcd, Psp, tol_grad, what)
+
+
+@pytest.mark.parametrize('graph', ['semantic', 'spatial', 'implicit', 'all', 'i+s'])
+def test_config1_every_gradient_elementwise_against_the_oracle(graph):
+    """BASELINE.json configs[0] shapes, every graph variant: outputs, log-probs and EVERY live parameter's gradient element by
+    element against the CPU oracle (the golden fixtures of test_config1_matches_reference_golden hold 10-number summaries per
+    tensor; the oracle itself is pinned to the reference's full gradients in tests/test_oracle_golden.py)."""
+    cfg, cd, sp = small_models(graph, device=DEV)
+    _oracle_vs_hip(cfg, cd, sp, make_batch(**SMALL), graph, what='config 1 [%s]' % graph)
+    # ... and chunk by chunk against the REFERENCE's own gradients (f8: 16 chunks x (norm + 4 random-sign projections) per tensor)
+    g = load_golden('f8_grad_sketch_' + graph.replace('+', 'p'))
+    _, worst = assert_sketch_close(g['grad_names'], g['grad_sketch'], named_grads(cd, sp), 1e-3, 'gradient sketches vs reference [%s]' % graph)
+    print('vs reference, worst chunk: %s %.2e' % worst)
 
 
 def test_real_data_shapes_ragged_answers_and_zero_rows():
     """Medical-Diff-VQA shapes (52 regions x 1024-d, config.yaml widths shrunk only in att_dim to keep the CPU oracle
     fast), ragged answer lengths (per-sample masks), an undetected region (all-zero ROI row -> question masked out
-    only if the projected row sums to zero, relation_encoder.py:23-27) and a fully isolated node."""
-    cfg = small_cfg(graph='all', D=1024, att_dim=128, heads=4, qdim=64, seq_length=12)
+    only if the projected row sums to zero, relation_encoder.py:23-27) and a fully isolated node: outputs, log-probs and every live
+    gradient element-wise against the oracle, and every gradient chunk-wise against the REFERENCE's own (f8 sketches)."""
+    cfg, batch = real_shape_case()
     cd, sp = build_models(cfg, 30, 31, DEV)
-    batch = make_batch(B=3, N=52, D=1024, Lq=9, T=7, seq_length=12, V=31, seed=5)
-    batch['input_1'][0, 5] = 0                               # undetected region
-    batch['labels'][1, 4:] = 0                               # shorter answers
-    batch['labels'][2, 6:] = 0
-    batch['masks'] = torch.zeros_like(batch['masks'])
-    for b in range(3):
-        n = int((batch['labels'][b] != 0).sum()) + 1
-        batch['masks'][b, :n] = 1
-    batch['d_adj'][0, 7, :] = 0
-    batch['d_adj'][0, :, 7] = 0                              # isolated node in the spatial graph
-    _oracle_vs_hip(cfg, cd, sp, batch)
+    _oracle_vs_hip(cfg, cd, sp, batch, what='real shapes')
+    g = load_golden('f8_grad_sketch_real_shapes')
+    _, worst = assert_sketch_close(g['grad_names'], g['grad_sketch'], named_grads(cd, sp), 1e-3, 'gradient sketches vs reference [real shapes]')
+    print('vs reference, worst chunk: %s %.2e' % worst)
 
 
 def test_explicit_relation_nongt5_matches_reference_golden():

@@ -1,17 +1,20 @@
 """The CPU oracle (oracle/ekaid_oracle.py) against the golden vectors captured from the reference
 (tests/golden/*.npz, written by tests/golden/make_golden.py).  Pins the oracle: every later HIP
 parity test compares against it."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from common import FULL, SMALL, build_models, oracle_params, small_models
+from common import FULL, SMALL, build_models, oracle_params, real_shape_case, small_models
 from ekaid_amd.config import bench_cfg
 from ekaid_amd.synthetic import make_batch
-from golden_util import assert_summary_close, load_golden, negligible_grad_names
+from golden_util import assert_sketch_close, assert_summary_close, load_golden, negligible_grad_names, tensor_sketch
 from oracle import ekaid_oracle as O
 
 TOL = 2e-5
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def close(a, b, tol=TOL, what=''):
@@ -156,6 +159,63 @@ def test_f3_blocks():
     close(mw, g['core_modw'], what='core_modw')
 
 
+@pytest.mark.parametrize('graph', ['semantic', 'spatial', 'implicit', 'all', 'i+s', 'real_shapes'])
+def test_f8_every_element_of_every_gradient_is_pinned_to_the_reference(graph):
+    """Whole-tensor sketches of the reference's gradients (tests/golden/make_grad_sketch.py: per 1/16 chunk of every gradient
+    tensor its norm and 4 random-sign projections): the oracle's gradients agree chunk by chunk, so no slice of any gradient is
+    left to the 8 sampled positions of the F1 summaries.  'real_shapes' = 52 regions, ragged answers, zero row, isolated node."""
+    g = load_golden('f8_grad_sketch_' + graph.replace('+', 'p'))
+    if graph == 'real_shapes':
+        cfg, batch = real_shape_case()
+        cd, sp = build_models(cfg, 30, 31, 'cpu')
+        graph = 'all'
+    else:
+        cfg, cd, sp = small_models(graph)
+        batch = make_batch(**SMALL)
+    Pcd, Psp = oracle_params(cd, True), oracle_params(sp, True)
+    loss, _ = O.train_loss(Pcd, Psp, cfg, batch, 'mode2', graph)
+    loss.backward()
+    close(loss, g['loss'], what='loss')
+    named = [('cd.' + k, Pcd[k].grad) for k, _ in cd.named_parameters()] + [('sp.' + k, Psp[k].grad) for k, _ in sp.named_parameters()]
+    extra, worst = assert_sketch_close(g['grad_names'], g['grad_sketch'], named, 2e-4, 'gradient sketches [%s]' % graph)
+    print('worst chunk: %s %.2e' % worst)
+    got = dict(named)
+    for k in extra:
+        if k == 'cd.w_emb.emb_.weight':      # frozen in the reference (language_model.py:29)
+            continue
+        assert float(got[k].abs().max()) == 0.0, 'oracle produced a gradient for dead parameter ' + k
+
+
+def test_f9_batch256_forward_at_the_metric_batch_size():
+    """BASELINE.json configs[2] shapes at the metric's own batch (256 pairs, full-width model): quirk Q-C makes the question vectors a
+    function of the batch size itself (language_model.py:149), so this is a case of its own.  The oracle against the REFERENCE run at
+    B = 256 (tests/golden/make_b256_golden.py): loss, question vectors, arg-max answers of all 4096 decode positions, their
+    log-probs, the log-prob of every label token, and whole-tensor sketches of the log-probs and of the pooled difference feature."""
+    g = load_golden('f9_b256')
+    cfg = bench_cfg()
+    cd, sp = build_models(cfg, 147, 148, 'cpu')
+    batch = make_batch(B=256, **FULL)
+    Pcd, Psp = oracle_params(cd), oracle_params(sp)
+    with torch.no_grad():
+        q = O.question_encoder(Pcd, batch['question'])
+        loss, res = O.train_loss(Pcd, Psp, cfg, batch, 'mode2', 'all')
+    close(loss, g['loss'], what='loss')
+    close(q[:4], g['q_rows'], what='question vectors')
+    lp = res['logp'][:, :16]
+    rows = [0, 85, 170, 255]
+    close(lp[rows], g['logp_rows'], what='log-prob rows')
+    close(res['outs'][5][rows], g['feat_diff_rows'], what='feat_diff rows')
+    am = lp.argmax(-1)
+    assert np.array_equal(am.numpy(), g['argmax'].astype(np.int64)), 'arg-max answers differ at B = 256'
+    tgt = batch['labels'][:, 1:17]
+    close(lp.gather(-1, am[..., None])[..., 0], g['logp_argmax'], what='logp at arg-max')
+    close(lp.gather(-1, tgt[..., None])[..., 0], g['logp_label'], what='logp at label')
+    for name, t in (('q', q), ('logp', lp), ('feat_diff', res['outs'][5])):
+        sk, ref = tensor_sketch(t), g[name + '_sketch']
+        scale = np.maximum(ref[:, :1], np.sqrt((ref[:, 0] ** 2).sum() / len(ref)))
+        assert (np.abs(sk - ref) / scale).max() <= 1e-4, name + ' sketch'
+
+
 def test_f3_greedy_sample_ids():
     g = load_golden('f3_sample')
     cfg, cd, sp = small_models('all')
@@ -166,6 +226,30 @@ def test_f3_greedy_sample_ids():
         seq, seq_lp = O.speaker_sample_greedy(Psp, cfg, res['outs'][3], res['outs'][4], res['outs'][5])
     assert np.array_equal(seq.numpy(), g['seq'])
     close(seq_lp, g['seq_logp'], what='seq_logp')
+
+
+def test_oracle_decodes_the_reference_written_checkpoint_like_the_reference(tmp_path):
+    """tests/golden/ref_checkpoint_small.pt.xz: a file written by the reference's own ``save_checkpoint`` from its own modules
+    (tests/golden/make_ref_checkpoint.py).  Loaded through the product's ``load_checkpoint``, its two state dicts drive the oracle to
+    the token ids the reference's evaluation loop decoded from it."""
+    import lzma
+    from ekaid_amd.utils.utils import load_checkpoint
+    gold = load_golden('ref_checkpoint_small_golden')
+    path = str(tmp_path / 'checkpoint_0.pt')
+    with lzma.open(os.path.join(ROOT, 'tests', 'golden', 'ref_checkpoint_small.pt.xz'), 'rb') as f, open(path, 'wb') as g:
+        g.write(f.read())
+    ck = load_checkpoint(path)
+    cfg = ck['model_cfg']
+    Pcd, Psp = ck['change_detector_state'], ck['speaker_state']
+    D = cfg.model.change_detector.feat_dim - 2
+    for i in range(2):
+        batch = make_batch(B=cfg.data.test.batch_size, N=8, D=D, Lq=20, T=16, seq_length=cfg.model.speaker.seq_length, V=148, seed=977 + i)
+        with torch.no_grad():
+            _, res = O.train_loss(Pcd, Psp, cfg, batch, 'mode2', 'all')
+            close(res['outs'][5], gold['feat_diff_%d' % i], what='feat_diff')
+            seq, seq_lp = O.speaker_sample_greedy(Psp, cfg, res['outs'][3], res['outs'][4], res['outs'][5])
+        assert np.array_equal(seq.numpy(), gold['seq_%d' % i])
+        close(seq_lp, gold['seq_logp_%d' % i], what='seq_logp')
 
 
 def test_f5_adam_two_steps():

@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 for w in base new; do
   d=$R; [ $w = base ] && d=$R/_base
   cd $d

@@ -326,6 +326,9 @@ def main(argv=None):
             if t % cfg.train.snapshot_interval == 0 or (t == cfg.train.max_iter and not args.no_final_snapshot):
                 end_of_epoch = i >= iters_per_epoch
                 checkpoint = None
+                # never snapshot weights behind an unchecked persistent launch (the snapshot interval need not be a multiple of the log
+                # interval); the Adam kernel has already refused the update of a faulted step on the device (ekaid_adam_step_dev)
+                hip.seq_status_check()
                 if rank == 0:
                     # the reference's three keys (train_mimic.py:283-287) + what a true resume needs; ``epoch`` /
                     # ``iter_in_epoch`` name the NEXT iteration to run
