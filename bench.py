@@ -78,6 +78,11 @@ def parse():
                          'picks it, and falls back to eager if the capture fails) or issued after the replay (eager: serialised)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the forward-only B=64 and T=90 lines')
+    ap.add_argument('--no-ladder', action='store_true', help='skip extra.per_gpu_ladder (the 128 / 64 / 32-pair steps of the 2 / 4 / 8-GPU points)')
+    ap.add_argument('--ladder-only', action='store_true', help='run only extra.per_gpu_ladder next to the timed step (tuning aid)')
+    ap.add_argument('--ladder-child', type=float, default=None, metavar='MS_256',
+                    help='(internal) run extra.per_gpu_ladder in THIS process and print it: bench.py starts itself this way so that the ladder has '
+                         'the process layout of a real rank (RCCL communicator created before any GPU work) and cannot take the headline line down')
     ap.add_argument('--cpu-batch', type=int, default=64)
     ap.add_argument('--global-qc', action='store_true', help='global-batch semantics for quirk Q-C')
     ap.add_argument('--eval', action='store_true', help='dropout off (parity mode); default is train mode')
@@ -88,6 +93,10 @@ def parse():
     ap.add_argument('--nodes', type=int, default=None, help='tuning aid: regions per image instead of 36 (the line then names a different workload)')
     ap.add_argument('--feat-dim', type=int, default=None, help='tuning aid: ROI feature width instead of 2048')
     ap.add_argument('--decode-steps', type=int, default=None, help='tuning aid: answer length (decode steps) instead of 16')
+    ap.add_argument('--seq-mode', choices=['auto', 'persistent', 'stepwise'], default='auto',
+                    help='decoder / GRU time loops: persistent kernels (one launch per sequence; they need every CU of the GPU to themselves) '
+                         'or the launch-per-product chains (stepwise: the safe choice if persistent launches time out next to resident '
+                         'collective kernels); auto = the library default (EKAID_SEQ_MODE, persistent), stepwise when ranks share a GPU')
     ap.add_argument('--spawn-timeout', type=int, default=1500,
                     help='--gpus N > 1 started without a launcher: seconds after which the spawned ranks are stopped')
     args = ap.parse_args()
@@ -246,6 +255,122 @@ def real_data_loop(graph, iters=120, time_from=80, answer_mix='short+90'):
             'decode_steps_run_histogram': out.get('decode_steps_run_histogram'), 'dataset_generation_s': round(gen_s, 2)}
 
 
+def comm_identity(dev, rank, world, backend_arg, grad_bytes):
+    """What the N > 1 line must prove by itself: the backend torch.distributed actually runs, the rank count as the COLLECTIVE sees it
+    (an all-gather, not argv), that the ranks sit on distinct devices (all-gathered PCI bus ids + uuids), the RCCL version, and the
+    raw bus bandwidth of an all-reduce of the step's gradient volume timed outside the step (busbw = 2 (W-1)/W x bytes / time: the
+    per-link figure to hold against xGMI's ~153 GB/s per link when the collective runs as a ring)."""
+    props = torch.cuda.get_device_properties(dev)
+    me = {'rank': rank, 'device_index': dev.index, 'name': props.name, 'arch': getattr(props, 'gcnArchName', None),
+          'pci': '%04x:%02x:%02x' % (getattr(props, 'pci_domain_id', 0), getattr(props, 'pci_bus_id', 0), getattr(props, 'pci_device_id', 0)),
+          'uuid': str(getattr(props, 'uuid', '')), 'pid': os.getpid()}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, me)
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)
+    backend = dist.get_backend()
+    # the 223 MB of live gradients over RCCL; a few MB when the backend stages through the host (gloo plumbing tests)
+    nbytes = grad_bytes if backend == 'nccl' else min(grad_bytes, 8 << 20)
+    buf = torch.zeros(nbytes // 4, device=dev)
+    iters = 10 if backend == 'nccl' else 2
+    for _ in range(3 if backend == 'nccl' else 1):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    dt = torch.tensor([(time.perf_counter() - t0) / iters], device=dev, dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    try:
+        ver = '.'.join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:            # noqa: BLE001
+        ver = None
+    return {'backend': backend, 'backend_requested': backend_arg, 'ranks': len(everyone), 'ranks_counted_by_allreduce': int(ones.item()),
+            'distinct_devices': len({(e['pci'], e['uuid']) for e in everyone}), 'devices': everyone, 'rccl_version': ver,
+            'allreduce_raw': {'bytes': nbytes, 'ms': round(dt * 1e3, 3), 'algbw_GBps': round(nbytes / dt / 1e9, 2),
+                              'busbw_GBps': round(2.0 * (world - 1) / world * nbytes / dt / 1e9, 2), 'iterations': iters}}
+
+
+def per_gpu_ladder(cfg, cd, sp, opt, dev, graph, full_batch, T, ms_256, steps=40, warmup=5):
+    """The 2 / 4 / 8-GPU operating points of the metric (global batch 256 cut over N GPUs: 128 / 64 / 32 pairs per GPU), each run on
+    THIS GPU exactly the way a rank of the N-GPU job runs it: the whole iteration replayed from one hipGraph, the bucketed gradient
+    all-reduce captured inside it and issued through RCCL (a world-1 communicator: the collective kernels run, nothing crosses a link).
+    Per rung: ms per step, launches per replay (kernel nodes of the captured graph), the path's algorithmic TFLOP/s against the matrix-pipe
+    roof, and the speed-up over the 1-GPU step this rung implies for N GPUs BEFORE link time (ms_256 / ms)."""
+    from ekaid_amd import ops
+    from ekaid_amd.engine import TrainStep
+    from ekaid_amd.synthetic import slice_batch
+    assert dist.is_initialized(), 'per_gpu_ladder runs in the --ladder-child process (world-1 RCCL communicator)'
+    split = ops.get_gemm_mode() == ops.GEMM_BF16_SPLIT
+    peak_alg = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_F32_MFMA_TFLOPS
+    fpp = flop_per_pair(N=SHAPE['N'], D=SHAPE['D'], Lq=SHAPE['Lq'], T=T, graph=graph)
+    rungs = []
+    was_force = opt.force_comm
+    opt.force_comm = True
+    try:
+        for n_gpus, per_gpu in ((2, 128), (4, 64), (8, 32)):
+            hb = slice_batch(full_batch, 0, per_gpu)              # rank 0's contiguous slice of the global batch
+            b = {k: v.to(dev) for k, v in hb.items()}
+            step = TrainStep(cfg, cd, sp, opt, graph, use_graph=True, comm='captured',
+                             count_nodes=os.environ.get('EKAID_LADDER_NODES', '1') != '0')
+            try:
+                ms = timed(lambda: step(b, T), steps, warmup)
+                nodes = step.node_counts
+            finally:
+                step.close()
+            tf = fpp * per_gpu / (ms * 1e-3) / 1e12
+            rungs.append({'n_gpus': n_gpus, 'per_gpu_batch': per_gpu, 'ms_per_step': round(ms, 3),
+                          'launches_per_step': (nodes or {}).get('kernel'), 'graph_nodes': nodes,
+                          'roofline': {'bound': 'mfma', 'algorithmic_f32_tflops': round(tf, 3), 'algorithmic_peak_tflops': round(peak_alg, 1),
+                                       'frac': round(tf / peak_alg, 4)},
+                          'implied_speedup_before_link_time': round(ms_256 / ms, 3),
+                          'implied_qa_pairs_per_s': round(256.0 / ms * 1e3, 1)})
+    finally:
+        opt.force_comm = was_force
+    return {'workload': 'BASELINE.json metric points at 2 / 4 / 8 GPUs (global batch 256 -> 128 / 64 / 32 pairs per GPU) run on ONE GPU as a '
+                        'rank runs them: hipGraph replay, bucketed all-reduce captured in the graph and issued through RCCL (world-1 '
+                        'communicator), %d timed replays after %d; speed-ups are over the 1-GPU step of this run and exclude link time' % (steps, warmup),
+            'ms_per_step_1gpu': round(ms_256, 3), 'flop_per_pair': fpp, 'rungs': rungs}
+
+
+def streamed_step(step_fn, host_batch, dev, T, steps, compact, ms_resident):
+    """The timed step fed by the input pipeline instead of a batch resident in HBM: a loader hands the SAME host batch over and over
+    (pageable memory, the reference's tuple layout), ``DevicePrefetcher`` stages it into pinned buffers -- label matrices compacted to
+    int8 N x N (``compact``) or left as the reference's float64 100 x 100 -- and copies it on a side stream while the previous step
+    runs; the compute stream waits at an event.  ``exposed_h2d_ms`` = time the compute stream stood at that fence per step.
+    ref: train_mimic.py:206-227 (synchronous pageable copies at the top of every iteration)."""
+    from ekaid_amd.datasets.rcc_dataset_pos_mimic import DevicePrefetcher
+
+    class Repeat:
+        def __iter__(self):
+            for _ in range(steps + 6):
+                yield host_batch
+    pf = DevicePrefetcher(Repeat(), dev, compact=compact, depth=2, timing=True, run_ahead=2)
+    t0 = n = None
+    for i, b in enumerate(pf):
+        if i == 6:                                  # warm-up: pinned buffers allocated, queue primed
+            torch.cuda.synchronize()
+            pf._fold_events(0)
+            pf._h2d_ms = pf._stall_ms = 0.0
+            pf.h2d_bytes = 0
+            t0, n = time.perf_counter(), 0
+        step_fn({k: v for k, v in b.items() if not k.startswith('_')}, T)
+        if t0 is not None:
+            n += 1
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    st = pf.stats()
+    return {'ms_per_step': round(ms, 3), 'pairs_per_s': round(host_batch['input_1'].shape[0] / ms * 1e3, 1),
+            'vs_resident_inputs': round(ms / ms_resident, 4), 'exposed_h2d_ms_per_step': round(st['stall_ms'] / n, 4),
+            'h2d_ms_per_batch': round(st['h2d_ms'] / n, 3), 'h2d_bytes_per_batch': int(st['h2d_bytes'] / n),
+            'loader_wait_ms_per_step': round(st['loader_wait_s'] / n * 1e3, 3),
+            'layout': 'int8 N x N label matrices (compact device feed)' if compact else 'float64 100 x 100 label matrices (the reference layout)'}
+
+
 def timed(fn, steps, warmup):
     for _ in range(warmup):
         fn()
@@ -326,10 +451,35 @@ def spawn_ranks(n, timeout_s):
     return rc
 
 
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    """stdout carries the ONE JSON line of the contract and nothing else: file descriptor 1 is pointed at stderr for the whole run (RCCL
+    prints its version banner there, gloo its connection notes, the dataset classes their progress) and the line is written to the
+    original descriptor at the end (``emit``)."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + '\n').encode()
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus, args.spawn_timeout))
+    claim_stdout()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -340,6 +490,14 @@ def main():
     local_rank = local_rank % max(torch.cuda.device_count(), 1)      # (several ranks may share a GPU in the gloo plumbing test)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    if args.ladder_child is not None:
+        # a world-1 RCCL communicator, created before any GPU work exactly as a rank of the N-GPU job creates its own
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if args.backend == 'nccl':
@@ -360,8 +518,23 @@ def main():
         # several ranks on one GPU (the single-GPU plumbing tests): two processes' persistent sequence kernels cannot both have all
         # their workgroups resident, their seams would time out -- the launch-per-product chains have no such requirement
         hip.check(hip.lib().ekaid_set_seq_mode(0), 'set_seq_mode')
+    if args.seq_mode != 'auto':
+        hip.check(hip.lib().ekaid_set_seq_mode(1 if args.seq_mode == 'persistent' else 0), 'set_seq_mode')
+    seq_mode_name = 'persistent' if hip.lib().ekaid_get_seq_mode() == 1 else 'stepwise'
+    if args.ladder_child is not None:
+        cfg = bench_cfg(D=SHAPE['D'], seq_length=SHAPE['seq_length'], graph=args.graph)
+        cd, sp = build_models(cfg, 147, 148, dev, train=not args.eval)
+        opt = FlatAdam([cd, sp], lr=1e-4, betas=(0.9, 0.999), eps=1e-8)
+        full = make_batch(B=256, seed=1238, **SHAPE)
+        T = DynamicSpeaker.count_steps(full['labels'], SHAPE['seq_length'])
+        ops.manual_seed(1238)
+        out = per_gpu_ladder(cfg, cd, sp, opt, dev, args.graph, full, T, args.ladder_child)
+        hip.seq_status_check()
+        emit(out)
+        dist.destroy_process_group()
+        return
     if args.real_only:
-        print(json.dumps({'real_b64': real_data_loop(args.graph)}))
+        emit({'real_b64': real_data_loop(args.graph)})
         return
 
     if args.scaling == 'strong':
@@ -505,9 +678,24 @@ def main():
                                'flop_per_pair': fpp, 'formula': 'bench.flop_per_pair(N=%d, D=%d, Lq=%d, T=%d, graph=%r): SURVEY.md 8(d)' % (
                                    SHAPE['N'], SHAPE['D'], SHAPE['Lq'], T, args.graph)}}
 
+    # ---- the metric's 2 / 4 / 8-GPU operating points on this one GPU (N = 1 only)
+    ladder = None
+    if (world == 1 and rank == 0 and args.scaling == 'strong' and global_batch == 256 and not args.no_ladder
+            and (not args.no_extra or args.ladder_only) and not use_graph):
+        # in a child process of its own (this one idles meanwhile): a rank's process layout, and a failure there costs the ladder only
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), '--ladder-child', '%.4f' % (elapsed / args.steps * 1e3), '--graph', args.graph,
+               '--seq-mode', args.seq_mode]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+            ladder = json.loads(lines[-1]) if r.returncode == 0 and lines else {'error': 'ladder child exited with %d' % r.returncode,
+                                                                                'stderr_tail': r.stderr[-600:]}
+        except subprocess.TimeoutExpired:
+            ladder = {'error': 'ladder child timed out'}
     # ---- extra lines (N = 1): configs[1] forward-only at batch 64, and the T = 90 worst case
     extra = None
-    if world == 1 and not args.no_extra and rank == 0:
+    if world == 1 and not args.no_extra and not args.ladder_only and rank == 0:
         extra = {}
         hb = make_batch(B=64, seed=77, **SHAPE)
         b64 = {k: v.to(dev) for k, v in hb.items()}
@@ -541,6 +729,14 @@ def main():
                                                  'ending by itself once every row has stopped; 8 steps per call on the step-wise chain), batch 64, '
                                                   'freshly initialised weights: the end token never comes, all %d steps of the maximum '
                                                   'answer length are decoded' % nsteps}
+        # the headline step through the input pipeline (pinned staging + side-stream copies), compact and reference label layouts
+        ms_res = timed(lambda: eager(b, T), 20, 3)
+        extra['train_b%d_streamed' % per_gpu] = {
+            'workload': 'the timed %d-pair train step fed by DevicePrefetcher (pinned double buffers, copies on a side stream) instead of '
+                        'inputs resident in HBM; ms_resident = the same step re-timed here with resident inputs (20 steps)' % per_gpu,
+            'ms_resident': round(ms_res, 3),
+            'compact': streamed_step(eager, host_batch, dev, T, 30, True, ms_res),
+            'reference_layout': streamed_step(eager, host_batch, dev, T, 30, False, ms_res)}
         # opt-in reduced-precision GEMM arithmetic (two bf16 terms per operand, three products): the same train step, NOT the
         # metric's arithmetic -- reported beside it with its measured log-prob deviation (cpu_baseline.parity_vs_hip_bf16x2)
         if ops.get_gemm_mode() == ops.GEMM_BF16_SPLIT:
@@ -609,7 +805,8 @@ def main():
         opt.comm_suspended = False
         nocomm.close()
         ms_nc = float(t_nc.item()) * 1e3
-        comm = {'exposed_comm_ms': round(max(0.0, elapsed / args.steps * 1e3 - ms_nc), 3), 'ms_per_step_without_comm': round(ms_nc, 3),
+        comm = {**comm_identity(dev, rank, world, args.backend, int(opt.total) * 4),
+                'exposed_comm_ms': round(max(0.0, elapsed / args.steps * 1e3 - ms_nc), 3), 'ms_per_step_without_comm': round(ms_nc, 3),
                 'allreduce_bytes': int(opt.total) * 4, 'buckets': len(opt.buckets),
                 'mode': ('captured in the hipGraph, overlapped' if graph_comm == 'captured' else 'after the replay, serialised')
                 if use_graph else 'eager, launched from gradient hooks, overlapped', 'capture_fallback': comm_fallback}
@@ -643,6 +840,7 @@ def main():
                        'global_batch': global_batch, 'per_gpu_batch': per_gpu,
                        'parallelism': 'dp%d' % world, 'question_attention': 'global-batch' if args.global_qc else 'local-batch',
                        'launch_path': ('hipGraph replay, all-reduce %s' % graph_comm) if use_graph else 'eager launches',
+                       'seq_mode': seq_mode_name,
                        'params_total': sum(p.numel() for m in (cd, sp) for p in m.parameters()), 'loss': round(loss_val, 5)},
             'roofline': roof,
             'phases_ms': phases if rank == 0 else None,
@@ -655,11 +853,13 @@ def main():
         }
         if comm is not None:
             out['comm'] = comm
+        if ladder is not None:
+            extra = dict(extra or {}, per_gpu_ladder=ladder)
         if extra is not None:
             out['extra'] = extra
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, cd, sp, args.cpu_batch, args.graph)
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
 

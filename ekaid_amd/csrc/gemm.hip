@@ -942,15 +942,18 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? EKAID_SPLIT_OCC_BIG : (TM * TN
 // TWO independent products of the same operand layout in one launch (64x64 tiles): workgroups [0, tiles of g0) work on g0,
 // the rest on g1; grid.z = the larger of the two K splits, a workgroup beyond its own problem's split count leaves at once.
 // For the recurrent steps, where two small GEMMs of one step have no dependence on each other (ekaid_gemm_slabs2).
-template <bool A_KC, bool B_KC, bool BIG, int NP = 3>
+// Also the launch behind ekaid_gemm_pair_f32 (two full products with their own epilogues, e.g. the query / key projections of a
+// graph-attention layer: 2 x 1152 tiles = three whole waves of resident workgroups instead of two launches of 1.5 waves each).
+// ASUM: the A row sums of the weight-gradient form (either problem may carry one); PIPE: the K-loop arm of the 128x128 tile.
+template <bool A_KC, bool B_KC, bool BIG, int NP = 3, bool ASUM = false, bool PIPE = EKAID_SPLIT_PIPE_BIG>
 __global__ __launch_bounds__(256, BIG ? EKAID_SPLIT_OCC_BIG : EKAID_SPLIT_OCC_SMALL) void gemm_split_pair_kernel(GemmArgs g0, GemmArgs g1) {
     const int n0 = g0.tiles_m * g0.tiles_n;
     const bool first = (int)blockIdx.x < n0;
     const GemmArgs& g = first ? g0 : g1;
     if ((int)blockIdx.z >= g.splitk) return;
     const int bx = first ? blockIdx.x : blockIdx.x - n0;
-    if constexpr (BIG) gemm_split_body<A_KC, B_KC, 2, 2, 32, 1, EKAID_SPLIT_PIPE_BIG, NP>(g, bx, blockIdx.z);
-    else gemm_split_body<A_KC, B_KC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL, EKAID_SPLIT_PIPE_SMALL, NP>(g, bx, blockIdx.z);
+    if constexpr (BIG) gemm_split_body<A_KC, B_KC, 2, 2, 32, 1, PIPE, NP, ASUM>(g, bx, blockIdx.z);
+    else gemm_split_body<A_KC, B_KC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL, EKAID_SPLIT_PIPE_SMALL, NP, ASUM>(g, bx, blockIdx.z);
 }
 
 #ifndef EKAID_GEMM_X2_TU      // (non-template kernels: defined once, in the main translation unit)
@@ -1372,22 +1375,36 @@ static int launch_product(const GemmArgs& a, int TMN, bool akc, bool bkc, int ba
 }
 #endif
 
-template <bool AK, bool BKC, bool BIG, int NP = 3>
+template <bool AK, bool BKC, bool BIG, int NP = 3, bool ASUM = false, bool PIPE = EKAID_SPLIT_PIPE_BIG>
 static int launch_pair(const GemmArgs& a0, const GemmArgs& a1, hipStream_t st) {
     constexpr int KB = BIG ? 32 : EKAID_SPLIT_KB_SMALL;
     constexpr size_t lds = NP * 2 * KB * (BIG ? 256 : 128);
     static_assert(lds <= 64 * 1024, "pair kernel: the tiles fit the default dynamic LDS limit");
     const int sk = a0.splitk > a1.splitk ? a0.splitk : a1.splitk;
     dim3 grid(a0.tiles_m * a0.tiles_n + a1.tiles_m * a1.tiles_n, 1, sk);
-    hipLaunchKernelGGL((gemm_split_pair_kernel<AK, BKC, BIG, NP>), grid, dim3(256), lds, st, a0, a1);
+    hipLaunchKernelGGL((gemm_split_pair_kernel<AK, BKC, BIG, NP, ASUM, PIPE>), grid, dim3(256), lds, st, a0, a1);
     return check_launch("gemm_split_pair_kernel");
 }
+// (the 128x128 tile takes the K-loop arm a solo launch of the same layout takes -- big_arm -- so that a product computed inside a pair is
+// bit-identical to the same product launched alone)
 template <int NP>
 static int pair_dispatch(const GemmArgs& a0, const GemmArgs& a1, bool big, bool akc, bool bkc, hipStream_t st) {
-#define EKAID_PAIR(BIG) (akc && bkc ? launch_pair<true, true, BIG, NP>(a0, a1, st) \
-                         : akc && !bkc ? launch_pair<true, false, BIG, NP>(a0, a1, st) : launch_pair<false, false, BIG, NP>(a0, a1, st))
-    return big ? EKAID_PAIR(true) : EKAID_PAIR(false);
-#undef EKAID_PAIR
+    const bool asum = a0.asum != nullptr || a1.asum != nullptr;
+    if (asum) {
+        if (akc || bkc) { set_error("gemm pair: A row sums need the weight-gradient layout"); return EKAID_ERR_UNSUPPORTED; }
+        return big ? launch_pair<false, false, true, NP, true, EKAID_SPLIT_PIPE_BIG>(a0, a1, st)
+                   : launch_pair<false, false, false, NP, true>(a0, a1, st);
+    }
+    if (big) {
+        if (akc && bkc) return big_arm(true, true) == 1 ? launch_pair<true, true, true, NP, false, false>(a0, a1, st)
+                                                        : launch_pair<true, true, true, NP, false, EKAID_SPLIT_PIPE_BIG>(a0, a1, st);
+        if (akc && !bkc) return big_arm(true, false) == 1 ? launch_pair<true, false, true, NP, false, false>(a0, a1, st)
+                                                          : launch_pair<true, false, true, NP, false, EKAID_SPLIT_PIPE_BIG>(a0, a1, st);
+        return big_arm(false, false) == 1 ? launch_pair<false, false, true, NP, false, false>(a0, a1, st)
+                                          : launch_pair<false, false, true, NP, false, EKAID_SPLIT_PIPE_BIG>(a0, a1, st);
+    }
+    return akc && bkc ? launch_pair<true, true, false, NP>(a0, a1, st)
+         : akc && !bkc ? launch_pair<true, false, false, NP>(a0, a1, st) : launch_pair<false, false, false, NP>(a0, a1, st);
 }
 #ifdef EKAID_GEMM_X2_TU
 int split_dispatch_x2(const GemmArgs& a, int TMN, bool akc, bool bkc, int batch, hipStream_t st) { return split_dispatch<2>(a, TMN, akc, bkc, batch, st); }
@@ -1426,6 +1443,25 @@ extern "C" int ekaid_gemm_plan_query(const ekaid_gemm_t* d, int* tile, int* spli
     plan_full(d, TMN, sk, kps, tm, tn);
     *tile = TMN; *splitk = sk;
     return EKAID_OK;
+}
+
+// the deterministic finish of a K-split product: slabs summed in slab order, epilogue applied, A-row-sum partials finished
+static int launch_reduce(const ekaid_gemm_t* d, const GemmArgs& a, hipStream_t st) {
+    const long long total = (long long)d->M * d->N;
+    const bool vec_ok = (d->N % 4 == 0) && (d->ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->C) & 15) == 0) &&
+                        total / 4 < (1ll << 30);
+    if (vec_ok) {
+        const int n4 = d->N / 4;
+        hipLaunchKernelGGL(splitk_reduce_vec_kernel<4>, dim3(cdiv((long long)d->M * n4, 256)), dim3(256), 0, st, a.ws, d->C,
+                           d->M, n4, d->ldc, a.splitk, a.e, a.asum_ws, a.asum, a.splitk * (a.tiles_n < ASUM_SHARE ? a.tiles_n : ASUM_SHARE));
+    } else {
+        int blocks = cdiv(total, 256);
+        if (blocks > 2048) blocks = 2048;
+        if (a.asum && (long long)blocks * 256 < d->M) blocks = cdiv(d->M, 256);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.ws, d->C, d->M, d->N, d->ldc,
+                           a.splitk, a.e, a.asum_ws, a.asum, a.splitk * (a.tiles_n < ASUM_SHARE ? a.tiles_n : ASUM_SHARE));
+    }
+    return check_launch("splitk_reduce_kernel");
 }
 
 extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t workspace_bytes, void* stream) {
@@ -1499,23 +1535,7 @@ extern "C" int ekaid_gemm_f32(const ekaid_gemm_t* d, void* workspace, size_t wor
     // bound by what a CU can sustain, not by the tail.  profiles/r02_planes_gemm_microbench.txt)
     int rc = launch_product(a, TMN, akc, bkc, batch, st);
     if (rc) return rc;
-    if (a.splitk > 1) {
-        const long long total = (long long)d->M * d->N;
-        const bool vec_ok = (d->N % 4 == 0) && (d->ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->C) & 15) == 0) &&
-                            total / 4 < (1ll << 30);
-        if (vec_ok) {
-            const int n4 = d->N / 4;
-            hipLaunchKernelGGL(splitk_reduce_vec_kernel<4>, dim3(cdiv((long long)d->M * n4, 256)), dim3(256), 0, st, a.ws, d->C,
-                               d->M, n4, d->ldc, a.splitk, a.e, a.asum_ws, a.asum, a.splitk * (a.tiles_n < ASUM_SHARE ? a.tiles_n : ASUM_SHARE));
-        } else {
-            int blocks = cdiv(total, 256);
-            if (blocks > 2048) blocks = 2048;
-            if (a.asum && (long long)blocks * 256 < d->M) blocks = cdiv(d->M, 256);
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.ws, d->C, d->M, d->N, d->ldc,
-                               a.splitk, a.e, a.asum_ws, a.asum, a.splitk * (a.tiles_n < ASUM_SHARE ? a.tiles_n : ASUM_SHARE));
-        }
-        rc = check_launch("splitk_reduce_kernel");
-    }
+    if (a.splitk > 1) rc = launch_reduce(d, a, st);
     if (rc == EKAID_OK && rowsum_after) {
         if (batch != 1) { set_error("ekaid_gemm_f32: a_rowsum with a batched product"); return EKAID_ERR_UNSUPPORTED; }
         rc = ekaid_colsum_acc(d->A, d->K, d->M, d->lda, d->a_rowsum, stream);
@@ -1568,5 +1588,65 @@ extern "C" int ekaid_gemm_slabs2(const ekaid_gemm_t* d0, float* slabs0, size_t s
     const bool akc = !d0->transA, bkc = d0->transB != 0;
     if (gemm_mode() == 2) return pair_dispatch_x2(a0, a1, T0 == 2, akc, bkc, st);
     return pair_dispatch<3>(a0, a1, T0 == 2, akc, bkc, st);
+}
+
+// ---- two independent products in one launch (include/ekaid_hip.h: ekaid_gemm_pair_f32)
+static size_t al256p(size_t x) { return (x + 255) & ~(size_t)255; }
+static bool pair_basic_ok(const ekaid_gemm_t* d) {
+    return d && d->A && d->B && d->C && d->M > 0 && d->N > 0 && d->K > 0 && d->batch1 == 1 && d->batch2 == 1 && !(d->transA && d->transB);
+}
+// can d0 and d1 share a launch?  Same arithmetic family (split kernels), same operand layout, the same square tile from the planner for
+// both, no tall-skinny reduction form, A row sums only in the layout whose staging can carry them.
+static bool pairable(const ekaid_gemm_t* d0, const ekaid_gemm_t* d1, int& TMN) {
+    if (gemm_mode() < 1 || !pair_basic_ok(d0) || !pair_basic_ok(d1)) return false;
+    if ((d0->transA != 0) != (d1->transA != 0) || (d0->transB != 0) != (d1->transB != 0)) return false;
+    int G, NO;
+    if (skinny_tn(d0, G, NO) || skinny_tn(d1, G, NO)) return false;
+    if ((d0->a_rowsum || d1->a_rowsum) && !d0->transA) return false;
+    if ((d0->post && d0->ldpost < d0->N) || (d1->post && d1->ldpost < d1->N) || (d0->R && d0->rdiv < 1) || (d1->R && d1->rdiv < 1)) return false;
+    int T0, T1, sk, kps, tm, tn;
+    plan_full(d0, T0, sk, kps, tm, tn);
+    plan_full(d1, T1, sk, kps, tm, tn);
+    if (T0 != T1 || (T0 != 1 && T0 != 2)) return false;
+    TMN = T0;
+    return true;
+}
+extern "C" size_t ekaid_gemm_pair_workspace_bytes(const ekaid_gemm_t* d0, const ekaid_gemm_t* d1) {
+    const size_t w0 = ekaid_gemm_workspace_bytes(d0), w1 = ekaid_gemm_workspace_bytes(d1);
+    int TMN;
+    if (pairable(d0, d1, TMN)) return al256p(w0) + w1;         // both slab sets are alive at once
+    return w0 > w1 ? w0 : w1;                                   // two launches, one after the other
+}
+extern "C" int ekaid_gemm_pair_f32(const ekaid_gemm_t* d0, const ekaid_gemm_t* d1, void* workspace, size_t workspace_bytes, void* stream) {
+    int TMN = 0;
+    if (!pairable(d0, d1, TMN)) {          // outside the pair kernel's envelope: two launches, same results
+        const int rc = ekaid_gemm_f32(d0, workspace, workspace_bytes, stream);
+        if (rc) return rc;
+        return ekaid_gemm_f32(d1, workspace, workspace_bytes, stream);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t w0 = ekaid_gemm_workspace_bytes(d0), w1 = ekaid_gemm_workspace_bytes(d1);
+    if ((w0 || w1) && (!workspace || workspace_bytes < al256p(w0) + w1)) {
+        set_error("ekaid_gemm_pair_f32: workspace too small (%zu < %zu)", workspace_bytes, al256p(w0) + w1);
+        return EKAID_ERR_ARG;
+    }
+    const ekaid_gemm_t* ds[2] = {d0, d1};
+    void* wss[2] = {workspace, (char*)workspace + al256p(w0)};
+    const size_t wbs[2] = {w0, w1};
+    GemmArgs a[2];
+    for (int i = 0; i < 2; ++i) {
+        int T;
+        const int rc = fill_args(ds[i], a[i], T, wss[i], wbs[i], 0);
+        if (rc) return rc;
+        if (ds[i]->a_rowsum) {
+            a[i].asum = ds[i]->a_rowsum;
+            if (a[i].splitk > 1) a[i].asum_ws = a[i].ws + (size_t)a[i].splitk * ds[i]->M * ds[i]->N;
+        }
+    }
+    const bool akc = !d0->transA, bkc = d0->transB != 0;
+    int rc = gemm_mode() == 2 ? pair_dispatch_x2(a[0], a[1], TMN == 2, akc, bkc, st) : pair_dispatch<3>(a[0], a[1], TMN == 2, akc, bkc, st);
+    for (int i = 0; i < 2 && rc == EKAID_OK; ++i)
+        if (a[i].splitk > 1) rc = launch_reduce(ds[i], a[i], st);
+    return rc;
 }
 #endif      // EKAID_GEMM_X2_TU

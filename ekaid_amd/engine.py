@@ -67,6 +67,35 @@ def forward_loss(cfg, cd, sp, b, T, graph='all', setting='mode2', denom=None, ma
 DETECTOR_KEYS = ('input_1', 'input_2', 'd_adj', 'q_adj', 'd_sem', 'q_sem', 'd_bb', 'q_bb', 'question')
 
 
+def graph_node_counts(g):
+    """{'kernel': n, 'memset': n, 'memcpy': n, 'other': n} of a captured graph created with ``CUDAGraph(keep_graph=True)`` (the launches
+    one replay issues), read from the raw hipGraph_t with hipGraphGetNodes / hipGraphNodeGetType; None where that is unavailable."""
+    import ctypes
+    try:
+        raw = g.raw_cuda_graph()
+        rt = ctypes.CDLL('libamdhip64.so')
+        rt.hipGraphGetNodes.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+        rt.hipGraphGetNodes.restype = ctypes.c_int
+        rt.hipGraphNodeGetType.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        rt.hipGraphNodeGetType.restype = ctypes.c_int
+        n = ctypes.c_size_t(0)
+        if rt.hipGraphGetNodes(ctypes.c_void_p(raw), None, ctypes.byref(n)) != 0 or n.value == 0:
+            return None
+        nodes = (ctypes.c_void_p * n.value)()
+        if rt.hipGraphGetNodes(ctypes.c_void_p(raw), nodes, ctypes.byref(n)) != 0:
+            return None
+        out = {'kernel': 0, 'memcpy': 0, 'memset': 0, 'other': 0}
+        names = {0: 'kernel', 1: 'memcpy', 2: 'memset'}          # hipGraphNodeTypeKernel / Memcpy / Memset
+        for i in range(n.value):
+            ty = ctypes.c_int(-1)
+            if rt.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(ty)) != 0:
+                return None
+            out[names.get(ty.value, 'other')] += 1
+        return out
+    except Exception:           # noqa: BLE001  (statistics only)
+        return None
+
+
 class InferStep:
     """Eval-mode detector forward, eager or replayed from a hipGraph captured once per input shape.  At serving batch sizes
     the ~300 launches of the forward are issued slower than the GPU runs them (16 pairs: 2.9 ms eager, 2.5 ms replayed; at
@@ -118,7 +147,8 @@ class TrainStep:
     With ``use_graph`` do not keep loss tensors of EARLIER eager steps of the same modules alive across the first call
     of a new shape (they pin autograd nodes to the eager stream; see ``_capture``)."""
 
-    def __init__(self, cfg, cd, sp, opt, graph='all', setting='mode2', use_graph=False, comm='eager', warmup=2, t_round=1):
+    def __init__(self, cfg, cd, sp, opt, graph='all', setting='mode2', use_graph=False, comm='eager', warmup=2, t_round=1,
+                 count_nodes=False):
         if comm not in ('eager', 'captured'):
             raise ValueError("comm must be 'eager' or 'captured'")
         self.cfg, self.cd, self.sp, self.opt = cfg, cd, sp, opt
@@ -132,6 +162,8 @@ class TrainStep:
         self.t_round = max(int(t_round), 1)
         self.capture_s = 0.0
         self.graph_pool_bytes = 0
+        self.count_nodes = count_nodes        # keep the raw hipGraph of a capture and count its nodes (``node_counts``: last capture)
+        self.node_counts = None
         self._graphs = {}
         self._pool = None
         self._epoch = None
@@ -183,11 +215,12 @@ class TrainStep:
 
     def _body(self, static, T, denom):
         hip.check(hip.lib().ekaid_dropout_epoch_advance(self._epoch.data_ptr(), 1, hip.stream()), 'dropout_epoch_advance')
+        will_step = self.comm == 'captured' or not self.opt.comm_active()
         self.opt.zero_grad()
         loss, sp_loss, _, _ = forward_loss(self.cfg, self.cd, self.sp, static, T, self.graph, self.setting, denom)
         loss.backward()
         self.calls_after_backward = hip.calls_issued()      # (tests: the first bucket's all-reduce was enqueued before this)
-        if self.comm == 'captured' or not self.opt.comm_active():
+        if will_step:
             self.opt.step()
         return loss, sp_loss
 
@@ -240,10 +273,13 @@ class TrainStep:
             torch.cuda.current_stream(dev).wait_stream(s)
             torch.cuda.synchronize(dev)
             ops.set_seed_state(seed_state)          # the capture draws the same site seeds as the first warm-up step
-            g = torch.cuda.CUDAGraph()
+            g = torch.cuda.CUDAGraph(keep_graph=True) if self.count_nodes else torch.cuda.CUDAGraph()
             # thread_local: the RCCL watchdog thread of torch.distributed queries events while this thread captures
             with torch.cuda.graph(g, pool=self._pool, capture_error_mode='thread_local'):
                 loss, sp_loss = self._body(static, T, sden)
+            if self.count_nodes:
+                self.node_counts = graph_node_counts(g)
+                g.instantiate()
             if self._pool is None:
                 self._pool = g.pool()
         finally:

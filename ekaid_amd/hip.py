@@ -107,6 +107,8 @@ SIGNATURES = {
     'ekaid_set_gemm_mode': [I],
     'ekaid_get_gemm_mode': [],
     'ekaid_gemm_f32': [POINTER(GemmDesc), P, c_size_t, P],
+    'ekaid_gemm_pair_workspace_bytes': [POINTER(GemmDesc), POINTER(GemmDesc)],
+    'ekaid_gemm_pair_f32': [POINTER(GemmDesc), POINTER(GemmDesc), P, c_size_t, P],
     'ekaid_gemm_slab_count': [POINTER(GemmDesc)],
     'ekaid_gemm_slabs': [POINTER(GemmDesc), P, c_size_t, P],
     'ekaid_gemm_slabs2': [POINTER(GemmDesc), P, c_size_t, POINTER(GemmDesc), P, c_size_t, P],
@@ -209,7 +211,7 @@ SIGNATURES = {
     'ekaid_adam_step_dev': [P, P, P, P, L, P, P, P, P, P],
     'ekaid_seq_fault_flag': [P, P],
 }
-_RESTYPES = {'ekaid_last_error': c_char_p, 'ekaid_gemm_workspace_bytes': c_size_t, 'ekaid_gru_seq_workspace_bytes': c_size_t, 'ekaid_gru_seq_persistent_workspace_bytes': c_size_t,
+_RESTYPES = {'ekaid_last_error': c_char_p, 'ekaid_gemm_workspace_bytes': c_size_t, 'ekaid_gemm_pair_workspace_bytes': c_size_t, 'ekaid_gru_seq_workspace_bytes': c_size_t, 'ekaid_gru_seq_persistent_workspace_bytes': c_size_t,
              'ekaid_speaker_seq_workspace_bytes': c_size_t, 'ekaid_speaker_seq_persistent_workspace_bytes': c_size_t,
              'ekaid_speaker_seq_persistent_status_ptr': c_void_p, 'ekaid_speaker_seq_bwd_persistent_workspace_bytes': c_size_t, 'ekaid_speaker_greedy_workspace_bytes': c_size_t, 'ekaid_speaker_greedy_persistent_workspace_bytes': c_size_t}
 
@@ -298,6 +300,7 @@ def require_cuda(*tensors):
 
 
 _workspaces = {}
+POISON = os.environ.get('EKAID_POISON', '0') not in ('0', '', 'off', 'false')
 
 
 def workspace(nbytes, device):
@@ -306,7 +309,38 @@ def workspace(nbytes, device):
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[device] = buf
+    if POISON:
+        buf.fill_(0xFF)              # every float read before it was written is a NaN (debug mode, see enable_poison; inside a
+                                     # capture the fill becomes a node of the graph: every replay poisons again)
     return buf
+
+
+_real_empty = None
+
+
+def enable_poison():
+    """Debug mode (EKAID_POISON=1, tests/conftest.py): every float tensor ``torch.empty`` / ``empty_like`` hands out on the device is
+    filled with NaN and the scratch workspace with 0xFF bytes before each use, so a kernel whose result depends on memory it did not
+    write (an uninitialised read, an output only partly written) turns that result into NaN instead of into whatever the allocator
+    happened to return -- the suspicion behind ADVICE r04 "replay numerics depend on block placement" (ekaid_amd/engine.py)."""
+    global _real_empty, POISON
+    POISON = True
+    if _real_empty is not None:
+        return
+    _real_empty = (torch.empty, torch.empty_like)
+
+    def empty(*a, **k):
+        t = _real_empty[0](*a, **k)
+        if t.is_cuda and t.dtype.is_floating_point:
+            t.fill_(float('nan'))
+        return t
+
+    def empty_like(*a, **k):
+        t = _real_empty[1](*a, **k)
+        if t.is_cuda and t.dtype.is_floating_point:
+            t.fill_(float('nan'))
+        return t
+    torch.empty, torch.empty_like = empty, empty_like
 
 
 def reserve_workspace(nbytes, device):

@@ -115,3 +115,17 @@ class FCNet(nn.Module):
         """Dropout probability applied to this FCNet's input (0 if none)."""
         first = self.main[0]
         return first.p if isinstance(first, nn.Dropout) else 0.0
+
+
+def fcnet_pair(fa, xa, fb, xb):
+    """``(fa(xa), fb(xb))`` for two single-layer FCNets whose products can share launches (``ops.linear_pair``: the query / key
+    projections of a graph-attention layer, graph_att_layer.py:79,90); any other combination runs the two nets one after the other."""
+    la = [m for m in fa.main if isinstance(m, WNLinear)]
+    lb = [m for m in fb.main if isinstance(m, WNLinear)]
+    plain = all(isinstance(t, torch.Tensor) and t.is_cuda for t in (xa, xb))
+    if len(la) != 1 or len(lb) != 1 or not plain or _UNFUSED_INPUT_DROPOUT:
+        return fa(xa), fb(xb)
+    pa = float(fa.input_dropout()) if fa.training else 0.0
+    pb = float(fb.input_dropout()) if fb.training else 0.0
+    return ops.linear_pair((xa, la[0].weight_v, la[0].bias, la[0].weight_g, fa.act, pa),
+                           (xb, lb[0].weight_v, lb[0].bias, lb[0].weight_g, fb.act, pb))

@@ -14,7 +14,7 @@ from torch.nn.utils import weight_norm
 
 from .. import ops
 from ..hip import ACT_RELU
-from .fc import FCNet, Linear
+from .fc import FCNet, Linear, fcnet_pair
 
 
 class GraphSelfAttentionLayer(nn.Module):
@@ -48,8 +48,10 @@ class GraphSelfAttentionLayer(nn.Module):
         M = self.nongt_dim if self.nongt_dim < N else N
         feat_q, feat_k, feat_s = ops.fanout(roi_feat, 3)          # three readers: query, key, aggregated values
         key_feat = feat_k if M == N else feat_k[:, :M].contiguous()
-        q_data = self.query(feat_q).view(R, N, A)
-        k_data = self.key(key_feat).view(R, M, A)
+        # query and key read the same rows through two dropout masks: two independent products of one shape, launched as pairs
+        # (forward and weight gradients; their input gradients join one running gradient of roi_feat and stay a chain)
+        q_data, k_data = fcnet_pair(self.query, feat_q, self.key, key_feat)
+        q_data, k_data = q_data.view(R, N, A), k_data.view(R, M, A)
         geo = None
         if position_embedding is not None and self.pos_emb_dim > 0:
             pe = position_embedding.float() if position_embedding.dtype != torch.float32 else position_embedding

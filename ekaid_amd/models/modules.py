@@ -215,10 +215,11 @@ class ChangeDetector(nn.Module):
         bef_d, aft_d = ops.halves(x_d)                                      # bef = x[:B], aft = x[B:]
         diff = ops.sub(aft_d, bef_d)                                        # (B, N, A)
         diff_c, diff_g, diff_e = ops.fanout(diff, 3)
-        c1d = self.context1(diff_c)                                         # shared by both images: computed once
-        g1d = self.gate1(diff_g)
-        c2 = self.context2(x_c)                                             # (2B, N, A), bias in the epilogue
-        g2 = self.gate2(x_g)
+        # context / gate read the same rows with different weights: pairs of independent products, launched pairwise
+        c1d, g1d = ops.linear_pair((diff_c, self.context1.weight, self.context1.bias, None),     # shared by both images: computed once
+                                   (diff_g, self.gate1.weight, self.gate1.bias, None))
+        c2, g2 = ops.linear_pair((x_c, self.context2.weight, self.context2.bias, None),          # (2B, N, A), bias in the epilogue
+                                 (x_g, self.gate2.weight, self.gate2.bias, None))
         gated = ops.gate_fuse(c2, g2, c1d, g1d, self.dropout.p, self.training).view(2 * B, N, A)
 
         # region attention of BOTH images in one pass over the 2B row-stacked slices (the reference calls it per image,

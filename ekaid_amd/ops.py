@@ -33,7 +33,7 @@ CHECK_FINITE = os.environ.get('EKAID_CHECK_FINITE', '0') not in ('0', 'off', 'fa
 
 def assert_finite(t, what):
     """AssertionError naming the producer if ``t`` holds an Inf / NaN (only when CHECK_FINITE is on)."""
-    if not CHECK_FINITE or t is None or not t.is_cuda or not t.dtype.is_floating_point:
+    if not CHECK_FINITE or t is None or not t.is_cuda or not t.dtype.is_floating_point or _defer is not None:
         return
     if torch.cuda.is_current_stream_capturing():
         return
@@ -168,12 +168,14 @@ def seq_in_c():
     return _SEQ_IN_C and _gemm_profile is None
 
 
-def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=None,
-         accumulate=False, bias=None, R=None, ldr=0, rdiv=1, rowmask=None, act=ACT_NONE,
-         batch=(1, 1), strides=(0, 0, 0, 0, 0, 0), a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_seed=0, a_rowsum=None,
-         post=None, ldpost=0):
-    """C = dropout(act(alpha * op(A) op(B) [+C] [+bias] [+R])) [+post] on raw device buffers (element offsets a_off..); ``a_rowsum``
-    (transA only): a_rowsum[m] += sum_k op(A)[m][k], the bias gradient riding on a weight-gradient product."""
+_PAIR = os.environ.get('EKAID_GEMM_PAIR', '1') != '0'      # A/B knob: 0 = every product its own launch
+_defer = None            # while a list: gemm() / deferred_call() record into it instead of launching (LinearPairFn)
+
+
+def _fill_desc(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=None,
+               accumulate=False, bias=None, R=None, ldr=0, rdiv=1, rowmask=None, act=ACT_NONE,
+               batch=(1, 1), strides=(0, 0, 0, 0, 0, 0), a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_seed=0, a_rowsum=None,
+               post=None, ldpost=0):
     d = GemmDesc()
     d.A = A.data_ptr() + 4 * a_off
     d.B = B.data_ptr() + 4 * b_off
@@ -197,6 +199,20 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=N
     d.a_rowsum = ptr(a_rowsum) if _BIAS_IN_WGRAD else None
     d.post = ptr(post)
     d.ldpost = ldpost
+    return d
+
+
+def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, **kw):
+    """C = dropout(act(alpha * op(A) op(B) [+C] [+bias] [+R])) [+post] on raw device buffers (element offsets a_off..); ``a_rowsum``
+    (transA only): a_rowsum[m] += sum_k op(A)[m][k], the bias gradient riding on a weight-gradient product.  Keyword arguments:
+    alpha, alpha_dev, accumulate, bias, R, ldr, rdiv, rowmask, act, batch, strides, a_off, b_off, c_off, drop_p, drop_seed, a_rowsum,
+    post, ldpost (``_fill_desc``)."""
+    if _defer is not None:
+        _defer.append(('gemm', (A, B, C, M, N, K, lda, ldb, ldc, transA, transB), kw))
+        return
+    d = _fill_desc(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, **kw)
+    batch = kw.get('batch', (1, 1))
+    a_rowsum = kw.get('a_rowsum')
     L = hip.lib()
     need = L.ekaid_gemm_workspace_bytes(ctypes.byref(d))
     ws = hip.workspace(need, C.device) if need else None
@@ -214,6 +230,117 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=N
         prof.append((e0, e1, 2.0 * M * N * K * nb, (int(transA), int(transB), M, N, K, nb, tile.value)))
     if a_rowsum is not None and not _BIAS_IN_WGRAD:          # A/B knob: the column sums as their own launches
         check(L.ekaid_colsum_acc(d.A, K, M, lda, ptr(a_rowsum), stream()), 'colsum_acc')
+
+
+def gemm_pair(g0, g1):
+    """Two INDEPENDENT products (``g`` = (positional arguments of ``gemm``, keyword arguments)) in one launch where the library's pair
+    kernel takes them (include/ekaid_hip.h: ekaid_gemm_pair_f32; results bit-identical to two ``gemm`` calls), else two launches."""
+    if not _PAIR or not _BIAS_IN_WGRAD:
+        gemm(*g0[0], **g0[1])
+        gemm(*g1[0], **g1[1])
+        return
+    d0, d1 = _fill_desc(*g0[0], **g0[1]), _fill_desc(*g1[0], **g1[1])
+    L = hip.lib()
+    need = L.ekaid_gemm_pair_workspace_bytes(ctypes.byref(d0), ctypes.byref(d1))
+    ws = hip.workspace(need, g0[0][2].device) if need else None
+    e0 = _prof_begin()
+    check(L.ekaid_gemm_pair_f32(ctypes.byref(d0), ctypes.byref(d1), ptr(ws), need, stream()), 'ekaid_gemm_pair_f32')
+    if e0 is not None:
+        tile, sk = ctypes.c_int(0), ctypes.c_int(1)
+        check(L.ekaid_gemm_plan_query(ctypes.byref(d0), ctypes.byref(tile), ctypes.byref(sk)), 'gemm_plan_query')
+        (_, _, _, M0, N0, K0, _, _, _, tA, tB), (_, _, _, M1, N1, K1) = g0[0], g1[0][:6]
+        _prof_end(e0, 2.0 * (M0 * N0 * K0 + M1 * N1 * K1), (int(tA), int(tB), M0, N0 + N1, K0, 1, tile.value))
+
+
+def deferred_call(fn):
+    """Run ``fn()`` now, or -- inside a deferral window -- after the products recorded before it have been launched."""
+    if _defer is not None:
+        _defer.append(('call', fn))
+    else:
+        fn()
+
+
+class _Deferring:
+    def __init__(self, queue):
+        self.queue = queue
+
+    def __enter__(self):
+        global _defer
+        assert _defer is None, 'deferral windows do not nest'
+        _defer = self.queue
+
+    def __exit__(self, *exc):
+        global _defer
+        _defer = None
+
+
+def _span(t):
+    """[first byte, past-the-end byte) a tensor may touch (whole remaining allocation for a non-contiguous view)."""
+    n = t.numel() if t.is_contiguous() else t.untyped_storage().nbytes() // t.element_size() - t.storage_offset()
+    return t.data_ptr(), t.data_ptr() + n * t.element_size()
+
+
+def _independent(g0, g1):
+    """May the two recorded products run in one launch?  Neither reads (operands, bias, residual, post) what the other writes, and
+    their outputs do not overlap -- judged on ADDRESS RANGES (gradient slots of different parameters are views of one flat buffer),
+    with one interleaved case allowed: disjoint column blocks of one row-major matrix (the weight-gradient blocks of a multi-input
+    layer, written with c_off)."""
+    def out_span(g):
+        C, M, N, ldc = g[0][2], g[0][3], g[0][4], g[0][8]
+        lo = C.data_ptr() + 4 * g[1].get('c_off', 0)
+        return lo, lo + 4 * ((M - 1) * ldc + N)
+
+    def overlap(x, y):
+        return x[0] < y[1] and y[0] < x[1]
+    s0, s1 = out_span(g0), out_span(g1)
+    if overlap(s0, s1):
+        ld0, ld1, n0, n1 = g0[0][8], g1[0][8], g0[0][4], g1[0][4]
+        d = (s1[0] - s0[0]) // 4                      # column offset of product 1's block relative to product 0's
+        if ld0 != ld1 or g0[0][3] != g1[0][3] or not ((0 < d < ld0 and n0 <= d and d + n1 <= ld0) or (-ld0 < d < 0 and n1 <= -d and -d + n0 <= ld0)):
+            return False
+    r0, r1 = g0[1].get('a_rowsum'), g1[1].get('a_rowsum')
+    if r0 is not None and r1 is not None and overlap(_span(r0), _span(r1)):
+        return False                                  # both would add into the same bias-gradient slot
+    for ga, sb in ((g0, s1), (g1, s0)):
+        kw = ga[1]
+        for t in (ga[0][0], ga[0][1], kw.get('post'), kw.get('R'), kw.get('bias'), kw.get('rowmask'), kw.get('alpha_dev')):
+            if t is not None and overlap(_span(t), sb):
+                return False
+    return True
+
+
+def flush_pairs(qa, qb):
+    """Launch what two deferral windows recorded: the i-th product of one with the i-th product of the other as a pair where they are
+    independent, everything else in its recorded order (calls after the products recorded before them)."""
+    if not _PAIR:
+        for q in (qa, qb):
+            for ent in q:
+                gemm(*ent[1], **ent[2]) if ent[0] == 'gemm' else ent[1]()
+        return
+    ia = ib = 0
+    while ia < len(qa) or ib < len(qb):
+        while ia < len(qa) and qa[ia][0] == 'call':
+            qa[ia][1]()
+            ia += 1
+        while ib < len(qb) and qb[ib][0] == 'call':
+            qb[ib][1]()
+            ib += 1
+        ga = qa[ia] if ia < len(qa) else None
+        gb = qb[ib] if ib < len(qb) else None
+        if ga is not None and gb is not None:
+            if _independent(ga[1:], gb[1:]):
+                gemm_pair(ga[1:], gb[1:])
+            else:
+                gemm(*ga[1], **ga[2])
+                gemm(*gb[1], **gb[2])
+            ia += 1
+            ib += 1
+        elif ga is not None:
+            gemm(*ga[1], **ga[2])
+            ia += 1
+        elif gb is not None:
+            gemm(*gb[1], **gb[2])
+            ib += 1
 
 
 # --------------------------------------------------------------------------- #
@@ -285,6 +412,19 @@ def gemm_slabs2(g0, g1):
     _prof_end(e0, 2.0 * (g0[2] * g0[3] * g0[4] + g1[2] * g1[3] * g1[4]),
               (int(g0[7]), int(g0[8]), g0[2], g0[3] + g1[3], g0[4], 2, 1))
     return outs[0], outs[1]
+
+
+def _launch_group(gs):
+    """The recorded products of one backward step of a layer (one per input): two of them go out as a pair (the column blocks they
+    read and write are disjoint), the rest one by one."""
+    i = 0
+    while i < len(gs):
+        if i + 1 < len(gs) and _defer is None and _independent(gs[i], gs[i + 1]):
+            gemm_pair(gs[i], gs[i + 1])
+            i += 2
+        else:
+            gemm(*gs[i][0], **gs[i][1])
+            i += 1
 
 
 def slab_array(*srcs):
@@ -421,6 +561,7 @@ class LinearFn(Function):
             db_buf, db = bias_grad_slot(ctx.bias_ref)          # filled by the first weight-gradient product below
         dxs = []
         off = 0
+        dgrads = []                                  # recorded input-gradient products: two independent ones share a launch
         for i, x in enumerate(xs2):
             K = x.shape[1]
             if need[5 + i]:
@@ -430,35 +571,37 @@ class LinearFn(Function):
                 post = None                          # another reader's gradient of the same tensor joins behind the dropout (GradSlot)
                 if slot is not None and slot.lent is not None and slot.lent.numel() == dx.numel():
                     post, slot.lent = slot.lent, None
-                gemm(dz, W, dx, M, K, N, N, Ktot, K, 0, 0, alpha_dev=scale, b_off=off,
-                     drop_p=float(pd), drop_seed=ctx.seeds[i], post=post, ldpost=K)          # input-dropout backward in the epilogue
+                dgrads.append(((dz, W, dx, M, K, N, N, Ktot, K, 0, 0), dict(alpha_dev=scale, b_off=off, drop_p=float(pd), drop_seed=ctx.seeds[i],
+                                                                            post=post, ldpost=K)))          # input-dropout backward in the epilogue
                 dxs.append(lend_grad(slot, dx.view(*ctx.lead[i], K)))
             else:
                 dxs.append(None)
             off += K
+        _launch_group(dgrads)
         dW = dscale = None
         if need[0] or (ctx.has_scale and need[2]):
             dW = grad_out(W)
             off = 0
+            wgrads = []
             for x, ld in zip(xs2, ctx.lds):
                 K = x.shape[1]
-                gemm(dz, x, dW, N, K, M, N, ld, Ktot, 1, 0, c_off=off, a_rowsum=db_buf)
+                wgrads.append(((dz, x, dW, N, K, M, N, ld, Ktot, 1, 0), dict(c_off=off, a_rowsum=db_buf)))
                 db_buf = None
                 off += K
+            _launch_group(wgrads)
             if ctx.has_scale and ctx.wn is not None:
                 # weight-normed layer (WNLinearFn): the unscaled wgrad becomes dv in place and dg comes out of the same two
                 # launches (was: dot + scale, then a third pass for the norm's own backward)
                 g, norm = ctx.wn
                 dg = grad_out(g)
-                check(L.ekaid_wn_grad_fused(ptr(dW), ptr(W), ptr(g), ptr(norm), ptr(scale), dW.numel(), ptr(dg), stream()),
-                      'wn_grad_fused')
+                deferred_call(lambda: check(L.ekaid_wn_grad_fused(ptr(dW), ptr(W), ptr(g), ptr(norm), ptr(scale), dW.numel(), ptr(dg), stream()),
+                                            'wn_grad_fused'))
                 dscale = dg.view(g.shape)
             elif ctx.has_scale:
                 dscale = torch.empty((), device=W.device, dtype=torch.float32)
-                check(L.ekaid_scale_dot(ptr(dW), ptr(W), ptr(scale), dW.numel(), ptr(dscale), stream()),
-                      'scale_dot')
+                deferred_call(lambda: check(L.ekaid_scale_dot(ptr(dW), ptr(W), ptr(scale), dW.numel(), ptr(dscale), stream()), 'scale_dot'))
         if db_buf is not None:      # no weight-gradient product ran: the column sums on their own
-            check(L.ekaid_colsum_acc(ptr(dz), M, N, N, ptr(db_buf), stream()), 'colsum_acc')
+            deferred_call(lambda: check(L.ekaid_colsum_acc(ptr(dz), M, N, N, ptr(db_buf), stream()), 'colsum_acc'))
         return (dW, db, dscale, None, None) + tuple(dxs)
 
 
@@ -649,6 +792,65 @@ def wn_linear(xs, v, g, b=None, act=ACT_NONE, drops=None):
     if drops is not None and not any(d > 0.0 for d in drops):
         drops = None
     return WNLinearFn.apply(v, b, g, act, drops, *xs)
+
+
+class _SubCtx:
+    """What LinearFn.forward / backward need of an autograd context, for one half of a LinearPairFn."""
+    wn = None
+    needs_input_grad = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+class LinearPairFn(Function):
+    """TWO independent linear layers (plain or weight-normed, one input each) as one node whose products go out pairwise: the two
+    forward products in one launch, the two weight-gradient products in one launch, the two input-gradient products in one launch
+    unless one joins the other through a GradSlot (readers of one tensor hand a running gradient along: then they stay a chain).
+    Each half is exactly LinearFn / WNLinearFn -- same epilogues, dropout, slots, gradient buffers -- run inside a deferral window;
+    results are bit-identical to two separate nodes (ekaid_gemm_pair_f32).
+    Arguments: wn_a, wn_b (weight-normed?), then the five leading LinearFn arguments + the input of layer a, then those of layer b.
+    ref: graph_att_layer.py:79,90 (query / key), modules.py:278-286 (context2 / gate2, context1 / gate1)."""
+
+    @staticmethod
+    def forward(ctx, wn_a, wn_b, *args):
+        a, b = args[:6], args[6:]
+        ca, cb = _SubCtx(), _SubCtx()
+        qa, qb = [], []
+        with _Deferring(qa):
+            ya = (WNLinearFn if wn_a else LinearFn).forward(ca, *a)
+        with _Deferring(qb):
+            yb = (WNLinearFn if wn_b else LinearFn).forward(cb, *b)
+        flush_pairs(qa, qb)
+        ctx.subs = (ca, cb)
+        return ya, yb
+
+    @staticmethod
+    def backward(ctx, dya, dyb):
+        ca, cb = ctx.subs
+        need = ctx.needs_input_grad
+        ca.needs_input_grad, cb.needs_input_grad = need[2:8], need[8:14]
+        assert dya is not None and dyb is not None, 'both halves of a paired layer must be used'
+        qa, qb = [], []
+        with _Deferring(qa):
+            ga = LinearFn.backward(ca, dya)
+        with _Deferring(qb):
+            gb = LinearFn.backward(cb, dyb)
+        flush_pairs(qa, qb)
+        return (None, None) + tuple(ga) + tuple(gb)
+
+
+def linear_pair(layer_a, layer_b):
+    """``layer`` = (x, W, b, g) with g = None for a plain nn.Linear (W = weight) or the weight-norm magnitude (W = weight_v), optionally
+    followed by (act, input dropout p).  Returns (y_a, y_b)."""
+    def unpack(layer):
+        x, W, b, g = layer[:4]
+        act = layer[4] if len(layer) > 4 else ACT_NONE
+        p = float(layer[5]) if len(layer) > 5 else 0.0
+        return (W, b, g, act, (p,) if p > 0.0 else None, x), g is not None
+    a, wn_a = unpack(layer_a)
+    b, wn_b = unpack(layer_b)
+    return LinearPairFn.apply(wn_a, wn_b, *a, *b)
 
 
 def predropped(alias, copy):

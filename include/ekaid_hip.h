@@ -91,6 +91,16 @@ typedef struct ekaid_gemm {
 
 size_t ekaid_gemm_workspace_bytes(const ekaid_gemm_t* g);
 int ekaid_gemm_f32(const ekaid_gemm_t* g, void* workspace, size_t workspace_bytes, void* stream);
+/* TWO independent products (neither reads what the other writes) in ONE launch: workgroups [0, tiles of g0) work on g0, the rest on
+ * g1, every product keeps the tiling, K split, epilogue and summation order of its own plan -- results are BIT-IDENTICAL to
+ * ekaid_gemm_f32(g0); ekaid_gemm_f32(g1).  Why: the detector's products are cut into 1152 tiles of 128x128 for 768 resident workgroup
+ * slots (1.5 waves); two of them in one grid are three whole waves, and a launch's fixed cost (~22 us) is paid once.  Taken for the
+ * query / key projections of a graph-attention layer, the context / gate pairs of the fusion tail, and the two input- and
+ * weight-gradient products of a two-input layer.  Pairs outside the pair kernel's envelope (different layouts or tiles, batched or
+ * tall-skinny products) run as two launches.  workspace_bytes >= ekaid_gemm_pair_workspace_bytes(g0, g1).
+ * ref: graph_att_layer.py:79,90 (query / key), modules.py:278-286 (context / gate), graph_att.py:80 (self_weights over [v | q]). */
+size_t ekaid_gemm_pair_workspace_bytes(const ekaid_gemm_t* g0, const ekaid_gemm_t* g1);
+int ekaid_gemm_pair_f32(const ekaid_gemm_t* g0, const ekaid_gemm_t* g1, void* workspace, size_t workspace_bytes, void* stream);
 /* What the planner launches for g (host-side, no launch): *tile = 1 (64x64), 2 (128x128), 3 (128x64), 4 (64x128) or 0 (tall-skinny
  * reduction kernels), *splitk = K slabs.  For profiles: bench.py attributes every timed launch to the kernel instantiation that ran. */
 int ekaid_gemm_plan_query(const ekaid_gemm_t* g, int* tile, int* splitk);

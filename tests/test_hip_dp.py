@@ -193,6 +193,15 @@ def test_bench_runs_on_two_ranks(extra, tmp_path):
     c = out['comm']
     assert c['allreduce_bytes'] > 200e6 and c['buckets'] > 1 and c['exposed_comm_ms'] >= 0.0 and c['ms_per_step_without_comm'] > 0
     assert ('hipGraph' in out['config']['launch_path']) == bool(extra)
+    # the line identifies its own communication set-up (what an 8-GPU run will be judged from): backend as torch.distributed reports
+    # it, ranks counted by the collectives themselves, devices all-gathered, raw all-reduce bandwidth outside the step
+    assert c['backend'] == 'gloo' and c['backend_requested'] == 'gloo'
+    assert c['ranks'] == 2 and c['ranks_counted_by_allreduce'] == 2 and len(c['devices']) == 2
+    assert c['distinct_devices'] == 1, 'two ranks share the one GPU of this box'
+    assert {d['rank'] for d in c['devices']} == {0, 1} and all(d['arch'] and d['pci'] for d in c['devices'])
+    assert len({d['pid'] for d in c['devices']}) == 2
+    assert c['allreduce_raw']['busbw_GBps'] > 0 and c['allreduce_raw']['bytes'] > 0 and 'rccl_version' in c
+    assert out['config']['seq_mode'] == 'stepwise', 'ranks sharing a GPU must run the launch-per-product chains'
 
 
 def test_bench_starts_its_own_ranks():

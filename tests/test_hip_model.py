@@ -495,22 +495,31 @@ def _all_gradients_elementwise(cd, sp, Pcd, Psp, tol, what):
     (a wrong gradient in any slice of any tensor fails, not just one that a sampled position happens to hit).  A parameter whose
     true gradient is exactly zero (key bias under a softmax, W2 bias under the batch softmax, the implicit label bias: noise around
     0 on both sides) only has to be equally negligible; dead / frozen parameters must have no gradient on either side."""
-    rows, bad = [], []
+    rows, bad, dead = [], [], []
     for tag, mod, P in (('cd.', cd, Pcd), ('sp.', sp, Psp)):
         for k, p in mod.named_parameters():
+            if not p.requires_grad:              # frozen in the reference too (w_emb.emb_, language_model.py:29): never differentiated
+                assert p.grad is None
+                continue
             go = P[k].grad
             if go is None or float(go.abs().max()) == 0.0:
-                assert p.grad is None or float(p.grad.abs().max()) == 0.0, '%s: gradient on %s%s, none in the oracle' % (what, tag, k)
+                if p.grad is not None:
+                    dead.append((tag + k, float(p.grad.abs().max())))     # judged below against the typical gradient size
                 continue
             assert p.grad is not None, '%s: no gradient on live parameter %s%s' % (what, tag, k)
             rows.append((tag + k, p.grad.detach().double().cpu(), go.detach().double()))
-    assert len(rows) > 40, 'too few live parameters compared (%d)' % len(rows)
-    med = float(np.median([float(go.norm()) / np.sqrt(go.numel()) for _, _, go in rows]))
+    assert len(rows) > 30, 'too few live parameters compared (%d)' % len(rows)
+    # a tensor whose largest gradient entry is 10^-4 of the typical tensor's is rounding noise around a mathematically exact zero (the key
+    # bias under a softmax, the W2 bias under the batch softmax, the label bias of the implicit relation: a constant added to every logit
+    # of a softmax row): sign-random on both sides, so it only has to be equally negligible
+    med = float(np.median([float(go.abs().max()) for _, _, go in rows]))
     worst = (None, 0.0)
+    nzero = 0
     for name, g, go in rows:
         scale = float(go.abs().max())
-        if float(go.norm()) / np.sqrt(go.numel()) <= 1e-6 * med:         # exact-zero gradient: equally negligible
-            if float(g.abs().max()) > 100e-6 * med:
+        if scale <= 1e-4 * med:
+            nzero += 1
+            if float(g.abs().max()) > 1e-3 * med:
                 bad.append((name, float(g.abs().max()), 0.0))
             continue
         err = float((g - go).abs().max()) / scale
@@ -518,6 +527,9 @@ def _all_gradients_elementwise(cd, sp, Pcd, Psp, tol, what):
             worst = (name, err)
         if err > tol:
             bad.append((name, err, scale))
+    assert nzero <= 8, 'too many gradients treated as exact zeros (%d)' % nzero
+    for name, gmax in dead:          # no gradient at all in the oracle (dead parameters, exact zeros): nothing but rounding noise here
+        assert gmax <= 1e-6 * med, '%s: gradient %.3e on %s, none in the oracle' % (what, gmax, name)
     print('%s: %d live gradients element-wise vs oracle, worst %s %.3e' % (what, len(rows), worst[0], worst[1]))
     assert not bad, '%s: %d gradients off element-wise (name, err / max, max): %s' % (what, len(bad), bad[:8])
 
@@ -598,12 +610,12 @@ def test_explicit_encoders_with_fewer_neighbours_than_nodes():
         cfg = small_cfg(graph=graph)
         cfg.model.change_detector.nongt_dim = 5
         cd, sp = build_models(cfg, 30, 31, DEV)
-        _oracle_vs_hip(cfg, cd, sp, make_batch(**SMALL), graph, check=('img.weight', 'context1.weight'))
+        _oracle_vs_hip(cfg, cd, sp, make_batch(**SMALL), graph)
     # implicit relation: the reference's row-sliced, re-read pair geometry (mimic_utils.py:186 + graph_att_layer.py:117-126)
     cfg = small_cfg(graph='implicit')
     cfg.model.change_detector.nongt_dim = 5
     cd, sp = build_models(cfg, 30, 31, DEV)
-    _oracle_vs_hip(cfg, cd, sp, make_batch(**SMALL), 'implicit', check=('img.weight', 'context1.weight'))
+    _oracle_vs_hip(cfg, cd, sp, make_batch(**SMALL), 'implicit')
 
 
 def test_batch_of_one_and_empty_image_flag():

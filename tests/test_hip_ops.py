@@ -74,6 +74,54 @@ def test_gemm_variants(M, N, K, mode, gemm_arith):
 
 
 @pytest.mark.parametrize('mode', ['nt', 'nn', 'tn'])
+@pytest.mark.parametrize('M0,M1,N,K', [(2304, 2304, 1024, 1024), (18432, 18432, 1024, 1024), (1152, 2304, 1024, 1024), (1024, 1024, 1024, 2304),
+                                       (256, 256, 2048, 1536), (300, 200, 500, 700), (4608, 4608, 128, 1024)])
+def test_gemm_pair_is_bit_identical_to_two_launches(M0, M1, N, K, mode, gemm_arith):
+    """ekaid_gemm_pair_f32: two independent products in one launch keep the plan (tile, K split, summation order) and the epilogue of
+    each, so every output bit equals the two-launch result -- for the three operand layouts, full epilogues (bias, activation,
+    dropout, post / accumulate), K-split products, the A row sums of the weight-gradient form, unequal row counts, ragged shapes, and
+    the pairs the planner sends to two launches."""
+    from ekaid_amd import hip as H, ops
+    from ekaid_amd.hip import ACT_RELU, ACT_TANH
+
+    def operands(M, seed):
+        A, B = rnd(M, K, seed=seed), rnd(K, N, seed=seed + 1)
+        if mode == 'nt':
+            return A.to(DEV), B.t().contiguous().to(DEV), 0, 1, K, K
+        if mode == 'nn':
+            return A.to(DEV), B.to(DEV), 0, 0, K, N
+        return A.t().contiguous().to(DEV), B.to(DEV), 1, 0, M, N
+    a0, b0, ta, tb, lda0, ldb0 = operands(M0, 11)
+    a1, b1, _, _, lda1, ldb1 = operands(M1, 21)
+    bias = rnd(N, seed=31).to(DEV)
+    post = rnd(M1, N, seed=32).to(DEV)
+    base = rnd(M0, N, seed=33).to(DEV)
+    rs0, rs1 = (torch.zeros(M0, device=DEV), torch.zeros(M1, device=DEV)) if mode == 'tn' else (None, None)
+
+    def run(pair):
+        c0, c1 = base.clone(), torch.full((M1, N), float('nan'), device=DEV)
+        r0 = rs0.clone() if rs0 is not None else None
+        r1 = rs1.clone() if rs1 is not None else None
+        g0 = ((a0, b0, c0, M0, N, K, lda0, ldb0, N, ta, tb), dict(accumulate=True, bias=bias, act=ACT_TANH, a_rowsum=r0))
+        g1 = ((a1, b1, c1, M1, N, K, lda1, ldb1, N, ta, tb), dict(alpha=0.5, act=ACT_RELU, drop_p=0.25, drop_seed=1234, post=post, ldpost=N,
+                                                                 a_rowsum=r1))
+        if pair:
+            ops.gemm_pair(g0, g1)
+        else:
+            ops.gemm(*g0[0], **g0[1])
+            ops.gemm(*g1[0], **g1[1])
+        torch.cuda.synchronize()
+        return c0, c1, r0, r1
+    solo, paired = run(False), run(True)
+    for x, y, name in zip(solo, paired, ('C0', 'C1', 'rowsum0', 'rowsum1')):
+        if x is not None:
+            assert torch.equal(x, y), '%s differs between the pair launch and two launches (%s %d/%dx%dx%d)' % (name, mode, M0, M1, N, K)
+    assert torch.isfinite(paired[1]).all()
+    want = torch.tanh(base.double().cpu() + (rnd(M0, K, seed=11).double() @ rnd(K, N, seed=12).double()) + bias.double().cpu())
+    check(paired[0], want, 2e-5 * max(1.0, math.sqrt(K) / 4), 'pair product 0')
+
+
+@pytest.mark.parametrize('mode', ['nt', 'nn', 'tn'])
 @pytest.mark.parametrize('M,N,K', [(512, 384, 1024), (256, 2048, 512), (4608, 1024, 2048), (1000, 600, 4096)])
 def test_gemm_split_accuracy(M, N, K, mode):
     """The 3-way bf16 split is f32-accurate: against float64, its error is no larger than 1.5x the error of the f32
@@ -802,7 +850,8 @@ def test_round2_kernels_int8_labels_loss_denominator_device_adam_dropout_epoch()
     pg, m, v = p0.clone().to(DEV), torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
     hyper = torch.tensor([1e-4, 0.9, 0.999, 1e-8, 0.5], device=DEV)
     stepd = torch.zeros(1, dtype=torch.int32, device=DEV)
-    derived = torch.zeros(2, device=DEV)
+    derived = torch.zeros(4, device=DEV)
+    fault = torch.zeros(1, device=DEV)
     for i, g in enumerate(grads):
         if i == 2:
             opt.param_groups[0]['lr'] = 3e-5
@@ -810,9 +859,40 @@ def test_round2_kernels_int8_labels_loss_denominator_device_adam_dropout_epoch()
         pr.grad = g.clone()
         opt.step()
         hcheck(hip.lib().ekaid_adam_step_dev(ptr(pg), ptr((2 * g).to(DEV)), ptr(m), ptr(v), 1000, ptr(hyper), ptr(stepd),
-                                             ptr(derived), stream()), 'adam_dev')
+                                             ptr(derived), ptr(fault) if i else None, stream()), 'adam_dev')
     assert int(stepd.item()) == 3
     check(pg - p0.to(DEV), pr.detach() - p0, 1e-5, 'device-state adam delta after 3 steps')
+    # fault guard (ABI 8): a step behind a persistent launch that abandoned itself is refused ON THE DEVICE -- weights, moments and
+    # the step counter stay as they are -- (a) when any rank raised the all-reduced fault flag, (b) when this device's status word is set
+    import ctypes
+    snap = (pg.clone(), m.clone(), v.clone())
+    gbad = torch.full((1000,), float('nan'), device=DEV)
+    fault.fill_(2.0)                                           # e.g. two of the ranks reported a fault
+    hcheck(hip.lib().ekaid_adam_step_dev(ptr(pg), ptr(gbad), ptr(m), ptr(v), 1000, ptr(hyper), ptr(stepd), ptr(derived), ptr(fault),
+                                         stream()), 'adam_dev')
+    assert int(stepd.item()) == 3 and all(torch.equal(a, b) for a, b in zip((pg, m, v), snap)), 'update applied despite the fault flag'
+    fault.zero_()
+    rt = ctypes.CDLL('libamdhip64.so')
+    word = ctypes.c_void_p(hip.lib().ekaid_speaker_seq_persistent_status_ptr(None))
+    one = ctypes.c_uint(0x101)
+    torch.cuda.synchronize()
+    assert rt.hipMemcpy(word, ctypes.byref(one), 4, 1) == 0     # host -> device: as if seam 1 of a forward launch had timed out
+    try:
+        flag = torch.full((1,), -1.0, device=DEV)
+        hcheck(hip.lib().ekaid_seq_fault_flag(ptr(flag), stream()), 'seq_fault_flag')
+        assert float(flag.item()) == 1.0
+        hcheck(hip.lib().ekaid_adam_step_dev(ptr(pg), ptr(gbad), ptr(m), ptr(v), 1000, ptr(hyper), ptr(stepd), ptr(derived), None,
+                                             stream()), 'adam_dev')
+        assert int(stepd.item()) == 3 and all(torch.equal(a, b) for a, b in zip((pg, m, v), snap)), 'update applied despite the status word'
+        with pytest.raises(hip.EkaidError):
+            hip.seq_status_check()                              # the host-side check reports it (and clears the word)
+    finally:
+        hcheck(hip.lib().ekaid_seq_status_clear(stream()), 'seq_status_clear')
+    hcheck(hip.lib().ekaid_seq_fault_flag(ptr(flag), stream()), 'seq_fault_flag')
+    assert float(flag.item()) == 0.0
+    hcheck(hip.lib().ekaid_adam_step_dev(ptr(pg), ptr((2 * grads[0]).to(DEV)), ptr(m), ptr(v), 1000, ptr(hyper), ptr(stepd), ptr(derived),
+                                         ptr(fault), stream()), 'adam_dev')
+    assert int(stepd.item()) == 4 and not torch.equal(pg, snap[0])
     # dropout epoch: NULL pointer = seed alone; with a pointer the mask is a function of (seed, epoch); GEMM epilogue too
     x = torch.ones(1 << 16, device=DEV)
     y0, y1, y2, y3 = (torch.empty_like(x) for _ in range(4))

@@ -262,3 +262,45 @@ def test_persistent_gru_equals_the_stepwise_chain(B, T):
         err = float((x - y).abs().max() / x.abs().max())
         assert err <= TOL, '%s: %.3e' % (k, err)
         assert torch.equal(got[k], again[k]), 'persistent GRU is not deterministic in %s' % k
+
+
+def test_greedy_decode_recovers_from_an_abandoned_persistent_launch():
+    """an abandoned persistent launch (seam time-out; forced here by raising the sticky status word first, which makes every
+    workgroup leave at its first seam) used to leave `counts` at zero -- read as "every answer ended at step 0" -- and a one-token
+    garbage answer was returned silently.  Now greedy_decode reads the word where it synchronises anyway, clears it, moves the device to
+    the launch-per-product chain and decodes again: same ids as the step-wise chain, a RuntimeWarning, sequence mode 0 afterwards."""
+    import ctypes
+    import warnings
+    from common import build_models
+    from ekaid_amd import hip, speaker_seq
+    from ekaid_amd.config import bench_cfg
+    hip.load()
+    L = hip.lib()
+    cfg = bench_cfg(D=256, seq_length=12)
+    cd, sp = build_models(cfg, 147, 148, 'cuda', train=False)
+    g = torch.Generator().manual_seed(11)
+    A = cfg.model.speaker.input_dim
+    bef, aft, diff = [torch.randn(16, A, generator=g).cuda() for _ in range(3)]
+    with torch.no_grad():
+        sp.logit.weight.mul_(8.0)
+    old = L.ekaid_get_seq_mode()
+    rt = ctypes.CDLL('libamdhip64.so')
+    try:
+        hip.check(L.ekaid_set_seq_mode(0), 'set_seq_mode')
+        want = [t.clone() for t in speaker_seq.greedy_decode(sp, bef, aft, diff)[:2]]
+        hip.check(L.ekaid_set_seq_mode(1), 'set_seq_mode')
+        torch.cuda.synchronize()
+        word = ctypes.c_void_p(L.ekaid_speaker_seq_persistent_status_ptr(None))
+        val = ctypes.c_uint(0x104)
+        assert rt.hipMemcpy(word, ctypes.byref(val), 4, 1) == 0
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            seq, lp, _ = speaker_seq.greedy_decode(sp, bef, aft, diff)
+        assert any('abandoned' in str(x.message) for x in w)
+        assert L.ekaid_get_seq_mode() == 0
+        hip.seq_status_check('after the fallback')                 # cleared
+        assert torch.equal(seq, want[0]) and float((lp - want[1]).abs().max()) <= 1e-5
+        assert int((seq != 0).sum()) > 16, 'answers longer than one token expected'
+    finally:
+        L.ekaid_seq_status_clear(hip.stream())
+        L.ekaid_set_seq_mode(old)

@@ -82,6 +82,9 @@ def parse(argv=None):
                         'backward (captured; auto) or issued after each replay (eager)')
     p.add_argument('--eval_batches', type=int, default=None, help='cap on validation batches per in-loop evaluation')
     p.add_argument('--exp_dir', default=None)
+    p.add_argument('--seq_mode', choices=['auto', 'persistent', 'stepwise'], default='auto',
+                   help='decoder / GRU time loops: one persistent launch per sequence (needs every CU of the GPU) or the launch-per-product '
+                        'chains; auto = library default (EKAID_SEQ_MODE), stepwise when ranks share a GPU')
     p.add_argument('--quiet', action='store_true')
     p.add_argument('--no_final_snapshot', action='store_true', help='benchmark aid: no checkpoint / evaluation at max_iter')
     p.add_argument('--t_round', type=int, default=None,
@@ -172,6 +175,8 @@ def main(argv=None):
     hip.check(hip.lib().ekaid_init(local_rank), 'ekaid_init')
     if world > max(torch.cuda.device_count(), 1):      # ranks sharing a GPU: no persistent sequence kernels (they need every CU at once)
         hip.check(hip.lib().ekaid_set_seq_mode(0), 'set_seq_mode')
+    if args.seq_mode != 'auto':
+        hip.check(hip.lib().ekaid_set_seq_mode(1 if args.seq_mode == 'persistent' else 0), 'set_seq_mode')
     random.seed(args.seed)
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)          # identical default initialisation and sample order on every rank
