@@ -637,7 +637,8 @@ def main():
         ms = sum(r[0] for r in rec)
         fl = sum(r[1] for r in rec)
         # the dominant kernel: every launch the planner ran on the 128x128-tile instantiations (ekaid_gemm_plan_query: tile 2) -- the
-        # set rocprofv3 lists as gemm_split_kernel<., ., 2, 2, 32, 1, ., 3, .>
+        # set rocprofv3 lists as gemm_split_kernel<., ., 2, 2, 32, 1, ., 3, .> plus gemm_split_pair_kernel<., ., true, 3, ., .> (the same
+        # tile body, two products per grid: ekaid_gemm_pair_f32)
         big = [r for r in rec if r[2][6] == 2]
         big_ms, big_fl = sum(r[0] for r in big), sum(r[1] for r in big)
         if args.gemm_shapes:
@@ -662,8 +663,8 @@ def main():
         fpp = flop_per_pair(N=SHAPE['N'], D=SHAPE['D'], Lq=SHAPE['Lq'], T=T, graph=args.graph)
         path_alg = fpp * per_gpu * args.steps / elapsed / 1e12
         roof = {'bound': 'mfma',
-                'kernel': ('ekaid::gemm_split_kernel<.,.,2,2,32,1,.,3> (128x128 tiles; f32 operands split exactly into 3 bf16, '
-                           '6 x v_mfma_f32_32x32x16_bf16 per product block, f32 accumulate)') if split else
+                'kernel': ('ekaid::gemm_split_kernel<.,.,2,2,32,1,.,3> + its two-products-per-grid form gemm_split_pair_kernel<.,.,true,3,.,.> '
+                           '(128x128 tiles; f32 operands split exactly into 3 bf16, 6 x v_mfma_f32_32x32x16_bf16 per product block, f32 accumulate)') if split else
                           'ekaid::gemm_mfma_kernel<.,.,2,2,32> (v_mfma_f32_32x32x2_f32)',
                 'achieved': round(mult * alg_big, 3), 'peak': peak, 'unit': 'TFLOP/s',
                 'frac': round(mult * alg_big / peak, 4), 'traffic': pmc_traffic() if split else None,

@@ -108,6 +108,57 @@ __global__ __launch_bounds__(64) void wn_multi_finish_kernel(WnMulti a, const do
         scales[t] = a.g[t][0] / nrm;
     }
 }
+// ---- backward through the weight norm of MANY layers at once (the raw weight gradients of a step are all there at the end of backward):
+// part[t][j] = partial <G_t, v_t> (f64), then every workgroup of layer t re-sums the layer's WN_MULTI_NB partials in a fixed order and
+// rewrites its slice  G = scale * G - (<G, v> g / ||v||^3) v ;  dg_t = <G, v> / ||v||.   Two launches instead of two per layer.
+struct WnGradMulti { float* G[WN_MULTI_MAX]; const float* v[WN_MULTI_MAX]; const float* g[WN_MULTI_MAX]; const float* norm[WN_MULTI_MAX];
+                     const float* scale[WN_MULTI_MAX]; float* dg[WN_MULTI_MAX]; long long n[WN_MULTI_MAX]; int count; };
+__global__ __launch_bounds__(256) void wn_grad_multi_dot_kernel(WnGradMulti a, double* part /* [count][NB] */) {
+    const int t = blockIdx.y, j = blockIdx.x;
+    const float* G = a.G[t];
+    const float* v = a.v[t];
+    const long long n = a.n[t];
+    double s = 0.0;
+    if (((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(G)) & 15) == 0) {
+        const long long n4 = n >> 2;
+        const f32x4* v4 = reinterpret_cast<const f32x4*>(v);
+        const f32x4* g4 = reinterpret_cast<const f32x4*>(G);
+        for (long long i = (long long)j * 256 + threadIdx.x; i < n4; i += (long long)WN_MULTI_NB * 256) {
+            const f32x4 x = v4[i], y = g4[i];
+            s += ((double)x[0] * y[0] + (double)x[1] * y[1]) + ((double)x[2] * y[2] + (double)x[3] * y[3]);
+        }
+        if (j == 0 && threadIdx.x < (n & 3)) s += (double)v[4 * n4 + threadIdx.x] * (double)G[4 * n4 + threadIdx.x];
+    } else {
+        for (long long i = (long long)j * 256 + threadIdx.x; i < n; i += (long long)WN_MULTI_NB * 256) s += (double)v[i] * (double)G[i];
+    }
+    s = wave_sum_f64(s);
+    __shared__ double w[4];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[t * WN_MULTI_NB + j] = (w[0] + w[1]) + (w[2] + w[3]);
+}
+__global__ __launch_bounds__(256) void wn_grad_multi_finish_kernel(WnGradMulti a, const double* part) {
+    const int t = blockIdx.y;
+    __shared__ double w[4];
+    __shared__ float bc;
+    {
+        double s = 0.0;                       // the layer's partials in a fixed order: lanes stride them, waves / lanes combined as below
+        for (int q = threadIdx.x; q < WN_MULTI_NB; q += 256) s += part[t * WN_MULTI_NB + q];
+        s = wave_sum_f64(s);
+        if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) bc = (float)((w[0] + w[1]) + (w[2] + w[3]));
+        __syncthreads();
+    }
+    const float dscale = bc, nrm = a.norm[t][0], sc = a.scale[t][0];
+    const float coef = -dscale * a.g[t][0] / (nrm * nrm * nrm);
+    float* G = a.G[t];
+    const float* v = a.v[t];
+    const long long n = a.n[t];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) G[i] = sc * G[i] + coef * v[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.dg[t][0] = dscale / nrm;
+}
+
 // ---- fused backward of one weight-normed layer: G (unscaled wgrad, in place) -> dv = scale * G - (<G, v> g / ||v||^3) v;
 // dg = <G, v> / ||v||.  Every workgroup re-reads the <= 256 dot partials (fixed order: deterministic).
 __global__ __launch_bounds__(256) void wn_grad_finish_kernel(float* G, const float* __restrict__ v, const float* g, const float* norm,
@@ -792,6 +843,31 @@ extern "C" int ekaid_wn_scale_multi(const float* const* v, const float* const* g
     hipLaunchKernelGGL(wn_multi_sumsq_kernel, dim3(WN_MULTI_NB, count), dim3(256), 0, ST, a, part);
     hipLaunchKernelGGL(wn_multi_finish_kernel, dim3(count), dim3(64), 0, ST, a, (const double*)part, scales, norms);
     return check_launch("wn_scale_multi");
+}
+extern "C" int ekaid_wn_grad_multi(float* const* G, const float* const* v, const float* const* g, const float* const* norm,
+                                   const float* const* scale, const long long* n, float* const* dg, int count, void* stream) {
+    if (count < 1 || count > WN_MULTI_MAX || !G || !v || !g || !norm || !scale || !n || !dg) {
+        set_error("wn_grad_multi: 1 <= count <= %d layers, non-null arrays", WN_MULTI_MAX);
+        return EKAID_ERR_ARG;
+    }
+    double* acc = reduction_scratch();
+    if (!acc) { set_error("wn_grad_multi: scratch alloc failed"); return EKAID_ERR_LAUNCH; }
+    WnGradMulti a;
+    a.count = count;
+    long long nmax = 0;
+    for (int i = 0; i < WN_MULTI_MAX; ++i) {
+        const bool on = i < count;
+        if (on && (!G[i] || !v[i] || !g[i] || !norm[i] || !scale[i] || !dg[i] || n[i] < 1)) { set_error("wn_grad_multi: null / empty layer %d", i); return EKAID_ERR_ARG; }
+        a.G[i] = on ? G[i] : nullptr; a.v[i] = on ? v[i] : nullptr; a.g[i] = on ? g[i] : nullptr; a.norm[i] = on ? norm[i] : nullptr;
+        a.scale[i] = on ? scale[i] : nullptr; a.dg[i] = on ? dg[i] : nullptr; a.n[i] = on ? n[i] : 0;
+        if (on && n[i] > nmax) nmax = n[i];
+    }
+    double* part = acc + 2 * RED_SLOT;          // the column-sum partial area (1 MiB): 32 x 128 doubles = 32 KiB
+    hipLaunchKernelGGL(wn_grad_multi_dot_kernel, dim3(WN_MULTI_NB, count), dim3(256), 0, ST, a, part);
+    int nb = (int)((nmax + 2047) / 2048);       // eight elements per thread of the largest layer; smaller layers leave idle workgroups
+    nb = nb < 1 ? 1 : (nb > 512 ? 512 : nb);
+    hipLaunchKernelGGL(wn_grad_multi_finish_kernel, dim3(nb, count), dim3(256), 0, ST, a, (const double*)part);
+    return check_launch("wn_grad_multi");
 }
 extern "C" int ekaid_wn_grad_fused(float* G, const float* v, const float* g, const float* norm, const float* scale, long long n,
                                    float* dg, void* stream) {

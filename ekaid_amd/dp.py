@@ -185,6 +185,11 @@ class GradBuckets:
         if self._launched[b]:
             return
         s, e, _ = self.buckets[b]
+        if self._gstore.is_cuda:
+            # the raw weight gradients of the weight-normed layers registered so far (every layer of this bucket is) become dv / dg
+            # BEFORE the bucket is reduced: ops.wn_grad_register
+            from . import ops
+            ops.wn_grad_flush()
         self._launched[b] = True
         self._next = max(self._next, b + 1)
         if self.launch_log is not None:

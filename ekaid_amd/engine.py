@@ -321,9 +321,11 @@ class TrainStep:
             for k in [k for k in self._graphs if k[2:5] != key[2:5]]:
                 del self._graphs[k]
             import time
-            # (statistics only, and WITHOUT a device synchronisation around the capture: an extra torch.cuda.synchronize() here changes
-            # which freed blocks the caching allocator hands to the capture's clones, and the first replay then no longer reproduces the
-            # eager step bit for bit -- measured, test_graph_replay_equals_eager; the cause was not tracked down)
+            # (statistics only.  Round 4 had seen the first replay differ from the eager step in its last bits when a device
+            # synchronisation was added here, and suspected an uninitialised read.  Re-tested in round 5 on the final tree: with the extra
+            # synchronize() the replay equals the eager steps bit for bit, also with every torch.empty output NaN-filled and the scratch
+            # workspace 0xFF-filled before each use (EKAID_POISON=1, hip.enable_poison; profiles/r05_capture_sync_check.txt) -- no kernel
+            # on the path reads memory it did not write, and no kernel choice depends on where a block lies)
             t0, m0 = time.perf_counter(), torch.cuda.memory_allocated()
             ent = self._capture(b, T, denom)
             self.capture_s += time.perf_counter() - t0

@@ -140,6 +140,7 @@ SIGNATURES = {
     'ekaid_scale_dot': [P, P, P, L, P, P],
     'ekaid_wn_scale_multi': [P, P, P, I, P, P, P],
     'ekaid_wn_grad_fused': [P, P, P, P, P, L, P, P],
+    'ekaid_wn_grad_multi': [P, P, P, P, P, P, P, I, P],
     'ekaid_colsum': [P, I, I, I, P, P],
     'ekaid_colsum_acc': [P, I, I, I, P, P],
     'ekaid_sum_n': [P, I, P, L, P],

@@ -414,6 +414,71 @@ def gemm_slabs2(g0, g1):
     return outs[0], outs[1]
 
 
+# --------------------------------------------------------------------------- #
+# backward through weight_norm for all layers of a step at once
+# --------------------------------------------------------------------------- #
+# A weight-normed layer's backward leaves its RAW weight gradient dW = dy^T x in the gradient slot of weight_v and registers the layer
+# here; ONE pair of launches (ekaid_wn_grad_multi) turns every registered dW into dv and fills the dg slots (two launches per layer
+# before: 30 per step).  When: at the end of the backward pass (an autograd engine callback), or earlier -- right before a gradient
+# bucket leaves for its all-reduce (dp.GradBuckets._launch flushes what is registered so far: every layer of a complete bucket is).  So
+# the transform always precedes the reduction, in every launch mode, and data-parallel runs stay bit-identical across modes.
+_wn_pending = []                 # [(dW pointer, v, g, norm, scale, dg pointer, elements)] -- the two gradients by ADDRESS only: a second
+                                 # reference to a gradient tensor makes autograd's AccumulateGrad clone it instead of adopting it
+_wn_callback_queued = False
+_WN_MULTI = os.environ.get('EKAID_WN_GRAD_MULTI', '1') != '0'      # A/B knob: 0 = two launches per layer inside its backward node
+
+
+def wn_grad_register(dW, v, g, norm, scale, dg):
+    global _wn_callback_queued
+    _wn_pending.append((dW.data_ptr(), v, g, norm, scale, dg.data_ptr(), dW.numel()))
+    if not _wn_callback_queued:
+        _wn_callback_queued = True
+        torch.autograd.Variable._execution_engine.queue_callback(_wn_end_of_backward)
+
+
+def _wn_end_of_backward():
+    global _wn_callback_queued
+    _wn_callback_queued = False
+    wn_grad_flush()
+
+
+def wn_grad_flush():
+    """Transform every registered raw weight gradient now (nothing registered: no launch)."""
+    mine = list(_wn_pending)
+    _wn_pending[:] = []
+    L = hip.lib()
+    for i0 in range(0, len(mine), 32):
+        chunk = mine[i0:i0 + 32]
+        n = len(chunk)
+        arr = lambda k: (ctypes.c_void_p * n)(*[e[k] if isinstance(e[k], int) else e[k].data_ptr() for e in chunk])        # noqa: E731
+        ns = (ctypes.c_longlong * n)(*[e[6] for e in chunk])
+        check(L.ekaid_wn_grad_multi(arr(0), arr(1), arr(2), arr(3), arr(4), ns, arr(5), n, stream()), 'wn_grad_multi')
+
+
+class pairing_window:
+    """``with ops.pairing_window():`` -- the products issued inside are recorded and, on exit, launched in their order with every two
+    CONSECUTIVE independent ones sharing a launch (ekaid_gemm_pair_f32 decides whether the pair kernel takes them); ``deferred_call``
+    bodies run after all of them.  For blocks of mutually independent products: the time-batched weight gradients of the decoder and of
+    the question GRU."""
+
+    def __enter__(self):
+        self.q = []
+        self.win = _Deferring(self.q)
+        self.win.__enter__()
+        return self
+
+    def __exit__(self, et, ev, tb):
+        self.win.__exit__(et, ev, tb)
+        if et is not None:
+            return False
+        gs = [(e[1], e[2]) for e in self.q if e[0] == 'gemm']
+        _launch_group(gs)
+        for e in self.q:
+            if e[0] == 'call':
+                e[1]()
+        return False
+
+
 def _launch_group(gs):
     """The recorded products of one backward step of a layer (one per input): two of them go out as a pair (the column blocks they
     read and write are disjoint), the rest one by one."""
@@ -594,8 +659,11 @@ class LinearFn(Function):
                 # launches (was: dot + scale, then a third pass for the norm's own backward)
                 g, norm = ctx.wn
                 dg = grad_out(g)
-                deferred_call(lambda: check(L.ekaid_wn_grad_fused(ptr(dW), ptr(W), ptr(g), ptr(norm), ptr(scale), dW.numel(), ptr(dg), stream()),
-                                            'wn_grad_fused'))
+                if _WN_MULTI and dW.is_contiguous():
+                    wn_grad_register(dW, W, g, norm, scale, dg)        # all layers of the step together, at the end of backward
+                else:
+                    deferred_call(lambda: check(L.ekaid_wn_grad_fused(ptr(dW), ptr(W), ptr(g), ptr(norm), ptr(scale), dW.numel(), ptr(dg), stream()),
+                                                'wn_grad_fused'))
                 dscale = dg.view(g.shape)
             elif ctx.has_scale:
                 dscale = torch.empty((), device=W.device, dtype=torch.float32)
@@ -1509,10 +1577,11 @@ class GRUSeqFn(Function):
         # weight gradients batched over time: K = T*B rows (previous states are the contiguous slice hall[0:T])
         dw_hh = grad_out(w_hh)
         hh_buf, db_hh = bias_grad_slot(b_hh)
-        gemm(dgh, hall, dw_hh, 3 * H, H, T * B, 3 * H, H, H, 1, 0, a_rowsum=hh_buf)
         ih_buf, db_ih = bias_grad_slot(b_ih)
         dw_ih = grad_out(w_ih)
-        gemm(dgi, x, dw_ih, 3 * H, E, B * T, 3 * H, E, E, 1, 0, a_rowsum=ih_buf)
+        with pairing_window():                        # two independent products of one layout: one launch
+            gemm(dgh, hall, dw_hh, 3 * H, H, T * B, 3 * H, H, H, 1, 0, a_rowsum=hh_buf)
+            gemm(dgi, x, dw_ih, 3 * H, E, B * T, 3 * H, E, E, 1, 0, a_rowsum=ih_buf)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)

@@ -58,9 +58,9 @@ def _tn(D, ldd, X, ldx, G, goff, ldg, Nout, Kin, rows, doff=0, xoff=0, bias=None
     for b2 in biases[1:]:           # a second bias with the same gradient (bias_ih / bias_hh of an LSTM cell)
         buf2, ret2 = ops.bias_grad_slot(b2)
         if ret is not None and ret2 is not None:       # both slots fresh: buf IS the column sum, add it to the zeroed second slot
-            check(hip.lib().ekaid_axpby(ptr(buf), ptr(buf2), ptr(buf2), buf.numel(), 1.0, 1.0, stream()), 'axpby')
+            ops.deferred_call(lambda buf=buf, buf2=buf2: check(hip.lib().ekaid_axpby(ptr(buf), ptr(buf2), ptr(buf2), buf.numel(), 1.0, 1.0, stream()), 'axpby'))
         else:
-            check(hip.lib().ekaid_colsum_acc(D.data_ptr() + 4 * doff, rows, Nout, ldd, ptr(buf2), stream()), 'colsum_acc')
+            ops.deferred_call(lambda buf2=buf2: check(hip.lib().ekaid_colsum_acc(D.data_ptr() + 4 * doff, rows, Nout, ldd, ptr(buf2), stream()), 'colsum_acc'))
         rets.append(ret2)
     return rets[0] if len(rets) == 1 else rets
 
@@ -339,29 +339,31 @@ class SpeakerSeqFn(Function):
                 carry_a, carry_l = ops.gemm_slabs2((DCAT, whh_a, B, R, 4 * R, NW, R, 0, 0, ow, 0), (DCAT, Wcat, B, R, NW, NW, R, 0, 0, ow, 0))
 
         # ---- time-batched weight gradients (K = T*B) and input gradients; DCAT column blocks with ld = NW
-        d_wih_a = ops.grad_out(wih_a)
-        _tn(DCAT, NW, ED, E, d_wih_a, 0, E + R, 4 * R, E, TB)
-        _tn(DCAT, NW, HL, R, d_wih_a, E, E + R, 4 * R, R, TB)
-        d_whh_a = ops.grad_out(whh_a)
-        d_bih_a, d_bhh_a = _tn(DCAT, NW, HA, R, d_whh_a, 0, R, 4 * R, R, TB, bias=(bih_a, bhh_a))   # the same gradient for both
-        d_w_fc = ops.grad_out(w_fc)
-        d_b_fc = _tn(DZFC, 3, HA, R, d_w_fc, 0, R, 3, R, TB, xoff=B * R, bias=b_fc)
-        d_w_p1 = ops.grad_out(w_p1)
-        d_b_p1 = _tn(DCAT, NW, HL, R, d_w_p1, 0, R, R, R, TB, doff=oP1, bias=b_p1)
-        d_w_wp = ops.grad_out(w_wp)
-        d_b_wp = _tn(DWP, NP, VP, R, d_w_wp, 0, R, NP, R, TB, bias=b_wp)
-        d_w_p2 = ops.grad_out(w_p2)
-        d_b_p2 = _tn(DPP, R, PW, NP, d_w_p2, 0, NP, R, NP, TB, bias=b_p2)
-        d_w_g1 = ops.grad_out(w_g1)
-        d_b_g1 = _tn(DCAT, NW, HL, R, d_w_g1, 0, G1, G1, R, TB, doff=oG1, bias=b_g1)
-        _tn(DCAT, NW, PA, R + A, d_w_g1, R, G1, G1, R + A, TB, doff=oG1)
-        d_w_g2 = ops.grad_out(w_g2)
-        d_b_g2 = _tn(DZ2, A, G1D, G1, d_w_g2, 0, G1, A, G1, TB, bias=b_g2)                              # input = dropout(relu(gate1x))
-        d_wih_l = ops.grad_out(wih_l)
-        _tn(DCAT, NW, Xd, We, d_wih_l, 0, We + A, 4 * R, We, TB, doff=oGL)
-        _tn(DCAT, NW, GA, A, d_wih_l, We, We + A, 4 * R, A, TB, doff=oGL)
-        d_whh_l = ops.grad_out(whh_l)
-        d_bih_l, d_bhh_l = _tn(DCAT, NW, HL, R, d_whh_l, 0, R, 4 * R, R, TB, doff=oGL, bias=(bih_l, bhh_l))
+        # (fifteen mutually independent products of one layout: recorded and launched two per grid, ops.pairing_window)
+        with ops.pairing_window():
+            d_wih_a = ops.grad_out(wih_a)
+            _tn(DCAT, NW, ED, E, d_wih_a, 0, E + R, 4 * R, E, TB)
+            _tn(DCAT, NW, HL, R, d_wih_a, E, E + R, 4 * R, R, TB)
+            d_whh_a = ops.grad_out(whh_a)
+            d_bih_a, d_bhh_a = _tn(DCAT, NW, HA, R, d_whh_a, 0, R, 4 * R, R, TB, bias=(bih_a, bhh_a))   # the same gradient for both
+            d_w_fc = ops.grad_out(w_fc)
+            d_b_fc = _tn(DZFC, 3, HA, R, d_w_fc, 0, R, 3, R, TB, xoff=B * R, bias=b_fc)
+            d_w_p1 = ops.grad_out(w_p1)
+            d_b_p1 = _tn(DCAT, NW, HL, R, d_w_p1, 0, R, R, R, TB, doff=oP1, bias=b_p1)
+            d_w_wp = ops.grad_out(w_wp)
+            d_b_wp = _tn(DWP, NP, VP, R, d_w_wp, 0, R, NP, R, TB, bias=b_wp)
+            d_w_p2 = ops.grad_out(w_p2)
+            d_b_p2 = _tn(DPP, R, PW, NP, d_w_p2, 0, NP, R, NP, TB, bias=b_p2)
+            d_w_g1 = ops.grad_out(w_g1)
+            d_b_g1 = _tn(DCAT, NW, HL, R, d_w_g1, 0, G1, G1, R, TB, doff=oG1, bias=b_g1)
+            _tn(DCAT, NW, PA, R + A, d_w_g1, R, G1, G1, R + A, TB, doff=oG1)
+            d_w_g2 = ops.grad_out(w_g2)
+            d_b_g2 = _tn(DZ2, A, G1D, G1, d_w_g2, 0, G1, A, G1, TB, bias=b_g2)                              # input = dropout(relu(gate1x))
+            d_wih_l = ops.grad_out(wih_l)
+            _tn(DCAT, NW, Xd, We, d_wih_l, 0, We + A, 4 * R, We, TB, doff=oGL)
+            _tn(DCAT, NW, GA, A, d_wih_l, We, We + A, 4 * R, A, TB, doff=oGL)
+            d_whh_l = ops.grad_out(whh_l)
+            d_bih_l, d_bhh_l = _tn(DCAT, NW, HL, R, d_whh_l, 0, R, 4 * R, R, TB, doff=oGL, bias=(bih_l, bhh_l))
         # embed path: dED = DGA . W_ih_att[:, :E]; per-step dropout backward; sum over t; relu; Linear(3A -> E)
         dED = torch.empty(T, B, E, **f32)
         _nn(DCAT, 0, NW, wih_a, 0, E + R, dED, 0, E, TB, E, 4 * R)

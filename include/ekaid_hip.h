@@ -173,6 +173,11 @@ int ekaid_wn_scale_multi(const float* const* v, const float* const* g, const lon
                          void* stream);
 int ekaid_wn_grad_fused(float* G, const float* v, const float* g, const float* norm, const float* scale, long long n, float* dg,
                         void* stream);
+/* wn_grad_multi:  wn_grad_fused for `count` <= 32 layers in two launches (HOST arrays of device pointers / element counts): the raw
+ *                 weight gradients of every weight-normed layer of a step are turned into dv / dg together at the end of backward
+ *                 (the transform is linear in the raw gradient, so it commutes with the data-parallel all-reduce). */
+int ekaid_wn_grad_multi(float* const* G, const float* const* v, const float* const* g, const float* const* norm, const float* const* scale,
+                        const long long* n, float* const* dg, int count, void* stream);
 
 /* column sum of an [M][N] matrix (bias gradient), out[N]; row-block partials summed in a fixed order (deterministic) */
 int ekaid_colsum(const float* x, int M, int N, int ldx, float* out, void* stream);

@@ -14,8 +14,8 @@ def fam(name):
         t = re.search(r'<(\w+), (\w+), (\d), (\d)', name)
         return 'gemm_split %sx%s %s%s' % (64 * int(t.group(3)), 64 * int(t.group(4)), 'k' if t.group(1) == 'true' else 'm', 'k' if t.group(2) == 'true' else 'n')
     if base == 'gemm_split_pair_kernel':
-        t = re.search(r'<(\w+), (\w+)', name)
-        return 'gemm_pair 64x64 %s%s' % ('k' if t.group(1) == 'true' else 'm', 'k' if t.group(2) == 'true' else 'n')
+        t = re.search(r'<(\w+), (\w+), (\w+)', name)          # <A_KC, B_KC, BIG, ...>: BIG = 128x128 tiles
+        return 'gemm_pair %s %s%s' % ('128x128' if t.group(3) == 'true' else '64x64', 'k' if t.group(1) == 'true' else 'm', 'k' if t.group(2) == 'true' else 'n')
     if base == 'at':
         return 'aten:' + name[:60]
     return base
