@@ -22,7 +22,10 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   "cpu_baseline": the CPU oracle (oracle/, test infrastructure: a port of the reference algorithm proven equal to the
                   reference on golden vectors) timed on this box's host cores on a bounded sample: full train step
                   (forward, backward, torch.optim.Adam) and eval forward at batch 64 (SURVEY.md section 8d);
-  "extra":        forward-only at batch 64 (configs[1]) and the T = 90 worst-case train step (N = 1 only).
+  "extra":        (N = 1 only) forward-only at batch 64 (configs[1]), greedy decoding, the step fed through the input pipeline
+                  (train_b256_streamed), the T = 90 worst-case train step, the real-data loop (configs[4] on one GPU), and
+                  per_gpu_ladder: the 128 / 64 / 32-pair steps of the metric's 2 / 4 / 8-GPU points, replayed from a hipGraph with the
+                  all-reduce captured and issued through a world-1 RCCL communicator (in a child process).
 """
 import argparse
 import contextlib
@@ -849,8 +852,8 @@ def main():
             'host_issue_ms_per_step_eager': round(host_issue_eager_ms, 3),
             'h2d': {'ms_per_batch': round(h2d_ms, 3), 'bytes_per_batch': h2d_bytes,
                     'note': 'pageable host memory, first transfer of the process, not overlapped; the reference layout '
-                            '(f64 100x100 label matrices); not part of value',
-                    'value_if_serialised': round(global_batch / (elapsed / args.steps + h2d_ms * 1e-3), 2)},
+                            '(f64 100x100 label matrices); not part of value.  What the step costs when its inputs come through the input '
+                            'pipeline instead (pinned staging, side-stream copies) is measured in extra.train_b256_streamed'},
         }
         if comm is not None:
             out['comm'] = comm
