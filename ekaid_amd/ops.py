@@ -115,6 +115,7 @@ def register_grad_slot(param, gflat, offset):
 
 def clear_grad_claims():
     _grad_claimed.clear()
+    _wn_pending[:] = []          # (a backward pass that died half way must not leave raw-gradient addresses behind for the next one)
 
 
 def grad_out(W, zero=False):
@@ -424,22 +425,16 @@ def gemm_slabs2(g0, g1):
 # the transform always precedes the reduction, in every launch mode, and data-parallel runs stay bit-identical across modes.
 _wn_pending = []                 # [(dW pointer, v, g, norm, scale, dg pointer, elements)] -- the two gradients by ADDRESS only: a second
                                  # reference to a gradient tensor makes autograd's AccumulateGrad clone it instead of adopting it
-_wn_callback_queued = False
 _WN_MULTI = os.environ.get('EKAID_WN_GRAD_MULTI', '1') != '0'      # A/B knob: 0 = two launches per layer inside its backward node
 
 
 def wn_grad_register(dW, v, g, norm, scale, dg):
-    global _wn_callback_queued
+    first = not _wn_pending
     _wn_pending.append((dW.data_ptr(), v, g, norm, scale, dg.data_ptr(), dW.numel()))
-    if not _wn_callback_queued:
-        _wn_callback_queued = True
-        torch.autograd.Variable._execution_engine.queue_callback(_wn_end_of_backward)
-
-
-def _wn_end_of_backward():
-    global _wn_callback_queued
-    _wn_callback_queued = False
-    wn_grad_flush()
+    if first:
+        # (one callback per batch of registrations; a flush in between -- a bucket leaving -- empties the list, and the next layer queues
+        # another.  A callback that finds nothing registered launches nothing, so a pass that died half way leaves no state behind.)
+        torch.autograd.Variable._execution_engine.queue_callback(wn_grad_flush)
 
 
 def wn_grad_flush():
