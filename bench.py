@@ -126,9 +126,10 @@ def pmc_traffic():
     if not cands:
         return None
     d = json.load(open(cands[-1]))['derived']
-    return {'shape': 'nn 18432x1024x1024 (28 launches per step at B=256)',
+    return {'shape': 'nn 18432x1024x1024 (the input-gradient shape of the 1024-wide layers: 8 solo launches + 3 two-product launches per step at B=256)',
             'fetch_bytes_per_launch': d['hbm_fetch_bytes_per_launch_corrected'],
             'write_bytes_per_launch': d['hbm_write_bytes_per_launch'],
+            'bytes_per_launch': d['hbm_fetch_bytes_per_launch_corrected'] + d['hbm_write_bytes_per_launch'],
             'algorithmic_bytes_per_launch': d['algorithmic_read_bytes_per_launch'] + d['algorithmic_write_bytes_per_launch'],
             'source': os.path.relpath(cands[-1], ROOT)}
 
