@@ -314,9 +314,12 @@ def per_gpu_ladder(cfg, cd, sp, opt, dev, graph, full_batch, T, ms_256, steps=40
     fpp = flop_per_pair(N=SHAPE['N'], D=SHAPE['D'], Lq=SHAPE['Lq'], T=T, graph=graph)
     rungs = []
     was_force = opt.force_comm
-    opt.force_comm = True
+    opt.force_comm = os.environ.get('EKAID_LADDER_COMM', '1') != '0'          # (tuning aid: 0 = the rungs without collectives)
+    order = ((2, 128), (4, 64), (8, 32))
+    if os.environ.get('EKAID_LADDER_ORDER') == 'rev':                         # (tuning aid: smallest rung first)
+        order = order[::-1]
     try:
-        for n_gpus, per_gpu in ((2, 128), (4, 64), (8, 32)):
+        for n_gpus, per_gpu in order:
             hb = slice_batch(full_batch, 0, per_gpu)              # rank 0's contiguous slice of the global batch
             b = {k: v.to(dev) for k, v in hb.items()}
             step = TrainStep(cfg, cd, sp, opt, graph, use_graph=True, comm='captured',
