@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 namespace ekaid {
 static thread_local char g_err[512] = "";
@@ -141,12 +142,20 @@ extern "C" int ekaid_seq_status_read(unsigned* host_value, void* stream) {
     if (!host_value) { ekaid::set_error("ekaid_seq_status_read: null pointer"); return EKAID_ERR_ARG; }
     unsigned* p = ekaid::seq_status_ptr();
     if (!p) { ekaid::set_error("ekaid_seq_status_read: no status word"); return EKAID_ERR_LAUNCH; }
-    if (hipMemcpyAsync(host_value, p, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+    // through a pinned word: a copy into pageable memory takes the runtime's staged path (tens of microseconds per read, and
+    // greedy_decode reads once per answer batch)
+    static unsigned* pinned = nullptr;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!pinned && hipHostMalloc((void**)&pinned, sizeof(unsigned), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pinned = nullptr; }
+    unsigned* dst = pinned ? pinned : host_value;
+    if (hipMemcpyAsync(dst, p, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
         hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
         (void)hipGetLastError();
         ekaid::set_error("ekaid_seq_status_read: copy failed");
         return EKAID_ERR_LAUNCH;
     }
+    *host_value = *dst;
     return EKAID_OK;
 }
 extern "C" int ekaid_seq_status_clear(void* stream) {

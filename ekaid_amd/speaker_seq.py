@@ -455,7 +455,7 @@ def greedy_decode(speaker, feat_bef, feat_aft, feat_diff, poll=None):
         for t0 in range(0, Tm, poll):
             t1 = min(Tm, t0 + poll)
             check(L.ekaid_speaker_greedy_steps(ctypes.byref(g), t0, t1, ptr(ws), need, stream()), 'speaker_greedy_steps')
-            done = (counts[:t1] == 0).nonzero()
+            done = (counts[:t1].cpu() == 0).nonzero()                        # ONE device->host read per call
             if done.numel():                                                 # everything had finished at step `first`
                 first = int(done[0])
                 seq[:, first + 1:] = 0
