@@ -304,11 +304,23 @@ _workspaces = {}
 POISON = os.environ.get('EKAID_POISON', '0') not in ('0', '', 'off', 'false')
 
 
+_retired = []           # outgrown scratch buffers: kept allocated, a captured hipGraph may still hold their address
+
+
 def workspace(nbytes, device):
-    """Grow-only per-device scratch buffer (split-K slabs)."""
+    """Grow-only per-device scratch buffer (split-K slabs, persistent-kernel hand-off buffers).  A buffer that has to grow is RETIRED,
+    never freed: a hipGraph captured while it was current replays kernels that write through its address (a second shape captured
+    later with a larger need -- more decode steps -- would otherwise leave the first graph scribbling over whatever the allocator put
+    there next).  Growth is by at least 1.5x, so the retired buffers together stay below twice the current one."""
     buf = _workspaces.get(device)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        if torch.cuda.is_current_stream_capturing():
+            raise EkaidError('hip.workspace: the scratch buffer would have to grow (%d -> %d bytes) inside a hipGraph capture; run the '
+                             'step once eagerly first (TrainStep warm-up) or call hip.reserve_workspace' % (0 if buf is None else buf.numel(), nbytes))
+        want = max(int(nbytes), 1 << 20, 0 if buf is None else buf.numel() * 3 // 2)
+        if buf is not None:
+            _retired.append(buf)
+        buf = torch.empty(want, dtype=torch.uint8, device=device)
         _workspaces[device] = buf
     if POISON:
         buf.fill_(0xFF)              # every float read before it was written is a NaN (debug mode, see enable_poison; inside a

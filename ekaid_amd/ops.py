@@ -293,6 +293,8 @@ def _independent(g0, g1):
 
     def overlap(x, y):
         return x[0] < y[1] and y[0] < x[1]
+    if g0[1].get('batch', (1, 1)) != (1, 1) or g1[1].get('batch', (1, 1)) != (1, 1):
+        return False                                  # batched products: out_span() does not follow their strides (never paired anyway)
     s0, s1 = out_span(g0), out_span(g1)
     if overlap(s0, s1):
         ld0, ld1, n0, n1 = g0[0][8], g1[0][8], g0[0][4], g1[0][4]
@@ -312,7 +314,10 @@ def _independent(g0, g1):
 
 def flush_pairs(qa, qb):
     """Launch what two deferral windows recorded: the i-th product of one with the i-th product of the other as a pair where they are
-    independent, everything else in its recorded order (calls after the products recorded before them)."""
+    independent, everything else in its recorded order (calls after the products recorded before them).  Each queue keeps its own
+    order and entry i of ``qa`` goes out before entry i of ``qb``; the contract of the caller is that no entry of one queue depends on a
+    LATER entry of the other (two layers that do not feed each other: LinearPairFn) -- ``_independent`` only decides whether two
+    entries may share a launch."""
     if not _PAIR:
         for q in (qa, qb):
             for ent in q:

@@ -218,6 +218,50 @@ def test_graph_replay_equals_eager():
     assert d_w == 0.0 and d_l == 0.0, 'hipGraph replay differs from the eager steps'
 
 
+def test_graphs_captured_at_growing_shapes_keep_replaying_correctly():
+    """train_mimic.py --hip_graph on ragged data: a batch with more rows / decode steps arrives AFTER a smaller shape was captured and
+    makes the scratch buffer grow.  The graph captured first must go on giving the eager result (hip.workspace retires an outgrown buffer
+    instead of freeing it under the captured kernels): small, large, small, large replayed from a scratch buffer that grows in between ==
+    the same replays with the buffer sized for the large shape from the start."""
+    from common import build_models
+    from ekaid_amd import hip as H, ops
+    from ekaid_amd.config import bench_cfg
+    from ekaid_amd.dp import FlatAdam
+    from ekaid_amd.engine import TrainStep
+    from ekaid_amd.synthetic import make_batch
+    cfg = bench_cfg(D=256, seq_length=12)
+    small = {k: v.cuda() for k, v in make_batch(B=2, N=12, D=256, Lq=8, T=3, seq_length=12, V=148, seed=5).items()}
+    large = {k: v.cuda() for k, v in make_batch(B=16, N=36, D=256, Lq=8, T=9, seq_length=12, V=148, seed=6).items()}
+    seq = [(small, 3), (large, 9), (small, 3), (large, 9)]
+    dev = small['input_1'].device
+    finals, losses, grown = [], [], []
+    for mode in ('presized', 'growing'):
+        saved = H._workspaces.pop(dev, None)           # start from no scratch buffer: the first (small) shape sizes it ...
+        if mode == 'presized':
+            H.reserve_workspace(1 << 30, dev)          # ... or from one no shape of this test outgrows
+        retired0 = len(H._retired)
+        cd, sp = build_models(cfg, 147, 148, 'cuda', train=True)
+        opt = FlatAdam([cd, sp], lr=1e-3)
+        ts = TrainStep(cfg, cd, sp, opt, use_graph=True)
+        try:
+            ops.manual_seed(4242)
+            ls = [float(ts(b, T)[0].detach()) for b, T in seq]
+            torch.cuda.synchronize()
+            grown.append(len(H._retired) - retired0)
+        finally:
+            ts.close()
+            torch.cuda.synchronize()
+            H._workspaces.pop(dev, None)
+            del H._retired[retired0:]
+            if saved is not None:
+                H._workspaces[dev] = saved
+        finals.append(torch.cat([p.detach().reshape(-1).double().cpu() for p in list(cd.parameters()) + list(sp.parameters())]))
+        losses.append(ls)
+    assert grown == [0, grown[1]] and grown[1] >= 1, 'the large shape was meant to outgrow the scratch buffer of the small one (%r)' % grown
+    assert losses[0] == losses[1], 'losses differ once the scratch buffer grows between the captures: %r vs %r' % (losses[1], losses[0])
+    assert torch.equal(finals[0], finals[1]), 'weights after small / large / small / large replays depend on the scratch buffer growing'
+
+
 def test_decode_steps_rounded_up_leave_loss_and_gradients_unchanged():
     """TrainStep(t_round=8): the decoder runs 8 steps for a batch whose answers need 5 (fewer captured graphs on ragged data).  The three
     extra steps read padding tokens and their log-prob rows meet an all-zero loss mask, so the loss and every gradient are those of the

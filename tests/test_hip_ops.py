@@ -121,6 +121,54 @@ def test_gemm_pair_is_bit_identical_to_two_launches(M0, M1, N, K, mode, gemm_ari
     check(paired[0], want, 2e-5 * max(1.0, math.sqrt(K) / 4), 'pair product 0')
 
 
+def test_scratch_buffer_that_grows_stays_valid_for_graphs_captured_before():
+    """hip.workspace: a hipGraph captured while a scratch buffer was current keeps writing through its address at every replay.  When
+    a later, larger product makes the buffer grow (train_mimic.py --hip_graph meeting a batch with more decode steps), the old buffer is
+    retired, not freed: the first graph's replay still gives its result and does not touch memory the allocator hands out afterwards."""
+    from ekaid_amd import hip as H, ops
+    dev = torch.empty(1, device=DEV).device
+    saved = H._workspaces.pop(dev, None)
+    retired0 = len(H._retired)
+    try:
+        import ctypes
+
+        def need(M, N, K):
+            d = ops._fill_desc(a, b, c_eager, M, N, K, M, N, N, 1, 0)
+            return H.lib().ekaid_gemm_workspace_bytes(ctypes.byref(d))
+        M, N, K = 256, 256, 9216                                      # weight-gradient form, K-split: slabs in the scratch buffer
+        a, b = rnd(K, M, seed=5).to(DEV), rnd(K, N, seed=6).to(DEV)
+        c_eager, c_graph = torch.empty(M, N, device=DEV), torch.zeros(M, N, device=DEV)
+        assert need(M, N, K) > 0, 'the test product must need slabs (K-split)'
+        ops.gemm(a, b, c_eager, M, N, K, M, N, N, 1, 0)               # sizes the buffer
+        small = H._workspaces[dev]
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
+            ops.gemm(a, b, c_graph, M, N, K, M, N, N, 1, 0)
+        M2, N2, K2 = 1024, 1024, 9216                                  # needs a larger buffer
+        assert need(M2, N2, K2) > small.numel() * 3 // 2, 'the second product was meant to outgrow the buffer'
+        a2, b2 = rnd(K2, M2, seed=7).to(DEV), rnd(K2, N2, seed=8).to(DEV)
+        c2 = torch.empty(M2, N2, device=DEV)
+        ops.gemm(a2, b2, c2, M2, N2, K2, M2, N2, N2, 1, 0)
+        big = H._workspaces[dev]
+        assert big is not small and big.numel() >= small.numel() * 3 // 2, 'the second product was meant to outgrow the buffer'
+        assert any(r is small for r in H._retired[retired0:]), 'the outgrown buffer must stay allocated'
+        small_n = small.numel()
+        del small
+        victims = [torch.zeros(small_n, dtype=torch.uint8, device=DEV) for _ in range(16)]           # would land on freed memory
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(c_graph, c_eager), 'replay through the retired scratch buffer'
+        assert all(int(v.max()) == 0 for v in victims), 'the replay wrote outside its own scratch buffer'
+        del g
+    finally:
+        torch.cuda.synchronize()
+        H._workspaces.pop(dev, None)
+        del H._retired[retired0:]
+        if saved is not None:
+            H._workspaces[dev] = saved
+
+
 @pytest.mark.parametrize('mode', ['nt', 'nn', 'tn'])
 @pytest.mark.parametrize('M,N,K', [(512, 384, 1024), (256, 2048, 512), (4608, 1024, 2048), (1000, 600, 4096)])
 def test_gemm_split_accuracy(M, N, K, mode):
