@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 namespace ekaid {
 static thread_local char g_err[512] = "";
@@ -28,8 +29,9 @@ int check_launch(const char* what) {
 }
 
 // ---- per-device state: the only mutable state of the library besides the thread-local error string.  Every field is
-// an atomic, so calls from different host threads / on different streams never race on it.
-constexpr int MAX_DEVICES = 64, ATTR_SLOTS = 64;
+// an atomic (the list of kernels whose LDS limit has been raised: behind a mutex), so calls from different host threads / on different
+// streams never race on it.
+constexpr int MAX_DEVICES = 64;
 struct DeviceState {
     std::atomic<int> ready{0};
     std::atomic<int> gemm_mode{-1};
@@ -37,7 +39,8 @@ struct DeviceState {
     std::atomic<const unsigned long long*> epoch{nullptr};
     std::atomic<double*> scratch{nullptr};
     std::atomic<unsigned*> seq_status{nullptr};   // device word the persistent sequence kernels set when a seam times out (sticky)        // two-stage reduction partials (pointwise.hip), device memory of THIS device
-    std::atomic<bool> attr[ATTR_SLOTS];
+    std::mutex attr_mu;
+    std::vector<const void*> attr_done;           // kernel functions whose dynamic-LDS limit has been raised on this device
 };
 static DeviceState g_dev[MAX_DEVICES];
 
@@ -98,10 +101,15 @@ unsigned* seq_status_ptr() {
     if (!s.seq_status.compare_exchange_strong(expected, p)) { (void)hipFree(p); p = expected; }
     return p;
 }
-bool func_attr_once(int slot) {
-    if (slot < 0 || slot >= ATTR_SLOTS) return true;
-    bool expected = false;
-    return device_state().attr[slot].compare_exchange_strong(expected, true);
+// keyed by the kernel's own address: every template instantiation is its own entry (numbered slots handed out by hand collided
+// once two families grew into each other's range)
+bool func_attr_once(const void* kernel) {
+    DeviceState& s = device_state();
+    std::lock_guard<std::mutex> lock(s.attr_mu);
+    for (const void* p : s.attr_done)
+        if (p == kernel) return false;
+    s.attr_done.push_back(kernel);
+    return true;
 }
 
 __global__ void epoch_advance_kernel(unsigned long long* e, unsigned long long by) { e[0] += by; }

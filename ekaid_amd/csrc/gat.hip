@@ -373,7 +373,7 @@ static int launch_fused(const float* S, const float* cond, const float* lbias, c
     const int n_per = (N + parts - 1) / parts;
     const size_t lds = sizeof(float) * (size_t)n_per * H * MMAX;
     if (lds > 64 * 1024) {
-        if (func_attr_once(48 + (MMAX == 40 ? 0 : (MMAX == 56 ? 1 : 2)))) {
+        if (func_attr_once((const void*)kern)) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 (void)hipGetLastError();
                 set_error("gat_fused_fwd: cannot raise dynamic LDS limit to %zu bytes", lds);
@@ -411,7 +411,12 @@ extern "C" int ekaid_gat_fused_fwd(const float* q, const float* k, const float* 
     const int rc = ekaid_gemm_f32(&g, nullptr, 0, stream);
     if (rc) return rc;
     // 2.+3. softmax and aggregation
+    // the aggregation runs at the f32 vector rate (160 v_fmac per output row and thread at 40 neighbour slots: 119-129 us for 512 slices of
+    // 36 nodes = 24 GFLOP executed), so every padded neighbour slot is paid in full: tiles of exactly 36 (the metric's region count)
+    // and 52 (the real files') next to the general ones
+    if (M <= 36) return launch_fused<4, 36>(S, cond, lbias, geo, R, N, M, A, H, dir, P, outT, ST);
     if (M <= 40) return launch_fused<4, 40>(S, cond, lbias, geo, R, N, M, A, H, dir, P, outT, ST);
+    if (M <= 52) return launch_fused<2, 52>(S, cond, lbias, geo, R, N, M, A, H, dir, P, outT, ST);
     if (M <= 56) return launch_fused<2, 56>(S, cond, lbias, geo, R, N, M, A, H, dir, P, outT, ST);
     return launch_fused<2, 64>(S, cond, lbias, geo, R, N, M, A, H, dir, P, outT, ST);
 }
@@ -437,6 +442,7 @@ extern "C" int ekaid_gat_dqk(const float* daff, const float* q, const float* k, 
     }
     // up to 40 nodes only: at 52 nodes the register tile (56 x 4) and 93 KB of LDS leave one workgroup per CU and the two batched
     // products are faster (619 vs 641 us for the whole backward of 512 slices); at 36 nodes 447 -> 364 us
+    if (N <= 36) return launch_dqk<36>(daff, q, k, R, N, M, A, H, scale, dq, dk, ST);
     if (N <= 40) return launch_dqk<40>(daff, q, k, R, N, M, A, H, scale, dq, dk, ST);
     set_error("gat_dqk: more than 40 nodes (N=%d): compose from batched products", N);
     return EKAID_ERR_UNSUPPORTED;

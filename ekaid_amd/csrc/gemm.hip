@@ -1140,8 +1140,7 @@ static int launch(const GemmArgs& a, int batch, hipStream_t st) {
     constexpr size_t lds = (A_ELEMS + B_ELEMS) * sizeof(float);
     auto kern = gemm_mfma_kernel<A_KC, B_KC, TM, TN, KB>;
     if (lds > 64 * 1024) {
-        constexpr int slot = (A_KC ? 1 : 0) + (B_KC ? 2 : 0) + 4 * (TM - 1) + 8 * (TN - 1);       // once per device and instantiation
-        if (func_attr_once(slot)) {
+        if (func_attr_once((const void*)kern)) {                                               // once per device and instantiation
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
                 (void)hipGetLastError();
                 set_error("gemm: cannot raise the dynamic LDS limit to %zu bytes", lds);
@@ -1160,8 +1159,7 @@ static int launch_split(const GemmArgs& a, int batch, hipStream_t st) {
     constexpr size_t lds = NP * 2 * KB * (BM + BN);     // NP bf16 planes per operand, unpadded
     auto kern = gemm_split_kernel<A_KC, B_KC, TM, TN, KB, PF, PIPE, NP, ASUM>;
     if (lds > 64 * 1024) {
-        constexpr int slot = (ASUM ? 32 : 16) + (A_KC ? 1 : 0) + (B_KC ? 2 : 0) + 4 * (TM - 1) + 8 * (TN - 1);
-        if (func_attr_once(slot)) {
+        if (func_attr_once((const void*)kern)) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
                 (void)hipGetLastError();
                 set_error("gemm: cannot raise the dynamic LDS limit to %zu bytes", lds);

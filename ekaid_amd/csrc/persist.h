@@ -26,10 +26,10 @@ constexpr int AUX_SC1 = 16;                                       // buffer cach
 // the caller to the launch-per-product chain (csrc/sequence.hip).  What this cannot see -- another process on the same GPU, a resident
 // collective kernel stalled on a late peer -- is caught at run time: bounded spins, the sticky status word, and the Adam kernel that
 // refuses the update of a faulted step (pointwise.hip: adam_prep_kernel).
-inline bool grid_fits(const void* kern, int slot, int G, int cus, size_t lds_bytes) {
+inline bool grid_fits(const void* kern, int G, int cus, size_t lds_bytes) {
     static const bool masked = getenv("HSA_CU_MASK") != nullptr || getenv("ROC_GLOBAL_CU_MASK") != nullptr;
     if (masked) return false;
-    if (func_attr_once(slot)) {
+    if (func_attr_once(kern)) {
         if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); return false; }
     }
     struct Ent { const void* k; size_t lds; int dev; int per_cu; };

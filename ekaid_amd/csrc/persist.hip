@@ -686,7 +686,7 @@ bool persistent_plan(const ekaid_speaker_seq_t* d, void* workspace, PersistPlan&
     {   // every workgroup resident at once? (the teacher-forced instantiation of this tile grouping; the greedy one is checked by its caller)
         const void* kern = pl.mtE == 2 ? reinterpret_cast<const void*>(spk_seq_fwd_persistent_kernel<PR, PA_, PP, 1, 2, false>)
                                        : reinterpret_cast<const void*>(spk_seq_fwd_persistent_kernel<PR, PA_, PP, 1, 1, false>);
-        if (!grid_fits(kern, pl.mtE == 2 ? 41 : 40, G, cus, pl.lds_bytes)) return false;
+        if (!grid_fits(kern, G, cus, pl.lds_bytes)) return false;
         pl.cus = cus;
     }
     const size_t Bp = 16 * (size_t)pl.nrb, f = sizeof(float);
@@ -721,9 +721,9 @@ bool persistent_plan(const ekaid_speaker_seq_t* d, void* workspace, PersistPlan&
 }
 
 template <int MTD, int MTE, bool GREEDY = false>
-int launch_fwd(const PFwd& a, const PersistPlan& pl, hipStream_t st, int slot) {
+int launch_fwd(const PFwd& a, const PersistPlan& pl, hipStream_t st) {
     auto kern = spk_seq_fwd_persistent_kernel<PR, PA_, PP, MTD, MTE, GREEDY>;
-    if (func_attr_once(slot)) {
+    if (func_attr_once(reinterpret_cast<const void*>(kern))) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             (void)hipGetLastError();
             set_error("ekaid_speaker_seq_fwd_persistent: cannot raise the dynamic LDS limit");
@@ -805,11 +805,11 @@ int launch_persistent_fwd(const ekaid_speaker_seq_t* d, const ekaid_speaker_gree
     // seam counters start at zero in EVERY launch (a memset node when captured)
     if (hipMemsetAsync(workspace, 0, al256((size_t)SYNC_WORDS * 4), st) != hipSuccess) { (void)hipGetLastError(); set_error("%s: memset failed", who); return EKAID_ERR_LAUNCH; }
     if (gq) {
-        if (pl.mtD == 1 && pl.mtE == 1) return launch_fwd<1, 1, true>(a, pl, st, 47);
-        if (pl.mtD == 1 && pl.mtE == 2) return launch_fwd<1, 2, true>(a, pl, st, 43);
+        if (pl.mtD == 1 && pl.mtE == 1) return launch_fwd<1, 1, true>(a, pl, st);
+        if (pl.mtD == 1 && pl.mtE == 2) return launch_fwd<1, 2, true>(a, pl, st);
     } else {
-        if (pl.mtD == 1 && pl.mtE == 1) return launch_fwd<1, 1>(a, pl, st, 40);
-        if (pl.mtD == 1 && pl.mtE == 2) return launch_fwd<1, 2>(a, pl, st, 41);
+        if (pl.mtD == 1 && pl.mtE == 1) return launch_fwd<1, 1>(a, pl, st);
+        if (pl.mtD == 1 && pl.mtE == 2) return launch_fwd<1, 2>(a, pl, st);
     }
     set_error("%s: no kernel for tile groups %d / %d", who, pl.mtD, pl.mtE);
     return EKAID_ERR_UNSUPPORTED;
@@ -835,7 +835,7 @@ extern "C" size_t ekaid_speaker_greedy_persistent_workspace_bytes(const ekaid_sp
     {
         const void* kern = pl.mtE == 2 ? reinterpret_cast<const void*>(spk_seq_fwd_persistent_kernel<PR, PA_, PP, 1, 2, true>)
                                        : reinterpret_cast<const void*>(spk_seq_fwd_persistent_kernel<PR, PA_, PP, 1, 1, true>);
-        if (!grid_fits(kern, pl.mtE == 2 ? 43 : 47, pl.G, pl.cus, pl.lds_bytes)) return 0;
+        if (!grid_fits(kern, pl.G, pl.cus, pl.lds_bytes)) return 0;
     }
     const size_t Bp = 16 * (size_t)pl.nrb;
     return pl.total + al256(Bp * 512 * sizeof(float)) + al256(Bp * 160 * sizeof(float));

@@ -397,7 +397,7 @@ bool bwd_plan(const ekaid_speaker_seq_t* d, void* workspace, BwdPlan& pl) {
     if (pl.jobsU > MAXJ || pl.jobs2 > MAXJ || pl.jobs3 > MAXJ || (d->B + G - 1) / G > 4) return false;
     pl.lds_bytes = (size_t)(4 + 2 * 5120 + 96 + 32 + 16 + 12 + pl.jobsU * 1024 + pl.jobs2 * 1536 + pl.jobs3 * 1536) * sizeof(float);
     if (pl.lds_bytes > 160 * 1024) return false;
-    if (!grid_fits(reinterpret_cast<const void*>(spk_seq_bwd_persistent_kernel<QR, QA, QP>), 44, G, cus, pl.lds_bytes)) return false;
+    if (!grid_fits(reinterpret_cast<const void*>(spk_seq_bwd_persistent_kernel<QR, QA, QP>), G, cus, pl.lds_bytes)) return false;
     const size_t Bp = 16 * (size_t)pl.nrb, f = sizeof(float);
     size_t o = al256((size_t)SYNC_WORDS * 4);
     pl.o_wt1 = o; o += al256((size_t)QA * 4 * QR * f);
@@ -495,7 +495,7 @@ extern "C" int ekaid_speaker_seq_bwd_persistent(const ekaid_speaker_seq_bwd_t* b
     if ((rc = ekaid_gemm_f32(&pl.gWp, gws, pl.gemm_bytes, stream))) return rc;
     if (hipMemsetAsync(workspace, 0, al256((size_t)SYNC_WORDS * 4), st) != hipSuccess) { (void)hipGetLastError(); set_error("ekaid_speaker_seq_bwd_persistent: memset failed"); return EKAID_ERR_LAUNCH; }
     auto kern = spk_seq_bwd_persistent_kernel<QR, QA, QP>;
-    if (func_attr_once(44)) {
+    if (func_attr_once(reinterpret_cast<const void*>(kern))) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             (void)hipGetLastError();
             set_error("ekaid_speaker_seq_bwd_persistent: cannot raise the dynamic LDS limit");

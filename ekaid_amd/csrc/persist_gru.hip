@@ -171,7 +171,7 @@ bool gru_persistent_plan(int B, int T, int H, bool backward, GruPlanP& pl) {
     if (pl.jobs > MAXJ * 2) return false;
     pl.lds_bytes = (size_t)(4 + 2 * 5120 + pl.jobs * (backward ? 512 : 256)) * sizeof(float);
     if (!grid_fits(backward ? reinterpret_cast<const void*>(gru_seq_bwd_persistent_kernel<GH>) : reinterpret_cast<const void*>(gru_seq_fwd_persistent_kernel<GH>),
-                   backward ? 46 : 45, G, cus, pl.lds_bytes)) return false;
+                   G, cus, pl.lds_bytes)) return false;
     const size_t Bp = 16 * (size_t)pl.nrb, f = sizeof(float);
     size_t o = al256((size_t)SYNC_WORDS * 4);
     pl.o_hfm = o; if (!backward) o += al256(2 * Bp * GH * f);
@@ -182,8 +182,8 @@ bool gru_persistent_plan(int B, int T, int H, bool backward, GruPlanP& pl) {
 }
 
 template <class K>
-int launch_gru(K kern, const PGru& a, const GruPlanP& pl, hipStream_t st, int slot, const char* what) {
-    if (func_attr_once(slot)) {
+int launch_gru(K kern, const PGru& a, const GruPlanP& pl, hipStream_t st, const char* what) {
+    if (func_attr_once(reinterpret_cast<const void*>(kern))) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             (void)hipGetLastError();
             set_error("%s: cannot raise the dynamic LDS limit", what);
@@ -223,7 +223,7 @@ extern "C" int ekaid_gru_seq_fwd_persistent(const float* gi, const float* w_hh, 
     a.status = seq_status_ptr();
     if (!a.status) { set_error("persistent sequence kernel: cannot allocate the status word"); return EKAID_ERR_LAUNCH; }
     if (hipMemsetAsync(workspace, 0, al256((size_t)SYNC_WORDS * 4), st) != hipSuccess) { (void)hipGetLastError(); set_error("ekaid_gru_seq_fwd_persistent: memset failed"); return EKAID_ERR_LAUNCH; }
-    return launch_gru(gru_seq_fwd_persistent_kernel<GH>, a, pl, st, 45, "gru_seq_fwd_persistent");
+    return launch_gru(gru_seq_fwd_persistent_kernel<GH>, a, pl, st, "gru_seq_fwd_persistent");
 }
 
 extern "C" int ekaid_gru_seq_bwd_persistent(const float* dout, const float* w_hh, const float* hall, const float* save, int B, int T, int H,
@@ -249,5 +249,5 @@ extern "C" int ekaid_gru_seq_bwd_persistent(const float* dout, const float* w_hh
     const int rc = ekaid_transpose(w_hh, 3 * GH, GH, GH, (float*)(ws + pl.o_wt), 3 * GH, stream);      // W_hh^T [H][3H]
     if (rc) return rc;
     if (hipMemsetAsync(workspace, 0, al256((size_t)SYNC_WORDS * 4), st) != hipSuccess) { (void)hipGetLastError(); set_error("ekaid_gru_seq_bwd_persistent: memset failed"); return EKAID_ERR_LAUNCH; }
-    return launch_gru(gru_seq_bwd_persistent_kernel<GH>, a, pl, st, 46, "gru_seq_bwd_persistent");
+    return launch_gru(gru_seq_bwd_persistent_kernel<GH>, a, pl, st, "gru_seq_bwd_persistent");
 }
