@@ -61,6 +61,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     if (NL <= 0) return;
     const float* Sr = S + r * N * A;
 
+    // the neighbour tile of this thread's first column block does not depend on the softmax: requested first, it arrives under the
+    // softmax phase (rows wider than 256 * VEC columns reload it per further block below)
+    float s[MMAX][VEC];
+    auto load_tile = [&](int cb) {
+#pragma unroll
+        for (int m = 0; m < MMAX; ++m) {
+            const float* sp = &Sr[(long long)min(m, M - 1) * A + cb];     // clamped row, zeroed below: no branch between the loads
+            if (VEC == 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(sp);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) s[m][e] = m < M ? v[e] : 0.f;
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) s[m][e] = m < M ? sp[e] : 0.f;
+            }
+        }
+    };
+    if (tid * VEC < A) load_tile(tid * VEC);
+
     // ---------------- edge softmax, one (n,h) row per wave pass, neighbour m on lane m.  Four rows per iteration: their inputs
     // (adjacency, label bias, affinity, geometry) are all requested before the first softmax is computed -- one exposed memory
     // round trip per four rows instead of one per row (the loads of a row cannot be hoisted above the P store of the previous one
@@ -102,19 +121,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 
     // ---------------- neighbour aggregation, thread-owned feature columns
     for (int cb = tid * VEC; cb < A; cb += 256 * VEC) {
-        float s[MMAX][VEC];
-#pragma unroll
-        for (int m = 0; m < MMAX; ++m) {
-            const float* sp = &Sr[(long long)min(m, M - 1) * A + cb];     // clamped row, zeroed below: no branch between the loads
-            if (VEC == 4) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(sp);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) s[m][e] = m < M ? v[e] : 0.f;
-            } else {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) s[m][e] = m < M ? sp[e] : 0.f;
-            }
-        }
+        if (cb != tid * VEC) load_tile(cb);
         float* op = outT + (((r * N + n_lo) * H) * (long long)A) + cb;
         for (int row = 0; row < NL * H; ++row, op += A) {
             float o[VEC];
