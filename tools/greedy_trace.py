@@ -1,5 +1,11 @@
+#!/usr/bin/env python3
+"""rocprofv3 target: the greedy _sample of test_mimic.py:119-122 alone (batch 64, 90 steps, freshly initialised weights), 100 times after one
+detector forward -- `rocprofv3 --kernel-trace --stats -- python3 tools/greedy_trace.py`, then tools/stats_read.py <csv> 100
+(profiles/r05_greedy_sample_kernels.txt)."""
 import sys, os
-sys.path.insert(0, '/root/repo'); os.chdir('/root/repo')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.chdir(ROOT)
 import torch
 from ekaid_amd.config import bench_cfg
 from ekaid_amd.engine import detector_forward
