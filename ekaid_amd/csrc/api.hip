@@ -45,9 +45,9 @@ struct DeviceState {
 static DeviceState g_dev[MAX_DEVICES];
 
 static int default_gemm_mode() {
-    const char* m = getenv("EKAID_GEMM_MODE");       // "f32" / "0": f32 MFMA; "bf16x2" / "2": reduced-precision split; default: exact split
+    const char* m = getenv("EKAID_GEMM_MODE");       // "f32" / "0": f32 MFMA; "f16x2" / "2": two-term f16 split where operand bounds are given; default: exact split
     if (m && (m[0] == 'f' || m[0] == '0')) return 0;
-    if (m && (strcmp(m, "2") == 0 || strcmp(m, "bf16x2") == 0)) return 2;
+    if (m && (strcmp(m, "2") == 0 || strcmp(m, "f16x2") == 0)) return 2;
     return 1;
 }
 DeviceState& device_state() {
@@ -112,6 +112,12 @@ bool func_attr_once(const void* kernel) {
     return true;
 }
 
+static std::atomic<long long> g_counts[EKAID_COUNT_N];
+void count_launch(int which) {
+    if (which >= 0 && which < EKAID_COUNT_N) g_counts[which].fetch_add(1, std::memory_order_relaxed);
+}
+long long launch_count(int which) { return (which >= 0 && which < EKAID_COUNT_N) ? g_counts[which].load(std::memory_order_relaxed) : -1; }
+
 __global__ void epoch_advance_kernel(unsigned long long* e, unsigned long long by) { e[0] += by; }
 }  // namespace ekaid
 
@@ -171,6 +177,9 @@ extern "C" int ekaid_seq_status_clear(void* stream) {
     if (!p || hipMemsetAsync(p, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess) { (void)hipGetLastError(); ekaid::set_error("ekaid_seq_status_clear failed"); return EKAID_ERR_LAUNCH; }
     return EKAID_OK;
 }
+
+namespace ekaid { long long launch_count(int which); }
+extern "C" long long ekaid_launch_count(int which) { return ekaid::launch_count(which); }
 
 extern "C" int ekaid_version(void) { return EKAID_ABI_VERSION; }
 extern "C" const char* ekaid_last_error(void) { return ekaid::g_err; }

@@ -29,6 +29,7 @@ const unsigned long long* dropout_epoch_ptr();     // device word folded into ev
 constexpr size_t EKAID_SCRATCH_BYTES = 2 * 2048 * sizeof(double) + (size_t(1) << 20);    // reduction slots + column-sum partials (pointwise.hip)
 double* device_scratch(size_t bytes);              // per-device reduction scratch (allocated at first use / by ekaid_init), or NULL
 unsigned* seq_status_ptr();                        // per-device word set (and left set) by a persistent sequence kernel whose seam timed out
+void count_launch(int which);                      // bumps a launch counter (ekaid_launch_count, include/ekaid_hip.h)
 bool func_attr_once(const void* kernel);           // true exactly once per (device, kernel function): "raise the LDS limit" bookkeeping
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3 };

@@ -95,6 +95,8 @@ struct GemmArgs {
     int slab_mode;        // 1: raw partial products go to ws even when splitk == 1 (ekaid_gemm_slabs: the consumer reduces)
     float* asum;          // optional (m-contiguous A only): asum[m] += sum_k op(A)[m][k] -- the bias gradient riding on a wgrad product
     float* asum_ws;       // its K-split partials [splitk][M] (behind the slabs in the workspace), finished by the reduce kernel
+    const float* a_amax;  // device vectors: a_amax[m] >= max_k |op(A)[m][k]|, b_amax[n] >= max_k |op(B)[k][n]| (ekaid_gemm_t.a_amax / b_amax); the
+    const float* b_amax;  // two-term f16 split scales every row of op(A) / column of op(B) by an exact power of two derived from them (NP = 2 only)
     Epi e;
 };
 
@@ -451,18 +453,25 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // faster: 182 vs 187 TF on the wgrad form.)
 // NP = 3: exact split (h + m + l == v).  NP = 2 (EKAID_GEMM_BF16X2, opt-in): h + m only, m rounded to nearest -- 16-17
 // significant bits per operand, three products per block instead of six (L is left untouched).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// NP = 2: the two-term f16 split.  With s an exact power of two that brings the largest element of the element's row of op(A) /
+// column of op(B) into [2^14, 2^15):
+//   h = f16(v s) (round to nearest: 11 significant bits),  l = f16(v s - h) (the exact f32 residual, |l| <= 2^-11 |v s|, rounded to 11 more)
+// so v s = h + l + e with |e| <= 2^-22 |v s| (a quarter of that on average) as long as l is a normal f16 -- elements within 2^-17 of the
+// row's largest; smaller ones keep an ABSOLUTE accuracy of 2^-25 (f16 subnormals, which the matrix pipe does not flush), i.e.
+// 2^-40 of the row's largest element.  Three products per block (h h + h l + l h on v_mfma_f32_32x32x16_f16): the dropped l l is
+// below 2^-22 |a b|.  M receives l; L is unused.  s = the scales of the four elements (one row: all equal).
 template <int NP = 3>
-__device__ __forceinline__ void split4(const f32x4& v, u32x2& H, u32x2& M, u32x2& L) {
+__device__ __forceinline__ void split4(const f32x4& v, const f32x4& s, u32x2& H, u32x2& M, u32x2& L) {
     if constexpr (NP == 2) {
-        unsigned u[4], m[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            u[e] = __float_as_uint(v[e]);
-            const float r1 = v[e] - __uint_as_float(u[e] & 0xFFFF0000u);
-            m[e] = __float_as_uint(r1) + 0x8000u;              // round the residual to the nearest bf16 (ties up)
-        }
-        H[0] = __builtin_amdgcn_perm(u[1], u[0], 0x07060302u); H[1] = __builtin_amdgcn_perm(u[3], u[2], 0x07060302u);
-        M[0] = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u); M[1] = __builtin_amdgcn_perm(m[3], m[2], 0x07060302u);
+        const f32x2 a0 = {v[0] * s[0], v[1] * s[1]}, a1 = {v[2] * s[2], v[3] * s[3]};
+        const f16x2 h0 = __builtin_convertvector(a0, f16x2), h1 = __builtin_convertvector(a1, f16x2);
+        const f32x2 r0 = {a0[0] - (float)h0[0], a0[1] - (float)h0[1]}, r1 = {a1[0] - (float)h1[0], a1[1] - (float)h1[1]};
+        const f16x2 l0 = __builtin_convertvector(r0, f16x2), l1 = __builtin_convertvector(r1, f16x2);
+        H[0] = __builtin_bit_cast(unsigned, h0); H[1] = __builtin_bit_cast(unsigned, h1);
+        M[0] = __builtin_bit_cast(unsigned, l0); M[1] = __builtin_bit_cast(unsigned, l1);
         return;
     }
 #if EKAID_SPLIT_ABLATE == 2              // timing-only: no split arithmetic (three copies of the raw words)
@@ -510,6 +519,16 @@ template <int BT>
 __device__ __forceinline__ int mc_read_off(int k, int row0, int tg, int tp) {   // row0: first of the tile's 32 rows
     const int key = BT == 128 ? (k & 3) : ((k >> 1) & 1);
     return k * (2 * BT) + 64 * ((row0 >> 5) ^ key) + 32 * tg + 8 * tp;
+}
+
+// power of two that brings a tensor whose largest magnitude is `amax` into [2^14, 2^15) (f16 tops out at 65504; the headroom also
+// covers the rounding of the largest element).  Zero, NaN and Inf bounds leave the operand as it is.
+__device__ __forceinline__ int f16_shift(const float amax) {
+    if (!(amax > 0.f) || !(amax < __builtin_inff())) return 0;
+    int e;
+    (void)frexpf(amax, &e);                    // amax = m 2^e, 0.5 <= m < 1
+    const int s = 15 - e;
+    return s < -126 ? -126 : (s > 126 ? 126 : s);
 }
 
 // PF = K-steps of global loads kept in flight (1: the next step's loads hide under this step's MFMAs -- enough for the
@@ -570,6 +589,33 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
     }
     const bool vecA = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (((A_KC ? g.K : g.M) & 3) == 0);
     const bool vecB = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (((B_KC ? g.K : g.N) & 3) == 0);
+    // two-term f16 split: the exact power-of-two scale of row m of op(A) / column n of op(B), from the callers' bounds (rows / columns
+    // past the matrix: 1).  A thread stages the same rows in every K-step, so its scales are loaded once, ahead of the loop.
+    auto scale_of = [&](const float* amax, int idx, int extent) -> float {
+        return (NP == 2 && idx < extent) ? ldexpf(1.f, f16_shift(amax[idx])) : 1.f;
+    };
+    constexpr int NSM = (NP == 2) ? 4 : 1;
+    f32x4 scA_mc = {1.f, 1.f, 1.f, 1.f}, scB_mc = {1.f, 1.f, 1.f, 1.f};      // m/n-contiguous staging: a float4 = 4 rows, the same 4 for every float4 of a thread
+    float scA_kc[A_KC ? NSM : 1], scB_kc[B_KC ? NSM : 1];                   // k-contiguous staging of the plain loop: one row per float4 (A_V4, B_V4 <= 4)
+    static_assert(NP != 2 || (A_V4 <= 4 && B_V4 <= 4), "scale registers of the plain loop");
+    if constexpr (NP == 2) {
+        if constexpr (A_KC) {
+#pragma unroll
+            for (int i = 0; i < A_V4; ++i) scA_kc[i] = scale_of(g.a_amax, m0 + (tid + i * 256) / (KB / 4), g.M);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) scA_mc[e] = scale_of(g.a_amax, m0 + 4 * (tid % (BM / 4)) + e, g.M);
+        }
+        if constexpr (B_KC) {
+#pragma unroll
+            for (int i = 0; i < B_V4; ++i) scB_kc[i] = scale_of(g.b_amax, n0 + (tid + i * 256) / (KB / 4), g.N);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) scB_mc[e] = scale_of(g.b_amax, n0 + 4 * (tid % (BN / 4)) + e, g.N);
+        }
+    }
+    auto scaleA_of = [&](int i) -> f32x4 { if constexpr (A_KC) { const float s = scA_kc[NP == 2 ? i : 0]; return f32x4{s, s, s, s}; } else return scA_mc; };
+    auto scaleB_of = [&](int i) -> f32x4 { if constexpr (B_KC) { const float s = scB_kc[NP == 2 ? i : 0]; return f32x4{s, s, s, s}; } else return scB_mc; };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -624,7 +670,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
             const int idx = tid + i * 256;
             const int off = A_KC ? kc_store_off<KB>(idx) : mc_store_off<BM>(idx);
             u32x2 H, M, L;
-            split4<NP>(ra[S][i], H, M, L);
+            split4<NP>(ra[S][i], scaleA_of(i), H, M, L);
             *reinterpret_cast<u32x2*>(ldsA + off) = H;
             *reinterpret_cast<u32x2*>(ldsA + A_PLANE + off) = M;
             if constexpr (NP == 3) *reinterpret_cast<u32x2*>(ldsA + 2 * A_PLANE + off) = L;
@@ -634,7 +680,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
             const int idx = tid + i * 256;
             const int off = B_KC ? kc_store_off<KB>(idx) : mc_store_off<BN>(idx);
             u32x2 H, M, L;
-            split4<NP>(rb[S][i], H, M, L);
+            split4<NP>(rb[S][i], scaleB_of(i), H, M, L);
             *reinterpret_cast<u32x2*>(ldsB + off) = H;
             *reinterpret_cast<u32x2*>(ldsB + B_PLANE + off) = M;
             if constexpr (NP == 3) *reinterpret_cast<u32x2*>(ldsB + 2 * B_PLANE + off) = L;
@@ -666,6 +712,12 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
         }
     };
     auto products = [&](f32x16& c, const bf16x8 (&a)[NP], const bf16x8 (&b)[NP]) {
+        if constexpr (NP == 2) {               // f16 planes (h, l): smallest terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[1]), __builtin_bit_cast(f16x8, b[0]), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[1]), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[0]), c, 0, 0, 0);
+            return;
+        }
         if constexpr (NP == 3) {
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
@@ -822,9 +874,21 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
 #pragma unroll
             for (int i = 0; i < PB; ++i) pb[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, vB[i], soB, 0));
         };
-        auto cvt1 = [&](const f32x4& v, char* base, int plane, int off) {
+        // scales of the 16-deep stages: a k-contiguous float4 lies in row idx >> 2
+        f32x4 psA[A_KC ? PA : 1], psB[B_KC ? PB : 1];
+        if constexpr (NP == 2 && A_KC) {
+#pragma unroll
+            for (int i = 0; i < PA; ++i) { const float s = scale_of(g.a_amax, m0 + ((tid + i * 256) >> 2), g.M); psA[i] = f32x4{s, s, s, s}; }
+        }
+        if constexpr (NP == 2 && B_KC) {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) { const float s = scale_of(g.b_amax, n0 + ((tid + i * 256) >> 2), g.N); psB[i] = f32x4{s, s, s, s}; }
+        }
+        auto pscaleA = [&](int c) -> f32x4 { if constexpr (A_KC) return psA[NP == 2 ? c : 0]; else return scA_mc; };
+        auto pscaleB = [&](int c) -> f32x4 { if constexpr (B_KC) return psB[NP == 2 ? c : 0]; else return scB_mc; };
+        auto cvt1 = [&](const f32x4& v, const f32x4& s, char* base, int plane, int off) {
             u32x2 H, M, L;
-            split4<NP>(v, H, M, L);
+            split4<NP>(v, s, H, M, L);
             *reinterpret_cast<u32x2*>(base + off) = H;
             *reinterpret_cast<u32x2*>(base + plane + off) = M;
             if constexpr (NP == 3) *reinterpret_cast<u32x2*>(base + 2 * plane + off) = L;
@@ -862,8 +926,8 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
                             if (c * (TM * TN) / NCV != grp) continue;
                             if (c < PA) {
                                 if constexpr (ASUM) if (mine) asum4 += pa[S][c];
-                                cvt1(pa[S][c], nA, SA_PLANE, stA[c]);
-                            } else cvt1(pb[S][c - PA], nB, SB_PLANE, stB[c - PA]);
+                                cvt1(pa[S][c], pscaleA(c), nA, SA_PLANE, stA[c]);
+                            } else cvt1(pb[S][c - PA], pscaleB(c - PA), nB, SB_PLANE, stB[c - PA]);
                         }
                     }
                 }
@@ -877,10 +941,10 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
 #pragma unroll
         for (int c = 0; c < PA; ++c) {
             if constexpr (ASUM) if (asum_cur) asum4 += pa[0][c];
-            cvt1(pa[0][c], ldsA, SA_PLANE, stA[c]);
+            cvt1(pa[0][c], pscaleA(c), ldsA, SA_PLANE, stA[c]);
         }
 #pragma unroll
-        for (int c = 0; c < PB; ++c) cvt1(pb[0][c], ldsA + NP * SA_PLANE, SB_PLANE, stB[c]);
+        for (int c = 0; c < PB; ++c) cvt1(pb[0][c], pscaleB(c), ldsA + NP * SA_PLANE, SB_PLANE, stB[c]);
         gload16(S0{}, 2);
         __syncthreads();
         for (int s0 = 0; s0 < nst; s0 += 2) {
@@ -916,6 +980,27 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
         if (ragged) mainloop(std::false_type{});
         else if constexpr (PIPE) pipelined();
         else mainloop(std::true_type{});
+    }
+    if constexpr (NP == 2) {
+        // back from the scaled domain: element (m, n) carries 2^(shift of row m + shift of column n), exact powers of two.  The shifts
+        // of the tile's rows and columns go through LDS (free: the last stage has been multiplied out)
+        int* const sh = reinterpret_cast<int*>(lds);
+        __syncthreads();
+        for (int t = tid; t < BM + BN; t += 256) {
+            const bool isA = t < BM;
+            const int idx = isA ? m0 + t : n0 + (t - BM);
+            sh[t] = (idx < (isA ? g.M : g.N)) ? f16_shift((isA ? g.a_amax : g.b_amax)[idx]) : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int sb = sh[BM + wn + 32 * j + r];
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    acc[i][j][t] = ldexpf(acc[i][j][t], -(sh[wm + 32 * i + 4 * h + (t & 3) + 8 * (t >> 2)] + sb));
+            }
     }
     if constexpr (ASUM) if (do_asum) {
         // the 256 / (BM / 4) threads that staged the same four rows are added up through LDS in thread order (deterministic)
@@ -1304,6 +1389,7 @@ static int fill_args(const ekaid_gemm_t* d, GemmArgs& a, int& TMN, void* workspa
     a.e.post = slab_mode ? nullptr : d->post; a.e.ldpost = d->ldpost;
     a.slab_mode = slab_mode;
     a.asum = nullptr; a.asum_ws = nullptr;
+    a.a_amax = d->a_amax; a.b_amax = d->b_amax;
     t_plan_slab = slab_mode;
     plan_full(d, TMN, a.splitk, a.k_per_split, a.tiles_m, a.tiles_n);
     t_plan_slab = 0;
@@ -1355,12 +1441,18 @@ int split_dispatch_x2(const GemmArgs& a, int TMN, bool akc, bool bkc, int batch,
 int pair_dispatch_x2(const GemmArgs& a0, const GemmArgs& a1, bool big, bool akc, bool bkc, hipStream_t st);
 
 #ifndef EKAID_GEMM_X2_TU
+// mode 2 (two-term f16 split) serves the products whose caller supplied bounds on both operands; every other product of the device
+// keeps the exact 3-way bf16 split
+static bool use_x2(const GemmArgs& a) { return gemm_mode() == 2 && a.a_amax != nullptr && a.b_amax != nullptr; }
 // the product kernel of one planned GEMM (arithmetic per device state, tile shape TMN from the planner)
 static int launch_product(const GemmArgs& a, int TMN, bool akc, bool bkc, int batch, hipStream_t st) {
     int rc;
     if (gemm_mode() >= 1 && TMN >= 1 && TMN <= 4) {
-        rc = gemm_mode() == 2 ? split_dispatch_x2(a, TMN, akc, bkc, batch, st) : split_dispatch<3>(a, TMN, akc, bkc, batch, st);
+        const bool x2 = use_x2(a);
+        rc = x2 ? split_dispatch_x2(a, TMN, akc, bkc, batch, st) : split_dispatch<3>(a, TMN, akc, bkc, batch, st);
+        count_launch(x2 ? EKAID_COUNT_GEMM_SPLIT2 : EKAID_COUNT_GEMM_SPLIT3);
     } else {
+        count_launch(EKAID_COUNT_GEMM_F32);
 #define EKAID_LAUNCH(AK, BKC) (TMN == 2 ? launch<AK, BKC, 2, 2, BK_BIG>(a, batch, st) : TMN == 1 ? launch<AK, BKC, 1, 1, BK_SMALL>(a, batch, st) \
                                : TMN == 3 ? launch<AK, BKC, 2, 1, BK_HALF>(a, batch, st) : launch<AK, BKC, 1, 2, BK_HALF>(a, batch, st))
         if (akc && bkc) rc = EKAID_LAUNCH(true, true);
@@ -1414,7 +1506,7 @@ int pair_dispatch_x2(const GemmArgs& a0, const GemmArgs& a1, bool big, bool akc,
 using namespace ekaid;
 
 extern "C" int ekaid_set_gemm_mode(int mode) {
-    if (mode < 0 || mode > 2) { set_error("ekaid_set_gemm_mode: mode must be 0 (f32 MFMA), 1 (exact bf16 3-way split) or 2 (bf16x2, reduced precision)"); return EKAID_ERR_ARG; }
+    if (mode < 0 || mode > 2) { set_error("ekaid_set_gemm_mode: mode must be 0 (f32 MFMA), 1 (exact bf16 3-way split) or 2 (two-term f16 split where operand bounds are given)"); return EKAID_ERR_ARG; }
     return set_gemm_mode(mode);
 }
 extern "C" int ekaid_get_gemm_mode(void) { return gemm_mode(); }
@@ -1584,7 +1676,7 @@ extern "C" int ekaid_gemm_slabs2(const ekaid_gemm_t* d0, float* slabs0, size_t s
         return launch_product(a1, T1, !d1->transA, d1->transB != 0, 1, st);
     }
     const bool akc = !d0->transA, bkc = d0->transB != 0;
-    if (gemm_mode() == 2) return pair_dispatch_x2(a0, a1, T0 == 2, akc, bkc, st);
+    count_launch(EKAID_COUNT_GEMM_SPLIT3); count_launch(EKAID_COUNT_GEMM_SPLIT3);     // (slab products carry no operand bounds)
     return pair_dispatch<3>(a0, a1, T0 == 2, akc, bkc, st);
 }
 
@@ -1602,6 +1694,8 @@ static bool pairable(const ekaid_gemm_t* d0, const ekaid_gemm_t* d1, int& TMN) {
     if (skinny_tn(d0, G, NO) || skinny_tn(d1, G, NO)) return false;
     if ((d0->a_rowsum || d1->a_rowsum) && !d0->transA) return false;
     if ((d0->post && d0->ldpost < d0->N) || (d1->post && d1->ldpost < d1->N) || (d0->R && d0->rdiv < 1) || (d1->R && d1->rdiv < 1)) return false;
+    // mode 2: both on the two-term f16 split or both on the exact split (a product inside a pair = the same product alone, bit for bit)
+    if (gemm_mode() == 2 && ((d0->a_amax && d0->b_amax) != (d1->a_amax && d1->b_amax))) return false;
     int T0, T1, sk, kps, tm, tn;
     plan_full(d0, T0, sk, kps, tm, tn);
     plan_full(d1, T1, sk, kps, tm, tn);
@@ -1642,7 +1736,9 @@ extern "C" int ekaid_gemm_pair_f32(const ekaid_gemm_t* d0, const ekaid_gemm_t* d
         }
     }
     const bool akc = !d0->transA, bkc = d0->transB != 0;
-    int rc = gemm_mode() == 2 ? pair_dispatch_x2(a[0], a[1], TMN == 2, akc, bkc, st) : pair_dispatch<3>(a[0], a[1], TMN == 2, akc, bkc, st);
+    const bool x2 = use_x2(a[0]) && use_x2(a[1]);
+    int rc = x2 ? pair_dispatch_x2(a[0], a[1], TMN == 2, akc, bkc, st) : pair_dispatch<3>(a[0], a[1], TMN == 2, akc, bkc, st);
+    count_launch(x2 ? EKAID_COUNT_GEMM_SPLIT2 : EKAID_COUNT_GEMM_SPLIT3); count_launch(x2 ? EKAID_COUNT_GEMM_SPLIT2 : EKAID_COUNT_GEMM_SPLIT3);
     for (int i = 0; i < 2 && rc == EKAID_OK; ++i)
         if (a[i].splitk > 1) rc = launch_reduce(ds[i], a[i], st);
     return rc;

@@ -731,6 +731,7 @@ int launch_fwd(const PFwd& a, const PersistPlan& pl, hipStream_t st) {
         }
     }
     hipLaunchKernelGGL(kern, dim3(pl.G), dim3(256), pl.lds_bytes, st, a);
+    count_launch(GREEDY ? EKAID_COUNT_GREEDY_PERSISTENT : EKAID_COUNT_SPK_FWD_PERSISTENT);
     return check_launch("speaker_seq_fwd_persistent");
 }
 

@@ -503,5 +503,6 @@ extern "C" int ekaid_speaker_seq_bwd_persistent(const ekaid_speaker_seq_bwd_t* b
         }
     }
     hipLaunchKernelGGL(kern, dim3(pl.G), dim3(256), pl.lds_bytes, st, a);
+    count_launch(EKAID_COUNT_SPK_BWD_PERSISTENT);
     return check_launch("speaker_seq_bwd_persistent");
 }

@@ -223,6 +223,7 @@ extern "C" int ekaid_gru_seq_fwd_persistent(const float* gi, const float* w_hh, 
     a.status = seq_status_ptr();
     if (!a.status) { set_error("persistent sequence kernel: cannot allocate the status word"); return EKAID_ERR_LAUNCH; }
     if (hipMemsetAsync(workspace, 0, al256((size_t)SYNC_WORDS * 4), st) != hipSuccess) { (void)hipGetLastError(); set_error("ekaid_gru_seq_fwd_persistent: memset failed"); return EKAID_ERR_LAUNCH; }
+    count_launch(EKAID_COUNT_GRU_FWD_PERSISTENT);
     return launch_gru(gru_seq_fwd_persistent_kernel<GH>, a, pl, st, "gru_seq_fwd_persistent");
 }
 
@@ -249,5 +250,6 @@ extern "C" int ekaid_gru_seq_bwd_persistent(const float* dout, const float* w_hh
     const int rc = ekaid_transpose(w_hh, 3 * GH, GH, GH, (float*)(ws + pl.o_wt), 3 * GH, stream);      // W_hh^T [H][3H]
     if (rc) return rc;
     if (hipMemsetAsync(workspace, 0, al256((size_t)SYNC_WORDS * 4), st) != hipSuccess) { (void)hipGetLastError(); set_error("ekaid_gru_seq_bwd_persistent: memset failed"); return EKAID_ERR_LAUNCH; }
+    count_launch(EKAID_COUNT_GRU_BWD_PERSISTENT);
     return launch_gru(gru_seq_bwd_persistent_kernel<GH>, a, pl, st, "gru_seq_bwd_persistent");
 }

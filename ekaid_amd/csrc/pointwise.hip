@@ -844,6 +844,102 @@ extern "C" int ekaid_wn_scale_multi(const float* const* v, const float* const* g
     hipLaunchKernelGGL(wn_multi_finish_kernel, dim3(count), dim3(64), 0, ST, a, (const double*)part, scales, norms);
     return check_launch("wn_scale_multi");
 }
+// ---- row and column maxima of |x| for up to AMAX_MAX row-strided matrices in one launch: the operand bounds of the two-term f16
+// GEMM split (ekaid_gemm_t.a_amax / b_amax).  |x| as an unsigned bit pattern orders like the value and an integer max does not depend
+// on arrival order: deterministic.  A NaN element has the largest pattern of all, so it surfaces in the bound (the consumer then
+// leaves that row unscaled).  One workgroup owns RB whole rows (row maxima: plain stores); column maxima: one atomic per thread,
+// column and workgroup into the zeroed output.
+constexpr int AMAX_MAX = 32;
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+struct AmaxMulti { const float* x[AMAX_MAX]; long long rows[AMAX_MAX]; int cols[AMAX_MAX]; int ld[AMAX_MAX]; unsigned* rowmax[AMAX_MAX]; unsigned* colmax[AMAX_MAX]; int count; };
+template <int RB>
+__global__ __launch_bounds__(256) void amax_rc_kernel(AmaxMulti a) {
+    __shared__ unsigned racc[RB];
+    const int t = blockIdx.y;
+    const long long rows = a.rows[t], r0 = (long long)blockIdx.x * RB;
+    if (r0 >= rows) return;
+    const float* x = a.x[t];
+    const int cols = a.cols[t], ld = a.ld[t];
+    unsigned* const rowmax = a.rowmax[t];
+    unsigned* const colmax = a.colmax[t];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < RB) racc[tid] = 0;
+    __syncthreads();
+    const int c4n = cols >> 2;
+    const int c4pad = (c4n + 63) & ~63;                  // whole waves take part in the row reductions
+    const int nr = (int)((rows - r0) < RB ? (rows - r0) : RB);
+    for (int c4 = tid; c4 < c4pad; c4 += 256) {
+        const bool ok = c4 < c4n;
+        const float* p = x + r0 * ld + 4 * (ok ? c4 : 0);
+        unsigned cm[4] = {0, 0, 0, 0};
+        for (int rb = 0; rb < nr; rb += 4) {
+            u32x4_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = rb + u < nr ? rb + u : nr - 1;                      // (clamped: a repeated row changes no maximum)
+                v[u] = *reinterpret_cast<const u32x4_t*>(p + (long long)r * ld);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                unsigned m = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned av = ok ? (v[u][e] & 0x7FFFFFFFu) : 0u;
+                    cm[e] = max(cm[e], av);
+                    m = max(m, av);
+                }
+                if (rowmax) {
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+                    if (lane == 0 && m && rb + u < nr) atomicMax(&racc[rb + u], m);
+                }
+            }
+        }
+        if (ok && colmax) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (cm[e]) atomicMax(colmax + 4 * c4 + e, cm[e]);
+        }
+    }
+    if (rowmax) {
+        __syncthreads();
+        if (tid < nr) rowmax[r0 + tid] = racc[tid];
+    }
+}
+extern "C" int ekaid_amax_rc_multi(const float* const* x, const long long* rows, const int* cols, const int* ld, float* const* rowmax,
+                                   float* const* colmax, int count, void* stream) {
+    if (count < 1 || count > AMAX_MAX || !x || !rows || !cols || !ld || !rowmax || !colmax) {
+        set_error("amax_rc_multi: 1 <= count <= %d matrices, non-null arrays", AMAX_MAX);
+        return EKAID_ERR_ARG;
+    }
+    AmaxMulti a;
+    a.count = count;
+    long long rmax = 0;
+    for (int i = 0; i < AMAX_MAX; ++i) {
+        const bool on = i < count;
+        if (on && (!x[i] || rows[i] < 0 || cols[i] < 0 || ld[i] < cols[i])) { set_error("amax_rc_multi: bad matrix %d", i); return EKAID_ERR_ARG; }
+        if (on && ((cols[i] & 3) || (ld[i] & 3) || (reinterpret_cast<uintptr_t>(x[i]) & 15))) {
+            set_error("amax_rc_multi: matrix %d is not made of whole 16-byte vectors (cols %d, ld %d)", i, cols[i], ld[i]);
+            return EKAID_ERR_UNSUPPORTED;
+        }
+        a.x[i] = on ? x[i] : nullptr; a.rows[i] = on ? rows[i] : 0; a.cols[i] = on ? cols[i] : 0; a.ld[i] = on ? ld[i] : 0;
+        a.rowmax[i] = on ? reinterpret_cast<unsigned*>(rowmax[i]) : nullptr; a.colmax[i] = on ? reinterpret_cast<unsigned*>(colmax[i]) : nullptr;
+        if (on && rows[i] > rmax) rmax = rows[i];
+        if (on && colmax[i] && cols[i] > 0 &&
+            hipMemsetAsync(colmax[i], 0, sizeof(float) * cols[i], ST) != hipSuccess) { (void)hipGetLastError(); set_error("amax_rc_multi: memset failed"); return EKAID_ERR_LAUNCH; }
+    }
+    if (rmax == 0) return EKAID_OK;
+    if (rmax >= 8192) {
+        hipLaunchKernelGGL(amax_rc_kernel<32>, dim3((unsigned)((rmax + 31) / 32), count), dim3(256), 0, ST, a);
+    } else {
+        hipLaunchKernelGGL(amax_rc_kernel<8>, dim3((unsigned)((rmax + 7) / 8), count), dim3(256), 0, ST, a);
+    }
+    return check_launch("amax_rc_multi");
+}
+extern "C" int ekaid_amax_rc(const float* x, long long rows, int cols, int ld, float* rowmax, float* colmax, void* stream) {
+    return ekaid_amax_rc_multi(&x, &rows, &cols, &ld, &rowmax, &colmax, 1, stream);
+}
+
 extern "C" int ekaid_wn_grad_multi(float* const* G, const float* const* v, const float* const* g, const float* const* norm,
                                    const float* const* scale, const long long* n, float* const* dg, int count, void* stream) {
     if (count < 1 || count > WN_MULTI_MAX || !G || !v || !g || !norm || !scale || !n || !dg) {

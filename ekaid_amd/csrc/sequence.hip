@@ -209,6 +209,7 @@ extern "C" int ekaid_speaker_seq_fwd(const ekaid_speaker_seq_t* d, void* workspa
     SpkPlan pl;
     if (!spk_plan(d, workspace, false, pl)) return EKAID_ERR_ARG;
     if (!workspace || workspace_bytes < pl.bytes) { set_error("ekaid_speaker_seq_fwd: workspace too small (%zu < %zu)", workspace_bytes, pl.bytes); return EKAID_ERR_ARG; }
+    count_launch(EKAID_COUNT_SPK_FWD_STEPWISE);
     const int T = d->T, B = d->B, R = d->R, A = d->A, P = d->P, G1 = d->G1;
     const int oP1 = 4 * R, oG1 = 5 * R, oGL = 5 * R + G1;
     const size_t BR = (size_t)B * R;
@@ -270,6 +271,7 @@ extern "C" int ekaid_speaker_seq_bwd(const ekaid_speaker_seq_bwd_t* b, void* wor
     SpkPlan pl;
     if (!spk_plan(d, workspace, true, pl)) return EKAID_ERR_ARG;
     if (!workspace || workspace_bytes < pl.bytes) { set_error("ekaid_speaker_seq_bwd: workspace too small (%zu < %zu)", workspace_bytes, pl.bytes); return EKAID_ERR_ARG; }
+    count_launch(EKAID_COUNT_SPK_BWD_STEPWISE);
     const int T = d->T, B = d->B, R = d->R, A = d->A, P = d->P, G1 = d->G1, NW = 9 * R + G1;
     const int oP1 = 4 * R, oG1 = 5 * R, oGL = 5 * R + G1;
     const size_t BR = (size_t)B * R;
@@ -400,6 +402,7 @@ extern "C" int ekaid_speaker_greedy_steps(const ekaid_speaker_greedy_t* q, int t
     GreedyPlan pl;
     if (!greedy_plan(q, workspace, pl)) return EKAID_ERR_ARG;
     if (!workspace || workspace_bytes < pl.bytes) { set_error("ekaid_speaker_greedy_steps: workspace too small (%zu < %zu)", workspace_bytes, pl.bytes); return EKAID_ERR_ARG; }
+    count_launch(EKAID_COUNT_GREEDY_STEPWISE);
     const int B = d->B, R = d->R, We = d->We;
     const size_t BR = (size_t)B * R;
     for (int t = t0; t < t1; ++t) {

@@ -39,6 +39,7 @@ class GemmDesc(Structure):
         ('drop_p', c_float), ('drop_seed', c_uint64),
         ('a_rowsum', c_void_p),
         ('post', c_void_p), ('ldpost', c_int),
+        ('a_amax', c_void_p), ('b_amax', c_void_p),
     ]
 
 
@@ -211,8 +212,11 @@ SIGNATURES = {
     'ekaid_adam_step': [P, P, P, P, L, F, F, F, F, I, F, P],
     'ekaid_adam_step_dev': [P, P, P, P, L, P, P, P, P, P],
     'ekaid_seq_fault_flag': [P, P],
+    'ekaid_launch_count': [I],
+    'ekaid_amax_rc': [P, L, I, I, P, P, P],
+    'ekaid_amax_rc_multi': [P, P, P, P, P, P, I, P],
 }
-_RESTYPES = {'ekaid_last_error': c_char_p, 'ekaid_gemm_workspace_bytes': c_size_t, 'ekaid_gemm_pair_workspace_bytes': c_size_t, 'ekaid_gru_seq_workspace_bytes': c_size_t, 'ekaid_gru_seq_persistent_workspace_bytes': c_size_t,
+_RESTYPES = {'ekaid_last_error': c_char_p, 'ekaid_launch_count': c_longlong, 'ekaid_gemm_workspace_bytes': c_size_t, 'ekaid_gemm_pair_workspace_bytes': c_size_t, 'ekaid_gru_seq_workspace_bytes': c_size_t, 'ekaid_gru_seq_persistent_workspace_bytes': c_size_t,
              'ekaid_speaker_seq_workspace_bytes': c_size_t, 'ekaid_speaker_seq_persistent_workspace_bytes': c_size_t,
              'ekaid_speaker_seq_persistent_status_ptr': c_void_p, 'ekaid_speaker_seq_bwd_persistent_workspace_bytes': c_size_t, 'ekaid_speaker_greedy_workspace_bytes': c_size_t, 'ekaid_speaker_greedy_persistent_workspace_bytes': c_size_t}
 
@@ -283,6 +287,18 @@ def seq_status_take():
     if v.value:
         check(lib().ekaid_seq_status_clear(stream()), 'seq_status_clear')
     return int(v.value)
+
+
+# indices of ekaid_launch_count (include/ekaid_hip.h)
+COUNT = dict(spk_fwd_persistent=0, spk_bwd_persistent=1, greedy_persistent=2, gru_fwd_persistent=3, gru_bwd_persistent=4,
+             spk_fwd_stepwise=5, spk_bwd_stepwise=6, greedy_stepwise=7, gemm_f32=8, gemm_split3=9, gemm_split2=10)
+
+
+def launch_counts():
+    """name -> launches issued so far by this process (ekaid_launch_count): which implementation served the calls made in between two
+    readings (persistent sequence kernels vs step-wise chains, GEMM arithmetic)."""
+    L = lib()
+    return {k: int(L.ekaid_launch_count(i)) for k, i in COUNT.items()}
 
 
 def ptr(t):

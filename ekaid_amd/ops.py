@@ -23,7 +23,7 @@ _seed_base = 1238
 _seed_counter = 0
 
 
-GEMM_F32_MFMA, GEMM_BF16_SPLIT, GEMM_BF16X2 = 0, 1, 2
+GEMM_F32_MFMA, GEMM_BF16_SPLIT, GEMM_F16X2 = 0, 1, 2
 
 # Debug mode: with EKAID_CHECK_FINITE=1 every layer output is checked for Inf / NaN (one small reduction + one host read per
 # check: a synchronisation each, like the reference's `assert not x.isnan().any()` after every layer, fc.py:42-48).  Off by
@@ -163,6 +163,18 @@ _BIAS_IN_WGRAD = os.environ.get('EKAID_BIAS_IN_WGRAD', '1') != '0'
 _SEQ_IN_C = os.environ.get('EKAID_SEQ_IN_C', '1') != '0'      # time loops of the GRU / decoder behind ONE C-ABI call each
 
 
+def amax_rc(x, rows, cols, ld, off=0, want_rows=True, want_cols=True):
+    """(rowmax [rows], colmax [cols]) of |x[off + r * ld + c]| on the device (either None when not wanted): the operand bounds of the
+    two-term f16 GEMM split (include/ekaid_hip.h: ekaid_amax_rc).  None, None when the matrix is not made of whole 16-byte vectors --
+    the product then stays on the exact split."""
+    if (cols & 3) or (ld & 3) or ((x.data_ptr() + 4 * off) & 15) or rows < 1 or cols < 1:
+        return None, None
+    rm = torch.empty(rows, device=x.device, dtype=torch.float32) if want_rows else None
+    cm = torch.empty(cols, device=x.device, dtype=torch.float32) if want_cols else None
+    check(hip.lib().ekaid_amax_rc(x.data_ptr() + 4 * off, rows, cols, ld, ptr(rm), ptr(cm), stream()), 'amax_rc')
+    return rm, cm
+
+
 def seq_in_c():
     """The sequence-level entry points are the default; the step-by-step Python loops (the same C-ABI calls, one by one) stay
     for the per-launch GEMM profile of bench.py and as the cross-check of tests (EKAID_SEQ_IN_C=0)."""
@@ -176,7 +188,7 @@ _defer = None            # while a list: gemm() / deferred_call() record into it
 def _fill_desc(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha_dev=None,
                accumulate=False, bias=None, R=None, ldr=0, rdiv=1, rowmask=None, act=ACT_NONE,
                batch=(1, 1), strides=(0, 0, 0, 0, 0, 0), a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_seed=0, a_rowsum=None,
-               post=None, ldpost=0):
+               post=None, ldpost=0, a_amax=None, b_amax=None):
     d = GemmDesc()
     d.A = A.data_ptr() + 4 * a_off
     d.B = B.data_ptr() + 4 * b_off
@@ -200,6 +212,11 @@ def _fill_desc(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha=1.0, alpha
     d.a_rowsum = ptr(a_rowsum) if _BIAS_IN_WGRAD else None
     d.post = ptr(post)
     d.ldpost = ldpost
+    # operand bounds of the two-term f16 split: (vector, element offset) or a vector -- the row maxima of op(A), the column maxima of op(B)
+    for name, v in (('a_amax', a_amax), ('b_amax', b_amax)):
+        if v is not None:
+            t, off = v if isinstance(v, tuple) else (v, 0)
+            setattr(d, name, t.data_ptr() + 4 * off)
     return d
 
 

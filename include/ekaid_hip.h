@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EKAID_ABI_VERSION 8
+#define EKAID_ABI_VERSION 9
 
 int ekaid_version(void);
 const char* ekaid_last_error(void);        /* thread-local */
@@ -87,6 +87,11 @@ typedef struct ekaid_gemm {
     const float* post;      /* optional (one batch): C = dropout(act(...)) + post[m * ldpost + n] -- a gradient of the same tensor that joins
                                this input-gradient product behind its dropout, instead of an n-ary sum kernel afterwards */
     int ldpost;
+    const float* a_amax;    /* optional DEVICE vectors (ABI 9): a_amax[m] >= max_k |op(A)[m][k]| (M entries), b_amax[n] >= max_k |op(B)[k][n]| */
+    const float* b_amax;    /* (N entries); ekaid_amax_rc computes them.  Under EKAID_GEMM_F16X2 an unbatched product that carries both runs
+                               as the two-term f16 split (3 matrix products per product); one that does not keeps the exact 3-way bf16
+                               split.  Ignored in the other modes.  A bound that is too SMALL overflows f16 (Inf / NaN in that row / column);
+                               one that is too large by 2^k costs k bits of the 2^17 : 1 range inside a row / column (see below). */
 } ekaid_gemm_t;
 
 size_t ekaid_gemm_workspace_bytes(const ekaid_gemm_t* g);
@@ -141,14 +146,32 @@ int ekaid_gemm_slabs2(const ekaid_gemm_t* g0, float* slabs0, size_t slab_bytes0,
  * Inputs must be finite in mode 1: an Inf operand gives NaN where mode 0 gives Inf (Inf - Inf in the split).  Unreachable on
  * this path -- every GEMM operand is a finite activation, weight or gradient; a non-finite one is already a failed run, and
  * EKAID_CHECK_FINITE=1 (ekaid_amd/ops.py) asserts exactly that per module output.
- *   EKAID_GEMM_BF16X2     (2)  OPT-IN, REDUCED PRECISION: two bf16 terms per operand (16-17 significant bits: the second term
- *                              is the residual rounded to nearest) and three products per block: half the matrix work of mode 1
- *                              at ~2^-16 relative error per product (between TF32's 2^-11 and f32's 2^-24).  Never the default:
- *                              the path's parity contract is stated for mode 1; bench.py reports mode 2 as an extra line with its
- *                              measured log-prob deviation.  EKAID_GEMM_MODE=bf16x2 selects it. */
+ *   EKAID_GEMM_F16X2      (2)  products whose descriptor carries a_amax AND b_amax: every operand element, scaled by an exact
+ *                              power of two s that brings the largest magnitude of its row of op(A) / column of op(B) into
+ *                              [2^14, 2^15) (the scales leave the result through the epilogue, exactly), is split into TWO f16
+ *                              values  v s = h + l + e,  h = f16(v s), l = f16(v s - h)  (round to nearest: 11 + 11 significant
+ *                              bits, |e| <= 2^-22 |v s|), and the three products h h + h l + l h are formed on
+ *                              v_mfma_f32_32x32x16_f16 with f32 accumulation; the dropped l l is below 2^-22 |a b|.  Half the
+ *                              matrix work of mode 1.  Per-product error <= ~2^-21 |a b| worst case, ~2^-25 rms -- below the
+ *                              accumulation error of an f32 fma chain from K ~ 64 on (measured against float64:
+ *                              tests/test_hip_ops.py::test_gemm_split_accuracy).  Elements more than 2^17 below the largest of
+ *                              their row / column keep an absolute accuracy of 2^-40 of that largest (f16 subnormals are not
+ *                              flushed by the matrix pipe).  Products WITHOUT bounds run as mode 1, so mode 2 is mode 1 plus a fast path for the
+ *                              call sites that supply bounds.  EKAID_GEMM_MODE=f16x2 selects it. */
 #define EKAID_GEMM_F32_MFMA 0
 #define EKAID_GEMM_BF16_SPLIT 1
-#define EKAID_GEMM_BF16X2 2
+#define EKAID_GEMM_F16X2 2
+/* Row and column maxima of |x|: rowmax[r] = max_c |x[r * ld + c]| (r < rows), colmax[c] = max_r |x[r * ld + c]| (c < cols); either
+ * output may be NULL.  These are the operand bounds of EKAID_GEMM_F16X2: for a product, a_amax = the row maxima of A when transA = 0
+ * (A stored [M][K]) or its column maxima when transA = 1 (stored [K][M]); b_amax = the row maxima of B when transB = 1 (stored [N][K])
+ * or its column maxima when transB = 0 (stored [K][N]); bounds taken over a larger block of the same rows / columns stay valid.
+ * Exact and order-independent (integer max of the magnitude's bit pattern); an all-zero row gives 0, a NaN element NaN.  One launch
+ * (+ one memset node per column output) for up to 32 matrices (x, rows, cols, ld, rowmax, colmax: HOST arrays).  cols, ld multiples of
+ * 4 and 16-byte aligned x, else EKAID_ERR_UNSUPPORTED (the caller then leaves the product on the exact split).
+ * No reference counterpart. */
+int ekaid_amax_rc_multi(const float* const* x, const long long* rows, const int* cols, const int* ld, float* const* rowmax,
+                        float* const* colmax, int count, void* stream);
+int ekaid_amax_rc(const float* x, long long rows, int cols, int ld, float* rowmax, float* colmax, void* stream);
 int ekaid_set_gemm_mode(int mode);
 int ekaid_get_gemm_mode(void);
 
@@ -617,6 +640,24 @@ int ekaid_adam_step_dev(float* p, const float* g, float* m, float* v, long long 
 /* flag[0] = 1.0f if the status word of the persistent sequence kernels is set on this device, else 0.0f (one tiny launch,
  * graph-capturable).  No reference counterpart: the reference has neither persistent kernels nor data parallelism. */
 int ekaid_seq_fault_flag(float* flag, void* stream);
+
+/* Launch counters (ABI 9): how many times this process has issued each of the routed kernels since the library was loaded -- host-side
+ * atomics, bumped by the entry point that launches (a launch recorded into a hipGraph counts once, at capture).  They let a caller --
+ * the parity tests -- prove WHICH implementation served a call made under the default routing (persistent sequence kernels vs the
+ * step-wise chains; which GEMM arithmetic).  Unknown index: -1.  No reference counterpart. */
+#define EKAID_COUNT_SPK_FWD_PERSISTENT 0    /* ekaid_speaker_seq_fwd_persistent (also when ekaid_speaker_seq_fwd routed there) */
+#define EKAID_COUNT_SPK_BWD_PERSISTENT 1    /* ekaid_speaker_seq_bwd_persistent */
+#define EKAID_COUNT_GREEDY_PERSISTENT 2     /* ekaid_speaker_greedy_steps_persistent (also when ekaid_speaker_greedy_steps routed there) */
+#define EKAID_COUNT_GRU_FWD_PERSISTENT 3    /* ekaid_gru_seq_fwd_persistent */
+#define EKAID_COUNT_GRU_BWD_PERSISTENT 4    /* ekaid_gru_seq_bwd_persistent */
+#define EKAID_COUNT_SPK_FWD_STEPWISE 5      /* ekaid_speaker_seq_fwd served by the launch-per-product chain */
+#define EKAID_COUNT_SPK_BWD_STEPWISE 6      /* ekaid_speaker_seq_bwd */
+#define EKAID_COUNT_GREEDY_STEPWISE 7       /* ekaid_speaker_greedy_steps served by the chain */
+#define EKAID_COUNT_GEMM_F32 8              /* products launched on the f32 matrix pipe (gemm mode 0, or a shape routed there) */
+#define EKAID_COUNT_GEMM_SPLIT3 9           /* products launched as the exact 3-way bf16 split (6 matrix products per product) */
+#define EKAID_COUNT_GEMM_SPLIT2 10          /* products launched as a 2-term split (3 matrix products per product) */
+#define EKAID_COUNT_N 11
+long long ekaid_launch_count(int which);
 
 #ifdef __cplusplus
 }

@@ -46,3 +46,43 @@ def real_shape_case():
     batch['d_adj'][0, 7, :] = 0
     batch['d_adj'][0, :, 7] = 0                              # isolated node in the spatial graph
     return cfg, batch
+
+
+# --------------------------------------------------------------------------- #
+# round-6 cases at the production widths (fixtures: tests/golden/make_wide_golden.py -> f10_*.npz)
+# --------------------------------------------------------------------------- #
+def wide_case(T, B=4):
+    """(cfg, batch): BASELINE.json shapes (36 regions x 2048-d, 20-token questions), yaml widths, T decode steps -- 40 and 90 reach the
+    persistent decoder backward (taken from 32 steps on; dynamic_speaker_change_pos.py:196-222)."""
+    cfg = bench_cfg(D=2048, seq_length=90)
+    return cfg, make_batch(B=B, N=36, D=2048, Lq=20, T=T, seq_length=90, V=148, seed=1238 + T)
+
+
+def real_full_case():
+    """(cfg, batch): Medical-Diff-VQA shapes at the yaml widths (52 regions x 1024-d: rcc_dataset_pos_mimic.py:107-108, feat_dim 1026),
+    batch 4, ragged answers of 2 ... 40 tokens with per-sample masks, an undetected region (all-zero ROI row), an isolated node."""
+    cfg = bench_cfg(D=1024, seq_length=90)
+    batch = make_batch(B=4, N=52, D=1024, Lq=20, T=41, seq_length=90, V=148, seed=52)
+    batch['input_1'][0, 5] = 0                               # undetected region
+    batch['input_2'][3, 51] = 0
+    for b, n in enumerate((40, 2, 17, 29)):                  # answer lengths in tokens (labels[:, 0] is <start>)
+        batch['labels'][b, 1 + n:] = 0
+    batch['masks'] = torch.zeros_like(batch['masks'])
+    for b in range(4):
+        n = int((batch['labels'][b] != 0).sum()) + 1
+        batch['masks'][b, :n] = 1
+    batch['d_adj'][0, 7, :] = 0
+    batch['d_adj'][0, :, 7] = 0                              # isolated node in the spatial graph
+    batch['q_sem'][2, 11, :] = 0
+    batch['q_sem'][2, :, 11] = 0                             # ... and one in the semantic graph of the other image
+    return cfg, batch
+
+
+def greedy_case(B=64):
+    """(cfg, (bef, aft, diff), logit scale, NULL-bias shift): decoder inputs of the greedy-decoding fixture, from numpy's portable PCG64."""
+    import numpy as np
+    cfg = bench_cfg(D=2048, seq_length=90)
+    A = cfg.model.speaker.input_dim
+    rng = np.random.default_rng([64, 1238])
+    feats = tuple(torch.from_numpy(rng.standard_normal((B, A), dtype=np.float32)) for _ in range(3))
+    return cfg, feats, 12.0, 3.0

@@ -1,0 +1,117 @@
+"""Round-6 fixtures: the REFERENCE at the production widths on the cases that reach the persistent recurrent kernels.
+
+    python tests/golden/make_wide_golden.py          (build container only: imports /root/reference via make_golden.py; ~ 2 minutes)
+
+Why: the persistent decoder backward (csrc/persist_bwd.hip) is taken from 32 decode steps on and the persistent greedy decoder
+(csrc/persist.hip, GREEDY stations) only exists at rnn_size 512 / input_dim 1024; the earlier fixtures stop at 16 steps or run at the
+small widths, so those kernels were only ever compared with the step-wise chain.  These pin them to the reference itself
+(dynamic_speaker_change_pos.py:182-222, 287-357):
+
+  f10_T40 / f10_T90   full-width train step (eval-with-grad), 36 regions x 2048-d, batch 4, 40 / 90 decode steps:
+                      loss, every log-prob, whole-tensor sketches of every gradient (float32 run) and of the
+                      float64 run of the same reference modules (the gradient truth)
+  f10_real_full       the real-data shapes at the yaml widths (52 regions x 1024-d, rcc_dataset_pos_mimic.py:107-108), batch 4,
+                      ragged answers of 2 ... 40 tokens, an undetected region (all-zero ROI row), an isolated node: same contents
+  f10_greedy_b64      greedy `_sample` at batch 64 on seeded decoder inputs with spread logits (logit.weight x 12, NULL bias + 3: answers of 1, 2, 3, 16 and 90 tokens; as
+                      tests/test_hip_persist.py does: random-init logits are nearly flat): token ids, stop positions, seq_logprobs, and the
+                      smallest top-1 / top-2 margin of any step that was decoded (how far the ids are from a rounding tie)
+"""
+import contextlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as G                                  # noqa: E402  (shims + reference import)
+
+from ekaid_amd.config import bench_cfg                   # noqa: E402
+from ekaid_amd.synthetic import make_batch               # noqa: E402
+from golden_util import sketch_named                     # noqa: E402
+
+sys.path.insert(0, os.path.join(G.ROOT, 'tests'))
+from common import greedy_case, real_full_case, wide_case   # noqa: E402
+
+
+@contextlib.contextmanager
+def float64_reference():
+    """The REFERENCE modules in float64 (as make_golden.gen_f4_ref64): tensors the reference creates inside forward follow the default
+    dtype, and its two hard .float() casts (graph_att.py:74, graph_att_layer.py:115) are widened for the run."""
+    torch.set_default_dtype(torch.float64)
+    real_float = torch.Tensor.float
+    torch.Tensor.float = lambda self, *a, **k: self.double()
+    try:
+        yield
+    finally:
+        torch.Tensor.float = real_float
+        torch.set_default_dtype(torch.float32)
+
+
+def train_case(name, cfg, batch):
+    """float32 run = what the reference computes (outputs, loss, its own gradients); float64 run = the gradient truth: at these widths
+    the reference's float32 gradients sit ~1e-3 from it, so a float32 implementation is held to "no farther from
+    the truth than max(1e-3, 3 x the reference's own float32 error)", tensor by tensor, chunk by chunk."""
+    cd, sp = G.build(cfg, 147, 148)
+    loss, sp_loss, outs, logp, logpos, _ = G.ref_step(cfg, cd, sp, batch, 'mode2', 'all')
+    loss.backward()
+    T = int((batch['labels'][:, 1:] != 0).any(0).sum()) + 1
+    names, sk = sketch_named(G.named_grads(cd, sp))
+    with float64_reference():
+        cd64, sp64 = G.build(cfg, 147, 148)
+        cd64.double()
+        sp64.double()
+        b64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in batch.items()}
+        loss64, _, _, logp64, _, _ = G.ref_step(cfg, cd64, sp64, b64, 'mode2', 'all', adj_dtype=torch.float64)
+        assert loss64.dtype == torch.float64 and logp64.dtype == torch.float64
+        loss64.backward()
+        names64, sk64 = sketch_named(G.named_grads(cd64, sp64))
+    assert names == names64
+    G.save(name, loss=loss, speaker_loss=sp_loss, steps=np.int64(T), logp=logp[:, :T], logpos=logpos[:, :T], feat_diff=outs[5],
+           att_bef=outs[1], grad_names=np.array(names), grad_sketch=sk, grad_sketch_f64=sk64, loss_f64=loss64,
+           logp_f64_maxdiff=np.float64((logp64[:, :T] - logp[:, :T].double()).abs().max()))
+
+
+def greedy():
+    cfg, feats, scale, bias0 = greedy_case()
+    cd, sp = G.build(cfg, 147, 148)
+    with torch.no_grad():
+        sp.logit.weight.mul_(scale)
+        sp.logit.bias[0] += bias0
+    margins = []
+    inner = sp.get_logprobs_state
+
+    def spy(it, *a):
+        out = inner(it, *a)
+        top = out[0].detach().topk(2, dim=1).values
+        margins.append((top[:, 0] - top[:, 1]).clone())
+        return out
+    sp.get_logprobs_state = spy
+    with torch.no_grad():
+        seq, lp = sp._sample(feats[0], feats[1], feats[2], None, cfg, sample_max=1)
+    del sp.get_logprobs_state
+    m = torch.stack(margins, 1)[:, :seq.shape[1]]                      # (B, steps run)
+    alive = torch.ones_like(seq, dtype=torch.bool)
+    alive[:, 1:] = (seq[:, :-1] != 0).cummin(1).values                 # step t of a row counts while every earlier token was non-NULL
+    alive = alive[:, :m.shape[1]]
+    # (step 0 forbids NULL: its margin is between the two best non-NULL words only when NULL is not the arg-max; keep it simple and
+    #  report the margin over steps >= 1 plus the step-0 margin among non-NULL words separately if ever needed)
+    mm = float(m[:, 1:][alive[:, 1:]].min())
+    stops = (seq != 0).sum(1)
+    print('greedy: answer lengths min %d / median %d / max %d, smallest decisive margin %.3e' %
+          (int(stops.min()), int(stops.median()), int(stops.max()), mm))
+    G.save('f10_greedy_b64', seq=seq.to(torch.int16), seq_logp=lp, lengths=stops.to(torch.int16), min_margin=np.float64(mm))
+
+
+def main():
+    for T in (40, 90):
+        cfg, batch = wide_case(T)
+        train_case('f10_T%d' % T, cfg, batch)
+    cfg, batch = real_full_case()
+    train_case('f10_real_full', cfg, batch)
+    greedy()
+
+
+if __name__ == '__main__':
+    main()

@@ -152,3 +152,36 @@ def assert_sketch_close(names_json, ref_sk, named, tol, what=''):
     assert not bad, '%s: %d tensors off (name, projection err, chunk-norm err): %s' % (what, len(bad), bad[:6])
     extra = [k for k, v in got.items() if v is not None and k not in names]
     return extra, worst
+
+
+def sketch_errors(names_json, ref_sk, sk_of):
+    """name -> worst chunk error of ``sk_of(i, name)`` (a [SK_CHUNKS, 1 + SK_PROJ] sketch, or None to skip) against ``ref_sk[i]``,
+    relative to max(chunk norm, tensor norm / sqrt(chunks)); tensors whose reference norm is an exact zero in disguise are left out."""
+    names = json.loads(str(names_json))
+    norms = np.sqrt((ref_sk[:, :, 0] ** 2).sum(1))
+    floor = 1e-6 * float(np.median(norms))
+    out = {}
+    for i, k in enumerate(names):
+        sk = sk_of(i, k)
+        if sk is None or norms[i] <= floor:
+            continue
+        scale = np.maximum(ref_sk[i][:, 0], norms[i] / np.sqrt(SK_CHUNKS))[:, None]
+        out[k] = max(float((np.abs(sk[:, 1:] - ref_sk[i][:, 1:]) / scale).max()), float((np.abs(sk[:, 0] - ref_sk[i][:, 0]) / scale[:, 0]).max()))
+    return out
+
+
+def assert_no_farther_from_truth(g, named, what='', tol=1e-3, factor=3.0):
+    """A fixture with the reference's float32 gradient sketches (``grad_sketch``) AND its float64 run's (``grad_sketch_f64``): every
+    tensor of ``named`` must sit no farther from the float64 truth than max(tol, factor x the reference's own float32 error), chunk by
+    chunk.  Returns (worst name, its error, the reference's error there)."""
+    got = dict(named)
+    truth = g['grad_sketch_f64']
+    ref_err = sketch_errors(g['grad_names'], truth, lambda i, k: g['grad_sketch'][i])
+    mine = sketch_errors(g['grad_names'], truth, lambda i, k: tensor_sketch(got[k]) if got.get(k) is not None else None)
+    missing = [k for k in ref_err if k not in mine]
+    assert not missing, '%s: no gradient for %s' % (what, missing[:6])
+    bad = [(k, e, ref_err[k]) for k, e in mine.items() if e > max(tol, factor * ref_err[k])]
+    assert not bad, '%s: %d gradients farther from the float64 truth than the reference float32 path (name, err, reference err): %s' % (
+        what, len(bad), bad[:6])
+    k = max(mine, key=lambda n: mine[n] / max(tol, factor * ref_err[n]))
+    return k, mine[k], ref_err[k]

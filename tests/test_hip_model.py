@@ -490,7 +490,7 @@ def test_full_size_batch256_size_independent_properties():
         assert (p.grad is None) == dead, 'gradient liveness of %s' % k
 
 
-def _all_gradients_elementwise(cd, sp, Pcd, Psp, tol, what):
+def _all_gradients_elementwise(cd, sp, Pcd, Psp, tol, what, tol_for=None):
     """EVERY live parameter's gradient, element by element, against the oracle's: max |hip - oracle| <= tol * max |oracle| per tensor
     (a wrong gradient in any slice of any tensor fails, not just one that a sampled position happens to hit).  A parameter whose
     true gradient is exactly zero (key bias under a softmax, W2 bias under the batch softmax, the implicit label bias: noise around
@@ -525,7 +525,7 @@ def _all_gradients_elementwise(cd, sp, Pcd, Psp, tol, what):
         err = float((g - go).abs().max()) / scale
         if err > worst[1]:
             worst = (name, err)
-        if err > tol:
+        if err > (tol_for(name) if tol_for else tol):
             bad.append((name, err, scale))
     assert nzero <= 8, 'too many gradients treated as exact zeros (%d)' % nzero
     for name, gmax in dead:          # no gradient at all in the oracle (dead parameters, exact zeros): nothing but rounding noise here

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(hip.SIGNATURES), (declared ^ set(hip.SIGNATURES))
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.ekaid_version() == 8
+    assert lib.ekaid_version() == 9
 
 
 def test_ctypes_mirrors_have_the_layout_of_the_c_structs(tmp_path):

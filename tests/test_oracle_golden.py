@@ -10,7 +10,7 @@ import torch
 from common import FULL, SMALL, build_models, oracle_params, real_shape_case, small_models
 from ekaid_amd.config import bench_cfg
 from ekaid_amd.synthetic import make_batch
-from golden_util import assert_sketch_close, assert_summary_close, load_golden, negligible_grad_names, tensor_sketch
+from golden_util import assert_no_farther_from_truth, assert_sketch_close, assert_summary_close, load_golden, negligible_grad_names, tensor_sketch
 from oracle import ekaid_oracle as O
 
 TOL = 2e-5
@@ -324,3 +324,45 @@ def test_f4_float64_oracle_agrees_with_float64_reference():
     assert live.sum() >= 70 and rel[live].max() <= 5e-5, (np.array(names)[live][np.argsort(-rel[live])[:3]], rel[live].max())
     ref32 = np.abs(G[:, 0] - R[:, 0]) / R[:, 0].clip(1e-300)
     assert np.median(ref32[live]) > 20 * np.median(rel[live])        # the float32 reference is far noisier than the gap between the truths
+
+
+@pytest.mark.parametrize('case', ['T40', 'T90', 'real_full'])
+def test_f10_production_width_long_answers_and_real_shapes(case):
+    """Round-6 fixtures (tests/golden/make_wide_golden.py): the REFERENCE at the yaml widths with 40 / 90 decode steps and at the real
+    52 x 1024 shapes with ragged 2 ... 40-token answers -- the cases whose backward runs in the persistent decoder kernel on the GPU.
+    The oracle: loss, every log-prob, every gradient chunk by chunk."""
+    from common import real_full_case, wide_case
+    g = load_golden('f10_' + case)
+    cfg, batch = real_full_case() if case == 'real_full' else wide_case(int(case[1:]))
+    cd, sp = build_models(cfg, 147, 148, 'cpu')
+    loss, res, named = run_oracle(cfg, cd, sp, batch, 'mode2', 'all')
+    T = int(g['steps'])
+    assert T == int((batch['labels'][:, 1:] != 0).any(0).sum()) + 1
+    close(loss, g['loss'], what='loss')
+    close(res['logp'][:, :T], g['logp'], 5e-5, 'logp')
+    if res['logp'].shape[1] > T:
+        assert float(res['logp'][:, T:].detach().abs().max()) == 0.0          # steps after the break stay zero (:190-191, :213)
+    assert np.array_equal(res['logp'][:, :T].argmax(-1).numpy(), g['logp'].argmax(-1))
+    close(res['outs'][5], g['feat_diff'], 5e-5, 'feat_diff')
+    close(res['outs'][1], g['att_bef'], 5e-5, 'att_bef')
+    # gradients: the float64 run of the reference is the truth; the oracle (float32) must be as close to it as the reference's float32 run
+    worst = assert_no_farther_from_truth(g, named, 'gradient sketches [%s]' % case)
+    print('worst vs float64 truth: %s %.2e (reference float32: %.2e)' % worst)
+
+
+def test_f10_greedy_sample_at_batch_64_full_width():
+    """The reference's greedy `_sample` (dynamic_speaker_change_pos.py:287-357) at the production widths, batch 64, spread logits:
+    identical token ids and stop positions, seq_logprobs."""
+    from common import greedy_case
+    g = load_golden('f10_greedy_b64')
+    cfg, feats, scale, bias0 = greedy_case()
+    cd, sp = build_models(cfg, 147, 148, 'cpu')
+    Psp = oracle_params(sp)
+    Psp['logit.weight'] *= scale
+    Psp['logit.bias'][0] += bias0
+    with torch.no_grad():
+        seq, seq_lp = O.speaker_sample_greedy(Psp, cfg, feats[0], feats[1], feats[2])
+    assert float(g['min_margin']) > 5e-4, 'fixture decided by a rounding tie'
+    assert np.array_equal(seq.numpy(), g['seq'].astype(np.int64))
+    assert np.array_equal((seq != 0).sum(1).numpy(), g['lengths'].astype(np.int64))
+    close(seq_lp, g['seq_logp'], 5e-5, what='seq_logp')
