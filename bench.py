@@ -325,7 +325,8 @@ def per_gpu_ladder(cfg, cd, sp, opt, dev, graph, full_batch, T, ms_256, steps=40
             step = TrainStep(cfg, cd, sp, opt, graph, use_graph=True, comm='captured',
                              count_nodes=os.environ.get('EKAID_LADDER_NODES', '1') != '0')
             try:
-                ms = timed(lambda: step(b, T), steps, warmup)
+                st_load = []
+                ms = timed(lambda: step(b, T), steps, warmup, st_load)
                 nodes = step.node_counts
             finally:
                 step.close()
@@ -334,6 +335,7 @@ def per_gpu_ladder(cfg, cd, sp, opt, dev, graph, full_batch, T, ms_256, steps=40
                           'launches_per_step': (nodes or {}).get('kernel'), 'graph_nodes': nodes,
                           'roofline': {'bound': 'mfma', 'algorithmic_f32_tflops': round(tf, 3), 'algorithmic_peak_tflops': round(peak_alg, 1),
                                        'frac': round(tf / peak_alg, 4)},
+                          'clocks_under_load': st_load[0] if st_load else None,
                           'implied_speedup_before_link_time': round(ms_256 / ms, 3),
                           'implied_qa_pairs_per_s': round(256.0 / ms * 1e3, 1)})
     finally:
@@ -378,15 +380,49 @@ def streamed_step(step_fn, host_batch, dev, T, steps, compact, ms_resident):
             'layout': 'int8 N x N label matrices (compact device feed)' if compact else 'float64 100 x 100 label matrices (the reference layout)'}
 
 
-def timed(fn, steps, warmup):
+def timed(fn, steps, warmup, state=None):
+    """ms per call; ``state`` (a list) receives the device state read while the last calls are still running on the GPU."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
+    if state is not None:
+        state.append(device_state())
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e3
+
+
+def device_state(index=0):
+    """Shader / memory clock (MHz), package power (W) and junction temperature (C) of the GPU as sysfs shows them right now -- read while
+    timed work is still queued on the device, so a line says which power-management state it was taken in (the same build and box run the
+    replayed small steps at 2.40 or at 2.1 GHz: DESIGN.md section 8).  Fields the box does not expose are left out; never raises."""
+    import glob
+    out = {}
+    try:
+        cards = sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk'))
+        if not cards:
+            return {'note': 'no sysfs clock files'}
+        d = os.path.dirname(cards[min(index, len(cards) - 1)])
+        for key, name in (('sclk_mhz', 'pp_dpm_sclk'), ('mclk_mhz', 'pp_dpm_mclk')):
+            try:
+                cur = [ln for ln in open(os.path.join(d, name)) if '*' in ln]
+                if cur:
+                    out[key] = int(''.join(ch for ch in cur[0].split(':')[1] if ch.isdigit()))
+            except (OSError, ValueError, IndexError):
+                pass
+        for key, pat, div in (('power_w', 'hwmon/hwmon*/power1_average', 1e6), ('power_w', 'hwmon/hwmon*/power1_input', 1e6),
+                              ('freq1_mhz', 'hwmon/hwmon*/freq1_input', 1e6), ('temp_junction_c', 'hwmon/hwmon*/temp2_input', 1e3),
+                              ('temp_edge_c', 'hwmon/hwmon*/temp1_input', 1e3)):
+            for f in glob.glob(os.path.join(d, pat)):
+                try:
+                    out.setdefault(key, round(int(open(f).read()) / div, 1))
+                except (OSError, ValueError):
+                    pass
+    except Exception as e:                      # noqa: BLE001  (a diagnostic must not cost the bench line)
+        out['error'] = '%s: %s' % (type(e).__name__, str(e)[:80])
+    return out
 
 
 def spawn_ranks(n, timeout_s):
@@ -601,14 +637,25 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    state_idle = device_state(local_rank)
+    # the K timed steps are also cut into (up to) four windows by events recorded on the launch stream -- no synchronisation inside the
+    # timed region; their times are read afterwards: median / min / max per step say how steady the device was during the run
+    nwin = min(4, args.steps)
+    win_at = [args.steps * i // nwin for i in range(nwin + 1)]
+    win_ev = [torch.cuda.Event(enable_timing=True) for _ in range(nwin + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if i in win_at:
+            win_ev[win_at.index(i)].record()
         loss, _ = step(b, T)
+    win_ev[nwin].record()
+    state_load = device_state(local_rank)                       # (the GPU is still working through the queued steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    win_ms = [win_ev[i].elapsed_time(win_ev[i + 1]) / max(1, win_at[i + 1] - win_at[i]) for i in range(nwin)]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -838,6 +885,12 @@ def main():
             'unit': 'QA-pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'ms_per_step_windows': {'windows': nwin, 'median': round(sorted(win_ms)[len(win_ms) // 2], 3), 'min': round(min(win_ms), 3),
+                                    'max': round(max(win_ms), 3), 'all': [round(x, 3) for x in win_ms],
+                                    'note': 'the %d timed steps cut into %d windows by events on the launch stream (GPU time per step inside '
+                                            'the one timed region; value is the wall clock over all of them)' % (args.steps, nwin)},
+            'clocks': {'before_timed_loop': state_idle, 'end_of_timed_loop_under_load': state_load,
+                       'source': 'sysfs pp_dpm_sclk / pp_dpm_mclk / hwmon of the GPU, rank 0'},
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f32', 'gemm_arithmetic': 'bf16x3-exact-split (6 MFMA products, f32 accumulate)' if ops.get_gemm_mode() == ops.GEMM_BF16_SPLIT else 'f32-mfma',
             'data': 'synthetic',

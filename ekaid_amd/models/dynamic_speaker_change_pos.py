@@ -10,8 +10,9 @@ Same constructors, ``_forward`` / ``_sample`` / ``get_logprobs_state`` / ``get_m
   * the teacher-forced loop length is found with ONE host synchronisation instead of one per step (:213).
 Scheduled sampling (``ss_prob > 0``, :197-208; inactive with the shipped config, config.py:137) runs step by step through
 autograd with the token draw on the device (``ekaid_ss_tokens``).
-Not supported (outside the path): multinomial / constrained sampling in ``_sample`` (the entry points decode greedily), beam
-search (``beam_size > 1``: broken in the reference, :273).
+``_sample`` covers every branch of the reference loop (:287-357): greedy decoding as one C-ABI call per answer batch, multinomial
+sampling with ``temperature`` (:336-343) and the decoding constraint (:324-327) step by step through ``get_logprobs_state``.
+Not supported (outside the path): beam search (``beam_size > 1``: broken in the reference, :273).
 """
 import torch
 import torch.nn as nn
