@@ -42,6 +42,16 @@ import torch.distributed as dist  # noqa: E402
 
 
 
+ARITH_NAME = {0: 'f32-mfma', 1: 'bf16x3-exact-split', 2: 'f16x2 (large products) + bf16x3-exact-split (rest)'}
+
+
+def algorithmic_peak(mode):
+    """f32-algorithmic TFLOP/s the matrix pipe allows under a GEMM arithmetic: the f32 pipe itself, or the bf16 / f16 pipe divided by the
+    products executed per algorithmic product -- 6 for the exact split; 3 under EKAID_GEMM_F16X2 (its large products; the small ones still
+    execute 6, so this roof is on the high side and the fractions quoted against it on the low side)."""
+    return PEAK_F32_MFMA_TFLOPS if mode == 0 else PEAK_BF16_MFMA_TFLOPS / (6.0 if mode == 1 else 3.0)
+
+
 def flop_per_pair(N=36, D=2048, Lq=20, T=16, graph='all', train=True, A=1024, Q=1024, H=4):
     """Algorithmic work of one QA pair, SURVEY.md section 8(d) (the minimum that reproduces the reference's outputs: last direction only,
     context1/gate1 once, core.embed hoisted): multiply-adds of img 2NDA, question Lq 3(600 Q + Q^2) + Lq Q^2, per encoder and image
@@ -174,13 +184,14 @@ def cpu_baseline(cfg, cd, sp, batch_size, graph, budget_s=25.0):
         T = SHAPE['T']
         _, _, _, logp = forward_loss(cfg, cd, sp, bb, T, graph)
         from ekaid_amd import ops
-        logp_x2 = None
-        if ops.get_gemm_mode() == ops.GEMM_BF16_SPLIT:
-            ops.set_gemm_mode(ops.GEMM_BF16X2)
+        logp_x2, mode_now = None, ops.get_gemm_mode()
+        other = {ops.GEMM_BF16_SPLIT: ops.GEMM_F16X2, ops.GEMM_F16X2: ops.GEMM_BF16_SPLIT}.get(mode_now)
+        if other is not None:                       # the same forward on the other split arithmetic
+            ops.set_gemm_mode(other)
             try:
                 _, _, _, logp_x2 = forward_loss(cfg, cd, sp, bb, T, graph)
             finally:
-                ops.set_gemm_mode(ops.GEMM_BF16_SPLIT)
+                ops.set_gemm_mode(mode_now)
         cd.train(was[0])
         sp.train(was[1])
         ref = res['logp'][:, :T]
@@ -212,7 +223,7 @@ def cpu_baseline(cfg, cd, sp, batch_size, graph, budget_s=25.0):
     return {'value': round(batch_size / dt, 3), 'unit': 'QA-pairs/s', 'cores': cores, 'kind': 'port',
             'value_best': round(batch_size / times[0], 3), 'value_worst': round(batch_size / times[-1], 3), 'timed_iterations': iters,
             'eval_forward_pairs_per_s': round(batch_size / min(fwd_s), 3), 'parity_vs_hip': parity,
-            'parity_vs_hip_bf16x2': parity_x2,
+            'parity_vs_hip_other_arithmetic': dict(parity_x2, gemm_arithmetic=ARITH_NAME[other]) if parity_x2 is not None else None,
             'sample': 'CPU oracle (PyTorch %s, %d threads = physical cores of this host, %d logical) full train step '
                       '(forward + backward + torch.optim.Adam) at batch %d: %d timed iterations after 1 warm-up, value = the MEDIAN iteration; eval '
                       'forward at batch %d: best of 2; same shapes and weights as the GPU run, dropout off' % (
@@ -309,8 +320,7 @@ def per_gpu_ladder(cfg, cd, sp, opt, dev, graph, full_batch, T, ms_256, steps=40
     from ekaid_amd.engine import TrainStep
     from ekaid_amd.synthetic import slice_batch
     assert dist.is_initialized(), 'per_gpu_ladder runs in the --ladder-child process (world-1 RCCL communicator)'
-    split = ops.get_gemm_mode() == ops.GEMM_BF16_SPLIT
-    peak_alg = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_F32_MFMA_TFLOPS
+    peak_alg = algorithmic_peak(ops.get_gemm_mode())
     fpp = flop_per_pair(N=SHAPE['N'], D=SHAPE['D'], Lq=SHAPE['Lq'], T=T, graph=graph)
     rungs = []
     was_force = opt.force_comm
@@ -695,6 +705,10 @@ def main():
         # tile body, two products per grid: ekaid_gemm_pair_f32)
         big = [r for r in rec if r[2][6] == 2]
         big_ms, big_fl = sum(r[0] for r in big), sum(r[1] for r in big)
+        # executed matrix-pipe flops: every launch priced with the products it runs per algorithmic product (6: exact 3-way bf16 split,
+        # 3: two-term f16 split, 1: f32 pipe) -- under EKAID_GEMM_F16X2 the large products run the two-term split, the rest the exact one
+        big_ex, all_ex = sum(r[1] * r[2][7] for r in big), sum(r[1] * r[2][7] for r in rec)
+        n_x2 = sum(1 for r in big if r[2][7] == 3)
         if args.gemm_shapes:
             agg = {}
             for t_ms, f, shape in rec:
@@ -702,34 +716,45 @@ def main():
                 a[0] += t_ms
                 a[1] += f
                 a[2] += 1
-            print('%-44s %6s %9s %8s' % ('(tA,tB,M,N,K,batch,tile)', 'calls', 'ms/step', 'TFLOP/s'), file=sys.stderr)
+            print('%-48s %6s %9s %8s' % ('(tA,tB,M,N,K,batch,tile,executed)', 'calls', 'ms/step', 'TFLOP/s'), file=sys.stderr)
             for shape, (t_ms, f, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
-                print('%-44s %6d %9.3f %8.2f' % (shape, n // 2, t_ms / 2, f / (t_ms * 1e-3) / 1e12), file=sys.stderr)
+                print('%-48s %6d %9.3f %8.2f' % (shape, n // 2, t_ms / 2, f / (t_ms * 1e-3) / 1e12), file=sys.stderr)
         for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
             if n1 != 'start':
                 phases[n1] = round(phases.get(n1, 0.0) + e0.elapsed_time(e1) / 2, 3)
-        split = ops.get_gemm_mode() == ops.GEMM_BF16_SPLIT
-        # bf16-split arithmetic executes SIX bf16 MFMA products per algorithmic f32 product: the roofline is the bf16
-        # matrix pipe and `achieved` counts the executed bf16 flops; the f32-MFMA arithmetic is priced on the f32 pipe
-        mult, peak = (6.0, PEAK_BF16_MFMA_TFLOPS) if split else (1.0, PEAK_F32_MFMA_TFLOPS)
+        mode = ops.get_gemm_mode()
+        split = mode != ops.GEMM_F32_MFMA
+        # the split arithmetics run on the bf16 / f16 matrix pipe (same rate): `achieved` counts the EXECUTED matrix flops (6 or 3 per
+        # algorithmic flop, launch by launch); the f32-MFMA arithmetic is priced on the f32 pipe
+        peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
         alg_big = big_fl / (big_ms * 1e-3) / 1e12 if big else 0.0
         alg_all = fl / (ms * 1e-3) / 1e12
+        ex_big = big_ex / (big_ms * 1e-3) / 1e12 if big else 0.0
+        ex_all = all_ex / (ms * 1e-3) / 1e12
+        mult_big = big_ex / big_fl if big_fl else 1.0
+        mult_all = all_ex / fl if fl else 1.0
         fpp = flop_per_pair(N=SHAPE['N'], D=SHAPE['D'], Lq=SHAPE['Lq'], T=T, graph=args.graph)
         path_alg = fpp * per_gpu * args.steps / elapsed / 1e12
-        roof = {'bound': 'mfma',
-                'kernel': ('ekaid::gemm_split_kernel<.,.,2,2,32,1,.,3> + its two-products-per-grid form gemm_split_pair_kernel<.,.,true,3,.,.> '
-                           '(128x128 tiles; f32 operands split exactly into 3 bf16, 6 x v_mfma_f32_32x32x16_bf16 per product block, f32 accumulate)') if split else
-                          'ekaid::gemm_mfma_kernel<.,.,2,2,32> (v_mfma_f32_32x32x2_f32)',
-                'achieved': round(mult * alg_big, 3), 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': round(mult * alg_big / peak, 4), 'traffic': pmc_traffic() if split else None,
-                'executed_flop_per_algorithmic_flop': int(mult),
-                'algorithmic_f32_tflops': round(alg_big, 3), 'algorithmic_peak_tflops': round(peak / mult, 1),
-                'launches_per_step': len(big) // 2, 'avg_launch_us': round(big_ms / max(len(big), 1) * 1e3, 2),
+        kernel_name = {ops.GEMM_F16X2: 'ekaid::gemm_split_kernel<.,.,2,2,32,1,.,2> + its two-products-per-grid form gemm_split_pair_kernel<.,.,true,2,.,.> '
+                                       '(128x128 tiles; f32 operands scaled per row / column by powers of two and split into TWO f16 terms, 3 x '
+                                       'v_mfma_f32_32x32x16_f16 per product block, f32 accumulate) -- %d of the %d launches of the 128x128-tile family per '
+                                       'step; the rest (batched or bound-less products) on the exact 3-way bf16 split <.,.,2,2,32,1,.,3>' % (n_x2 // 2, len(big) // 2),
+                       ops.GEMM_BF16_SPLIT: 'ekaid::gemm_split_kernel<.,.,2,2,32,1,.,3> + its two-products-per-grid form gemm_split_pair_kernel<.,.,true,3,.,.> '
+                                            '(128x128 tiles; f32 operands split exactly into 3 bf16, 6 x v_mfma_f32_32x32x16_bf16 per product block, f32 accumulate)',
+                       ops.GEMM_F32_MFMA: 'ekaid::gemm_mfma_kernel<.,.,2,2,32> (v_mfma_f32_32x32x2_f32)'}[mode]
+        roof = {'bound': 'mfma', 'kernel': kernel_name,
+                'achieved': round(ex_big, 3), 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': round(ex_big / peak, 4), 'traffic': pmc_traffic() if split else None,
+                'executed_flop_per_algorithmic_flop': round(mult_big, 3),
+                'algorithmic_f32_tflops': round(alg_big, 3), 'algorithmic_peak_tflops': round(peak / mult_big, 1),
+                'launches_per_step': len(big) // 2, 'launches_on_the_two_term_split': n_x2 // 2,
+                'avg_launch_us': round(big_ms / max(len(big), 1) * 1e3, 2),
                 'kernel_ms_per_step': round(big_ms / 2, 3), 'kernel_flop_per_step': big_fl / 2,
                 'gemm_family': {'launches_per_step': len(rec) // 2, 'ms_per_step': round(ms / 2, 3),
                                 'flop_per_step': fl / 2, 'algorithmic_f32_tflops': round(alg_all, 3),
-                                'frac_of_peak': round(mult * alg_all / peak, 4)},
-                'whole_step': {'algorithmic_f32_tflops_per_gpu': round(path_alg, 3), 'frac_of_peak': round(path_alg * mult / peak, 4),
+                                'executed_flop_per_algorithmic_flop': round(mult_all, 3),
+                                'frac_of_peak': round(ex_all / peak, 4)},
+                'whole_step': {'algorithmic_f32_tflops_per_gpu': round(path_alg, 3), 'frac_of_peak': round(path_alg * mult_all / peak, 4),
                                'flop_per_pair': fpp, 'formula': 'bench.flop_per_pair(N=%d, D=%d, Lq=%d, T=%d, graph=%r): SURVEY.md 8(d)' % (
                                    SHAPE['N'], SHAPE['D'], SHAPE['Lq'], T, args.graph)}}
 
@@ -792,24 +817,24 @@ def main():
             'ms_resident': round(ms_res, 3),
             'compact': streamed_step(eager, host_batch, dev, T, 30, True, ms_res),
             'reference_layout': streamed_step(eager, host_batch, dev, T, 30, False, ms_res)}
-        # opt-in reduced-precision GEMM arithmetic (two bf16 terms per operand, three products): the same train step, NOT the
-        # metric's arithmetic -- reported beside it with its measured log-prob deviation (cpu_baseline.parity_vs_hip_bf16x2)
-        if ops.get_gemm_mode() == ops.GEMM_BF16_SPLIT:
-            ops.set_gemm_mode(ops.GEMM_BF16X2)
+        # the same train step on the OTHER split arithmetic (exact 3-way bf16 split <-> two-term f16 split for the large products), same box,
+        # same minute: what the arithmetic of `value` buys; its log-prob deviation is in cpu_baseline.parity_vs_hip_other_arithmetic
+        mode_now = ops.get_gemm_mode()
+        other = {ops.GEMM_BF16_SPLIT: ops.GEMM_F16X2, ops.GEMM_F16X2: ops.GEMM_BF16_SPLIT}.get(mode_now)
+        if other is not None:
+            ops.set_gemm_mode(other)
             try:
                 msx2 = timed(lambda: eager(b, T), 20, 3)
             finally:
-                ops.set_gemm_mode(ops.GEMM_BF16_SPLIT)
-            extra['train_b%d_bf16x2' % per_gpu] = {
-                'ms_per_step': round(msx2, 3), 'pairs_per_s': round(per_gpu / msx2 * 1e3, 1),
-                'workload': 'the timed train step on the OPT-IN bf16x2 GEMM arithmetic (EKAID_GEMM_MODE=bf16x2: 16-17 significant bits per '
-                            'operand, 3 MFMA products instead of 6); reduced precision, not comparable with `value`'}
+                ops.set_gemm_mode(mode_now)
+            extra['train_b%d_other_arithmetic' % per_gpu] = {
+                'gemm_arithmetic': ARITH_NAME[other], 'ms_per_step': round(msx2, 3), 'pairs_per_s': round(per_gpu / msx2 * 1e3, 1),
+                'workload': 'the timed train step with ekaid_set_gemm_mode(%d) instead of (%d), 20 eager steps' % (other, mode_now)}
         h90 = make_batch(B=per_gpu, seed=78, **dict(SHAPE, T=90))
         b90 = {k: v.to(dev) for k, v in h90.items()}
         T90 = DynamicSpeaker.count_steps(h90['labels'], SHAPE['seq_length'])
         ms90 = timed(lambda: eager(b90, T90), 8, 2)
-        split_now = ops.get_gemm_mode() == ops.GEMM_BF16_SPLIT
-        peak_alg = PEAK_BF16_MFMA_TFLOPS / 6.0 if split_now else PEAK_F32_MFMA_TFLOPS       # algorithmic f32 TFLOP/s the matrix pipe allows
+        peak_alg = algorithmic_peak(ops.get_gemm_mode())                # algorithmic f32 TFLOP/s the matrix pipe allows
         f90 = flop_per_pair(N=SHAPE['N'], D=SHAPE['D'], Lq=SHAPE['Lq'], T=T90, graph=args.graph)
         tf90 = f90 * per_gpu / (ms90 * 1e-3) / 1e12
         extra['train_T90'] = {'ms_per_step': round(ms90, 3), 'pairs_per_s': round(per_gpu / ms90 * 1e3, 1), 'decode_steps': T90,
@@ -892,7 +917,10 @@ def main():
             'clocks': {'before_timed_loop': state_idle, 'end_of_timed_loop_under_load': state_load,
                        'source': 'sysfs pp_dpm_sclk / pp_dpm_mclk / hwmon of the GPU, rank 0'},
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
-            'dtype': 'f32', 'gemm_arithmetic': 'bf16x3-exact-split (6 MFMA products, f32 accumulate)' if ops.get_gemm_mode() == ops.GEMM_BF16_SPLIT else 'f32-mfma',
+            'dtype': 'f32', 'gemm_arithmetic': {ops.GEMM_BF16_SPLIT: 'bf16x3-exact-split (6 MFMA products, f32 accumulate)',
+                                                ops.GEMM_F16X2: 'f16x2 two-term split with per-row / per-column power-of-two scales (3 MFMA products, f32 accumulate) for the '
+                                                                'products that carry operand bounds -- the large unbatched ones --, bf16x3-exact-split (6 products) for the rest',
+                                                ops.GEMM_F32_MFMA: 'f32-mfma'}[ops.get_gemm_mode()],
             'data': 'synthetic',
             'config': {'workload': '%s: synthetic %d-region x 2-image graphs, %d-d ROI features, 20-token questions, %d decode '
                                    'steps, graph=%s, train step (fwd+bwd+all-reduce+Adam), dropout %s' % (

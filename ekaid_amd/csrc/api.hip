@@ -46,9 +46,11 @@ static DeviceState g_dev[MAX_DEVICES];
 
 static int default_gemm_mode() {
     const char* m = getenv("EKAID_GEMM_MODE");       // "f32" / "0": f32 MFMA; "f16x2" / "2": two-term f16 split where operand bounds are given; default: exact split
-    if (m && (m[0] == 'f' || m[0] == '0')) return 0;
     if (m && (strcmp(m, "2") == 0 || strcmp(m, "f16x2") == 0)) return 2;
-    return 1;
+    if (m && (strcmp(m, "0") == 0 || strcmp(m, "f32") == 0)) return 0;
+    if (m && (strcmp(m, "1") == 0 || strcmp(m, "bf16x3") == 0)) return 1;
+    if (m && m[0]) fprintf(stderr, "libekaid_hip: unknown EKAID_GEMM_MODE '%s' (f32 | bf16x3 | f16x2): using the default\n", m);
+    return EKAID_GEMM_MODE_DEFAULT;
 }
 DeviceState& device_state() {
     int d = 0;

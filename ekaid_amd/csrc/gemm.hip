@@ -184,8 +184,12 @@ __device__ __forceinline__ void loader_mask(const TileLoader<NV>& L, f32x4* r, i
 }
 
 // epilogue shared by the MFMA kernels.  C/D map of the 32x32 MFMA: col = lane&31, row = (t&3) + 8*(t>>2) + 4*(lane>>5)
-template <int TM, int TN>
-__device__ __forceinline__ void write_tiles(const GemmArgs& g, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int r, int h, int z) {
+// sh (two-term f16 split only, else nullptr): LDS table of the power-of-two shifts the tile's BM rows and BN columns were scaled by; every
+// accumulator leaves the scaled domain as it is consumed (exact).  Read tile by tile: hoisted ahead of the stores, the 32 + 2 shifts of a
+// lane cost more registers than the 128x128 pair kernels have left (49 spilled VGPRs, 1500 scratch instructions: measured)
+template <int TM, int TN, bool RESCALE = false>
+__device__ __forceinline__ void write_tiles(const GemmArgs& g, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int r, int h, int z,
+                                            const int* sh = nullptr) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     const bool slab = g.splitk > 1 || g.slab_mode;
     float* C;
@@ -212,6 +216,18 @@ __device__ __forceinline__ void write_tiles(const GemmArgs& g, f32x16 (&acc)[TM]
                 const int mb = m0 + wm + 32 * i + 4 * h;
                 float* cp0 = C + (long long)mb * ldc + n;
                 float cold[16], postv[16], pre[16];              // the operands of this lane's 16 elements, all requested before the first store
+                f32x16 tile = acc[i][jj];
+                if constexpr (RESCALE) {
+                    const int sb = sh[BM + wn + 32 * jj + r];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {                // rows 4h + 8q .. + 3 of the tile: four consecutive table entries
+                        const int4 sa = *reinterpret_cast<const int4*>(&sh[wm + 32 * i + 4 * h + 8 * q]);
+                        tile[4 * q + 0] = ldexpf(tile[4 * q + 0], -(sa.x + sb));
+                        tile[4 * q + 1] = ldexpf(tile[4 * q + 1], -(sa.y + sb));
+                        tile[4 * q + 2] = ldexpf(tile[4 * q + 2], -(sa.z + sb));
+                        tile[4 * q + 3] = ldexpf(tile[4 * q + 3], -(sa.w + sb));
+                    }
+                }
                 const bool has_cold = !slab && g.e.beta, has_post = !slab && g.e.post, has_res = !slab && g.e.R;
                 const float* pp0 = has_post ? g.e.post + (long long)mb * g.e.ldpost + n : nullptr;
                 const float bias = (!slab && g.e.bias) ? g.e.bias[n] : 0.f;
@@ -228,7 +244,7 @@ __device__ __forceinline__ void write_tiles(const GemmArgs& g, f32x16 (&acc)[TM]
                     const int dm = (t & 3) + 8 * (t >> 2);
                     if (CHECK && mb + dm >= g.M) continue;
                     float* cp = cp0 + (long long)dm * ldc;
-                    *cp = slab ? acc[i][jj][t] : epilogue(acc[i][jj][t], cold[t], pre[t], postv[t], seed, mb + dm, n, g.e, alpha);
+                    *cp = slab ? tile[t] : epilogue(tile[t], cold[t], pre[t], postv[t], seed, mb + dm, n, g.e, alpha);
                 }
             }
     };
@@ -981,26 +997,19 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
         else if constexpr (PIPE) pipelined();
         else mainloop(std::true_type{});
     }
+    const int* sh_tab = nullptr;
     if constexpr (NP == 2) {
-        // back from the scaled domain: element (m, n) carries 2^(shift of row m + shift of column n), exact powers of two.  The shifts
-        // of the tile's rows and columns go through LDS (free: the last stage has been multiplied out)
-        int* const sh = reinterpret_cast<int*>(lds);
+        // the shifts of the tile's rows and columns, for write_tiles, through LDS (free: the last stage has been multiplied out).  Kept
+        // behind the A-row-sum scratch of the weight-gradient form (GR * BM floats from the start of the LDS)
+        int* const sh = reinterpret_cast<int*>(lds) + (ASUM ? (256 / (BM / 4)) * BM : 0);
         __syncthreads();
         for (int t = tid; t < BM + BN; t += 256) {
             const bool isA = t < BM;
             const int idx = isA ? m0 + t : n0 + (t - BM);
             sh[t] = (idx < (isA ? g.M : g.N)) ? f16_shift((isA ? g.a_amax : g.b_amax)[idx]) : 0;
         }
+        sh_tab = sh;
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int sb = sh[BM + wn + 32 * j + r];
-#pragma unroll
-                for (int t = 0; t < 16; ++t)
-                    acc[i][j][t] = ldexpf(acc[i][j][t], -(sh[wm + 32 * i + 4 * h + (t & 3) + 8 * (t >> 2)] + sb));
-            }
     }
     if constexpr (ASUM) if (do_asum) {
         // the 256 / (BM / 4) threads that staged the same four rows are added up through LDS in thread order (deterministic)
@@ -1016,7 +1025,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmArgs& g, const int blo
             else g.asum[m0 + tid] += sum;
         }
     }
-    write_tiles<TM, TN>(g, acc, m0, n0, wm, wn, r, h, z);
+    write_tiles<TM, TN, NP == 2>(g, acc, m0, n0, wm, wn, r, h, z, sh_tab);
 }
 
 template <bool A_KC, bool B_KC, int TM, int TN, int KB, int PF, bool PIPE, int NP = 3, bool ASUM = false>
@@ -1034,6 +1043,22 @@ template <bool A_KC, bool B_KC, bool BIG, int NP = 3, bool ASUM = false, bool PI
 __global__ __launch_bounds__(256, BIG ? EKAID_SPLIT_OCC_BIG : EKAID_SPLIT_OCC_SMALL) void gemm_split_pair_kernel(GemmArgs g0, GemmArgs g1) {
     const int n0 = g0.tiles_m * g0.tiles_n;
     const bool first = (int)blockIdx.x < n0;
+    if constexpr (NP == 2) {
+        // two inlined copies of the tile body, each reading ITS problem straight from the kernel arguments: with one body working on
+        // `first ? g0 : g1` every field is a select between two argument blocks held in scalar registers, and the two-term kernels -- four
+        // more pointers, the scale tables -- ran out of them (100 SGPRs, then 23-49 spilled VGPRs and ~1500 scratch instructions in the
+        // epilogue: the pairs ran SLOWER than two solo launches)
+        if (first) {
+            if ((int)blockIdx.z >= g0.splitk) return;
+            if constexpr (BIG) gemm_split_body<A_KC, B_KC, 2, 2, 32, 1, PIPE, NP, ASUM>(g0, blockIdx.x, blockIdx.z);
+            else gemm_split_body<A_KC, B_KC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL, EKAID_SPLIT_PIPE_SMALL, NP, ASUM>(g0, blockIdx.x, blockIdx.z);
+        } else {
+            if ((int)blockIdx.z >= g1.splitk) return;
+            if constexpr (BIG) gemm_split_body<A_KC, B_KC, 2, 2, 32, 1, PIPE, NP, ASUM>(g1, blockIdx.x - n0, blockIdx.z);
+            else gemm_split_body<A_KC, B_KC, 1, 1, EKAID_SPLIT_KB_SMALL, EKAID_SPLIT_PF_SMALL, EKAID_SPLIT_PIPE_SMALL, NP, ASUM>(g1, blockIdx.x - n0, blockIdx.z);
+        }
+        return;
+    }
     const GemmArgs& g = first ? g0 : g1;
     if ((int)blockIdx.z >= g.splitk) return;
     const int bx = first ? blockIdx.x : blockIdx.x - n0;
@@ -1448,7 +1473,7 @@ static bool use_x2(const GemmArgs& a) { return gemm_mode() == 2 && a.a_amax != n
 static int launch_product(const GemmArgs& a, int TMN, bool akc, bool bkc, int batch, hipStream_t st) {
     int rc;
     if (gemm_mode() >= 1 && TMN >= 1 && TMN <= 4) {
-        const bool x2 = use_x2(a);
+        const bool x2 = use_x2(a) && batch == 1;          // (the bound vectors have no batch strides)
         rc = x2 ? split_dispatch_x2(a, TMN, akc, bkc, batch, st) : split_dispatch<3>(a, TMN, akc, bkc, batch, st);
         count_launch(x2 ? EKAID_COUNT_GEMM_SPLIT2 : EKAID_COUNT_GEMM_SPLIT3);
     } else {
@@ -1496,7 +1521,7 @@ static int pair_dispatch(const GemmArgs& a0, const GemmArgs& a1, bool big, bool 
     return akc && bkc ? launch_pair<true, true, false, NP>(a0, a1, st)
          : akc && !bkc ? launch_pair<true, false, false, NP>(a0, a1, st) : launch_pair<false, false, false, NP>(a0, a1, st);
 }
-#ifdef EKAID_GEMM_X2_TU
+#if defined(EKAID_GEMM_X2_TU) && !defined(EKAID_ONE_KERNEL_TU)      // (EKAID_ONE_KERNEL_TU: tools' single-instantiation builds)
 int split_dispatch_x2(const GemmArgs& a, int TMN, bool akc, bool bkc, int batch, hipStream_t st) { return split_dispatch<2>(a, TMN, akc, bkc, batch, st); }
 int pair_dispatch_x2(const GemmArgs& a0, const GemmArgs& a1, bool big, bool akc, bool bkc, hipStream_t st) { return pair_dispatch<2>(a0, a1, big, akc, bkc, st); }
 #endif

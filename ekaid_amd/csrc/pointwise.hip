@@ -847,14 +847,28 @@ extern "C" int ekaid_wn_scale_multi(const float* const* v, const float* const* g
 // ---- row and column maxima of |x| for up to AMAX_MAX row-strided matrices in one launch: the operand bounds of the two-term f16
 // GEMM split (ekaid_gemm_t.a_amax / b_amax).  |x| as an unsigned bit pattern orders like the value and an integer max does not depend
 // on arrival order: deterministic.  A NaN element has the largest pattern of all, so it surfaces in the bound (the consumer then
-// leaves that row unscaled).  One workgroup owns RB whole rows (row maxima: plain stores); column maxima: one atomic per thread,
-// column and workgroup into the zeroed output.
+// leaves that row unscaled).  One workgroup owns RB whole rows, each of its four waves RB / 4 of them: a wave walks a row in 1024-column
+// spans (four 16-byte loads per lane and row, four rows in flight), keeps the running maximum of each of its rows in a register and
+// reduces it across the lanes ONCE per row (DPP), and keeps the column maxima of its lanes' columns in registers; per span the four
+// waves' column maxima meet in LDS and leave as one atomic per column and workgroup into the zeroed output.
 constexpr int AMAX_MAX = 32;
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 struct AmaxMulti { const float* x[AMAX_MAX]; long long rows[AMAX_MAX]; int cols[AMAX_MAX]; int ld[AMAX_MAX]; unsigned* rowmax[AMAX_MAX]; unsigned* colmax[AMAX_MAX]; int count; };
+// max over the 64 lanes of a wave, valid in lane 63 (max is idempotent: any exchange pattern that reaches every lane will do)
+__device__ __forceinline__ unsigned wave_max_u32_lane63(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));     // row_half_mirror
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));     // row_mirror: every lane = its row of 16
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true));     // row_bcast15 into rows 1, 3
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true));     // row_bcast31 into rows 2, 3
+    return v;
+}
 template <int RB>
 __global__ __launch_bounds__(256) void amax_rc_kernel(AmaxMulti a) {
-    __shared__ unsigned racc[RB];
+    constexpr int RW = RB / 4;                            // rows per wave
+    constexpr int SPAN = 1024;                            // columns per span: 4 chunks of 64 lanes x 4 floats
+    __shared__ unsigned cmax[4][SPAN];
     const int t = blockIdx.y;
     const long long rows = a.rows[t], r0 = (long long)blockIdx.x * RB;
     if (r0 >= rows) return;
@@ -862,48 +876,66 @@ __global__ __launch_bounds__(256) void amax_rc_kernel(AmaxMulti a) {
     const int cols = a.cols[t], ld = a.ld[t];
     unsigned* const rowmax = a.rowmax[t];
     unsigned* const colmax = a.colmax[t];
-    const int tid = threadIdx.x, lane = tid & 63;
-    if (tid < RB) racc[tid] = 0;
-    __syncthreads();
-    const int c4n = cols >> 2;
-    const int c4pad = (c4n + 63) & ~63;                  // whole waves take part in the row reductions
-    const int nr = (int)((rows - r0) < RB ? (rows - r0) : RB);
-    for (int c4 = tid; c4 < c4pad; c4 += 256) {
-        const bool ok = c4 < c4n;
-        const float* p = x + r0 * ld + 4 * (ok ? c4 : 0);
-        unsigned cm[4] = {0, 0, 0, 0};
-        for (int rb = 0; rb < nr; rb += 4) {
-            u32x4_t v[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned rm[RW];
+#pragma unroll
+    for (int j = 0; j < RW; ++j) rm[j] = 0;
+    for (int col0 = 0; col0 < cols; col0 += SPAN) {
+        unsigned cm[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cm[c][e] = 0;
+        bool ok[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ok[c] = col0 + 256 * c + 4 * lane < cols;
+#pragma unroll
+        for (int j0 = 0; j0 < RW; j0 += 4) {
+            u32x4_t v[4][4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int r = rb + u < nr ? rb + u : nr - 1;                      // (clamped: a repeated row changes no maximum)
-                v[u] = *reinterpret_cast<const u32x4_t*>(p + (long long)r * ld);
+                long long row = r0 + wave + 4 * (j0 + u);
+                row = row < rows ? row : rows - 1;                                    // (clamped: a repeated row changes no maximum ...
+                const float* p = x + row * ld + col0 + 4 * lane;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[u][c] = ok[c] ? *reinterpret_cast<const u32x4_t*>(p + 256 * c) : u32x4_t{0, 0, 0, 0};
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
+                const bool mine = r0 + wave + 4 * (j0 + u) < rows;                    // ... of a column; its row maximum is not stored)
                 unsigned m = 0;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned av = ok ? (v[u][e] & 0x7FFFFFFFu) : 0u;
-                    cm[e] = max(cm[e], av);
-                    m = max(m, av);
-                }
-                if (rowmax) {
+                for (int c = 0; c < 4; ++c)
 #pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
-                    if (lane == 0 && m && rb + u < nr) atomicMax(&racc[rb + u], m);
-                }
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned av = v[u][c][e] & 0x7FFFFFFFu;
+                        cm[c][e] = max(cm[c][e], av);
+                        m = max(m, av);
+                    }
+                if (mine) rm[j0 + u] = max(rm[j0 + u], m);
             }
         }
-        if (ok && colmax) {
+        if (colmax) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (cm[e]) atomicMax(colmax + 4 * c4 + e, cm[e]);
+            for (int c = 0; c < 4; ++c)
+                *reinterpret_cast<u32x4_t*>(&cmax[wave][256 * c + 4 * lane]) = u32x4_t{cm[c][0], cm[c][1], cm[c][2], cm[c][3]};
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < SPAN / 256; ++q) {
+                const int cc = tid + 256 * q;
+                const unsigned m = max(max(cmax[0][cc], cmax[1][cc]), max(cmax[2][cc], cmax[3][cc]));
+                if (m && col0 + cc < cols) atomicMax(colmax + col0 + cc, m);
+            }
+            __syncthreads();
         }
     }
     if (rowmax) {
-        __syncthreads();
-        if (tid < nr) rowmax[r0 + tid] = racc[tid];
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+            const unsigned m = wave_max_u32_lane63(rm[j]);
+            const long long row = r0 + wave + 4 * j;
+            if (lane == 63 && row < rows) rowmax[row] = m;
+        }
     }
 }
 extern "C" int ekaid_amax_rc_multi(const float* const* x, const long long* rows, const int* cols, const int* ld, float* const* rowmax,
@@ -929,10 +961,10 @@ extern "C" int ekaid_amax_rc_multi(const float* const* x, const long long* rows,
             hipMemsetAsync(colmax[i], 0, sizeof(float) * cols[i], ST) != hipSuccess) { (void)hipGetLastError(); set_error("amax_rc_multi: memset failed"); return EKAID_ERR_LAUNCH; }
     }
     if (rmax == 0) return EKAID_OK;
-    if (rmax >= 8192) {
+    if (rmax >= 4096) {
         hipLaunchKernelGGL(amax_rc_kernel<32>, dim3((unsigned)((rmax + 31) / 32), count), dim3(256), 0, ST, a);
     } else {
-        hipLaunchKernelGGL(amax_rc_kernel<8>, dim3((unsigned)((rmax + 7) / 8), count), dim3(256), 0, ST, a);
+        hipLaunchKernelGGL(amax_rc_kernel<16>, dim3((unsigned)((rmax + 15) / 16), count), dim3(256), 0, ST, a);
     }
     return check_launch("amax_rc_multi");
 }

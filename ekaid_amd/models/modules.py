@@ -180,6 +180,15 @@ class ChangeDetector(nn.Module):
         wn = self._wn_layers(setting, graph)
         if wn and input_1.is_cuda:
             ops.wn_prepare(wn)
+        if input_1.is_cuda and ops.get_gemm_mode() == ops.GEMM_F16X2:
+            # two-term f16 GEMM split: the row / column maxima of every weight this call multiplies with, one launch per 32 weights
+            plain = [self.img.weight, self.context1.weight, self.context2.weight, self.gate1.weight, self.gate2.weight, self.embed[0].weight]
+            live_v = {v.data_ptr() for v, _ in wn}
+            for _, m in self.named_modules():             # linear_out_2 of the graph-attention layers whose query / key run (same liveness)
+                lo = getattr(m, 'linear_out_2', None)
+                if lo is not None and getattr(m, 'query', None) is not None and any(p.data_ptr() in live_v for p in m.query.parameters()):
+                    plain.append(lo.weight)
+            ops.weight_bounds_prepare([v for v, _ in wn] + plain)
 
         # both images through the shared ROI projection, stacked: rows [0, B*N) = main, [B*N, 2*B*N) = reference
         x = ops.linear_rowstack((input_1, input_2), self.img.weight, self.img.bias).view(2 * B, N, A)
@@ -235,6 +244,7 @@ class ChangeDetector(nn.Module):
         input_attended = ops.sub(attended_2, attended_1)
         pred = self.fc1(input_attended)
         ops.wn_release()
+        ops.weight_bounds_release()
         return pred, att_b.view(B, 1, N), att_a.view(B, 1, N), attended_1, attended_2, input_attended
 
 

@@ -47,8 +47,8 @@ def assert_finite(t, what):
 
 def set_gemm_mode(mode):
     """Arithmetic of every GEMM on the path (include/ekaid_hip.h: ekaid_set_gemm_mode): GEMM_F32_MFMA, GEMM_BF16_SPLIT
-    (exact 3-way bf16 split, six bf16 MFMA products, f32 accumulation; the default) or GEMM_BF16X2 (opt-in, reduced
-    precision: two bf16 terms per operand, three products)."""
+    (exact 3-way bf16 split, six bf16 MFMA products, f32 accumulation) or GEMM_F16X2 (the products whose call site supplies operand
+    bounds run as the two-term f16 split, three MFMA products; every other product as GEMM_BF16_SPLIT)."""
     hip.check(hip.lib().ekaid_set_gemm_mode(int(mode)), 'set_gemm_mode')
 
 
@@ -129,6 +129,13 @@ def grad_out(W, zero=False):
     return torch.zeros_like(W) if zero else torch.empty_like(W)
 
 
+def in_grad_slot(t, param):
+    """Is ``t`` the flat-buffer slot of ``param`` (the view ``grad_out`` hands out when it claims the slot)?  Only such a buffer outlives
+    its backward node: autograd adopts it as ``param.grad`` without copying, so a kernel launched LATER in the pass may still write it."""
+    ent = _grad_slots.get(param.data_ptr())
+    return ent is not None and param.data_ptr() in _grad_claimed and t.data_ptr() == ent[1].data_ptr() + 4 * ent[2] and t.numel() == ent[3]
+
+
 def bias_grad_slot(b):
     """(buffer the bias gradient is accumulated into -- the bias' zeroed slot of the flat gradient buffer --, what the backward
     node hands to autograd for it).  The buffer goes to ``gemm(..., a_rowsum=)`` of the layer's weight-gradient product, whose
@@ -173,6 +180,61 @@ def amax_rc(x, rows, cols, ld, off=0, want_rows=True, want_cols=True):
     cm = torch.empty(cols, device=x.device, dtype=torch.float32) if want_cols else None
     check(hip.lib().ekaid_amax_rc(x.data_ptr() + 4 * off, rows, cols, ld, ptr(rm), ptr(cm), stream()), 'amax_rc')
     return rm, cm
+
+
+F16X2_MIN_WORK = int(os.environ.get('EKAID_F16X2_MIN_WORK', 1 << 28))      # M * N * K below which a product is not worth its bounds pass
+
+
+def f16x2_wanted(M, N, K):
+    """Should the call site of an M x N x K product compute operand bounds for the two-term f16 split?  (Mode 2 only; small products
+    stay on the exact split: a bounds pass is a launch of its own.)"""
+    return get_gemm_mode() == GEMM_F16X2 and M * N * K >= F16X2_MIN_WORK and min(M, N, K) >= 32
+
+
+_wb_cache = {}           # weight data_ptr -> (row maxima [N], column maxima [K]) for the current step (weight_bounds_prepare / _release)
+
+
+def weight_bounds_prepare(weights):
+    """Row / column maxima of every 2-D weight in ``weights`` in ONE launch per 32 (the layers pick them up through ``weight_bounds``);
+    valid until ``weight_bounds_release`` -- the weights do not change inside a step."""
+    _wb_cache.clear()
+    if get_gemm_mode() != GEMM_F16X2:
+        return
+    ws = [w for w in weights if w.dim() == 2 and w.is_contiguous() and not (w.shape[1] & 3) and not (w.data_ptr() & 15) and w.numel() >= (1 << 14)]
+    L = hip.lib()
+    for i0 in range(0, len(ws), 32):
+        chunk = ws[i0:i0 + 32]
+        n = len(chunk)
+        dev = chunk[0].device
+        tot_r, tot_c = sum(w.shape[0] for w in chunk), sum(w.shape[1] for w in chunk)
+        buf = torch.empty(tot_r + tot_c, device=dev, dtype=torch.float32)
+        rms, cms, o = [], [], 0
+        for w in chunk:
+            rms.append(buf[o:o + w.shape[0]])
+            o += w.shape[0]
+        for w in chunk:
+            cms.append(buf[o:o + w.shape[1]])
+            o += w.shape[1]
+        xs = (ctypes.c_void_p * n)(*[w.data_ptr() for w in chunk])
+        rows = (ctypes.c_longlong * n)(*[w.shape[0] for w in chunk])
+        cols = (ctypes.c_int * n)(*[w.shape[1] for w in chunk])
+        rp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in rms])
+        cp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in cms])
+        check(L.ekaid_amax_rc_multi(xs, rows, cols, cols, rp, cp, n, stream()), 'amax_rc_multi')
+        for w, r, c in zip(chunk, rms, cms):
+            _wb_cache[w.data_ptr()] = (r, c)
+
+
+def weight_bounds_release():
+    _wb_cache.clear()
+
+
+def weight_bounds(W):
+    """(row maxima, column maxima) of the 2-D weight ``W``: the prepared ones, else one launch."""
+    ent = _wb_cache.get(W.data_ptr())
+    if ent is not None and ent[0].numel() == W.shape[0] and ent[1].numel() == W.shape[1]:
+        return ent
+    return amax_rc(W, W.shape[0], W.shape[1], W.shape[1])
 
 
 def seq_in_c():
@@ -245,9 +307,18 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, **kw):
         nb = batch[0] * batch[1]
         tile, sk = ctypes.c_int(0), ctypes.c_int(1)
         check(L.ekaid_gemm_plan_query(ctypes.byref(d), ctypes.byref(tile), ctypes.byref(sk)), 'gemm_plan_query')
-        prof.append((e0, e1, 2.0 * M * N * K * nb, (int(transA), int(transB), M, N, K, nb, tile.value)))
+        prof.append((e0, e1, 2.0 * M * N * K * nb, (int(transA), int(transB), M, N, K, nb, tile.value, _executed_per_product(kw, nb))))
     if a_rowsum is not None and not _BIAS_IN_WGRAD:          # A/B knob: the column sums as their own launches
         check(L.ekaid_colsum_acc(d.A, K, M, lda, ptr(a_rowsum), stream()), 'colsum_acc')
+
+
+def _executed_per_product(kw, nb):
+    """Matrix-pipe products the library executes per algorithmic product for a launch with these keyword arguments: 1 on the f32 pipe,
+    6 for the exact 3-way bf16 split, 3 for the two-term f16 split (mode 2, both operand bounds given, unbatched: csrc/gemm.hip use_x2)."""
+    mode = get_gemm_mode()
+    if mode == GEMM_F32_MFMA:
+        return 1
+    return 3 if (mode == GEMM_F16X2 and nb == 1 and kw.get('a_amax') is not None and kw.get('b_amax') is not None) else 6
 
 
 def gemm_pair(g0, g1):
@@ -267,7 +338,9 @@ def gemm_pair(g0, g1):
         tile, sk = ctypes.c_int(0), ctypes.c_int(1)
         check(L.ekaid_gemm_plan_query(ctypes.byref(d0), ctypes.byref(tile), ctypes.byref(sk)), 'gemm_plan_query')
         (_, _, _, M0, N0, K0, _, _, _, tA, tB), (_, _, _, M1, N1, K1) = g0[0], g1[0][:6]
-        _prof_end(e0, 2.0 * (M0 * N0 * K0 + M1 * N1 * K1), (int(tA), int(tB), M0, N0 + N1, K0, 1, tile.value))
+        both = dict(a_amax=g0[1].get('a_amax') if g1[1].get('a_amax') is not None else None,
+                    b_amax=g0[1].get('b_amax') if g1[1].get('b_amax') is not None else None)
+        _prof_end(e0, 2.0 * (M0 * N0 * K0 + M1 * N1 * K1), (int(tA), int(tB), M0, N0 + N1, K0, 1, tile.value, _executed_per_product(both, 1)))
 
 
 def deferred_call(fn):
@@ -412,7 +485,7 @@ def gemm_slabs(A, B, M, N, K, lda, ldb, transA, transB, a_off=0, b_off=0):
     buf = torch.empty(n * M * N, device=A.device, dtype=torch.float32)
     e0 = _prof_begin()
     check(L.ekaid_gemm_slabs(ctypes.byref(d), ptr(buf), buf.numel() * 4, stream()), 'ekaid_gemm_slabs')
-    _prof_end(e0, 2.0 * M * N * K, (int(transA), int(transB), M, N, K, 1, 1))
+    _prof_end(e0, 2.0 * M * N * K, (int(transA), int(transB), M, N, K, 1, 1, _executed_per_product({}, 1)))
     return SlabSet(buf, n, M, N)
 
 
@@ -433,7 +506,7 @@ def gemm_slabs2(g0, g1):
     check(L.ekaid_gemm_slabs2(ctypes.byref(ds[0]), ptr(bufs[0]), bufs[0].numel() * 4, ctypes.byref(ds[1]), ptr(bufs[1]),
                               bufs[1].numel() * 4, stream()), 'ekaid_gemm_slabs2')
     _prof_end(e0, 2.0 * (g0[2] * g0[3] * g0[4] + g1[2] * g1[3] * g1[4]),
-              (int(g0[7]), int(g0[8]), g0[2], g0[3] + g1[3], g0[4], 2, 1))
+              (int(g0[7]), int(g0[8]), g0[2], g0[3] + g1[3], g0[4], 2, 1, _executed_per_product({}, 1)))
     return outs[0], outs[1]
 
 
@@ -540,8 +613,9 @@ def gemm_profile_begin():
 
 
 def gemm_profile_end():
-    """Stop collecting; returns [(milliseconds, flops, (transA, transB, M, N, K, batch, tile))] (synchronises); tile = the kernel
-    instantiation the planner chose (ekaid_gemm_plan_query: 2 = 128x128 tiles, 1 = 64x64, 3 / 4 = 128x64 / 64x128, 0 = tall-skinny)."""
+    """Stop collecting; returns [(milliseconds, flops, (transA, transB, M, N, K, batch, tile, executed))] (synchronises); tile = the kernel
+    instantiation the planner chose (ekaid_gemm_plan_query: 2 = 128x128 tiles, 1 = 64x64, 3 / 4 = 128x64 / 64x128, 0 = tall-skinny);
+    executed = matrix-pipe products per algorithmic product (1 f32 pipe, 6 exact bf16 split, 3 two-term f16 split)."""
     global _gemm_profile
     rec, _gemm_profile = _gemm_profile, None
     torch.cuda.synchronize()
@@ -604,6 +678,10 @@ class LinearFn(Function):
         assert sum(x.shape[1] for x in xs2) == Ktot, 'input widths do not add up to in_features'
         y = torch.empty(M, N, device=W.device, dtype=torch.float32)
         Wt = weight_transposed(W) if _use_transposed(M) else None
+        # two-term f16 split (mode 2): row / column maxima of every operand, taken once here and reused by the backward products
+        x2 = f16x2_wanted(M, N, min(x.shape[1] for x in xs2))
+        ctx.wb = weight_bounds(W) if x2 else (None, None)
+        ctx.xb = [amax_rc(x, M, x.shape[1], ld) if x2 else (None, None) for x, ld in zip(xs2, lds)]
         off = 0
         for i, (x, ld) in enumerate(zip(xs2, lds)):
             last = i == len(xs2) - 1
@@ -613,7 +691,7 @@ class LinearFn(Function):
                      bias=b if last else None, act=act if last else ACT_NONE, b_off=off * N)
             else:
                 gemm(x, W, y, M, N, K, ld, Ktot, N, 0, 1, alpha_dev=scale, accumulate=i > 0,
-                     bias=b if last else None, act=act if last else ACT_NONE, b_off=off)
+                     bias=b if last else None, act=act if last else ACT_NONE, b_off=off, a_amax=ctx.xb[i][0], b_amax=ctx.wb[0])
             off += K
         ctx.act = act
         ctx.has_b = b is not None
@@ -638,6 +716,8 @@ class LinearFn(Function):
         else:
             dz = dy
         need = ctx.needs_input_grad
+        # (mode 2: the bounds of dz serve both gradient products -- its row maxima the input gradient, its column maxima the weight gradient)
+        dzb = amax_rc(dz, M, N, N) if ctx.wb[0] is not None else (None, None)
         db = db_buf = None
         if ctx.has_b and need[1]:
             db_buf, db = bias_grad_slot(ctx.bias_ref)          # filled by the first weight-gradient product below
@@ -654,7 +734,8 @@ class LinearFn(Function):
                 if slot is not None and slot.lent is not None and slot.lent.numel() == dx.numel():
                     post, slot.lent = slot.lent, None
                 dgrads.append(((dz, W, dx, M, K, N, N, Ktot, K, 0, 0), dict(alpha_dev=scale, b_off=off, drop_p=float(pd), drop_seed=ctx.seeds[i],
-                                                                            post=post, ldpost=K)))          # input-dropout backward in the epilogue
+                                                                            post=post, ldpost=K, a_amax=dzb[0],
+                                                                            b_amax=(ctx.wb[1], off) if ctx.wb[1] is not None else None)))          # input-dropout backward in the epilogue
                 dxs.append(lend_grad(slot, dx.view(*ctx.lead[i], K)))
             else:
                 dxs.append(None)
@@ -665,9 +746,9 @@ class LinearFn(Function):
             dW = grad_out(W)
             off = 0
             wgrads = []
-            for x, ld in zip(xs2, ctx.lds):
+            for (x, ld), xb in zip(zip(xs2, ctx.lds), ctx.xb):
                 K = x.shape[1]
-                wgrads.append(((dz, x, dW, N, K, M, N, ld, Ktot, 1, 0), dict(c_off=off, a_rowsum=db_buf)))
+                wgrads.append(((dz, x, dW, N, K, M, N, ld, Ktot, 1, 0), dict(c_off=off, a_rowsum=db_buf, a_amax=dzb[1], b_amax=xb[1])))
                 db_buf = None
                 off += K
             _launch_group(wgrads)
@@ -676,11 +757,21 @@ class LinearFn(Function):
                 # launches (was: dot + scale, then a third pass for the norm's own backward)
                 g, norm = ctx.wn
                 dg = grad_out(g)
-                if _WN_MULTI and dW.is_contiguous():
-                    wn_grad_register(dW, W, g, norm, scale, dg)        # all layers of the step together, at the end of backward
+                if _WN_MULTI and dW.is_contiguous() and in_grad_slot(dW, W) and in_grad_slot(dg, g):
+                    # all layers of the step together, at the end of backward -- ONLY for gradients that live in their flat-buffer
+                    # slots: a temporary (p.grad already set: a second backward without zero_grad, gradient accumulation; a layer used
+                    # twice in one step; no optimizer attached) is consumed by AccumulateGrad when this node ends and freed, so its
+                    # transform must run inside the node
+                    wn_grad_register(dW, W, g, norm, scale, dg)
                 else:
-                    deferred_call(lambda: check(L.ekaid_wn_grad_fused(ptr(dW), ptr(W), ptr(g), ptr(norm), ptr(scale), dW.numel(), ptr(dg), stream()),
-                                                'wn_grad_fused'))
+                    def fused_now():
+                        # an EARLIER use of this layer in the same pass may have left its raw gradient in the slot for the end-of-pass
+                        # transform: autograd is about to add this node's (transformed) gradient to that buffer, so it must be transformed
+                        # first -- everything registered so far is
+                        if any(e[1].data_ptr() == W.data_ptr() for e in _wn_pending):
+                            wn_grad_flush()
+                        check(L.ekaid_wn_grad_fused(ptr(dW), ptr(W), ptr(g), ptr(norm), ptr(scale), dW.numel(), ptr(dg), stream()), 'wn_grad_fused')
+                    deferred_call(fused_now)
                 dscale = dg.view(g.shape)
             elif ctx.has_scale:
                 dscale = torch.empty((), device=W.device, dtype=torch.float32)
@@ -772,11 +863,14 @@ class LinearRowStackFn(Function):
         y = torch.empty(sum(Ms), N, device=W.device, dtype=torch.float32)
         r0 = 0
         Wt = weight_transposed(W) if _use_transposed(sum(Ms)) else None
-        for x, ld, M in zip(xs2, lds, Ms):
+        x2 = f16x2_wanted(min(Ms), N, K)
+        ctx.wb = weight_bounds(W) if x2 else (None, None)
+        ctx.xb = [amax_rc(x, M, K, ld) if x2 else (None, None) for x, ld, M in zip(xs2, lds, Ms)]
+        for (x, ld, M), xb in zip(zip(xs2, lds, Ms), ctx.xb):
             if Wt is not None:
                 gemm(x, Wt, y, M, N, K, ld, N, N, 0, 0, bias=b, c_off=r0 * N)
             else:
-                gemm(x, W, y, M, N, K, ld, K, N, 0, 1, bias=b, c_off=r0 * N)
+                gemm(x, W, y, M, N, K, ld, K, N, 0, 1, bias=b, c_off=r0 * N, a_amax=xb[0], b_amax=ctx.wb[0])
             r0 += M
         ctx.save_for_backward(W, *xs2)
         ctx.bias_ref = b.detach() if b is not None else None
@@ -795,11 +889,12 @@ class LinearRowStackFn(Function):
         if ctx.has_b and need[1]:
             db_buf, db = bias_grad_slot(ctx.bias_ref)
         dW = None
+        dyb = amax_rc(dy, Mtot, N, N) if ctx.wb[0] is not None else (None, None)
         if need[0]:
             dW = grad_out(W)
             r0 = 0
             for i, (x, ld, M) in enumerate(zip(xs2, ctx.lds, ctx.Ms)):     # every row block adds its rows' column sums
-                gemm(dy, x, dW, N, K, M, N, ld, K, 1, 0, accumulate=i > 0, a_off=r0 * N, a_rowsum=db_buf)
+                gemm(dy, x, dW, N, K, M, N, ld, K, 1, 0, accumulate=i > 0, a_off=r0 * N, a_rowsum=db_buf, a_amax=dyb[1], b_amax=ctx.xb[i][1])
                 r0 += M
         elif db_buf is not None:
             check(hip.lib().ekaid_colsum_acc(ptr(dy), Mtot, N, N, ptr(db_buf), stream()), 'colsum_acc')
@@ -808,7 +903,7 @@ class LinearRowStackFn(Function):
         for i, (x, M) in enumerate(zip(xs2, ctx.Ms)):
             if need[2 + i]:
                 dx = torch.empty(M, K, device=W.device, dtype=torch.float32)
-                gemm(dy, W, dx, M, K, N, N, K, K, 0, 0, a_off=r0 * N)
+                gemm(dy, W, dx, M, K, N, N, K, K, 0, 0, a_off=r0 * N, a_amax=(dyb[0], r0) if dyb[0] is not None else None, b_amax=ctx.wb[1])
                 dxs.append(dx.view(*ctx.lead[i], K))
             else:
                 dxs.append(None)
@@ -882,6 +977,8 @@ def wn_linear(xs, v, g, b=None, act=ACT_NONE, drops=None):
 class _SubCtx:
     """What LinearFn.forward / backward need of an autograd context, for one half of a LinearPairFn."""
     wn = None
+    wb = (None, None)
+    xb = ()
     needs_input_grad = ()
 
     def save_for_backward(self, *tensors):

@@ -86,3 +86,19 @@ def greedy_case(B=64):
     rng = np.random.default_rng([64, 1238])
     feats = tuple(torch.from_numpy(rng.standard_normal((B, A), dtype=np.float32)) for _ in range(3))
     return cfg, feats, 12.0, 3.0
+
+
+def oracle_gradients(cfg, cd, sp, batch, double=False, graph='all'):
+    """(loss, result dict, {name: gradient}) of the CPU oracle on the weights of the modules ``cd`` / ``sp``; ``double``: the whole run in
+    float64 (weights, inputs, every intermediate) -- the gradient truth where float32 itself drifts (long answers at full width)."""
+    from oracle import ekaid_oracle as O
+    Pcd, Psp = oracle_params(cd, not double), oracle_params(sp, not double)
+    if double:
+        Pcd = {k: (v.double().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in Pcd.items()}
+        Psp = {k: (v.double().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in Psp.items()}
+        batch = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in batch.items()}
+    loss, res = O.train_loss(Pcd, Psp, cfg, batch, 'mode2', graph)
+    loss.backward()
+    grads = {('cd.' + k): Pcd[k].grad for k, _ in cd.named_parameters()}
+    grads.update({('sp.' + k): Psp[k].grad for k, _ in sp.named_parameters()})
+    return loss.detach(), res, grads

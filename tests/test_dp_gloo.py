@@ -39,7 +39,8 @@ def _worker(rank, world, port, bucket_mb, overlap, q):
     out = []
     for step in range(3):
         gb.zero_grad()
-        x = xs[rank * 4:(rank + 1) * 4]
+        per = 8 // world
+        x = xs[rank * per:(rank + 1) * per]
         model(x).pow(2).sum().backward()
         gb.finish()
         out.append(gb.gflat.clone())
@@ -47,24 +48,30 @@ def _worker(rank, world, port, bucket_mb, overlap, q):
     # Q-C gather: rows gathered in rank order, backward = sum over ranks of the local slice
     a = (torch.arange(6.).view(2, 3) + 10 * rank).requires_grad_(True)
     g = _AllGatherRows.apply(a, None)
-    (g * torch.arange(12.).view(4, 3)).sum().backward()
+    (g * torch.arange(6. * world).view(2 * world, 3)).sum().backward()
     q.put((rank, [o.tolist() for o in out], names, len(gb.buckets), g.detach().tolist(), a.grad.tolist()))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('bucket_mb,overlap', [(1e-5, True), (32.0, True), (1e-5, False)])
-def test_bucketed_allreduce_matches_single_process(bucket_mb, overlap):
+@pytest.mark.parametrize('world,bucket_mb,overlap', [(2, 1e-5, True), (2, 32.0, True), (2, 1e-5, False), (8, 1e-5, True), (8, 32.0, True)])
+def test_bucketed_allreduce_matches_single_process(world, bucket_mb, overlap):
+    """world 2 and world 8 (the node size the path is built for: the first 8-GPU run must not also be the first 8-rank run)."""
+    import socket
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29600 + int(bucket_mb > 1) * 7 + int(overlap) * 3 + os.getpid() % 50
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket_mb, overlap, q)) for r in range(2)]
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, bucket_mb, overlap, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(2))
+    res = sorted(q.get(timeout=300) for _ in range(world))
     for p in procs:
         p.join(60)
-    (r0, g0, names0, nb0, gath0, ga0), (r1, g1, names1, nb1, gath1, ga1) = res
-    assert g0 == g1, 'ranks disagree after all-reduce'
+    (r0, g0, names0, nb0, gath0, ga0), (r1, g1, names1, nb1, gath1, ga1) = res[0], res[-1]
+    assert [r[0] for r in res] == list(range(world))
+    assert all(r[1] == g0 for r in res), 'ranks disagree after all-reduce'
+    assert all(r[2] == names0 and r[3] == nb0 for r in res)
     assert names0 == names1 and set(names0) == {'a.weight', 'a.bias', 'b.weight', 'b.bias'}
     assert names0[0].startswith('b.'), 'flat order must follow backward completion order (last layer first)'
     assert nb0 == (4 if bucket_mb < 1 else 1)
@@ -72,8 +79,9 @@ def test_bucketed_allreduce_matches_single_process(bucket_mb, overlap):
     torch.manual_seed(100)
     xs = torch.randn(8, 6)
     m = Toy()
-    m(xs[:4]).pow(2).sum().backward()
-    m(xs[4:]).pow(2).sum().backward()
+    per = 8 // world
+    for r in range(world):
+        m(xs[r * per:(r + 1) * per]).pow(2).sum().backward()
     want = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
     flat = torch.tensor(g0[-1])
     off = 0
@@ -81,9 +89,11 @@ def test_bucketed_allreduce_matches_single_process(bucket_mb, overlap):
         k = want[n].numel()
         assert torch.allclose(flat[off:off + k], want[n].reshape(-1), atol=1e-5), n
         off += (k + 7) // 8 * 8          # every tensor starts on an 8-element group (ekaid_amd/dp.py)
-    # gather semantics
-    assert gath0 == gath1 == [[0., 1., 2.], [3., 4., 5.], [10., 11., 12.], [13., 14., 15.]]
-    assert ga0 == [[0., 2., 4.], [6., 8., 10.]] and ga1 == [[12., 14., 16.], [18., 20., 22.]]
+    # gather semantics: rows in rank order on every rank; backward = the sum over ranks of the gradient of the rank's own rows
+    want_g = [[10. * r + 3 * i + j for j in range(3)] for r in range(world) for i in range(2)]
+    assert all(r[4] == want_g for r in res)
+    for r in res:
+        assert r[5] == [[world * (6. * r[0] + 3 * i + j) for j in range(3)] for i in range(2)]
 
 
 def _ragged_worker(rank, world, port, q):

@@ -172,8 +172,9 @@ def test_scratch_buffer_that_grows_stays_valid_for_graphs_captured_before():
 @pytest.mark.parametrize('mode', ['nt', 'nn', 'tn'])
 @pytest.mark.parametrize('M,N,K', [(512, 384, 1024), (256, 2048, 512), (4608, 1024, 2048), (1000, 600, 4096)])
 def test_gemm_split_accuracy(M, N, K, mode):
-    """The 3-way bf16 split is f32-accurate: against float64, its error is no larger than 1.5x the error of the f32
-    MFMA (an exact f32 fma chain) on the same data -- including data with a wide dynamic range."""
+    """The 3-way bf16 split AND the two-term f16 split (row / column scaled) are f32-accurate: against float64, their error is no
+    larger than 1.5x the error of the f32 MFMA (an exact f32 fma chain) on the same data -- including data with a wide dynamic range
+    (exp(3 N(0, 1)) per row of A and column of B: ~2^26 between rows)."""
     from ekaid_amd import ops
     g = torch.Generator().manual_seed(77)
     A = torch.randn(M, K, generator=g) * torch.exp(3 * torch.randn(M, 1, generator=g))
@@ -190,19 +191,114 @@ def test_gemm_split_accuracy(M, N, K, mode):
     errs = {}
     old = ops.get_gemm_mode()
     try:
-        for name, m in (('f32', ops.GEMM_F32_MFMA), ('bf16x3', ops.GEMM_BF16_SPLIT)):
+        for name, m in (('f32', ops.GEMM_F32_MFMA), ('bf16x3', ops.GEMM_BF16_SPLIT), ('f16x2', ops.GEMM_F16X2)):
             ops.set_gemm_mode(m)
-            C = torch.empty(M, N, device=DEV)
-            ops.gemm(a, b, C, M, N, K, lda, ldb, N, ta, tb)
+            C = torch.full((M, N), float('nan'), device=DEV)
+            kw = _bounds_kw(a, b, ta, tb) if m == ops.GEMM_F16X2 else {}
+            ran = _gemm_counted(a, b, C, M, N, K, lda, ldb, ta, tb, **kw)
+            assert ran[{'f32': 'gemm_f32', 'bf16x3': 'gemm_split3', 'f16x2': 'gemm_split2'}[name]] >= 1, (name, ran)
             e = (C.double().cpu() - want).abs() / scale
             errs[name] = (float(e.max()), float(e.mean()))
     finally:
         ops.set_gemm_mode(old)
-    print('gemm accuracy %s %dx%dx%d: f32 max %.2e mean %.2e | bf16x3 max %.2e mean %.2e' % (
-        mode, M, N, K, errs['f32'][0], errs['f32'][1], errs['bf16x3'][0], errs['bf16x3'][1]))
-    assert errs['bf16x3'][0] <= 1.5 * errs['f32'][0] + 1e-9
-    assert errs['bf16x3'][1] <= 1.5 * errs['f32'][1] + 1e-10
-    assert errs['bf16x3'][0] < 2e-6
+    print('gemm accuracy %s %dx%dx%d: f32 max %.2e mean %.2e | bf16x3 max %.2e mean %.2e | f16x2 max %.2e mean %.2e' % (
+        mode, M, N, K, errs['f32'][0], errs['f32'][1], errs['bf16x3'][0], errs['bf16x3'][1], errs['f16x2'][0], errs['f16x2'][1]))
+    for name in ('bf16x3', 'f16x2'):
+        assert errs[name][0] <= 1.5 * errs['f32'][0] + 1e-9, name
+        assert errs[name][1] <= 1.5 * errs['f32'][1] + 1e-10, name
+        assert errs[name][0] < 2e-6, name
+
+
+def _bounds_kw(a, b, ta, tb):
+    """a_amax / b_amax of a product from its stored operands (include/ekaid_hip.h: the row maxima of A stored [M][K] or its column maxima
+    stored [K][M]; the row maxima of B stored [N][K] or its column maxima stored [K][N])."""
+    from ekaid_amd import ops
+    ar, ac = ops.amax_rc(a, a.shape[0], a.shape[1], a.shape[1])
+    br, bc = ops.amax_rc(b, b.shape[0], b.shape[1], b.shape[1])
+    return dict(a_amax=ac if ta else ar, b_amax=br if tb else bc)
+
+
+def _gemm_counted(a, b, C, M, N, K, lda, ldb, ta, tb, **kw):
+    """ops.gemm + which arithmetic the library ran it on (launch counters)."""
+    from ekaid_amd import hip, ops
+    c0 = hip.launch_counts()
+    ops.gemm(a, b, C, M, N, K, lda, ldb, N, ta, tb, **kw)
+    c1 = hip.launch_counts()
+    return {k: c1[k] - c0[k] for k in c0}
+
+
+def test_amax_rc_row_and_column_maxima():
+    """ekaid_amax_rc(_multi): exact row / column maxima of |x| for contiguous and row-strided matrices, narrow and wide, with zero rows,
+    a NaN, ragged row counts; the multi-matrix launch; refusal of matrices that are not whole 16-byte vectors."""
+    import ctypes
+    from ekaid_amd import hip, ops
+    g = torch.Generator().manual_seed(21)
+    for rows, cols, ld in [(1, 4, 4), (5, 64, 64), (37, 300, 300), (129, 1024, 1024), (600, 2048, 2052), (4100, 36, 40), (33, 4096, 4096), (8200, 256, 256)]:
+        buf = (torch.randn(rows, ld, generator=g) * torch.exp(2 * torch.randn(rows, 1, generator=g))).to(DEV)
+        if rows > 3:
+            buf[2] = 0
+        x = buf[:, :cols]
+        rm, cm = ops.amax_rc(buf, rows, cols, ld)
+        torch.cuda.synchronize()
+        assert torch.equal(rm, x.abs().amax(1)), (rows, cols, ld)
+        assert torch.equal(cm, x.abs().amax(0)), (rows, cols, ld)
+        r_only, none = ops.amax_rc(buf, rows, cols, ld, want_cols=False)
+        assert none is None and torch.equal(r_only, rm)
+    buf = torch.randn(40, 128, generator=g).to(DEV)
+    buf[7, 5] = float('nan')
+    rm, cm = ops.amax_rc(buf, 40, 128, 128)
+    assert torch.isnan(rm[7]) and torch.isnan(cm[5]) and int(torch.isnan(rm).sum()) == 1 and int(torch.isnan(cm).sum()) == 1
+    assert ops.amax_rc(torch.randn(8, 30, device=DEV), 8, 30, 30) == (None, None)            # not whole float4s: the caller stays on the exact split
+    L = hip.lib()
+    x = torch.randn(8, 30, device=DEV)
+    out = torch.empty(8, device=DEV)
+    assert L.ekaid_amax_rc(x.data_ptr(), 8, 30, 30, out.data_ptr(), None, hip.stream()) == hip.ERR_UNSUPPORTED
+    ws = [torch.randn(r, c, generator=g).to(DEV) for r, c in ((64, 128), (1024, 1024), (3, 2048), (512, 36))]
+    ops.set_gemm_mode(ops.GEMM_F16X2)
+    try:
+        ops.weight_bounds_prepare(ws)
+        for w in ws:
+            r, c = ops.weight_bounds(w)
+            assert torch.equal(r, w.abs().amax(1)) and torch.equal(c, w.abs().amax(0))
+    finally:
+        ops.weight_bounds_release()
+        ops.set_gemm_mode(ops.GEMM_BF16_SPLIT)
+
+
+def test_gemm_f16x2_is_exact_where_the_dropped_term_vanishes():
+    """Integer operands: one side with at most 11 significant bits (its low plane is zero), the other with up to 22 (both planes),
+    sums exact in f32 -> the two-term f16 split must give the integer result bit for bit in all three layouts (catches a wrong lane / k
+    mapping of the f16 fragments, a wrong row / column scale in the staging or in the epilogue), also with rows / columns scaled by
+    2^+-40 (exact powers of two: the per-row scales absorb them)."""
+    from ekaid_amd import ops
+    g = torch.Generator().manual_seed(6)
+    old = ops.get_gemm_mode()
+    ops.set_gemm_mode(ops.GEMM_F16X2)
+    try:
+        for (M, N, K, amax, bmax) in [(128, 128, 32, 1 << 13, 30), (192, 320, 32, 30, 1 << 13), (76, 44, 24, 1 << 13, 30),
+                                      (256, 192, 64, 1000, 120), (132, 72, 96, 60, 1 << 10)]:
+            A = torch.randint(-amax, amax + 1, (M, K), generator=g).float()
+            B = torch.randint(-bmax, bmax + 1, (K, N), generator=g).float()
+            ra = torch.pow(2.0, torch.randint(-40, 41, (M, 1), generator=g).float())
+            cb = torch.pow(2.0, torch.randint(-40, 41, (1, N), generator=g).float())
+            want = (A.double() @ B.double())
+            for scaled in (False, True):
+                A2, B2 = (A * ra, B * cb) if scaled else (A, B)
+                w2 = (want * ra.double() * cb.double()).float() if scaled else want.float()
+                for mode in ('nt', 'nn', 'tn'):
+                    if mode == 'nt':
+                        a, b, ta, tb, lda, ldb = A2, B2.t().contiguous(), 0, 1, K, K
+                    elif mode == 'nn':
+                        a, b, ta, tb, lda, ldb = A2, B2, 0, 0, K, N
+                    else:
+                        a, b, ta, tb, lda, ldb = A2.t().contiguous(), B2, 1, 0, M, N
+                    a, b = a.to(DEV), b.to(DEV)
+                    C = torch.full((M, N), float('nan'), device=DEV)
+                    ran = _gemm_counted(a, b, C, M, N, K, lda, ldb, ta, tb, **_bounds_kw(a, b, ta, tb))
+                    assert ran['gemm_split2'] == 1, ran
+                    assert torch.equal(C.cpu(), w2), (mode, scaled, M, N, K, float((C.cpu() - w2).abs().max()))
+    finally:
+        ops.set_gemm_mode(old)
 
 
 def test_gemm_split_is_exact_on_bf16_representable_products():
@@ -1427,36 +1523,124 @@ def test_check_finite_debug_mode():
 
 
 @pytest.mark.parametrize('mode', ['nt', 'nn', 'tn'])
-@pytest.mark.parametrize('M,N,K', [(256, 2048, 512), (4608, 1024, 2048), (700, 130, 333), (36, 36, 256)])
-def test_gemm_bf16x2_opt_in_arithmetic(M, N, K, mode):
-    """EKAID_GEMM_BF16X2 (opt-in, reduced precision): two bf16 terms per operand, three products.  Against float64 its error
-    stays below 6e-5 of |A|.|B| (2^-16 per product, three dropped / rounded terms) -- two decades tighter than bf16 itself,
-    a decade and a half looser than the default exact split, which the same data must still meet at 5e-7."""
+@pytest.mark.parametrize('M,N,K', [(256, 2048, 512), (4608, 1024, 2048), (700, 132, 336), (36, 36, 256), (2304, 1024, 1024), (1024, 1024, 2304)])
+def test_gemm_f16x2_variants(M, N, K, mode):
+    """EKAID_GEMM_F16X2 over the tile shapes, K splits and epilogues the planner picks (64x64, 128x128, split-K + reduce, ragged M / N,
+    bias + activation + accumulate, the A-row-sum of the weight-gradient form, two products in one launch), with operands whose rows
+    span 2^+-20, a zero row, and a product WITHOUT bounds in the same mode (it must run on the exact split): <= 5e-7 of the element's
+    condition scale against float64, like the exact split."""
     from ekaid_amd import ops
     g = torch.Generator().manual_seed(M + N + K)
-    A = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))
-    Bm = torch.randn(K, N, generator=g)
+    A = torch.randn(M, K, generator=g) * torch.pow(2.0, torch.randint(-20, 21, (M, 1), generator=g).float())
+    Bm = torch.randn(K, N, generator=g) * torch.pow(2.0, torch.randint(-20, 21, (1, N), generator=g).float())
+    A[M // 2] = 0
+    bias = torch.randn(N, generator=g)
     want = A.double() @ Bm.double()
-    mag = A.double().abs() @ Bm.double().abs()
+    mag = A.double().abs() @ Bm.double().abs() + 1e-300
     if mode == 'nt':
         a, b, ta, tb, lda, ldb = A, Bm.t().contiguous(), 0, 1, K, K
     elif mode == 'nn':
         a, b, ta, tb, lda, ldb = A, Bm, 0, 0, K, N
     else:
         a, b, ta, tb, lda, ldb = A.t().contiguous(), Bm, 1, 0, M, N
-    a, b = a.to(DEV), b.to(DEV)
+    a, b, bias_d = a.to(DEV), b.to(DEV), bias.to(DEV)
     old = ops.get_gemm_mode()
-    errs = {}
+    ops.set_gemm_mode(ops.GEMM_F16X2)
     try:
-        for name, md in (('x3', ops.GEMM_BF16_SPLIT), ('x2', ops.GEMM_BF16X2)):
-            ops.set_gemm_mode(md)
-            C = torch.full((M, N), float('nan'), device=DEV)
-            ops.gemm(a, b, C, M, N, K, lda, ldb, N, ta, tb)
-            errs[name] = float(((C.double().cpu() - want).abs() / mag).max())
-            if ta == 0:
-                S = ops.gemm_slabs(a, b, M, N, K, lda, ldb, ta, tb)
-                assert float(((S.total().double().cpu() - want).abs() / mag).max()) <= (6e-5 if name == 'x2' else 5e-7)
+        kw = _bounds_kw(a, b, ta, tb)
+        C = torch.full((M, N), float('nan'), device=DEV)
+        ran = _gemm_counted(a, b, C, M, N, K, lda, ldb, ta, tb, **kw)
+        assert ran['gemm_split2'] == 1 and ran['gemm_split3'] == 0, ran
+        assert float(((C.double().cpu() - want).abs() / mag).max()) <= 5e-7
+        assert float(C[M // 2].abs().max()) == 0.0                                     # the zero row stays exactly zero
+        C2 = torch.full((M, N), float('nan'), device=DEV)                              # no bounds: the exact split, same mode
+        ran = _gemm_counted(a, b, C2, M, N, K, lda, ldb, ta, tb)
+        assert ran['gemm_split3'] == 1 and ran['gemm_split2'] == 0, ran
+        assert float(((C2.double().cpu() - want).abs() / mag).max()) <= 5e-7
+        # epilogue: relu(0.5 * A.B + C0 + bias), the scales must leave before it
+        C0 = torch.randn(M, N, generator=g) * mag.float() * 0.1
+        C3 = C0.clone().to(DEV)
+        ops.gemm(a, b, C3, M, N, K, lda, ldb, N, ta, tb, alpha=0.5, accumulate=True, bias=bias_d, act=ops.ACT_RELU, **kw)
+        w3 = torch.relu(0.5 * want + C0.double() + bias.double())
+        assert float(((C3.double().cpu() - w3).abs() / (mag + C0.double().abs() + bias.double().abs())).max()) <= 1e-6
+        if ta:                                                                         # bias gradient riding on the A operand (unscaled sums)
+            rs = torch.zeros(M, device=DEV)
+            C4 = torch.empty(M, N, device=DEV)
+            ops.gemm(a, b, C4, M, N, K, lda, ldb, N, ta, tb, a_rowsum=rs, **kw)
+            assert torch.equal(C4, C)
+            sw = A.double().sum(1)
+            assert float((rs.double().cpu() - sw).abs().max() / A.double().abs().sum(1).max()) <= 1e-6
+        # two products in one launch = the two alone, bit for bit
+        Ca, Cb = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+        b2 = (b * 0.75).contiguous()
+        kw2 = _bounds_kw(a, b2, ta, tb)
+        ops.gemm(a, b2, Cb, M, N, K, lda, ldb, N, ta, tb, **kw2)
+        want_b = Cb.clone()
+        Ca.fill_(float('nan'))
+        Cb.fill_(float('nan'))
+        ops.gemm_pair(((a, b, Ca, M, N, K, lda, ldb, N, ta, tb), dict(kw)), ((a, b2, Cb, M, N, K, lda, ldb, N, ta, tb), dict(kw2)))
+        assert torch.equal(Ca, C) and torch.equal(Cb, want_b)
     finally:
         ops.set_gemm_mode(old)
-    assert errs['x3'] <= 5e-7, errs
-    assert 1e-7 < errs['x2'] <= 6e-5, errs
+
+
+@pytest.mark.parametrize('multi', [True, False])
+def test_weight_norm_backward_of_gradients_outside_their_flat_slots(multi, monkeypatch):
+    """the deferred weight-norm backward (ekaid_wn_grad_multi at the end of the pass) keeps the raw gradient by ADDRESS, which
+    is only sound for a gradient that lives in its flat-buffer slot.  The cases where ``grad_out`` hands out a temporary -- a second
+    backward without zero_grad (p.grad already set: gradient accumulation), a weight-normed layer used twice in one step, no optimizer
+    attached at all -- must be transformed inside their node.  All three against the weight_norm(dim=None) formula in float64, under
+    both settings of the A/B knob."""
+    from ekaid_amd import ops
+    from ekaid_amd.dp import FlatAdam
+    from ekaid_amd.models.fc import FCNet
+    monkeypatch.setattr(ops, '_WN_MULTI', multi)
+    g = torch.Generator().manual_seed(3)
+    fa, fb = FCNet([96, 64], dropout=0).to(DEV), FCNet([64, 64], dropout=0).to(DEV)
+    with torch.no_grad():
+        for p in list(fa.parameters()) + list(fb.parameters()):
+            p.copy_(torch.randn(p.shape, generator=g).to(DEV) * (0.3 if p.dim() > 0 else 1.0))
+            if p.dim() == 0:
+                p.abs_().add_(0.5)                                                   # weight_g: a positive magnitude
+    x1, x2 = torch.randn(40, 96, generator=g).to(DEV), torch.randn(40, 96, generator=g).to(DEV)
+
+    def loss_of(xa, xb):                       # fb (and fa) used TWICE in one step
+        return (fb(fa(xa)) * 0.7).sum() + (fb(fa(xb)) ** 2).sum() * 0.1
+
+    def want(times):
+        P = {k: v.detach().double().cpu().requires_grad_(True) for k, v in list(fa.named_parameters()) + [('b.' + k, v) for k, v in fb.named_parameters()]}
+
+        def layer(pre, x):
+            v, gm, b = P[pre + 'main.0.weight_v'], P[pre + 'main.0.weight_g'], P[pre + 'main.0.bias']
+            return torch.relu(x @ (v * (gm / v.norm())).t() + b)
+        tot = 0.0
+        for _ in range(times):
+            ya, yb = layer('b.', layer('', x1.double().cpu())), layer('b.', layer('', x2.double().cpu()))
+            tot = tot + (ya * 0.7).sum() + (yb ** 2).sum() * 0.1
+        tot.backward()
+        return {k: v.grad for k, v in P.items()}
+
+    def got():
+        return {**{k: p.grad for k, p in fa.named_parameters()}, **{'b.' + k: p.grad for k, p in fb.named_parameters()}}
+
+    def compare(times, what):
+        torch.cuda.synchronize()
+        w, h = want(times), got()
+        for k in w:
+            assert h[k] is not None, (what, k)
+            check(h[k], w[k], 2e-5, '%s: grad %s' % (what, k))
+    # (1) no optimizer: every gradient buffer is a temporary
+    loss_of(x1, x2).backward()
+    compare(1, 'no slots')
+    # (2) flat slots (FlatAdam discovers the layout on a first backward), the layers used twice: first use in the slot, second a temporary
+    opt = FlatAdam([fa, fb], lr=0.0)
+    opt.zero_grad()
+    loss_of(x1, x2).backward()
+    opt.step()
+    opt.zero_grad()
+    loss_of(x1, x2).backward()
+    compare(1, 'slots, shared layers')
+    # (3) a second backward WITHOUT zero_grad: p.grad is set, every buffer is a temporary that AccumulateGrad adds and frees
+    loss_of(x1, x2).backward()
+    compare(2, 'accumulation into set gradients')
+    ops.clear_grad_claims()

@@ -6,16 +6,16 @@ library's launch counters (ekaid_launch_count) that the persistent decoder forwa
   * 40 and 90 decode steps at the yaml widths (dynamic_speaker_change_pos.py:182-222), batch 4
   * the real-data shapes at the yaml widths (52 regions x 1024-d, ragged 2 ... 40-token answers, zero ROI row, isolated nodes)
   * greedy `_sample` at batch 64 (dynamic_speaker_change_pos.py:287-357)
-Tolerances: log-probs <= 1e-3 of the reference (BASELINE.json), arg-max / token ids identical, every gradient no farther from the
-float64 run of the reference than max(1e-3, 3 x the reference's own float32 error) chunk by chunk, and element-wise <= 1e-3 of the
-tensor's largest entry against the CPU oracle."""
+Tolerances: log-probs <= 1e-3 of the reference (BASELINE.json; element-wise widened by the reference's own float32-vs-float64 drift),
+arg-max / token ids identical, every gradient no farther from the float64 run of the reference than max(1e-3, 3 x the reference's own
+float32 error) chunk by chunk, and element-wise no farther from the float64 oracle than max(2e-3, half the float32 oracle's error)."""
 import numpy as np
 import pytest
 import torch
 
-from common import build_models, greedy_case, oracle_params, real_full_case, wide_case
+from common import build_models, greedy_case, oracle_gradients, real_full_case, wide_case
 from golden_util import assert_no_farther_from_truth, load_golden
-from test_hip_model import LOGIT_TOL, _all_gradients_elementwise, close, elementwise_rel, hip_step, named_grads
+from test_hip_model import LOGIT_TOL, close, hip_step, named_grads
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -24,7 +24,6 @@ DEV = 'cuda'
 @pytest.mark.parametrize('case', ['T40', 'T90', 'real_full'])
 def test_long_answers_at_full_width_match_the_reference_through_the_persistent_kernels(case):
     from ekaid_amd import hip
-    from oracle import ekaid_oracle as O
     g = load_golden('f10_' + case)
     cfg, batch = real_full_case() if case == 'real_full' else wide_case(int(case[1:]))
     cd, sp = build_models(cfg, 147, 148, DEV)
@@ -43,25 +42,61 @@ def test_long_answers_at_full_width_match_the_reference_through_the_persistent_k
     T = int(g['steps'])
     close(loss, g['loss'], 1e-4, 'loss')
     e = close(logp[:, :T], g['logp'], LOGIT_TOL, 'logp')
-    ew, frac = elementwise_rel(logp[:, :T], g['logp'], 1e-2)
-    assert ew <= LOGIT_TOL, 'element-wise relative log-prob error %.3e' % ew
+    # element-wise: within 1e-3 relative of the reference's float32 log-prob, widened by twice the gap between the reference's own
+    # float32 and float64 runs at that entry (over 40 / 90 decode steps the float32 reference drifts 2.6e-4 / 9.3e-4 from its float64
+    # self; the HIP path lands nearer the float64 values)
+    ref32, ref64 = torch.from_numpy(g['logp']).double(), torch.from_numpy(g['logp_f64']).double()
+    d = (logp[:, :T].detach().double().cpu() - ref32).abs()
+    allow = LOGIT_TOL * ref32.abs() + 2.0 * (ref32 - ref64).abs() + 1e-6
+    assert bool((d <= allow).all()), 'log-probs outside 1e-3 relative (+ the reference float32 drift): worst excess %.3e' % float((d - allow).max())
+    d64 = float((logp[:, :T].detach().double().cpu() - ref64).abs().max())
     assert np.array_equal(logp[:, :T].argmax(-1).cpu().numpy(), g['logp'].argmax(-1))
     if logp.shape[1] > T:
-        assert float(logp[:, T:].abs().max()) == 0.0
+        assert float(logp[:, T:].detach().abs().max()) == 0.0
     close(logpos[:, :T], g['logpos'], LOGIT_TOL, 'POS log-probs')
     close(outs[5], g['feat_diff'], 1e-4, 'feat_diff')
     close(outs[1], g['att_bef'], 1e-4, 'att_bef')
     worst = assert_no_farther_from_truth(g, named_grads(cd, sp), 'gradients [%s]' % case)
-    print('%s: logp rel-to-max %.2e, element-wise %.2e (%.0f %% of entries); worst gradient vs float64 truth: %s %.2e (reference float32 %.2e)'
-          % ((case, e, ew, 100 * frac) + worst))
-    # ... and every element of every gradient against the oracle (float32 on the host cores).  The weight_g scalars are <dW, v>/||v||,
-    # 10^6-term sums with heavy cancellation: two float32 paths differ there by more than 1e-3 (the reference's own float32 value
-    # sits up to 1e-2 from the truth); they are held to the float64 truth above instead.
-    Pcd, Psp = oracle_params(cd, True), oracle_params(sp, True)
-    loss_o, res = O.train_loss(Pcd, Psp, cfg, batch, 'mode2', 'all')
-    loss_o.backward()
-    close(logp[:, :T], res['logp'][:, :T], LOGIT_TOL, 'logp vs oracle')
-    _all_gradients_elementwise(cd, sp, Pcd, Psp, 1e-3, 'oracle vs hip [%s]' % case, tol_for=lambda k: 3e-2 if k.endswith('weight_g') else 1e-3)
+    print('%s: logp vs reference float32 rel-to-max %.2e, max |d| vs its float64 run %.2e (float32 reference itself: %.2e); worst gradient chunk '
+          'vs float64 truth: %s %.2e (reference float32 %.2e)' % ((case, e, d64, float(g['logp_f64_maxdiff'])) + worst))
+    # ... and EVERY element of every gradient against the oracle run in float64 on this host (pinned to the reference's float64 run in
+    # tests/test_oracle_golden.py): no farther from it than max(2e-3 of the tensor's largest entry, HALF the error of the float32 oracle) --
+    # at these lengths float32 on the host drifts 1-3 % from the truth (recurrent amplification of rounding), the HIP path ~0.1 %
+    _, _, g64 = oracle_gradients(cfg, cd, sp, batch, double=True)
+    _, _, g32 = oracle_gradients(cfg, cd, sp, batch, double=False)
+    frozen = {'cd.' + k for k, p in cd.named_parameters() if not p.requires_grad} | {'sp.' + k for k, p in sp.named_parameters() if not p.requires_grad}
+    assert frozen == {'cd.w_emb.emb_.weight'}                 # frozen in the reference too (language_model.py:29): never differentiated
+    for k in frozen:
+        assert dict(named_grads(cd, sp))[k] is None
+        g64.pop(k), g32.pop(k)                                # (the oracle differentiates every table it is handed)
+    _elementwise_vs_truth(dict(named_grads(cd, sp)), g64, g32, case)
+
+
+def _elementwise_vs_truth(got, g64, g32, what):
+    live = [k for k, v in g64.items() if v is not None and float(v.abs().max()) > 0.0]
+    assert len(live) > 60, 'too few live gradients (%d)' % len(live)
+    med = float(np.median([float(g64[k].abs().max()) for k in live]))
+    bad, worst, nzero = [], (None, 0.0, 0.0), 0
+    for k, v in g64.items():
+        if v is None or float(v.abs().max()) == 0.0:              # dead / frozen: nothing but rounding noise may arrive on the HIP side
+            assert got.get(k) is None or float(got[k].abs().max()) <= 1e-6 * med, 'gradient on dead parameter %s' % k
+            continue
+        assert got.get(k) is not None, 'no gradient on live parameter %s' % k
+        h = got[k].detach().double().cpu()
+        scale = float(v.abs().max())
+        if scale <= 1e-4 * med:                                   # an exact zero in disguise (a bias under a softmax): equally negligible
+            nzero += 1
+            assert float(h.abs().max()) <= 1e-3 * med, k
+            continue
+        e_hip = float((h - v).abs().max()) / scale
+        e_32 = float((g32[k].double() - v).abs().max()) / scale
+        if e_hip > worst[1]:
+            worst = (k, e_hip, e_32)
+        if e_hip > max(2e-3, 0.5 * e_32):
+            bad.append((k, e_hip, e_32))
+    assert nzero <= 8
+    print('%s: %d gradients element-wise vs the float64 oracle, worst %s %.2e of its largest entry (float32 oracle there: %.2e)' % ((what, len(live)) + worst))
+    assert not bad, '%s: %d gradients farther from the float64 truth than allowed (name, hip, float32 oracle): %s' % (what, len(bad), bad[:8])
 
 
 def test_greedy_sample_at_batch_64_full_width_matches_the_reference_through_the_persistent_kernel():
@@ -87,4 +122,5 @@ def test_greedy_sample_at_batch_64_full_width_matches_the_reference_through_the_
     assert got.shape == want.shape and np.array_equal(got, want), 'token ids differ in %d of %d positions' % (int((got != want).sum()), want.size)
     assert np.array_equal((got != 0).sum(1), g['lengths'].astype(np.int64))
     close(lp, g['seq_logp'], LOGIT_TOL, 'seq_logprobs')
+    close(lp, g['seq_logp_f64'], LOGIT_TOL, 'seq_logprobs vs the float64 run')
     assert len(sp.module_weights) >= int(g['lengths'].max())

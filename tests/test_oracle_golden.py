@@ -348,6 +348,21 @@ def test_f10_production_width_long_answers_and_real_shapes(case):
     # gradients: the float64 run of the reference is the truth; the oracle (float32) must be as close to it as the reference's float32 run
     worst = assert_no_farther_from_truth(g, named, 'gradient sketches [%s]' % case)
     print('worst vs float64 truth: %s %.2e (reference float32: %.2e)' % worst)
+    # ... and the oracle's own float64 run IS that truth (the GPU test measures the HIP path element by element against it): log-probs
+    # and every gradient chunk against the float64 run of the reference
+    from common import oracle_gradients
+    from golden_util import sketch_errors
+    loss64, res64, g64 = oracle_gradients(cfg, cd, sp, batch, double=True)
+    assert abs(float(loss64) - float(g['loss_f64'])) <= 1e-7 * abs(float(g['loss_f64']))
+    assert float((res64['logp'][:, :T].detach() - torch.from_numpy(g['logp_f64']).double()).abs().max()) <= 2e-6      # (stored as float32)
+    e = sketch_errors(g['grad_names'], g['grad_sketch_f64'], lambda i, k: tensor_sketch(g64[k]) if g64.get(k) is not None else None)
+    # (what is left between the two float64 runs is the position-embedding wave-length table -- float64 in the float64 reference run,
+    #  float32 in the pipeline and in the oracle, as in F4 -- amplified by the recurrence: median 3e-5 over 90 steps, and up to 2e-3 on
+    #  the weight_g scalars, whose <dW, v> sums cancel heavily.  The float32 paths sit 1e-2 ... 1e-1 from either.)
+    k = max(e, key=e.get)
+    print('float64 oracle vs float64 reference, worst chunk: %s %.2e, median %.2e' % (k, e[k], float(np.median(list(e.values())))))
+    bad = {n: v for n, v in e.items() if v > (5e-3 if n.endswith('weight_g') else 2e-4)}
+    assert not bad, bad
 
 
 def test_f10_greedy_sample_at_batch_64_full_width():
