@@ -23,7 +23,7 @@ int gemm_mode();                                   // 0 = f32 MFMA, 1 = exact bf
 int set_gemm_mode(int mode);
 int seq_mode();                                    // 0 = step-wise sequence chains, 1 = persistent sequence kernels where supported (per device)
 #ifndef EKAID_GEMM_MODE_DEFAULT
-#define EKAID_GEMM_MODE_DEFAULT 1                  // (flipped to 2 once the two-term f16 split has passed every parity gate: DESIGN.md section 4.1)
+#define EKAID_GEMM_MODE_DEFAULT 2                  // the two-term f16 split for products that carry operand bounds, the exact 3-way bf16 split for the rest
 #endif
 #ifndef EKAID_SEQ_MODE_DEFAULT
 #define EKAID_SEQ_MODE_DEFAULT 1

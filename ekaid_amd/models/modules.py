@@ -40,11 +40,6 @@ class SelfAttention(nn.Module):
         self.dropout = nn.Dropout(0.1)
         self.layer_norm = nn.LayerNorm(cd.att_dim, eps=1e-6)
 
-    def _heads(self, x, B, L):
-        # (B, L, nh*dh) -> (B*nh, L, dh)
-        return x.view(B, L, self.num_attention_heads, self.attention_head_size).permute(0, 2, 1, 3) \
-                .reshape(B * self.num_attention_heads, L, self.attention_head_size)
-
     def forward(self, query_states, key_states, value_states, bl=None):
         """Each state: tensor (B, L, 2A), or tuple (v (B*L, A), q_exp (B*L, A)) standing for the concat
         (then ``bl = (B, L)`` must be given)."""
@@ -52,14 +47,11 @@ class SelfAttention(nn.Module):
             B, L = bl
         else:
             B, L = query_states.shape[0], query_states.shape[1]
-        nh, dh = self.num_attention_heads, self.attention_head_size
-        q = self._heads(self.query(query_states).view(B, L, -1), B, L)
-        k = self._heads(self.key(key_states).view(B, L, -1), B, L)
-        v = self._heads(self.value(value_states).view(B, L, -1), B, L)
-        scores = ops.bmm(q, k, transB=True, alpha=1.0 / math.sqrt(dh))          # (B*nh, L, L)
-        probs = ops.dropout(ops.softmax(scores), self.dropout.p, self.training)
-        ctx = ops.bmm(probs, v)                                                   # (B*nh, L, dh)
-        ctx = ctx.view(B, nh, L, dh).permute(0, 2, 1, 3).reshape(B, L, self.all_head_size)
+        # heads as a strided batch dimension of the two products: no head-major copies of q / k / v, the context lands in (B, L, A)
+        q = self.query(query_states).view(B, L, -1)
+        k = self.key(key_states).view(B, L, -1)
+        v = self.value(value_states).view(B, L, -1)
+        ctx = ops.head_attention(q, k, v, self.num_attention_heads, self.dropout.p, self.training)
         return ops.layer_norm(ctx, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
 
 

@@ -1641,7 +1641,10 @@ class GRUSeqFn(Function):
         dev = x.device
         L = hip.lib()
         gi = torch.empty(B, T, 3 * H, device=dev, dtype=torch.float32)
-        gemm(x, w_ih, gi, B * T, 3 * H, E, E, E, 3 * H, 0, 1, bias=b_ih)
+        x2 = f16x2_wanted(B * T, 3 * H, E)              # (mode 2: bounds of x and W_ih, reused by the three time-batched products)
+        ctx.xb = amax_rc(x, B * T, E, E) if x2 else (None, None)
+        ctx.wb = weight_bounds(w_ih) if x2 else (None, None)
+        gemm(x, w_ih, gi, B * T, 3 * H, E, E, E, 3 * H, 0, 1, bias=b_ih, a_amax=ctx.xb[0], b_amax=ctx.wb[0])
         hall = torch.zeros(T + 1, B, H, device=dev, dtype=torch.float32)     # time-major states, hall[0] = h0 = 0
         save = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
         if seq_in_c():
@@ -1693,13 +1696,17 @@ class GRUSeqFn(Function):
         hh_buf, db_hh = bias_grad_slot(b_hh)
         ih_buf, db_ih = bias_grad_slot(b_ih)
         dw_ih = grad_out(w_ih)
+        x2 = ctx.wb[0] is not None
+        dgib = amax_rc(dgi, B * T, 3 * H, 3 * H) if x2 else (None, None)
+        dghb = amax_rc(dgh, T * B, 3 * H, 3 * H, want_rows=False) if x2 else (None, None)
+        hb = amax_rc(hall, T * B, H, H, want_rows=False) if x2 else (None, None)
         with pairing_window():                        # two independent products of one layout: one launch
-            gemm(dgh, hall, dw_hh, 3 * H, H, T * B, 3 * H, H, H, 1, 0, a_rowsum=hh_buf)
-            gemm(dgi, x, dw_ih, 3 * H, E, B * T, 3 * H, E, E, 1, 0, a_rowsum=ih_buf)
+            gemm(dgh, hall, dw_hh, 3 * H, H, T * B, 3 * H, H, H, 1, 0, a_rowsum=hh_buf, a_amax=dghb[1], b_amax=hb[1])
+            gemm(dgi, x, dw_ih, 3 * H, E, B * T, 3 * H, E, E, 1, 0, a_rowsum=ih_buf, a_amax=dgib[1], b_amax=ctx.xb[1])
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            gemm(dgi, w_ih, dx, B * T, E, 3 * H, 3 * H, E, E, 0, 0)
+            gemm(dgi, w_ih, dx, B * T, E, 3 * H, 3 * H, E, E, 0, 0, a_amax=dgib[0], b_amax=ctx.wb[1])
         return dx, dw_ih, dw_hh, db_ih, db_hh
 
 
@@ -1984,3 +1991,63 @@ class BmmFn(Function):
             dA = BmmFn.apply(B, dC, False, True, alpha)      # B dC^T
             dB = BmmFn.apply(A, dC, False, False, alpha)     # A dC
         return dA, dB, None, None, None
+
+
+class HeadAttentionFn(Function):
+    """softmax(q_h k_h^T / sqrt(dh)) v_h for every (sample, head) of (B, L, heads * dh) tensors, WITHOUT the head-major copies: the
+    batched products take the heads as a second batch dimension with a stride of dh inside the rows (ekaid_gemm_t batch2 / strides),
+    and the result is written straight into the (B, L, heads * dh) layout the LayerNorm reads.  Dropout on the probabilities.
+    ref: modules.py:43-75 (SelfAttention.transpose_for_scores / permute / view: four materialised transposes per call)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, p, training):
+        require_cuda(q, k, v)
+        q, k, v = _c(q), _c(k), _c(v)
+        B, Lq, D = q.shape
+        dh = D // heads
+        L = hip.lib()
+        f32 = dict(device=q.device, dtype=torch.float32)
+        scores = torch.empty(B, heads, Lq, Lq, **f32)
+        st_in, st_sc = (Lq * D, dh), (heads * Lq * Lq, Lq * Lq)
+        gemm(q, k, scores, Lq, Lq, dh, D, D, Lq, 0, 1, alpha=1.0 / math.sqrt(dh), batch=(B, heads),
+             strides=(st_in[0], st_in[1], st_in[0], st_in[1], st_sc[0], st_sc[1]))
+        probs = torch.empty_like(scores)
+        check(L.ekaid_softmax_fwd(ptr(scores), ptr(probs), B * heads * Lq, Lq, 0, stream()), 'softmax_fwd')
+        pd, seed = probs, 0
+        if training and p > 0.0:
+            pd, seed = torch.empty_like(probs), next_seed()
+            check(L.ekaid_dropout(ptr(probs), ptr(pd), probs.numel(), float(p), seed, stream()), 'dropout')
+        out = torch.empty(B, Lq, D, **f32)
+        gemm(pd, v, out, Lq, dh, Lq, Lq, D, D, 0, 0, batch=(B, heads),
+             strides=(st_sc[0], st_sc[1], st_in[0], st_in[1], st_in[0], st_in[1]))
+        ctx.cfg = (heads, float(p) if training else 0.0, seed)
+        ctx.save_for_backward(q, k, v, probs, pd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, probs, pd = ctx.saved_tensors
+        heads, p, seed = ctx.cfg
+        B, Lq, D = q.shape
+        dh = D // heads
+        L = hip.lib()
+        dout = _c(dout)
+        st_in, st_sc = (Lq * D, dh), (heads * Lq * Lq, Lq * Lq)
+        s_in, s_sc = (st_in[0], st_in[1]), (st_sc[0], st_sc[1])
+        alpha = 1.0 / math.sqrt(dh)
+        dpd = torch.empty_like(probs)                       # d probs_dropped[b, h] = dout_bh v_bh^T
+        gemm(dout, v, dpd, Lq, Lq, dh, D, D, Lq, 0, 1, batch=(B, heads), strides=s_in + s_in + s_sc)
+        dv = torch.empty_like(v)                            # dv_bh = probs_dropped_bh^T dout_bh
+        gemm(pd, dout, dv, Lq, dh, Lq, Lq, D, D, 1, 0, batch=(B, heads), strides=s_sc + s_in + s_in)
+        if p > 0.0:
+            check(L.ekaid_dropout(ptr(dpd), ptr(dpd), dpd.numel(), p, seed, stream()), 'dropout')
+        dsc = torch.empty_like(probs)
+        check(L.ekaid_softmax_bwd(ptr(probs), ptr(dpd), ptr(dsc), B * heads * Lq, Lq, 0, stream()), 'softmax_bwd')
+        dq, dk = torch.empty_like(q), torch.empty_like(k)
+        gemm(dsc, k, dq, Lq, dh, Lq, Lq, D, D, 0, 0, alpha=alpha, batch=(B, heads), strides=s_sc + s_in + s_in)
+        gemm(dsc, q, dk, Lq, dh, Lq, Lq, D, D, 1, 0, alpha=alpha, batch=(B, heads), strides=s_sc + s_in + s_in)
+        return dq, dk, dv, None, None, None
+
+
+def head_attention(q, k, v, heads, p=0.0, training=False):
+    return HeadAttentionFn.apply(q, k, v, heads, p, training)

@@ -35,25 +35,34 @@ PARAM_NAMES = ('embed.0.weight', 'core.embed.0.weight', 'core.embed.0.bias',
                'logit.weight', 'logit.bias')
 
 
-def _nt(X, xoff, ldx, W, woff, ldw, Y, yoff, ldy, M, N, K, bias=None, acc=False, act=ACT_NONE):
-    """Y[M,N] (+)= X[M,K] . W[N,K]^T (+ bias) with element offsets / leading dims."""
-    gemm(X, W, Y, M, N, K, ldx, ldw, ldy, 0, 1, accumulate=acc, bias=bias, act=act, a_off=xoff, b_off=woff, c_off=yoff)
+def _nt(X, xoff, ldx, W, woff, ldw, Y, yoff, ldy, M, N, K, bias=None, acc=False, act=ACT_NONE, ab=None, bb=None):
+    """Y[M,N] (+)= X[M,K] . W[N,K]^T (+ bias) with element offsets / leading dims; ab / bb: operand bounds (ops.gemm a_amax / b_amax)."""
+    gemm(X, W, Y, M, N, K, ldx, ldw, ldy, 0, 1, accumulate=acc, bias=bias, act=act, a_off=xoff, b_off=woff, c_off=yoff, a_amax=ab, b_amax=bb)
 
 
-def _nn(D, doff, ldd, W, woff, ldw, Y, yoff, ldy, M, N, K, acc=False):
+def _nn(D, doff, ldd, W, woff, ldw, Y, yoff, ldy, M, N, K, acc=False, ab=None, bb=None):
     """Y[M,N] (+)= D[M,K] . W[K,N]   (dgrad: W stored [out=K][in], column block at woff)."""
-    gemm(D, W, Y, M, N, K, ldd, ldw, ldy, 0, 0, accumulate=acc, a_off=doff, b_off=woff, c_off=yoff)
+    gemm(D, W, Y, M, N, K, ldd, ldw, ldy, 0, 0, accumulate=acc, a_off=doff, b_off=woff, c_off=yoff, a_amax=ab, b_amax=bb)
 
 
-def _tn(D, ldd, X, ldx, G, goff, ldg, Nout, Kin, rows, doff=0, xoff=0, bias=None):
+def _cols(bounds, off=0):
+    """The column maxima of a bounds pair as an ops.gemm a_amax / b_amax argument, from column ``off`` on (None when there are none)."""
+    return None if bounds is None or bounds[1] is None else (bounds[1], off)
+
+
+def _tn(D, ldd, X, ldx, G, goff, ldg, Nout, Kin, rows, doff=0, xoff=0, bias=None, db=None, xb=None):
     """G[Nout,Kin] = D[rows,Nout]^T . X[rows,Kin]   (wgrad over rows = T*B); ``bias``: parameter(s) whose gradient is the column
-    sum of D -- it rides on this product (ops.gemm a_rowsum); returns their autograd values."""
+    sum of D -- it rides on this product (ops.gemm a_rowsum); returns their autograd values.  db / xb: bounds pairs of the matrices D
+    and X are column blocks of (ops.amax_rc: their column maxima serve the two-term f16 split; None = exact split)."""
+    kw = {}
+    if db is not None and xb is not None and db[1] is not None and xb[1] is not None and ops.f16x2_wanted(Nout, Kin, rows):
+        kw = dict(a_amax=(db[1], doff % ldd), b_amax=(xb[1], xoff % ldx))       # (offsets: rows * ld + first column)
     if bias is None:
-        gemm(D, X, G, Nout, Kin, rows, ldd, ldx, ldg, 1, 0, a_off=doff, b_off=xoff, c_off=goff)
+        gemm(D, X, G, Nout, Kin, rows, ldd, ldx, ldg, 1, 0, a_off=doff, b_off=xoff, c_off=goff, **kw)
         return None
     biases = bias if isinstance(bias, (tuple, list)) else (bias,)
     buf, ret = ops.bias_grad_slot(biases[0])
-    gemm(D, X, G, Nout, Kin, rows, ldd, ldx, ldg, 1, 0, a_off=doff, b_off=xoff, c_off=goff, a_rowsum=buf)
+    gemm(D, X, G, Nout, Kin, rows, ldd, ldx, ldg, 1, 0, a_off=doff, b_off=xoff, c_off=goff, a_rowsum=buf, **kw)
     rets = [ret]
     for b2 in biases[1:]:           # a second bias with the same gradient (bias_ih / bias_hh of an LSTM cell)
         buf2, ret2 = ops.bias_grad_slot(b2)
@@ -127,10 +136,20 @@ class SpeakerSeqFn(Function):
         check(L.ekaid_embedding_fwd(tok_tb.data_ptr(), TB, ptr(emb), We, ptr(Xr), We, 0, 1, stream()), 'embedding_fwd')
         Xd = torch.empty_like(Xr)
         _drop(Xr, Xd, TB * We, p, seeds['xt'])
+        # two-term f16 split (mode 2) for the time-batched products: bounds of their operands, taken once and kept for the backward pass
+        x2 = ops.f16x2_wanted(TB, 4 * R, We)
+        none2 = (None, None)
+        if x2:
+            ops.weight_bounds_prepare([wih_a, wih_l, w_lo, w_g1])
+        wb = {k: (ops.weight_bounds(w) if x2 else none2) for k, w in (('wih_a', wih_a), ('wih_l', wih_l), ('w_lo', w_lo), ('w_g1', w_g1))}
+        if x2:
+            ops.weight_bounds_release()
+        edb = ops.amax_rc(ED, TB, E, E) if x2 else none2
+        xdb = ops.amax_rc(Xd, TB, We, We) if x2 else none2
         GXA = torch.empty(T, B, 4 * R, **f32)     # att-LSTM input-side gates: dropout(embed) part + b_ih
-        _nt(ED, 0, E, wih_a, 0, E + R, GXA, 0, 4 * R, TB, 4 * R, E, bias=bih_a)
+        _nt(ED, 0, E, wih_a, 0, E + R, GXA, 0, 4 * R, TB, 4 * R, E, bias=bih_a, ab=edb[0], bb=wb['wih_a'][0])
         GXL = torch.empty(T, B, 4 * R, **f32)     # lang-LSTM input-side gates: word part + b_ih
-        _nt(Xd, 0, We, wih_l, 0, We + A, GXL, 0, 4 * R, TB, 4 * R, We, bias=bih_l)
+        _nt(Xd, 0, We, wih_l, 0, We + A, GXL, 0, 4 * R, TB, 4 * R, We, bias=bih_l, ab=xdb[0], bb=wb['wih_l'][0])
         # row-concatenated weights applied to h_lang_{t-1} (a copy, no arithmetic)
         Wcat = torch.cat([wih_a[:, E:], w_p1, w_g1[:, :R], whh_l], 0).contiguous()          # (NW, R)
 
@@ -204,7 +223,8 @@ class SpeakerSeqFn(Function):
         HO = torch.empty(T, B, R, **f32)
         _drop(HL, HO, TB * R, p, seeds['out'], B * R, 0)
         logits = torch.empty(T, B, V, **f32)
-        _nt(HO, 0, R, w_lo, 0, R, logits, 0, V, TB, V, R, bias=b_lo)
+        hob = ops.amax_rc(HO, TB, R, R) if x2 else none2
+        _nt(HO, 0, R, w_lo, 0, R, logits, 0, V, TB, V, R, bias=b_lo, ab=hob[0], bb=wb['w_lo'][0])
         logp = torch.empty(T, B, V, **f32)
         check(L.ekaid_softmax_fwd(ptr(logits), ptr(logp), TB, V, 1, stream()), 'softmax_fwd')
         logpos = torch.empty(T, B, NP, **f32)
@@ -215,6 +235,7 @@ class SpeakerSeqFn(Function):
         ctx.biases = tuple(t.detach() for t in (b_e, bih_a, bhh_a, b_fc, b_p1, b_wp, b_p2, b_g1, b_g2, bih_l, bhh_l, b_lo))
         ctx.wrefs = (w_p1.detach(), whh_l.detach())   # (read through Wcat in the backward pass; needed for their slots only)
         ctx.pp = (p, p5, seeds, seeds_t)
+        ctx.bounds = (wb, edb, xdb, hob)
         ctx.save_for_backward(bef, aft, diff, tok_tb, embed_pre, ED, Xd, HA, CA, HL, CL, SA, SL, MW, VP, PW, PA, AT,
                               G1D, GT, GA, HO, logp, logpos, emb, w_e, wih_a, whh_a, w_fc, w_wp, w_p2, w_g1, w_g2,
                               wih_l, w_lo, Wcat)
@@ -240,10 +261,14 @@ class SpeakerSeqFn(Function):
         # ---- head (time-batched)
         dlogits = torch.empty(T, B, V, **f32)
         check(L.ekaid_softmax_bwd(ptr(logp), ptr(dlogp), ptr(dlogits), TB, V, 1, stream()), 'softmax_bwd')
+        wb, edb, xdb, hob = ctx.bounds
+        x2 = edb[0] is not None
+        none2 = (None, None)
+        dlb = ops.amax_rc(dlogits, TB, V, V) if x2 else none2
         d_w_lo = ops.grad_out(w_lo)
-        d_b_lo = _tn(dlogits, V, HO, R, d_w_lo, 0, R, V, R, TB, bias=b_lo)
+        d_b_lo = _tn(dlogits, V, HO, R, d_w_lo, 0, R, V, R, TB, bias=b_lo, db=dlb, xb=hob)
         dHO = torch.empty(T, B, R, **f32)
-        _nn(dlogits, 0, V, w_lo, 0, R, dHO, 0, R, TB, R, V)
+        _nn(dlogits, 0, V, w_lo, 0, R, dHO, 0, R, TB, R, V, ab=dlb[0], bb=_cols(wb['w_lo']))
         dHLo = torch.empty(T, B, R, **f32)        # gradient reaching h_lang_t through the output dropout
         _drop(dHO, dHLo, TB * R, p, seeds['out'])
         # dDPl: gradient reaching dpos through log_softmax(output_pos); d_bef/d_diff/d_aft and the cell-state carries start at
@@ -340,33 +365,39 @@ class SpeakerSeqFn(Function):
 
         # ---- time-batched weight gradients (K = T*B) and input gradients; DCAT column blocks with ld = NW
         # (fifteen mutually independent products of one layout: recorded and launched two per grid, ops.pairing_window)
+        # (mode 2: ONE pass over DCAT gives the column maxima of all its blocks; one pass per right-hand operand -- the state buffers HL / HA
+        # over all T + 1 steps, which bounds either of their shifted views)
+        cb = (lambda t, rows, cols: ops.amax_rc(t, rows, cols, cols, want_rows=False)) if x2 else (lambda t, rows, cols: None)
+        dcb, hlb, hab = cb(DCAT, TB, NW), cb(HL, TB + B, R), cb(HA, TB + B, R)
+        vpb, pab, g1b, gab, dz2b = cb(VP, TB, R), cb(PA, TB, R + A), cb(G1D, TB, G1), cb(GA, TB, A), cb(DZ2, TB, A)
         with ops.pairing_window():
             d_wih_a = ops.grad_out(wih_a)
-            _tn(DCAT, NW, ED, E, d_wih_a, 0, E + R, 4 * R, E, TB)
-            _tn(DCAT, NW, HL, R, d_wih_a, E, E + R, 4 * R, R, TB)
+            _tn(DCAT, NW, ED, E, d_wih_a, 0, E + R, 4 * R, E, TB, db=dcb, xb=edb)
+            _tn(DCAT, NW, HL, R, d_wih_a, E, E + R, 4 * R, R, TB, db=dcb, xb=hlb)
             d_whh_a = ops.grad_out(whh_a)
-            d_bih_a, d_bhh_a = _tn(DCAT, NW, HA, R, d_whh_a, 0, R, 4 * R, R, TB, bias=(bih_a, bhh_a))   # the same gradient for both
+            d_bih_a, d_bhh_a = _tn(DCAT, NW, HA, R, d_whh_a, 0, R, 4 * R, R, TB, bias=(bih_a, bhh_a), db=dcb, xb=hab)   # the same gradient for both
             d_w_fc = ops.grad_out(w_fc)
             d_b_fc = _tn(DZFC, 3, HA, R, d_w_fc, 0, R, 3, R, TB, xoff=B * R, bias=b_fc)
             d_w_p1 = ops.grad_out(w_p1)
-            d_b_p1 = _tn(DCAT, NW, HL, R, d_w_p1, 0, R, R, R, TB, doff=oP1, bias=b_p1)
+            d_b_p1 = _tn(DCAT, NW, HL, R, d_w_p1, 0, R, R, R, TB, doff=oP1, bias=b_p1, db=dcb, xb=hlb)
             d_w_wp = ops.grad_out(w_wp)
             d_b_wp = _tn(DWP, NP, VP, R, d_w_wp, 0, R, NP, R, TB, bias=b_wp)
             d_w_p2 = ops.grad_out(w_p2)
             d_b_p2 = _tn(DPP, R, PW, NP, d_w_p2, 0, NP, R, NP, TB, bias=b_p2)
             d_w_g1 = ops.grad_out(w_g1)
-            d_b_g1 = _tn(DCAT, NW, HL, R, d_w_g1, 0, G1, G1, R, TB, doff=oG1, bias=b_g1)
-            _tn(DCAT, NW, PA, R + A, d_w_g1, R, G1, G1, R + A, TB, doff=oG1)
+            d_b_g1 = _tn(DCAT, NW, HL, R, d_w_g1, 0, G1, G1, R, TB, doff=oG1, bias=b_g1, db=dcb, xb=hlb)
+            _tn(DCAT, NW, PA, R + A, d_w_g1, R, G1, G1, R + A, TB, doff=oG1, db=dcb, xb=pab)
             d_w_g2 = ops.grad_out(w_g2)
-            d_b_g2 = _tn(DZ2, A, G1D, G1, d_w_g2, 0, G1, A, G1, TB, bias=b_g2)                              # input = dropout(relu(gate1x))
+            d_b_g2 = _tn(DZ2, A, G1D, G1, d_w_g2, 0, G1, A, G1, TB, bias=b_g2, db=dz2b, xb=g1b)                # input = dropout(relu(gate1x))
             d_wih_l = ops.grad_out(wih_l)
-            _tn(DCAT, NW, Xd, We, d_wih_l, 0, We + A, 4 * R, We, TB, doff=oGL)
-            _tn(DCAT, NW, GA, A, d_wih_l, We, We + A, 4 * R, A, TB, doff=oGL)
+            _tn(DCAT, NW, Xd, We, d_wih_l, 0, We + A, 4 * R, We, TB, doff=oGL, db=dcb, xb=xdb)
+            _tn(DCAT, NW, GA, A, d_wih_l, We, We + A, 4 * R, A, TB, doff=oGL, db=dcb, xb=gab)
             d_whh_l = ops.grad_out(whh_l)
-            d_bih_l, d_bhh_l = _tn(DCAT, NW, HL, R, d_whh_l, 0, R, 4 * R, R, TB, doff=oGL, bias=(bih_l, bhh_l))
+            d_bih_l, d_bhh_l = _tn(DCAT, NW, HL, R, d_whh_l, 0, R, 4 * R, R, TB, doff=oGL, bias=(bih_l, bhh_l), db=dcb, xb=hlb)
         # embed path: dED = DGA . W_ih_att[:, :E]; per-step dropout backward; sum over t; relu; Linear(3A -> E)
         dED = torch.empty(T, B, E, **f32)
-        _nn(DCAT, 0, NW, wih_a, 0, E + R, dED, 0, E, TB, E, 4 * R)
+        rows_a = ops.amax_rc(DCAT, TB, 4 * R, NW, want_cols=False)[0] if x2 else None          # row maxima of the att-gate block only
+        _nn(DCAT, 0, NW, wih_a, 0, E + R, dED, 0, E, TB, E, 4 * R, ab=rows_a, bb=_cols(wb['wih_a']))
         check(L.ekaid_dropout_steps(ptr(dED), ptr(dED), B * E, T, B * E, p, seeds['ed'], stream()), 'dropout_steps')
         d_epre = torch.empty(B, E, **f32)
         check(L.ekaid_colsum(ptr(dED), T, B * E, B * E, ptr(d_epre), stream()), 'colsum')
@@ -381,7 +412,8 @@ class SpeakerSeqFn(Function):
         _nn(d_ez, 0, E, w_e, 2 * A, 3 * A, d_aft, 0, A, B, A, E, acc=True)
         # word path: dXd = DGL . W_ih_lang[:, :We]; dropout backward; relu + table scatter-add
         dX = torch.empty(T, B, We, **f32)
-        _nn(DCAT, oGL, NW, wih_l, 0, We + A, dX, 0, We, TB, We, 4 * R)
+        rows_l = ops.amax_rc(DCAT, TB, 4 * R, NW, off=oGL, want_cols=False)[0] if x2 else None
+        _nn(DCAT, oGL, NW, wih_l, 0, We + A, dX, 0, We, TB, We, 4 * R, ab=rows_l, bb=_cols(wb['wih_l']))
         _drop(dX, dX, TB * We, p, seeds['xt'])
         d_emb = ops.grad_out(emb, zero=True)
         ops.embedding_grad(tok_tb, emb, dX, We, 0, True, -1, d_emb)

@@ -88,7 +88,7 @@ def greedy_case(B=64):
     return cfg, feats, 12.0, 3.0
 
 
-def oracle_gradients(cfg, cd, sp, batch, double=False, graph='all'):
+def oracle_gradients(cfg, cd, sp, batch, double=False, graph='all', setting='mode2'):
     """(loss, result dict, {name: gradient}) of the CPU oracle on the weights of the modules ``cd`` / ``sp``; ``double``: the whole run in
     float64 (weights, inputs, every intermediate) -- the gradient truth where float32 itself drifts (long answers at full width)."""
     from oracle import ekaid_oracle as O
@@ -97,8 +97,14 @@ def oracle_gradients(cfg, cd, sp, batch, double=False, graph='all'):
         Pcd = {k: (v.double().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in Pcd.items()}
         Psp = {k: (v.double().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in Psp.items()}
         batch = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in batch.items()}
-    loss, res = O.train_loss(Pcd, Psp, cfg, batch, 'mode2', graph)
+    loss, res = O.train_loss(Pcd, Psp, cfg, batch, setting, graph)
     loss.backward()
     grads = {('cd.' + k): Pcd[k].grad for k, _ in cd.named_parameters()}
     grads.update({('sp.' + k): Psp[k].grad for k, _ in sp.named_parameters()})
     return loss.detach(), res, grads
+
+
+def mode0_case():
+    """(cfg, batch): setting 'mode0' at the yaml widths -- the SSRE block (modules.py:17-77) in place of the graph encoders."""
+    cfg = bench_cfg(D=2048, seq_length=90, setting='mode0')
+    return cfg, make_batch(B=2, **FULL)

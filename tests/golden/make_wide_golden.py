@@ -12,6 +12,8 @@ small widths, so those kernels were only ever compared with the step-wise chain.
                       float64 run of the same reference modules (the gradient truth)
   f10_real_full       the real-data shapes at the yaml widths (52 regions x 1024-d, rcc_dataset_pos_mimic.py:107-108), batch 4,
                       ragged answers of 2 ... 40 tokens, an undetected region (all-zero ROI row), an isolated node: same contents
+  f10_mode0_full      setting 'mode0' at the yaml widths (modules.py:17-77, 267-275: the SSRE block -- Q / K / V projections of [v | q],
+                      4-head attention, LayerNorm -- instead of the graph encoders), batch 2, 16 decode steps: same contents
   f10_greedy_b64      greedy `_sample` at batch 64 on seeded decoder inputs with spread logits (logit.weight x 12, NULL bias + 3: answers of 1, 2, 3, 16 and 90 tokens; as
                       tests/test_hip_persist.py does: random-init logits are nearly flat): token ids, stop positions, seq_logprobs, and the
                       smallest top-1 / top-2 margin of any step that was decoded (how far the ids are from a rounding tie)
@@ -32,7 +34,7 @@ from ekaid_amd.synthetic import make_batch               # noqa: E402
 from golden_util import sketch_named                     # noqa: E402
 
 sys.path.insert(0, os.path.join(G.ROOT, 'tests'))
-from common import greedy_case, real_full_case, wide_case   # noqa: E402
+from common import greedy_case, mode0_case, real_full_case, wide_case   # noqa: E402
 
 
 @contextlib.contextmanager
@@ -49,14 +51,14 @@ def float64_reference():
         torch.set_default_dtype(torch.float32)
 
 
-def train_case(name, cfg, batch):
+def train_case(name, cfg, batch, setting='mode2'):
     """float32 run = what the reference computes (outputs, loss, its own gradients); float64 run = the gradient truth: at these widths
     the reference's float32 gradients sit ~1e-3 from it, so a float32 implementation is held to "no farther from
     the truth than max(1e-3, 3 x the reference's own float32 error)", tensor by tensor, chunk by chunk.  The float64 log-probs are kept
     too: over 40 / 90 decode steps the reference's float32 log-probs drift 2.6e-4 / 9.3e-4 from its own float64 run, so an entry's
     relative 1e-3 tolerance is widened by twice that entry's float32-vs-float64 gap."""
     cd, sp = G.build(cfg, 147, 148)
-    loss, sp_loss, outs, logp, logpos, _ = G.ref_step(cfg, cd, sp, batch, 'mode2', 'all')
+    loss, sp_loss, outs, logp, logpos, _ = G.ref_step(cfg, cd, sp, batch, setting, 'all')
     loss.backward()
     T = int((batch['labels'][:, 1:] != 0).any(0).sum()) + 1
     names, sk = sketch_named(G.named_grads(cd, sp))
@@ -65,7 +67,7 @@ def train_case(name, cfg, batch):
         cd64.double()
         sp64.double()
         b64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in batch.items()}
-        loss64, _, _, logp64, _, _ = G.ref_step(cfg, cd64, sp64, b64, 'mode2', 'all', adj_dtype=torch.float64)
+        loss64, _, _, logp64, _, _ = G.ref_step(cfg, cd64, sp64, b64, setting, 'all', adj_dtype=torch.float64)
         assert loss64.dtype == torch.float64 and logp64.dtype == torch.float64
         loss64.backward()
         names64, sk64 = sketch_named(G.named_grads(cd64, sp64))
@@ -121,7 +123,12 @@ def greedy_run(double):
 
 
 def main():
+    if 'mode0' in sys.argv[1:]:
+        cfg, batch = mode0_case()
+        return train_case('f10_mode0_full', cfg, batch, setting='mode0')
     if 'greedy' not in sys.argv[1:]:
+        cfg, batch = mode0_case()
+        train_case('f10_mode0_full', cfg, batch, setting='mode0')
         for T in (40, 90):
             cfg, batch = wide_case(T)
             train_case('f10_T%d' % T, cfg, batch)

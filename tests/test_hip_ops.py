@@ -254,6 +254,7 @@ def test_amax_rc_row_and_column_maxima():
     out = torch.empty(8, device=DEV)
     assert L.ekaid_amax_rc(x.data_ptr(), 8, 30, 30, out.data_ptr(), None, hip.stream()) == hip.ERR_UNSUPPORTED
     ws = [torch.randn(r, c, generator=g).to(DEV) for r, c in ((64, 128), (1024, 1024), (3, 2048), (512, 36))]
+    old = ops.get_gemm_mode()
     ops.set_gemm_mode(ops.GEMM_F16X2)
     try:
         ops.weight_bounds_prepare(ws)
@@ -262,7 +263,7 @@ def test_amax_rc_row_and_column_maxima():
             assert torch.equal(r, w.abs().amax(1)) and torch.equal(c, w.abs().amax(0))
     finally:
         ops.weight_bounds_release()
-        ops.set_gemm_mode(ops.GEMM_BF16_SPLIT)
+        ops.set_gemm_mode(old)
 
 
 def test_gemm_f16x2_is_exact_where_the_dropped_term_vanishes():

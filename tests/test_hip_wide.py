@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from common import build_models, greedy_case, oracle_gradients, real_full_case, wide_case
+from common import build_models, greedy_case, mode0_case, oracle_gradients, real_full_case, wide_case
 from golden_util import assert_no_farther_from_truth, load_golden
 from test_hip_model import LOGIT_TOL, close, hip_step, named_grads
 
@@ -21,23 +21,27 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
 
-@pytest.mark.parametrize('case', ['T40', 'T90', 'real_full'])
+@pytest.mark.parametrize('case', ['T40', 'T90', 'real_full', 'mode0_full'])
 def test_long_answers_at_full_width_match_the_reference_through_the_persistent_kernels(case):
+    """(+ 'mode0_full': setting 'mode0' at the yaml widths -- SSRE: Q / K / V projections of [v | q], 4-head attention with the heads as a
+    strided batch dimension, LayerNorm -- batch 2, 16 decode steps: the same bars; the step-wise decoder backward serves 16 steps.)"""
     from ekaid_amd import hip
     g = load_golden('f10_' + case)
-    cfg, batch = real_full_case() if case == 'real_full' else wide_case(int(case[1:]))
+    setting = 'mode0' if case == 'mode0_full' else 'mode2'
+    cfg, batch = real_full_case() if case == 'real_full' else mode0_case() if case == 'mode0_full' else wide_case(int(case[1:]))
     cd, sp = build_models(cfg, 147, 148, DEV)
     hip.load()
     assert hip.lib().ekaid_get_seq_mode() == 1, 'the default sequence mode is the persistent one'
     c0 = hip.launch_counts()
-    loss, sp_loss, outs, logp, logpos = hip_step(cfg, cd, sp, batch, 'mode2', 'all')
+    loss, sp_loss, outs, logp, logpos = hip_step(cfg, cd, sp, batch, setting, 'all')
     loss.backward()
     torch.cuda.synchronize()
     hip.seq_status_check(case)
     c1 = hip.launch_counts()
     ran = {k: c1[k] - c0[k] for k in c0}
     assert ran['spk_fwd_persistent'] == 1 and ran['spk_fwd_stepwise'] == 0, ran
-    assert ran['spk_bwd_persistent'] == 1 and ran['spk_bwd_stepwise'] == 0, ran       # >= 32 decode steps: the persistent backward
+    if setting == 'mode2':
+        assert ran['spk_bwd_persistent'] == 1 and ran['spk_bwd_stepwise'] == 0, ran       # >= 32 decode steps: the persistent backward
     assert ran['gru_fwd_persistent'] == 1, ran
     T = int(g['steps'])
     close(loss, g['loss'], 1e-4, 'loss')
@@ -62,8 +66,8 @@ def test_long_answers_at_full_width_match_the_reference_through_the_persistent_k
     # ... and EVERY element of every gradient against the oracle run in float64 on this host (pinned to the reference's float64 run in
     # tests/test_oracle_golden.py): no farther from it than max(2e-3 of the tensor's largest entry, HALF the error of the float32 oracle) --
     # at these lengths float32 on the host drifts 1-3 % from the truth (recurrent amplification of rounding), the HIP path ~0.1 %
-    _, _, g64 = oracle_gradients(cfg, cd, sp, batch, double=True)
-    _, _, g32 = oracle_gradients(cfg, cd, sp, batch, double=False)
+    _, _, g64 = oracle_gradients(cfg, cd, sp, batch, double=True, setting=setting)
+    _, _, g32 = oracle_gradients(cfg, cd, sp, batch, double=False, setting=setting)
     frozen = {'cd.' + k for k, p in cd.named_parameters() if not p.requires_grad} | {'sp.' + k for k, p in sp.named_parameters() if not p.requires_grad}
     assert frozen == {'cd.w_emb.emb_.weight'}                 # frozen in the reference too (language_model.py:29): never differentiated
     for k in frozen:
@@ -74,7 +78,7 @@ def test_long_answers_at_full_width_match_the_reference_through_the_persistent_k
 
 def _elementwise_vs_truth(got, g64, g32, what):
     live = [k for k, v in g64.items() if v is not None and float(v.abs().max()) > 0.0]
-    assert len(live) > 60, 'too few live gradients (%d)' % len(live)
+    assert len(live) > 50, 'too few live gradients (%d)' % len(live)          # (89 with the graph encoders, 55 under setting mode0)
     med = float(np.median([float(g64[k].abs().max()) for k in live]))
     bad, worst, nzero = [], (None, 0.0, 0.0), 0
     for k, v in g64.items():

@@ -326,16 +326,17 @@ def test_f4_float64_oracle_agrees_with_float64_reference():
     assert np.median(ref32[live]) > 20 * np.median(rel[live])        # the float32 reference is far noisier than the gap between the truths
 
 
-@pytest.mark.parametrize('case', ['T40', 'T90', 'real_full'])
+@pytest.mark.parametrize('case', ['T40', 'T90', 'real_full', 'mode0_full'])
 def test_f10_production_width_long_answers_and_real_shapes(case):
     """Round-6 fixtures (tests/golden/make_wide_golden.py): the REFERENCE at the yaml widths with 40 / 90 decode steps and at the real
     52 x 1024 shapes with ragged 2 ... 40-token answers -- the cases whose backward runs in the persistent decoder kernel on the GPU.
     The oracle: loss, every log-prob, every gradient chunk by chunk."""
-    from common import real_full_case, wide_case
+    from common import mode0_case, real_full_case, wide_case
     g = load_golden('f10_' + case)
-    cfg, batch = real_full_case() if case == 'real_full' else wide_case(int(case[1:]))
+    setting = 'mode0' if case == 'mode0_full' else 'mode2'          # (mode0: the SSRE + LayerNorm block at the yaml widths, modules.py:17-77)
+    cfg, batch = real_full_case() if case == 'real_full' else mode0_case() if case == 'mode0_full' else wide_case(int(case[1:]))
     cd, sp = build_models(cfg, 147, 148, 'cpu')
-    loss, res, named = run_oracle(cfg, cd, sp, batch, 'mode2', 'all')
+    loss, res, named = run_oracle(cfg, cd, sp, batch, setting, 'all')
     T = int(g['steps'])
     assert T == int((batch['labels'][:, 1:] != 0).any(0).sum()) + 1
     close(loss, g['loss'], what='loss')
@@ -352,7 +353,7 @@ def test_f10_production_width_long_answers_and_real_shapes(case):
     # and every gradient chunk against the float64 run of the reference
     from common import oracle_gradients
     from golden_util import sketch_errors
-    loss64, res64, g64 = oracle_gradients(cfg, cd, sp, batch, double=True)
+    loss64, res64, g64 = oracle_gradients(cfg, cd, sp, batch, double=True, setting=setting)
     assert abs(float(loss64) - float(g['loss_f64'])) <= 1e-7 * abs(float(g['loss_f64']))
     assert float((res64['logp'][:, :T].detach() - torch.from_numpy(g['logp_f64']).double()).abs().max()) <= 2e-6      # (stored as float32)
     e = sketch_errors(g['grad_names'], g['grad_sketch_f64'], lambda i, k: tensor_sketch(g64[k]) if g64.get(k) is not None else None)

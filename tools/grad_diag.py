@@ -1,6 +1,6 @@
 """Why does a full-width long-answer case differ element-wise between the HIP path and the CPU oracle?  Prints, per gradient tensor of
 one f10 case: HIP vs float64 truth (sketch), oracle-on-this-host vs truth, reference float32 vs truth, HIP vs oracle element-wise
-(max / max and l2-relative), under the sequence / GEMM modes given.      python tools/grad_diag.py T40 [stepwise] [f32]"""
+(max / max and l2-relative), under the sequence / GEMM modes given.      python tools/grad_diag.py T40 [stepwise] [f32 | split3 | f16x2] [allx2]"""
 import json
 import os
 import sys
@@ -25,6 +25,12 @@ def main():
         hip.check(hip.lib().ekaid_set_seq_mode(0), 'seq mode')
     if 'f32' in sys.argv:
         ops.set_gemm_mode(ops.GEMM_F32_MFMA)
+    if 'split3' in sys.argv:
+        ops.set_gemm_mode(ops.GEMM_BF16_SPLIT)
+    if 'f16x2' in sys.argv:
+        ops.set_gemm_mode(ops.GEMM_F16X2)
+    if 'allx2' in sys.argv:
+        ops.F16X2_MIN_WORK = 0
     torch.set_num_threads(int(os.environ.get('DIAG_THREADS', '16')))
     g = load_golden('f10_' + case)
     cfg, batch = real_full_case() if case == 'real_full' else wide_case(int(case[1:]))
