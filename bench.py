@@ -144,6 +144,62 @@ def pmc_traffic():
             'source': os.path.relpath(cands[-1], ROOT)}
 
 
+def gat_roofline(R, N, A=1024, H=4):
+    """The graph-attention core (north_star's named kernel: neighbour gather + edge softmax + weighted aggregation) as the step runs it,
+    against the HBM roof (reported separately from the matrix-pipe line).  R graph slices of N regions, timed alone with
+    HIP events on the launch stream: forward = the batched affinity product + gat_fused_fwd_kernel, backward = the batched products +
+    masked_softmax_bwd + gat_dqk.  Algorithmic bytes per slice: forward reads q, k, S (3 N A) and writes the aggregated values (N H A) and
+    the probabilities (N H M); backward reads d(values) (N H A), q, k, S and the probabilities and writes dq, dk, dS.  `traffic`: the
+    committed rocprofv3 PMC summary of the same kernels (tools/pmc_gat_all.sh: FETCH_SIZE doubled as the gfx950 guide prescribes)."""
+    from ekaid_amd import ops
+    g = torch.Generator().manual_seed(0)
+    dev = 'cuda'
+    q, k, S = (torch.randn(R, N, A, generator=g).to(dev).requires_grad_(True) for _ in range(3))
+    cond = (torch.rand(R, N, N, generator=g) > 0.4).float().to(dev)
+    lb = (torch.randn(R, N, N, generator=g) * 0.3).to(dev).requires_grad_(True)
+    w = torch.randn(R, N, H * A, generator=g).to(dev)
+
+    def run():
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        out, P = ops.gat_attention(q, k, S, cond, lb, None, H, 1)
+        e1.record()
+        torch.autograd.grad(out, [q, k, S, lb], w)
+        e2.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3, e1.elapsed_time(e2) * 1e3
+    for _ in range(3):
+        run()
+    res = [run() for _ in range(9)]
+    fwd, bwd = sorted(x[0] for x in res)[4], sorted(x[1] for x in res)[4]
+    M = N
+    b_fwd = R * (3 * N * A * 4 + N * H * A * 4 + N * H * M * 4)
+    b_bwd = R * (N * H * A * 4 + 3 * N * A * 4 + N * H * M * 4 + 3 * N * A * 4)
+    traffic = None
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_gat_n%d.json' % N)))
+    if cands:
+        try:
+            ks = json.load(open(cands[-1]))['kernels']
+            traffic = {name: {k2: v['derived'][k2] for k2 in ('median_duration_us', 'hbm_fetch_bytes_corrected', 'hbm_write_bytes', 'algorithmic_bytes',
+                                                             'hbm_traffic_over_algorithmic', 'frac_of_8TBps') if k2 in v.get('derived', {})}
+                       for name, v in ks.items() if 'derived' in v}
+            traffic['source'] = os.path.relpath(cands[-1], ROOT)
+        except (KeyError, ValueError):
+            traffic = None
+    return {'bound': 'hbm', 'kernel': 'graph-attention core: batched affinity product + ekaid::gat_fused_fwd_kernel (forward); batched products + '
+                                      'masked_softmax_bwd_kernel + gat_dqk_kernel (backward)',
+            'shape': {'slices': R, 'regions': N, 'width': A, 'heads': H},
+            'forward': {'us': round(fwd, 1), 'algorithmic_bytes': b_fwd, 'achieved': round(b_fwd / fwd / 1e3, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                        'frac': round(b_fwd / fwd / 1e3 / 8000.0, 4)},
+            'backward': {'us': round(bwd, 1), 'algorithmic_bytes': b_bwd, 'achieved': round(b_bwd / bwd / 1e3, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                         'frac': round(b_bwd / bwd / 1e3 / 8000.0, 4)},
+            'traffic': traffic,
+            'note': 'timed alone, launches back to back (9 runs, median); in the 256-pair step the forward kernel takes ~112 us per launch (its store '
+                    'drain overlaps the next kernel).  The aggregated values are (R, N, heads x width): 302 MB of the 514 MB at R = 512 -- the reference '
+                    'keeps un-projected values per head (graph_att_layer.py:164-172)'}
+
+
 def physical_cores():
     try:
         import psutil
@@ -199,10 +255,16 @@ def cpu_baseline(cfg, cd, sp, batch_size, graph, budget_s=25.0):
         def deltas(lp):
             got = lp[:, :T].cpu()
             d = (got - ref).abs()
+            diff = got.argmax(-1) != ref.argmax(-1)
+            top = ref.topk(2, dim=-1).values
+            margin = (top[..., 0] - top[..., 1])
             return {'logit_max_abs_delta': float(d.max()),
                     'logit_max_rel_delta_to_range': float(d.max() / ref.abs().max()),
                     'logit_max_elementwise_rel_delta': float((d / ref.abs().clamp_min(1e-6)).max()),
-                    'argmax_identical': bool(torch.equal(got.argmax(-1), ref.argmax(-1)))}
+                    'argmax_identical': bool(torch.equal(got.argmax(-1), ref.argmax(-1))),
+                    # (these are the weights the timed steps have just trained, not a fixture: two candidate words may tie within rounding)
+                    'argmax_positions': int(diff.numel()), 'argmax_differing': int(diff.sum()),
+                    'oracle_top2_margin_at_differing_positions_max': float(margin[diff].max()) if bool(diff.any()) else None}
         parity = deltas(logp)
         parity_x2 = deltas(logp_x2) if logp_x2 is not None else None
         t0 = time.perf_counter()
@@ -414,7 +476,23 @@ def device_state(index=0):
         cards = sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk'))
         if not cards:
             return {'note': 'no sysfs clock files'}
-        d = os.path.dirname(cards[min(index, len(cards) - 1)])
+        # the card whose PCI address is that of HIP device `index` (a box may expose more cards in sysfs than GPUs to the process, in
+        # another order: the first card is not necessarily ours)
+        d = None
+        try:
+            props = torch.cuda.get_device_properties(index)
+            want = '%04x:%02x:%02x.' % (getattr(props, 'pci_domain_id', 0), getattr(props, 'pci_bus_id', 0), getattr(props, 'pci_device_id', 0))
+            for c in cards:
+                if os.path.basename(os.path.realpath(os.path.dirname(c))).startswith(want):
+                    d = os.path.dirname(c)
+                    out['pci'] = want + '0'
+                    break
+        except Exception:                       # noqa: BLE001
+            d = None
+        if d is None:
+            d = os.path.dirname(cards[min(index, len(cards) - 1)])
+            out['note'] = 'PCI address of the HIP device not found in sysfs: card picked by index'
+        out['cards_in_sysfs'] = len(cards)
         for key, name in (('sclk_mhz', 'pp_dpm_sclk'), ('mclk_mhz', 'pp_dpm_mclk')):
             try:
                 cur = [ln for ln in open(os.path.join(d, name)) if '*' in ln]
@@ -785,6 +863,29 @@ def main():
         cd.train(not args.eval); sp.train(not args.eval)             # noqa: E702
         extra['forward_only_b64'] = {'ms': round(ms64, 3), 'pairs_per_s': round(64 / ms64 * 1e3, 1),
                                      'workload': 'BASELINE.json configs[1]: eval forward, batch 64, T=16'}
+        # setting 'mode0' (modules.py:17-77, 267-275): the SSRE block -- Q / K / V projections of [v | q], 4-head attention with the heads
+        # as a strided batch dimension, LayerNorm -- in place of the graph encoders: north_star's "multi-head QKV attention" and "fused
+        # LayerNorm" live only here; same shapes, eval forward and a train step at batch 64
+        try:
+            cfg0 = bench_cfg(D=SHAPE['D'], seq_length=SHAPE['seq_length'], graph=args.graph, setting='mode0')
+            cdm, spm = build_models(cfg0, 147, 148, dev, train=False)
+            with torch.no_grad():
+                ms0 = timed(lambda: forward_loss(cfg0, cdm, spm, b64, T, args.graph, 'mode0'), 20, 3)
+            cdm.train(); spm.train()                                     # noqa: E702
+
+            def mode0_step():
+                for p_ in list(cdm.parameters()) + list(spm.parameters()):
+                    p_.grad = None
+                ops.clear_grad_claims()
+                forward_loss(cfg0, cdm, spm, b64, T, args.graph, 'mode0')[0].backward()
+            ms0t = timed(mode0_step, 10, 3)
+            extra['mode0_b64'] = {'forward_ms': round(ms0, 3), 'forward_pairs_per_s': round(64 / ms0 * 1e3, 1),
+                                  'fwd_bwd_ms': round(ms0t, 3), 'fwd_bwd_pairs_per_s': round(64 / ms0t * 1e3, 1),
+                                  'workload': "setting='mode0' (SSRE: QKV projections + 4-head attention + LayerNorm instead of the graph encoders), "
+                                              'batch 64, T=16: eval forward, and forward + backward in train mode (no optimizer step)'}
+            del cdm, spm
+        except Exception as e:                  # noqa: BLE001  (a side measurement must not cost the line)
+            extra['mode0_b64'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
         # test_mimic.py's path (configs[1] + answer generation): eval forward, then greedy decode.  On freshly initialised weights (a
         # second model pair: the trained one stops after as many steps as its training length happens to teach it) the answers never
         # emit the end token, so every run decodes all seq_length (90) steps: a fixed worst-case workload
@@ -946,6 +1047,11 @@ def main():
             extra = dict(extra or {}, per_gpu_ladder=ladder)
         if extra is not None:
             out['extra'] = extra
+        if world == 1 and not args.no_extra:
+            try:
+                out['roofline_gat'] = gat_roofline(2 * per_gpu, SHAPE['N'])
+            except Exception as e:              # noqa: BLE001  (a side measurement must not cost the line)
+                out['roofline_gat'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, cd, sp, args.cpu_batch, args.graph)
         emit(out)

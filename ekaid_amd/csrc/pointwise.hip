@@ -889,11 +889,12 @@ __global__ __launch_bounds__(256) void amax_rc_kernel(AmaxMulti a) {
         bool ok[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) ok[c] = col0 + 256 * c + 4 * lane < cols;
+        constexpr int U = RW < 4 ? RW : 4;             // rows of a wave in flight together
 #pragma unroll
-        for (int j0 = 0; j0 < RW; j0 += 4) {
-            u32x4_t v[4][4];
+        for (int j0 = 0; j0 < RW; j0 += U) {
+            u32x4_t v[U][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 long long row = r0 + wave + 4 * (j0 + u);
                 row = row < rows ? row : rows - 1;                                    // (clamped: a repeated row changes no maximum ...
                 const float* p = x + row * ld + col0 + 4 * lane;
@@ -901,7 +902,7 @@ __global__ __launch_bounds__(256) void amax_rc_kernel(AmaxMulti a) {
                 for (int c = 0; c < 4; ++c) v[u][c] = ok[c] ? *reinterpret_cast<const u32x4_t*>(p + 256 * c) : u32x4_t{0, 0, 0, 0};
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const bool mine = r0 + wave + 4 * (j0 + u) < rows;                    // ... of a column; its row maximum is not stored)
                 unsigned m = 0;
 #pragma unroll
@@ -939,7 +940,7 @@ __global__ __launch_bounds__(256) void amax_rc_kernel(AmaxMulti a) {
     }
 }
 extern "C" int ekaid_amax_rc_multi(const float* const* x, const long long* rows, const int* cols, const int* ld, float* const* rowmax,
-                                   float* const* colmax, int count, void* stream) {
+                                   float* const* colmax, int count, int colmax_zeroed, void* stream) {
     if (count < 1 || count > AMAX_MAX || !x || !rows || !cols || !ld || !rowmax || !colmax) {
         set_error("amax_rc_multi: 1 <= count <= %d matrices, non-null arrays", AMAX_MAX);
         return EKAID_ERR_ARG;
@@ -957,19 +958,20 @@ extern "C" int ekaid_amax_rc_multi(const float* const* x, const long long* rows,
         a.x[i] = on ? x[i] : nullptr; a.rows[i] = on ? rows[i] : 0; a.cols[i] = on ? cols[i] : 0; a.ld[i] = on ? ld[i] : 0;
         a.rowmax[i] = on ? reinterpret_cast<unsigned*>(rowmax[i]) : nullptr; a.colmax[i] = on ? reinterpret_cast<unsigned*>(colmax[i]) : nullptr;
         if (on && rows[i] > rmax) rmax = rows[i];
-        if (on && colmax[i] && cols[i] > 0 &&
+        if (on && colmax[i] && cols[i] > 0 && !colmax_zeroed &&
             hipMemsetAsync(colmax[i], 0, sizeof(float) * cols[i], ST) != hipSuccess) { (void)hipGetLastError(); set_error("amax_rc_multi: memset failed"); return EKAID_ERR_LAUNCH; }
     }
     if (rmax == 0) return EKAID_OK;
-    if (rmax >= 4096) {
-        hipLaunchKernelGGL(amax_rc_kernel<32>, dim3((unsigned)((rmax + 31) / 32), count), dim3(256), 0, ST, a);
-    } else {
-        hipLaunchKernelGGL(amax_rc_kernel<16>, dim3((unsigned)((rmax + 15) / 16), count), dim3(256), 0, ST, a);
-    }
+    // rows per workgroup: as many as still leave ~2 workgroups per CU (a 2304-row operand of a 32-pair step cut into 32-row panels is 72
+    // workgroups on 256 CUs, each walking 128 KB with four loads in flight: ~20 us for 9 MB)
+    if (rmax >= 16384) hipLaunchKernelGGL(amax_rc_kernel<32>, dim3((unsigned)((rmax + 31) / 32), count), dim3(256), 0, ST, a);
+    else if (rmax >= 8192) hipLaunchKernelGGL(amax_rc_kernel<16>, dim3((unsigned)((rmax + 15) / 16), count), dim3(256), 0, ST, a);
+    else if (rmax >= 4096) hipLaunchKernelGGL(amax_rc_kernel<8>, dim3((unsigned)((rmax + 7) / 8), count), dim3(256), 0, ST, a);
+    else hipLaunchKernelGGL(amax_rc_kernel<4>, dim3((unsigned)((rmax + 3) / 4), count), dim3(256), 0, ST, a);
     return check_launch("amax_rc_multi");
 }
-extern "C" int ekaid_amax_rc(const float* x, long long rows, int cols, int ld, float* rowmax, float* colmax, void* stream) {
-    return ekaid_amax_rc_multi(&x, &rows, &cols, &ld, &rowmax, &colmax, 1, stream);
+extern "C" int ekaid_amax_rc(const float* x, long long rows, int cols, int ld, float* rowmax, float* colmax, int colmax_zeroed, void* stream) {
+    return ekaid_amax_rc_multi(&x, &rows, &cols, &ld, &rowmax, &colmax, 1, colmax_zeroed, stream);
 }
 
 extern "C" int ekaid_wn_grad_multi(float* const* G, const float* const* v, const float* const* g, const float* const* norm,

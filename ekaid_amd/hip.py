@@ -213,8 +213,8 @@ SIGNATURES = {
     'ekaid_adam_step_dev': [P, P, P, P, L, P, P, P, P, P],
     'ekaid_seq_fault_flag': [P, P],
     'ekaid_launch_count': [I],
-    'ekaid_amax_rc': [P, L, I, I, P, P, P],
-    'ekaid_amax_rc_multi': [P, P, P, P, P, P, I, P],
+    'ekaid_amax_rc': [P, L, I, I, P, P, I, P],
+    'ekaid_amax_rc_multi': [P, P, P, P, P, P, I, I, P],
 }
 _RESTYPES = {'ekaid_last_error': c_char_p, 'ekaid_launch_count': c_longlong, 'ekaid_gemm_workspace_bytes': c_size_t, 'ekaid_gemm_pair_workspace_bytes': c_size_t, 'ekaid_gru_seq_workspace_bytes': c_size_t, 'ekaid_gru_seq_persistent_workspace_bytes': c_size_t,
              'ekaid_speaker_seq_workspace_bytes': c_size_t, 'ekaid_speaker_seq_persistent_workspace_bytes': c_size_t,

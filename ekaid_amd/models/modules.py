@@ -173,6 +173,7 @@ class ChangeDetector(nn.Module):
         if wn and input_1.is_cuda:
             ops.wn_prepare(wn)
         if input_1.is_cuda and ops.get_gemm_mode() == ops.GEMM_F16X2:
+            ops.bounds_pool_reset(input_1.device)            # (the step begins here: one clear for the column maxima of all its bounds passes)
             # two-term f16 GEMM split: the row / column maxima of every weight this call multiplies with, one launch per 32 weights
             plain = [self.img.weight, self.context1.weight, self.context2.weight, self.gate1.weight, self.gate2.weight, self.embed[0].weight]
             live_v = {v.data_ptr() for v, _ in wn}

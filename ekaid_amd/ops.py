@@ -170,6 +170,43 @@ _BIAS_IN_WGRAD = os.environ.get('EKAID_BIAS_IN_WGRAD', '1') != '0'
 _SEQ_IN_C = os.environ.get('EKAID_SEQ_IN_C', '1') != '0'      # time loops of the GRU / decoder behind ONE C-ABI call each
 
 
+# Column maxima are accumulated with atomics into ZEROED outputs.  Instead of one memset node per bounds pass, the column outputs of a
+# step are slices of one pool that is cleared once, where the step begins (``bounds_pool_reset``: the detector's forward).  A slice is
+# handed out once between two resets; an exhausted pool, or a caller that never resets, falls back to a fresh zeroed tensor per pass.
+_BOUNDS_POOL_FLOATS = 1 << 18
+_bounds_pool = {}            # device -> [zeroed buffer, next free element, generation]
+
+
+def bounds_pool_reset(device):
+    """Clear the pool of column-maxima outputs (one memset node) and start handing out its slices from the top.  Bounds taken before
+    a reset are STALE afterwards (their memory is cleared and handed out again): whoever keeps bounds across other work -- a forward
+    pass keeps them for its backward pass -- remembers ``bounds_generation`` and takes them afresh if it has moved on (two forward passes
+    before the first backward: the second one's reset must not leave the first with the second's maxima)."""
+    ent = _bounds_pool.get(device)
+    if ent is None:
+        _bounds_pool[device] = [torch.zeros(_BOUNDS_POOL_FLOATS, device=device, dtype=torch.float32), 0, 1]
+    else:
+        ent[0].zero_()
+        ent[1] = 0
+        ent[2] += 1
+
+
+def bounds_generation(device):
+    ent = _bounds_pool.get(device)
+    return ent[2] if ent is not None else 0
+
+
+def _zeroed_cols(device, n):
+    """(n zeroed floats, came from the pool)"""
+    ent = _bounds_pool.get(device)
+    n4 = (n + 3) & ~3
+    if ent is not None and ent[1] + n4 <= _BOUNDS_POOL_FLOATS:
+        out = ent[0][ent[1]:ent[1] + n]
+        ent[1] += n4
+        return out, True
+    return torch.empty(n, device=device, dtype=torch.float32), False
+
+
 def amax_rc(x, rows, cols, ld, off=0, want_rows=True, want_cols=True):
     """(rowmax [rows], colmax [cols]) of |x[off + r * ld + c]| on the device (either None when not wanted): the operand bounds of the
     two-term f16 GEMM split (include/ekaid_hip.h: ekaid_amax_rc).  None, None when the matrix is not made of whole 16-byte vectors --
@@ -177,18 +214,23 @@ def amax_rc(x, rows, cols, ld, off=0, want_rows=True, want_cols=True):
     if (cols & 3) or (ld & 3) or ((x.data_ptr() + 4 * off) & 15) or rows < 1 or cols < 1:
         return None, None
     rm = torch.empty(rows, device=x.device, dtype=torch.float32) if want_rows else None
-    cm = torch.empty(cols, device=x.device, dtype=torch.float32) if want_cols else None
-    check(hip.lib().ekaid_amax_rc(x.data_ptr() + 4 * off, rows, cols, ld, ptr(rm), ptr(cm), stream()), 'amax_rc')
+    cm, pooled = _zeroed_cols(x.device, cols) if want_cols else (None, False)
+    check(hip.lib().ekaid_amax_rc(x.data_ptr() + 4 * off, rows, cols, ld, ptr(rm), ptr(cm), int(pooled), stream()), 'amax_rc')
     return rm, cm
 
 
-F16X2_MIN_WORK = int(os.environ.get('EKAID_F16X2_MIN_WORK', 1 << 28))      # M * N * K below which a product is not worth its bounds pass
+# M * N * K below which a layer's products are not worth the bounds passes they need (each pass = a memset node + a kernel: ~10 us even
+# for a small operand).  Measured on the replayed 128 / 64 / 32-pair steps (profiles/r06_ladder_f16x2_threshold.txt): with every product
+# >= 2^28 on the two-term split the 2304-row layers of a 32-pair step lose more to their ~70 extra graph nodes than their products gain.
+F16X2_MIN_WORK = int(float(os.environ.get('EKAID_F16X2_MIN_WORK', 6e9)))
+# the same for a block of products that SHARE their passes (the decoder's fifteen time-batched weight gradients read one matrix: one pass)
+F16X2_MIN_WORK_SHARED = int(float(os.environ.get('EKAID_F16X2_MIN_WORK_SHARED', 1.5e9)))
 
 
-def f16x2_wanted(M, N, K):
+def f16x2_wanted(M, N, K, min_work=None):
     """Should the call site of an M x N x K product compute operand bounds for the two-term f16 split?  (Mode 2 only; small products
     stay on the exact split: a bounds pass is a launch of its own.)"""
-    return get_gemm_mode() == GEMM_F16X2 and M * N * K >= F16X2_MIN_WORK and min(M, N, K) >= 32
+    return get_gemm_mode() == GEMM_F16X2 and M * N * K >= (F16X2_MIN_WORK if min_work is None else min_work) and min(M, N, K) >= 32
 
 
 _wb_cache = {}           # weight data_ptr -> (row maxima [N], column maxima [K]) for the current step (weight_bounds_prepare / _release)
@@ -206,21 +248,23 @@ def weight_bounds_prepare(weights):
         chunk = ws[i0:i0 + 32]
         n = len(chunk)
         dev = chunk[0].device
-        tot_r, tot_c = sum(w.shape[0] for w in chunk), sum(w.shape[1] for w in chunk)
-        buf = torch.empty(tot_r + tot_c, device=dev, dtype=torch.float32)
+        tot_r, tot_c = sum(w.shape[0] for w in chunk), sum((w.shape[1] + 3) & ~3 for w in chunk)
+        buf = torch.empty(tot_r, device=dev, dtype=torch.float32)
+        cbuf, pooled = _zeroed_cols(dev, tot_c)
         rms, cms, o = [], [], 0
         for w in chunk:
             rms.append(buf[o:o + w.shape[0]])
             o += w.shape[0]
+        o = 0
         for w in chunk:
-            cms.append(buf[o:o + w.shape[1]])
-            o += w.shape[1]
+            cms.append(cbuf[o:o + w.shape[1]])
+            o += (w.shape[1] + 3) & ~3
         xs = (ctypes.c_void_p * n)(*[w.data_ptr() for w in chunk])
         rows = (ctypes.c_longlong * n)(*[w.shape[0] for w in chunk])
         cols = (ctypes.c_int * n)(*[w.shape[1] for w in chunk])
         rp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in rms])
         cp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in cms])
-        check(L.ekaid_amax_rc_multi(xs, rows, cols, cols, rp, cp, n, stream()), 'amax_rc_multi')
+        check(L.ekaid_amax_rc_multi(xs, rows, cols, cols, rp, cp, n, int(pooled), stream()), 'amax_rc_multi')
         for w, r, c in zip(chunk, rms, cms):
             _wb_cache[w.data_ptr()] = (r, c)
 
@@ -682,6 +726,7 @@ class LinearFn(Function):
         x2 = f16x2_wanted(M, N, min(x.shape[1] for x in xs2))
         ctx.wb = weight_bounds(W) if x2 else (None, None)
         ctx.xb = [amax_rc(x, M, x.shape[1], ld) if x2 else (None, None) for x, ld in zip(xs2, lds)]
+        ctx.bgen = bounds_generation(W.device)
         off = 0
         for i, (x, ld) in enumerate(zip(xs2, lds)):
             last = i == len(xs2) - 1
@@ -717,6 +762,9 @@ class LinearFn(Function):
             dz = dy
         need = ctx.needs_input_grad
         # (mode 2: the bounds of dz serve both gradient products -- its row maxima the input gradient, its column maxima the weight gradient)
+        if ctx.wb[0] is not None and ctx.bgen != bounds_generation(W.device):          # another forward pass has recycled the pool since: afresh
+            ctx.wb = amax_rc(W, N, Ktot, Ktot)
+            ctx.xb = [amax_rc(x, M, x.shape[1], ld) for x, ld in zip(xs2, ctx.lds)]
         dzb = amax_rc(dz, M, N, N) if ctx.wb[0] is not None else (None, None)
         db = db_buf = None
         if ctx.has_b and need[1]:
@@ -866,6 +914,7 @@ class LinearRowStackFn(Function):
         x2 = f16x2_wanted(min(Ms), N, K)
         ctx.wb = weight_bounds(W) if x2 else (None, None)
         ctx.xb = [amax_rc(x, M, K, ld) if x2 else (None, None) for x, ld, M in zip(xs2, lds, Ms)]
+        ctx.bgen = bounds_generation(W.device)
         for (x, ld, M), xb in zip(zip(xs2, lds, Ms), ctx.xb):
             if Wt is not None:
                 gemm(x, Wt, y, M, N, K, ld, N, N, 0, 0, bias=b, c_off=r0 * N)
@@ -889,6 +938,9 @@ class LinearRowStackFn(Function):
         if ctx.has_b and need[1]:
             db_buf, db = bias_grad_slot(ctx.bias_ref)
         dW = None
+        if ctx.wb[0] is not None and ctx.bgen != bounds_generation(W.device):          # (stale: see bounds_pool_reset)
+            ctx.wb = amax_rc(W, N, K, K)
+            ctx.xb = [amax_rc(x, M, K, ld) for x, ld, M in zip(xs2, ctx.lds, ctx.Ms)]
         dyb = amax_rc(dy, Mtot, N, N) if ctx.wb[0] is not None else (None, None)
         if need[0]:
             dW = grad_out(W)
@@ -979,6 +1031,7 @@ class _SubCtx:
     wn = None
     wb = (None, None)
     xb = ()
+    bgen = 0
     needs_input_grad = ()
 
     def save_for_backward(self, *tensors):
@@ -1644,6 +1697,7 @@ class GRUSeqFn(Function):
         x2 = f16x2_wanted(B * T, 3 * H, E)              # (mode 2: bounds of x and W_ih, reused by the three time-batched products)
         ctx.xb = amax_rc(x, B * T, E, E) if x2 else (None, None)
         ctx.wb = weight_bounds(w_ih) if x2 else (None, None)
+        ctx.bgen = bounds_generation(dev)
         gemm(x, w_ih, gi, B * T, 3 * H, E, E, E, 3 * H, 0, 1, bias=b_ih, a_amax=ctx.xb[0], b_amax=ctx.wb[0])
         hall = torch.zeros(T + 1, B, H, device=dev, dtype=torch.float32)     # time-major states, hall[0] = h0 = 0
         save = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
@@ -1697,6 +1751,8 @@ class GRUSeqFn(Function):
         ih_buf, db_ih = bias_grad_slot(b_ih)
         dw_ih = grad_out(w_ih)
         x2 = ctx.wb[0] is not None
+        if x2 and ctx.bgen != bounds_generation(dev):                  # (stale: see bounds_pool_reset)
+            ctx.xb, ctx.wb = amax_rc(x, B * T, E, E), amax_rc(w_ih, 3 * H, E, E)
         dgib = amax_rc(dgi, B * T, 3 * H, 3 * H) if x2 else (None, None)
         dghb = amax_rc(dgh, T * B, 3 * H, 3 * H, want_rows=False) if x2 else (None, None)
         hb = amax_rc(hall, T * B, H, H, want_rows=False) if x2 else (None, None)

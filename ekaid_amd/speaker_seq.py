@@ -55,7 +55,7 @@ def _tn(D, ldd, X, ldx, G, goff, ldg, Nout, Kin, rows, doff=0, xoff=0, bias=None
     sum of D -- it rides on this product (ops.gemm a_rowsum); returns their autograd values.  db / xb: bounds pairs of the matrices D
     and X are column blocks of (ops.amax_rc: their column maxima serve the two-term f16 split; None = exact split)."""
     kw = {}
-    if db is not None and xb is not None and db[1] is not None and xb[1] is not None and ops.f16x2_wanted(Nout, Kin, rows):
+    if db is not None and xb is not None and db[1] is not None and xb[1] is not None and ops.f16x2_wanted(Nout, Kin, rows, 0):
         kw = dict(a_amax=(db[1], doff % ldd), b_amax=(xb[1], xoff % ldx))       # (offsets: rows * ld + first column)
     if bias is None:
         gemm(D, X, G, Nout, Kin, rows, ldd, ldx, ldg, 1, 0, a_off=doff, b_off=xoff, c_off=goff, **kw)
@@ -137,7 +137,7 @@ class SpeakerSeqFn(Function):
         Xd = torch.empty_like(Xr)
         _drop(Xr, Xd, TB * We, p, seeds['xt'])
         # two-term f16 split (mode 2) for the time-batched products: bounds of their operands, taken once and kept for the backward pass
-        x2 = ops.f16x2_wanted(TB, 4 * R, We)
+        x2 = ops.f16x2_wanted(TB, 4 * R, We, ops.F16X2_MIN_WORK_SHARED)
         none2 = (None, None)
         if x2:
             ops.weight_bounds_prepare([wih_a, wih_l, w_lo, w_g1])
@@ -235,7 +235,7 @@ class SpeakerSeqFn(Function):
         ctx.biases = tuple(t.detach() for t in (b_e, bih_a, bhh_a, b_fc, b_p1, b_wp, b_p2, b_g1, b_g2, bih_l, bhh_l, b_lo))
         ctx.wrefs = (w_p1.detach(), whh_l.detach())   # (read through Wcat in the backward pass; needed for their slots only)
         ctx.pp = (p, p5, seeds, seeds_t)
-        ctx.bounds = (wb, edb, xdb, hob)
+        ctx.bounds = (wb, edb, xdb, hob, ops.bounds_generation(dev))
         ctx.save_for_backward(bef, aft, diff, tok_tb, embed_pre, ED, Xd, HA, CA, HL, CL, SA, SL, MW, VP, PW, PA, AT,
                               G1D, GT, GA, HO, logp, logpos, emb, w_e, wih_a, whh_a, w_fc, w_wp, w_p2, w_g1, w_g2,
                               wih_l, w_lo, Wcat)
@@ -261,9 +261,12 @@ class SpeakerSeqFn(Function):
         # ---- head (time-batched)
         dlogits = torch.empty(T, B, V, **f32)
         check(L.ekaid_softmax_bwd(ptr(logp), ptr(dlogp), ptr(dlogits), TB, V, 1, stream()), 'softmax_bwd')
-        wb, edb, xdb, hob = ctx.bounds
+        wb, edb, xdb, hob, bgen = ctx.bounds
         x2 = edb[0] is not None
         none2 = (None, None)
+        if x2 and bgen != ops.bounds_generation(dev):                  # another forward pass has recycled the bounds pool since: afresh
+            wb = {k: ops.amax_rc(w, w.shape[0], w.shape[1], w.shape[1]) for k, w in (('wih_a', wih_a), ('wih_l', wih_l), ('w_lo', w_lo), ('w_g1', w_g1))}
+            edb, xdb, hob = ops.amax_rc(ED, TB, E, E), ops.amax_rc(Xd, TB, We, We), ops.amax_rc(HO, TB, R, R)
         dlb = ops.amax_rc(dlogits, TB, V, V) if x2 else none2
         d_w_lo = ops.grad_out(w_lo)
         d_b_lo = _tn(dlogits, V, HO, R, d_w_lo, 0, R, V, R, TB, bias=b_lo, db=dlb, xb=hob)

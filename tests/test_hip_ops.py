@@ -252,7 +252,16 @@ def test_amax_rc_row_and_column_maxima():
     L = hip.lib()
     x = torch.randn(8, 30, device=DEV)
     out = torch.empty(8, device=DEV)
-    assert L.ekaid_amax_rc(x.data_ptr(), 8, 30, 30, out.data_ptr(), None, hip.stream()) == hip.ERR_UNSUPPORTED
+    assert L.ekaid_amax_rc(x.data_ptr(), 8, 30, 30, out.data_ptr(), None, 0, hip.stream()) == hip.ERR_UNSUPPORTED
+    # the pool of column outputs: cleared once, slices handed out once each; an exhausted pool falls back to a memset per pass
+    ops.bounds_pool_reset(torch.device(DEV, torch.cuda.current_device()))
+    xs = [torch.randn(64, 4096, generator=g).to(DEV) for _ in range(70)]                    # 70 x 4096 columns > the pool's 2^18 floats
+    outs = [ops.amax_rc(t, 64, 4096, 4096) for t in xs]
+    for t, (rm, cm) in zip(xs, outs):
+        assert torch.equal(rm, t.abs().amax(1)) and torch.equal(cm, t.abs().amax(0))
+    ops.bounds_pool_reset(torch.device(DEV, torch.cuda.current_device()))
+    rm, cm = ops.amax_rc(xs[3], 64, 4096, 4096)
+    assert torch.equal(cm, xs[3].abs().amax(0))
     ws = [torch.randn(r, c, generator=g).to(DEV) for r, c in ((64, 128), (1024, 1024), (3, 2048), (512, 36))]
     old = ops.get_gemm_mode()
     ops.set_gemm_mode(ops.GEMM_F16X2)
@@ -1645,3 +1654,35 @@ def test_weight_norm_backward_of_gradients_outside_their_flat_slots(multi, monke
     loss_of(x1, x2).backward()
     compare(2, 'accumulation into set gradients')
     ops.clear_grad_claims()
+
+
+def test_bounds_kept_for_backward_survive_another_forward_pass(monkeypatch):
+    """The column maxima of a step's bounds passes live in one pool that the detector's forward clears (ops.bounds_pool_reset).  A layer
+    keeps the bounds of x and W for its backward pass; if ANOTHER forward pass recycles the pool in between (two forward passes, then
+    the first one's backward), the kept vectors hold the second pass's maxima -- a million times too small here, i.e. f16 overflow -- unless
+    the backward notices the pool's generation and takes them afresh."""
+    from ekaid_amd import hip, ops
+    monkeypatch.setattr(ops, 'F16X2_MIN_WORK', 0)
+    old = ops.get_gemm_mode()
+    ops.set_gemm_mode(ops.GEMM_F16X2)
+    dev = torch.device(DEV, torch.cuda.current_device())
+    try:
+        g = torch.Generator().manual_seed(9)
+        W = (torch.randn(256, 512, generator=g) * 0.05).to(DEV).requires_grad_(True)
+        b = torch.zeros(256, device=DEV, requires_grad=True)
+        x1 = torch.randn(1024, 512, generator=g).to(DEV).requires_grad_(True)
+        x2 = (x1.detach() * 1e-6).requires_grad_(True)
+        ops.bounds_pool_reset(dev)
+        c0 = hip.launch_counts()
+        y1 = ops.linear(x1, W, b)
+        ops.bounds_pool_reset(dev)                         # "the next forward pass begins"
+        y2 = ops.linear(x2, W * 1e-6, b)
+        (y1 * torch.linspace(-1, 1, 256, device=DEV)).sum().backward()
+        c1 = hip.launch_counts()
+        assert c1['gemm_split2'] - c0['gemm_split2'] >= 4          # both forward products, the input- and the weight-gradient product
+        dy = torch.linspace(-1, 1, 256).double().expand(1024, 256)
+        check(W.grad, dy.t() @ x1.detach().double().cpu(), 1e-5, 'dW after another forward pass recycled the bounds pool')
+        check(x1.grad, dy @ W.detach().double().cpu(), 1e-5, 'dx')
+        assert torch.isfinite(y2).all()
+    finally:
+        ops.set_gemm_mode(old)
