@@ -1718,6 +1718,9 @@ static bool pairable(const ekaid_gemm_t* d0, const ekaid_gemm_t* d1, int& TMN) {
     int G, NO;
     if (skinny_tn(d0, G, NO) || skinny_tn(d1, G, NO)) return false;
     if ((d0->a_rowsum || d1->a_rowsum) && !d0->transA) return false;
+    // (the row-sum pair kernel exists on the pipelined K loop only: under the tuning override EKAID_GEMM_BIG=plain a solo product of
+    //  this layout takes the plain loop, and a pair must stay bit-identical to its two solo launches -- ADVICE r05)
+    if ((d0->a_rowsum || d1->a_rowsum) && big_arm(false, false) == 1) return false;
     if ((d0->post && d0->ldpost < d0->N) || (d1->post && d1->ldpost < d1->N) || (d0->R && d0->rdiv < 1) || (d1->R && d1->rdiv < 1)) return false;
     // mode 2: both on the two-term f16 split or both on the exact split (a product inside a pair = the same product alone, bit for bit)
     if (gemm_mode() == 2 && ((d0->a_amax && d0->b_amax) != (d1->a_amax && d1->b_amax))) return false;

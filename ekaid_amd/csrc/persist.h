@@ -32,21 +32,27 @@ inline bool grid_fits(const void* kern, int G, int cus, size_t lds_bytes) {
     if (func_attr_once(kern)) {
         if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); return false; }
     }
+    // occupancy per (kernel, dynamic LDS, device): the LDS need varies with batch and sequence length, so the table is sized for every
+    // persistent kernel x a few shapes x 8 devices; lookups are lock-free, inserts re-check under the mutex (no duplicate slots from
+    // racing threads); a full table just asks the runtime again
     struct Ent { const void* k; size_t lds; int dev; int per_cu; };
-    static Ent cache[16];
+    constexpr int CAP = 256;
+    static Ent cache[CAP];
     static std::atomic<int> n_cache{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const int n = n_cache.load(std::memory_order_acquire);
-    for (int i = 0; i < n && i < 16; ++i)
-        if (cache[i].k == kern && cache[i].lds == lds_bytes && cache[i].dev == dev) return (long long)cache[i].per_cu * cus >= G;
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds_bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
-    static std::mutex mu;
-    {
+    auto find = [&](int n) -> int {
+        for (int i = 0; i < n && i < CAP; ++i)
+            if (cache[i].k == kern && cache[i].lds == lds_bytes && cache[i].dev == dev) return cache[i].per_cu;
+        return -1;
+    };
+    int per_cu = find(n_cache.load(std::memory_order_acquire));
+    if (per_cu < 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds_bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+        static std::mutex mu;
         std::lock_guard<std::mutex> lk(mu);
         const int m = n_cache.load(std::memory_order_relaxed);
-        if (m < 16) { cache[m] = Ent{kern, lds_bytes, dev, per_cu}; n_cache.store(m + 1, std::memory_order_release); }
+        if (find(m) < 0 && m < CAP) { cache[m] = Ent{kern, lds_bytes, dev, per_cu}; n_cache.store(m + 1, std::memory_order_release); }
     }
     return (long long)per_cu * cus >= G;
 }

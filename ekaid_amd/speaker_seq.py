@@ -436,13 +436,20 @@ def speaker_sequence(speaker, feat_bef, feat_aft, feat_diff, tok_tb):
 
 
 @torch.no_grad()
-def greedy_decode(speaker, feat_bef, feat_aft, feat_diff, poll=None):
+def greedy_decode(speaker, feat_bef, feat_aft, feat_diff, poll=None, _before_launch=None):
     """Greedy ``_sample`` (eval mode) through ``ekaid_speaker_greedy_steps``: ``poll`` decode steps per C-ABI call, the chosen
     tokens feed the next step on the device, the host reads the "still running" counters once per call.  ``poll=None``: the whole
     sequence in ONE call where the persistent kernel takes it (it ends by itself at the step after which every row has stopped),
     8 steps per call on the step-wise chain.  Returns
     (seq, seq_logprobs, module weights per step run), seq zeroed after the step at which every sample had finished -- what the
-    reference's loop leaves behind (dynamic_speaker_change_pos.py:309-357, test_mimic.py:119-122)."""
+    reference's loop leaves behind (dynamic_speaker_change_pos.py:309-357, test_mimic.py:119-122).
+    The sticky status word of the persistent kernels is also the TRAINING fault signal (the Adam guard, ``hip.seq_status_check``): a word
+    that is already set when decoding begins belongs to an earlier launch and is raised here, not consumed -- only a fault of this
+    decode's own launch takes the fall-back below.  ``_before_launch``: test hook, called after that entry check."""
+    if hip.lib().ekaid_get_seq_mode() == 1:
+        hip.seq_status_check('before greedy decoding (a fault of an earlier persistent launch)')
+    if _before_launch is not None:
+        _before_launch()
     sd = dict(speaker.named_parameters())
     (emb, w_e, b_e, wih_a, whh_a, bih_a, bhh_a, w_fc, b_fc, w_p1, b_p1, w_wp, b_wp, w_p2, b_p2,
      w_g1, b_g1, w_g2, b_g2, wih_l, whh_l, bih_l, bhh_l, w_lo, b_lo) = [sd[n].detach().contiguous() for n in PARAM_NAMES]

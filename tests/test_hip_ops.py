@@ -98,10 +98,10 @@ def test_gemm_pair_is_bit_identical_to_two_launches(M0, M1, N, K, mode, gemm_ari
     base = rnd(M0, N, seed=33).to(DEV)
     rs0, rs1 = (torch.zeros(M0, device=DEV), torch.zeros(M1, device=DEV)) if mode == 'tn' else (None, None)
 
-    def run(pair):
+    def run(pair, one_sided=False):
         c0, c1 = base.clone(), torch.full((M1, N), float('nan'), device=DEV)
         r0 = rs0.clone() if rs0 is not None else None
-        r1 = rs1.clone() if rs1 is not None else None
+        r1 = rs1.clone() if (rs1 is not None and not one_sided) else None
         g0 = ((a0, b0, c0, M0, N, K, lda0, ldb0, N, ta, tb), dict(accumulate=True, bias=bias, act=ACT_TANH, a_rowsum=r0))
         g1 = ((a1, b1, c1, M1, N, K, lda1, ldb1, N, ta, tb), dict(alpha=0.5, act=ACT_RELU, drop_p=0.25, drop_seed=1234, post=post, ldpost=N,
                                                                  a_rowsum=r1))
@@ -117,6 +117,10 @@ def test_gemm_pair_is_bit_identical_to_two_launches(M0, M1, N, K, mode, gemm_ari
         if x is not None:
             assert torch.equal(x, y), '%s differs between the pair launch and two launches (%s %d/%dx%dx%d)' % (name, mode, M0, M1, N, K)
     assert torch.isfinite(paired[1]).all()
+    if mode == 'tn':                      # the A row sums on ONE side only: still the two solo launches, bit for bit
+        for x, y, name in zip(run(False, True), run(True, True), ('C0', 'C1', 'rowsum0', 'rowsum1')):
+            if x is not None:
+                assert torch.equal(x, y), '%s differs with one-sided row sums (%s %d/%dx%dx%d)' % (name, mode, M0, M1, N, K)
     want = torch.tanh(base.double().cpu() + (rnd(M0, K, seed=11).double() @ rnd(K, N, seed=12).double()) + bias.double().cpu())
     check(paired[0], want, 2e-5 * max(1.0, math.sqrt(K) / 4), 'pair product 0')
 

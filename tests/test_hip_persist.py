@@ -292,10 +292,18 @@ def test_greedy_decode_recovers_from_an_abandoned_persistent_launch():
         torch.cuda.synchronize()
         word = ctypes.c_void_p(L.ekaid_speaker_seq_persistent_status_ptr(None))
         val = ctypes.c_uint(0x104)
-        assert rt.hipMemcpy(word, ctypes.byref(val), 4, 1) == 0
+
+        def raise_word():
+            assert rt.hipMemcpy(word, ctypes.byref(val), 4, 1) == 0
+        # a word that is ALREADY set when decoding begins is an earlier launch's fault (training): raised, not consumed
+        raise_word()
+        with pytest.raises(hip.EkaidError, match='earlier persistent launch'):
+            speaker_seq.greedy_decode(sp, bef, aft, diff)
+        L.ekaid_seq_status_clear(hip.stream())
+        torch.cuda.synchronize()
         with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter('always')
-            seq, lp, _ = speaker_seq.greedy_decode(sp, bef, aft, diff)
+            seq, lp, _ = speaker_seq.greedy_decode(sp, bef, aft, diff, _before_launch=raise_word)     # ... one raised by this decode's own launch: fall-back
         assert any('abandoned' in str(x.message) for x in w)
         assert L.ekaid_get_seq_mode() == 0
         hip.seq_status_check('after the fallback')                 # cleared

@@ -176,6 +176,11 @@ def main(argv=None):
     if world > max(torch.cuda.device_count(), 1):      # ranks sharing a GPU: no persistent sequence kernels (they need every CU at once)
         hip.check(hip.lib().ekaid_set_seq_mode(0), 'set_seq_mode')
     if args.seq_mode != 'auto':
+        if args.seq_mode == 'persistent' and world > max(torch.cuda.device_count(), 1):
+            #  the plan-time occupancy check only sees this process: two ranks' persistent kernels on one GPU cannot both be
+            # fully resident, their seams would time out -- refused rather than left to the time-out
+            raise SystemExit('--seq_mode persistent with %d ranks on %d GPU(s): ranks that share a GPU must use the step-wise chains' % (
+                world, torch.cuda.device_count()))
         hip.check(hip.lib().ekaid_set_seq_mode(1 if args.seq_mode == 'persistent' else 0), 'set_seq_mode')
     random.seed(args.seed)
     np.random.seed(args.seed)
