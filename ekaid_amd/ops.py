@@ -189,6 +189,7 @@ def bounds_pool_reset(device):
         ent[0].zero_()
         ent[1] = 0
         ent[2] += 1
+    del _xb_cache[:]
 
 
 def bounds_generation(device):
@@ -271,6 +272,7 @@ def weight_bounds_prepare(weights):
 
 def weight_bounds_release():
     _wb_cache.clear()
+    del _xb_cache[:]
 
 
 def weight_bounds(W):
@@ -279,6 +281,24 @@ def weight_bounds(W):
     if ent is not None and ent[0].numel() == W.shape[0] and ent[1].numel() == W.shape[1]:
         return ent
     return amax_rc(W, W.shape[0], W.shape[1], W.shape[1])
+
+
+_xb_cache = []           # [(tensor, (M, K, ld), bounds, pool generation)]: the bounds of the last few layer INPUTS of this forward pass
+
+
+def input_bounds(x, M, K, ld):
+    """``amax_rc(x, M, K, ld)`` for a layer input, taken once when several layers read the same tensor (the encoder output feeds context2,
+    gate2 and the region embedding: three passes over 75 MB at 256 pairs, two of them saved).  An entry keeps its tensor alive, so a hit
+    on (address, shape) is a hit on the same memory, not on a recycled block; eight entries, dropped with the pool they point into."""
+    gen = bounds_generation(x.device)
+    for t, shape, b, g in _xb_cache:
+        if g == gen and shape == (M, K, ld) and t.data_ptr() == x.data_ptr():
+            return b
+    b = amax_rc(x, M, K, ld)
+    if b[0] is not None:
+        _xb_cache.append((x, (M, K, ld), b, gen))
+        del _xb_cache[:-8]
+    return b
 
 
 def seq_in_c():
@@ -725,7 +745,7 @@ class LinearFn(Function):
         # two-term f16 split (mode 2): row / column maxima of every operand, taken once here and reused by the backward products
         x2 = f16x2_wanted(M, N, min(x.shape[1] for x in xs2))
         ctx.wb = weight_bounds(W) if x2 else (None, None)
-        ctx.xb = [amax_rc(x, M, x.shape[1], ld) if x2 else (None, None) for x, ld in zip(xs2, lds)]
+        ctx.xb = [input_bounds(x, M, x.shape[1], ld) if x2 else (None, None) for x, ld in zip(xs2, lds)]
         ctx.bgen = bounds_generation(W.device)
         off = 0
         for i, (x, ld) in enumerate(zip(xs2, lds)):
@@ -1057,12 +1077,19 @@ class LinearPairFn(Function):
         with _Deferring(qb):
             yb = (WNLinearFn if wn_b else LinearFn).forward(cb, *b)
         flush_pairs(qa, qb)
+        # both halves' saved tensors go through the REAL context (released after backward, version-checked, visible to saved-tensor
+        # hooks); the sub-contexts keep only plain Python state
+        ctx.n_saved = (len(ca.saved_tensors), len(cb.saved_tensors))
+        ctx.save_for_backward(*ca.saved_tensors, *cb.saved_tensors)
+        ca.saved_tensors = cb.saved_tensors = None
         ctx.subs = (ca, cb)
         return ya, yb
 
     @staticmethod
     def backward(ctx, dya, dyb):
         ca, cb = ctx.subs
+        saved = ctx.saved_tensors
+        ca.saved_tensors, cb.saved_tensors = saved[:ctx.n_saved[0]], saved[ctx.n_saved[0]:]
         need = ctx.needs_input_grad
         ca.needs_input_grad, cb.needs_input_grad = need[2:8], need[8:14]
         assert dya is not None and dyb is not None, 'both halves of a paired layer must be used'
@@ -1072,6 +1099,7 @@ class LinearPairFn(Function):
         with _Deferring(qb):
             gb = LinearFn.backward(cb, dyb)
         flush_pairs(qa, qb)
+        ca.saved_tensors = cb.saved_tensors = None
         return (None, None) + tuple(ga) + tuple(gb)
 
 
