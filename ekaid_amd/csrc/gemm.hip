@@ -1,8 +1,10 @@
-// f32 GEMM on the CDNA4 matrix cores, two arithmetics behind one entry point (ekaid_gemm_f32):
-//   gemm_split_kernel (default): exact 3-way bf16 split of every operand element, six v_mfma_f32_32x32x16_bf16
-//                                products per f32 product, f32 accumulation (described further down);
+// f32 GEMM on the CDNA4 matrix cores, three arithmetics behind one entry point (ekaid_gemm_f32):
+//   gemm_split_kernel<.., NP = 2>: two-term f16 split with per-row / per-column power-of-two scales, three v_mfma_f32_32x32x16_f16
+//                                products per f32 product -- the default for products that carry operand bounds (a_amax / b_amax);
+//   gemm_split_kernel<.., NP = 3>: exact 3-way bf16 split of every operand element, six v_mfma_f32_32x32x16_bf16 products per f32
+//                                product -- every other product (EKAID_GEMM_MODE=bf16x3: all of them);
 //   gemm_mfma_kernel           : v_mfma_f32_32x32x2_f32, an exact k-ordered f32 fma chain (EKAID_GEMM_MODE=f32).
-// Both share the tiling, the operand loaders, the split-K planner and the epilogue.
+// All share the tiling, the operand loaders, the split-K planner and the epilogue; f32 accumulation throughout.
 //
 // C[M,N] = epilogue( alpha * op(A)[M,K] . op(B)[K,N] )     row-major everywhere
 //   transA = 0 : A stored [M][K] (k-contiguous)      transA = 1 : A stored [K][M] (m-contiguous)
@@ -467,8 +469,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // equally exact, but the 64-bit register pairs of the packed subtracts push the 128x128 kernel over its 168-VGPR budget
 // (62-179 spilled registers in the k-contiguous variants: 2.5x slower) and, applied only where it fits, measured no
 // faster: 182 vs 187 TF on the wgrad form.)
-// NP = 3: exact split (h + m + l == v).  NP = 2 (EKAID_GEMM_BF16X2, opt-in): h + m only, m rounded to nearest -- 16-17
-// significant bits per operand, three products per block instead of six (L is left untouched).
+// NP = 3: the exact split (h + m + l == v), six products per block.
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
