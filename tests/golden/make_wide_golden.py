@@ -71,9 +71,18 @@ def train_case(name, cfg, batch, setting='mode2'):
         assert loss64.dtype == torch.float64 and logp64.dtype == torch.float64
         loss64.backward()
         names64, sk64 = sketch_named(G.named_grads(cd64, sp64))
+        g64 = dict(G.named_grads(cd64, sp64))
     assert names == names64
+    # element-wise error of the reference's float32 gradients against its float64 run, per tensor: max |g32 - g64| / max |g64| -- the yardstick
+    # of the GPU test's element-wise bar (a float32 implementation is as good as the reference when it stays within 1.5 x of this)
+    import json
+    g32 = dict(G.named_grads(cd, sp))
+    tops = {k: float(g64[k].abs().max()) if g64[k] is not None else 0.0 for k in json.loads(names)}
+    med = float(np.median([v for v in tops.values() if v > 0]))
+    elem = np.array([float((g32[k].double() - g64[k]).abs().max()) / tops[k] if tops[k] > 1e-4 * med else 0.0      # (zeros in disguise -- a bias under a softmax -- carry no yardstick)
+                     for k in json.loads(names)])
     G.save(name, loss=loss, speaker_loss=sp_loss, steps=np.int64(T), logp=logp[:, :T], logpos=logpos[:, :T], feat_diff=outs[5],
-           att_bef=outs[1], grad_names=np.array(names), grad_sketch=sk, grad_sketch_f64=sk64, loss_f64=loss64,
+           att_bef=outs[1], grad_names=np.array(names), grad_sketch=sk, grad_sketch_f64=sk64, grad_elem_err_f32=elem, loss_f64=loss64,
            logp_f64=logp64[:, :T].detach().float(),
            logp_f64_maxdiff=np.float64((logp64[:, :T].detach() - logp[:, :T].detach().double()).abs().max()))
 

@@ -8,7 +8,7 @@ library's launch counters (ekaid_launch_count) that the persistent decoder forwa
   * greedy `_sample` at batch 64 (dynamic_speaker_change_pos.py:287-357)
 Tolerances: log-probs <= 1e-3 of the reference (BASELINE.json; element-wise widened by the reference's own float32-vs-float64 drift),
 arg-max / token ids identical, every gradient no farther from the float64 run of the reference than max(1e-3, 3 x the reference's own
-float32 error) chunk by chunk, and element-wise no farther from the float64 oracle than max(2e-3, 1.5 x the float32 oracle's error)."""
+float32 error) chunk by chunk, and element-wise no farther from the float64 oracle than max(2e-3, 1.5 x the float32 reference's own error)."""
 import numpy as np
 import pytest
 import torch
@@ -64,22 +64,23 @@ def test_long_answers_at_full_width_match_the_reference_through_the_persistent_k
     print('%s: logp vs reference float32 rel-to-max %.2e, max |d| vs its float64 run %.2e (float32 reference itself: %.2e); worst gradient chunk '
           'vs float64 truth: %s %.2e (reference float32 %.2e)' % ((case, e, d64, float(g['logp_f64_maxdiff'])) + worst))
     # ... and EVERY element of every gradient against the oracle run in float64 on this host (pinned to the reference's float64 run in
-    # tests/test_oracle_golden.py): no farther from it than max(2e-3 of the tensor's largest entry, 1.5 x the error of the float32 oracle) --
+    # tests/test_oracle_golden.py): no farther from it than max(2e-3 of the tensor's largest entry, 1.5 x the error of the REFERENCE's float32 run, stored with the fixture) --
     # at these lengths ANY float32-grade arithmetic drifts from the truth by recurrent amplification of its rounding: the float32 oracle on
     # the host 1-3 %, this path 0.2-1.5 % under the default two-term f16 split and the same under plain v_mfma_f32 (0.1 % under the exact
     # 3-way split, whose products carry no rounding at all): profiles/r06_grad_error_by_gemm_mode.txt.  The weight_g scalars (<dW, v> / ||v||:
     # 10^6-term sums with heavy cancellation) are held to 3e-2: 1.5e-2 on the question attention's W2 under either float32-grade arithmetic
+    import json
     _, _, g64 = oracle_gradients(cfg, cd, sp, batch, double=True, setting=setting)
-    _, _, g32 = oracle_gradients(cfg, cd, sp, batch, double=False, setting=setting)
+    e32 = dict(zip(json.loads(str(g['grad_names'])), g['grad_elem_err_f32'].tolist()))     # the REFERENCE's float32 run against its float64 run, per tensor
     frozen = {'cd.' + k for k, p in cd.named_parameters() if not p.requires_grad} | {'sp.' + k for k, p in sp.named_parameters() if not p.requires_grad}
     assert frozen == {'cd.w_emb.emb_.weight'}                 # frozen in the reference too (language_model.py:29): never differentiated
     for k in frozen:
         assert dict(named_grads(cd, sp))[k] is None
-        g64.pop(k), g32.pop(k)                                # (the oracle differentiates every table it is handed)
-    _elementwise_vs_truth(dict(named_grads(cd, sp)), g64, g32, case)
+        g64.pop(k)                                            # (the oracle differentiates every table it is handed)
+    _elementwise_vs_truth(dict(named_grads(cd, sp)), g64, e32, case)
 
 
-def _elementwise_vs_truth(got, g64, g32, what):
+def _elementwise_vs_truth(got, g64, e32, what):
     live = [k for k, v in g64.items() if v is not None and float(v.abs().max()) > 0.0]
     assert len(live) > 50, 'too few live gradients (%d)' % len(live)          # (89 with the graph encoders, 55 under setting mode0)
     med = float(np.median([float(g64[k].abs().max()) for k in live]))
@@ -96,14 +97,14 @@ def _elementwise_vs_truth(got, g64, g32, what):
             assert float(h.abs().max()) <= 1e-3 * med, k
             continue
         e_hip = float((h - v).abs().max()) / scale
-        e_32 = float((g32[k].double() - v).abs().max()) / scale
+        e_32 = float(e32.get(k, 0.0))
         if e_hip > worst[1]:
             worst = (k, e_hip, e_32)
         if e_hip > max(3e-2 if k.endswith('weight_g') else 2e-3, 1.5 * e_32):
             bad.append((k, e_hip, e_32))
     assert nzero <= 8
-    print('%s: %d gradients element-wise vs the float64 oracle, worst %s %.2e of its largest entry (float32 oracle there: %.2e)' % ((what, len(live)) + worst))
-    assert not bad, '%s: %d gradients farther from the float64 truth than allowed (name, hip, float32 oracle): %s' % (what, len(bad), bad[:8])
+    print('%s: %d gradients element-wise vs the float64 oracle, worst %s %.2e of its largest entry (float32 reference there: %.2e)' % ((what, len(live)) + worst))
+    assert not bad, '%s: %d gradients farther from the float64 truth than allowed (name, hip, float32 reference): %s' % (what, len(bad), bad[:8])
 
 
 def test_greedy_sample_at_batch_64_full_width_matches_the_reference_through_the_persistent_kernel():
