@@ -847,11 +847,17 @@ extern "C" int ekaid_wn_scale_multi(const float* const* v, const float* const* g
 // ---- row and column maxima of |x| for up to AMAX_MAX row-strided matrices in one launch: the operand bounds of the two-term f16
 // GEMM split (ekaid_gemm_t.a_amax / b_amax).  |x| as an unsigned bit pattern orders like the value and an integer max does not depend
 // on arrival order: deterministic.  A NaN element has the largest pattern of all, so it surfaces in the bound (the consumer then
-// leaves that row unscaled).  One workgroup owns RB whole rows, each of its four waves RB / 4 of them: a wave walks a row in 1024-column
-// spans (four 16-byte loads per lane and row, four rows in flight), keeps the running maximum of each of its rows in a register and
-// reduces it across the lanes ONCE per row (DPP), and keeps the column maxima of its lanes' columns in registers; per span the four
-// waves' column maxima meet in LDS and leave as one atomic per column and workgroup into the zeroed output.
+// leaves that row unscaled).
+// Work split: a workgroup owns ONE 256-column slice (each lane one 16-byte vector per row) and every `panels`-th 64-row chunk of it;
+// a wave takes 16 rows of the chunk, all 16 loads in flight.  Column maxima stay in four registers per lane for the workgroup's whole
+// life, meet the other waves' in LDS at the end and leave as ONE atomic per column and workgroup -- so an output word sees `panels`
+// atomics, not rows / 32 of them: same-address atomics retire one after the other (~40 ns each, measured: the 576-panel form of this
+// kernel spent 23 us on a 9 MB operand), and `panels` <= 64 keeps that tail under ~3 us.  A row's maximum is reduced across the lanes
+// (DPP), parked in the lane numbered like the row, and leaves as one 16-lane atomic per wave and chunk (a plain store when the matrix
+// has a single slice): contention there is the slice count.
 constexpr int AMAX_MAX = 32;
+constexpr int AMAX_SLICE = 256;                           // columns per workgroup
+constexpr int AMAX_CHUNK = 64;                            // rows per workgroup iteration: 16 per wave
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 struct AmaxMulti { const float* x[AMAX_MAX]; long long rows[AMAX_MAX]; int cols[AMAX_MAX]; int ld[AMAX_MAX]; unsigned* rowmax[AMAX_MAX]; unsigned* colmax[AMAX_MAX]; int count; };
 // max over the 64 lanes of a wave, valid in lane 63 (max is idempotent: any exchange pattern that reaches every lane will do)
@@ -864,83 +870,65 @@ __device__ __forceinline__ unsigned wave_max_u32_lane63(unsigned v) {
     v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true));     // row_bcast31 into rows 2, 3
     return v;
 }
-template <int RB>
 __global__ __launch_bounds__(256) void amax_rc_kernel(AmaxMulti a) {
-    constexpr int RW = RB / 4;                            // rows per wave
-    constexpr int SPAN = 1024;                            // columns per span: 4 chunks of 64 lanes x 4 floats
-    __shared__ unsigned cmax[4][SPAN];
-    const int t = blockIdx.y;
-    const long long rows = a.rows[t], r0 = (long long)blockIdx.x * RB;
-    if (r0 >= rows) return;
-    const float* x = a.x[t];
+    constexpr int RW = AMAX_CHUNK / 4;                    // rows per wave and chunk
+    __shared__ unsigned cmax[4][AMAX_SLICE];
+    const int t = blockIdx.z;
+    const long long rows = a.rows[t];
     const int cols = a.cols[t], ld = a.ld[t];
+    const int col0 = blockIdx.y * AMAX_SLICE;
+    if (col0 >= cols || rows <= 0) return;
+    const float* x = a.x[t];
     unsigned* const rowmax = a.rowmax[t];
     unsigned* const colmax = a.colmax[t];
+    const bool one_slice = cols <= AMAX_SLICE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned rm[RW];
+    const bool ok = col0 + 4 * lane < cols;
+    const long long nchunks = (rows + AMAX_CHUNK - 1) / AMAX_CHUNK;
+    unsigned cm[4] = {0, 0, 0, 0};
+    for (long long ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        const long long rbase = ch * AMAX_CHUNK + wave * RW;
+        if (rbase >= rows) continue;                                                  // (a ragged last chunk: this wave has no row in it)
+        u32x4_t v[RW];
 #pragma unroll
-    for (int j = 0; j < RW; ++j) rm[j] = 0;
-    for (int col0 = 0; col0 < cols; col0 += SPAN) {
-        unsigned cm[4][4];
+        for (int u = 0; u < RW; ++u) {
+            long long row = rbase + u;
+            row = row < rows ? row : rows - 1;                                        // (clamped: a repeated row changes no column maximum;
+            v[u] = ok ? *reinterpret_cast<const u32x4_t*>(x + row * ld + col0 + 4 * lane) : u32x4_t{0, 0, 0, 0};      // its row maximum is not stored)
+        }
+        unsigned mine = 0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int u = 0; u < RW; ++u) {
+            unsigned m = 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) cm[c][e] = 0;
-        bool ok[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) ok[c] = col0 + 256 * c + 4 * lane < cols;
-        constexpr int U = RW < 4 ? RW : 4;             // rows of a wave in flight together
-#pragma unroll
-        for (int j0 = 0; j0 < RW; j0 += U) {
-            u32x4_t v[U][4];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                long long row = r0 + wave + 4 * (j0 + u);
-                row = row < rows ? row : rows - 1;                                    // (clamped: a repeated row changes no maximum ...
-                const float* p = x + row * ld + col0 + 4 * lane;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[u][c] = ok[c] ? *reinterpret_cast<const u32x4_t*>(p + 256 * c) : u32x4_t{0, 0, 0, 0};
+            for (int e = 0; e < 4; ++e) {
+                const unsigned av = v[u][e] & 0x7FFFFFFFu;
+                cm[e] = max(cm[e], av);
+                m = max(m, av);
             }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool mine = r0 + wave + 4 * (j0 + u) < rows;                    // ... of a column; its row maximum is not stored)
-                unsigned m = 0;
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const unsigned av = v[u][c][e] & 0x7FFFFFFFu;
-                        cm[c][e] = max(cm[c][e], av);
-                        m = max(m, av);
-                    }
-                if (mine) rm[j0 + u] = max(rm[j0 + u], m);
+            if (rowmax) {
+                const unsigned whole = (unsigned)__builtin_amdgcn_readlane((int)wave_max_u32_lane63(m), 63);
+                mine = lane == u ? whole : mine;
             }
         }
-        if (colmax) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                *reinterpret_cast<u32x4_t*>(&cmax[wave][256 * c + 4 * lane]) = u32x4_t{cm[c][0], cm[c][1], cm[c][2], cm[c][3]};
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < SPAN / 256; ++q) {
-                const int cc = tid + 256 * q;
-                const unsigned m = max(max(cmax[0][cc], cmax[1][cc]), max(cmax[2][cc], cmax[3][cc]));
-                if (m && col0 + cc < cols) atomicMax(colmax + col0 + cc, m);
-            }
-            __syncthreads();
+        if (rowmax && lane < RW && rbase + lane < rows) {
+            if (one_slice) rowmax[rbase + lane] = mine;
+            else if (mine) atomicMax(rowmax + rbase + lane, mine);
         }
     }
-    if (rowmax) {
-#pragma unroll
-        for (int j = 0; j < RW; ++j) {
-            const unsigned m = wave_max_u32_lane63(rm[j]);
-            const long long row = r0 + wave + 4 * j;
-            if (lane == 63 && row < rows) rowmax[row] = m;
-        }
+    if (colmax) {
+        *reinterpret_cast<u32x4_t*>(&cmax[wave][4 * lane]) = u32x4_t{cm[0], cm[1], cm[2], cm[3]};
+        __syncthreads();
+        const unsigned m = max(max(cmax[0][tid], cmax[1][tid]), max(cmax[2][tid], cmax[3][tid]));
+        if (m && col0 + tid < cols) atomicMax(colmax + col0 + tid, m);
     }
 }
+static int amax_panels_override() {
+    static const int v = [] { const char* e = getenv("EKAID_AMAX_PANELS"); return e ? atoi(e) : 0; }();
+    return v;
+}
 extern "C" int ekaid_amax_rc_multi(const float* const* x, const long long* rows, const int* cols, const int* ld, float* const* rowmax,
-                                   float* const* colmax, int count, int colmax_zeroed, void* stream) {
+                                   float* const* colmax, int count, int outputs_zeroed, void* stream) {
     if (count < 1 || count > AMAX_MAX || !x || !rows || !cols || !ld || !rowmax || !colmax) {
         set_error("amax_rc_multi: 1 <= count <= %d matrices, non-null arrays", AMAX_MAX);
         return EKAID_ERR_ARG;
@@ -948,6 +936,7 @@ extern "C" int ekaid_amax_rc_multi(const float* const* x, const long long* rows,
     AmaxMulti a;
     a.count = count;
     long long rmax = 0;
+    int cmaxw = 0;
     for (int i = 0; i < AMAX_MAX; ++i) {
         const bool on = i < count;
         if (on && (!x[i] || rows[i] < 0 || cols[i] < 0 || ld[i] < cols[i])) { set_error("amax_rc_multi: bad matrix %d", i); return EKAID_ERR_ARG; }
@@ -957,21 +946,32 @@ extern "C" int ekaid_amax_rc_multi(const float* const* x, const long long* rows,
         }
         a.x[i] = on ? x[i] : nullptr; a.rows[i] = on ? rows[i] : 0; a.cols[i] = on ? cols[i] : 0; a.ld[i] = on ? ld[i] : 0;
         a.rowmax[i] = on ? reinterpret_cast<unsigned*>(rowmax[i]) : nullptr; a.colmax[i] = on ? reinterpret_cast<unsigned*>(colmax[i]) : nullptr;
-        if (on && rows[i] > rmax) rmax = rows[i];
-        if (on && colmax[i] && cols[i] > 0 && !colmax_zeroed &&
+        if (on && rows[i] > 0 && cols[i] > 0) {
+            if (rows[i] > rmax) rmax = rows[i];
+            if (cols[i] > cmaxw) cmaxw = cols[i];
+        }
+        // both outputs are atomic-max targets (the row output only when the matrix has several slices; one without columns has no
+        // workgroup at all): cleared here unless the caller hands in zeroed memory
+        if (on && rowmax[i] && rows[i] > 0 && (cols[i] == 0 || (!outputs_zeroed && cols[i] > AMAX_SLICE)) &&
+            hipMemsetAsync(rowmax[i], 0, sizeof(float) * rows[i], ST) != hipSuccess) { (void)hipGetLastError(); set_error("amax_rc_multi: memset failed"); return EKAID_ERR_LAUNCH; }
+        if (on && colmax[i] && cols[i] > 0 && !outputs_zeroed &&
             hipMemsetAsync(colmax[i], 0, sizeof(float) * cols[i], ST) != hipSuccess) { (void)hipGetLastError(); set_error("amax_rc_multi: memset failed"); return EKAID_ERR_LAUNCH; }
     }
     if (rmax == 0) return EKAID_OK;
-    // rows per workgroup: as many as still leave ~2 workgroups per CU (a 2304-row operand of a 32-pair step cut into 32-row panels is 72
-    // workgroups on 256 CUs, each walking 128 KB with four loads in flight: ~20 us for 9 MB)
-    if (rmax >= 16384) hipLaunchKernelGGL(amax_rc_kernel<32>, dim3((unsigned)((rmax + 31) / 32), count), dim3(256), 0, ST, a);
-    else if (rmax >= 8192) hipLaunchKernelGGL(amax_rc_kernel<16>, dim3((unsigned)((rmax + 15) / 16), count), dim3(256), 0, ST, a);
-    else if (rmax >= 4096) hipLaunchKernelGGL(amax_rc_kernel<8>, dim3((unsigned)((rmax + 7) / 8), count), dim3(256), 0, ST, a);
-    else hipLaunchKernelGGL(amax_rc_kernel<4>, dim3((unsigned)((rmax + 3) / 4), count), dim3(256), 0, ST, a);
+    // row panels: enough workgroups (panels x slices x matrices) to cover the chip about twice, never more than 64 per matrix (the
+    // same-address atomic tail above) nor than there are 64-row chunks
+    const int slices = (cmaxw + AMAX_SLICE - 1) / AMAX_SLICE;
+    const long long nchunks = (rmax + AMAX_CHUNK - 1) / AMAX_CHUNK;
+    long long panels = (512 + (long long)slices * count - 1) / ((long long)slices * count);
+    panels = panels > 64 ? 64 : panels;
+    if (amax_panels_override() > 0) panels = amax_panels_override();
+    panels = panels > nchunks ? nchunks : panels;
+    panels = panels < 1 ? 1 : panels;
+    hipLaunchKernelGGL(amax_rc_kernel, dim3((unsigned)panels, (unsigned)slices, (unsigned)count), dim3(256), 0, ST, a);
     return check_launch("amax_rc_multi");
 }
-extern "C" int ekaid_amax_rc(const float* x, long long rows, int cols, int ld, float* rowmax, float* colmax, int colmax_zeroed, void* stream) {
-    return ekaid_amax_rc_multi(&x, &rows, &cols, &ld, &rowmax, &colmax, 1, colmax_zeroed, stream);
+extern "C" int ekaid_amax_rc(const float* x, long long rows, int cols, int ld, float* rowmax, float* colmax, int outputs_zeroed, void* stream) {
+    return ekaid_amax_rc_multi(&x, &rows, &cols, &ld, &rowmax, &colmax, 1, outputs_zeroed, stream);
 }
 
 extern "C" int ekaid_wn_grad_multi(float* const* G, const float* const* v, const float* const* g, const float* const* norm,

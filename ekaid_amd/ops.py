@@ -170,10 +170,11 @@ _BIAS_IN_WGRAD = os.environ.get('EKAID_BIAS_IN_WGRAD', '1') != '0'
 _SEQ_IN_C = os.environ.get('EKAID_SEQ_IN_C', '1') != '0'      # time loops of the GRU / decoder behind ONE C-ABI call each
 
 
-# Column maxima are accumulated with atomics into ZEROED outputs.  Instead of one memset node per bounds pass, the column outputs of a
-# step are slices of one pool that is cleared once, where the step begins (``bounds_pool_reset``: the detector's forward).  A slice is
-# handed out once between two resets; an exhausted pool, or a caller that never resets, falls back to a fresh zeroed tensor per pass.
-_BOUNDS_POOL_FLOATS = 1 << 18
+# Column maxima (and the row maxima of matrices wider than one 256-column slice) are accumulated with atomics into ZEROED outputs.
+# Instead of one memset node per output, the outputs of a step are slices of one pool that is cleared once, where the step begins
+# (``bounds_pool_reset``: the detector's forward).  A slice is handed out once between two resets; an exhausted pool, or a caller that
+# never resets, falls back to fresh memory that the C side clears per pass.
+_BOUNDS_POOL_FLOATS = 1 << 21          # 8 MB: a 256-pair step takes ~0.8 M row + 0.1 M column maxima
 _bounds_pool = {}            # device -> [zeroed buffer, next free element, generation]
 
 
@@ -197,6 +198,9 @@ def bounds_generation(device):
     return ent[2] if ent is not None else 0
 
 
+_AMAX_SLICE = 256            # columns per workgroup of ekaid_amax_rc (pointwise.hip: AMAX_SLICE)
+
+
 def _zeroed_cols(device, n):
     """(n zeroed floats, came from the pool)"""
     ent = _bounds_pool.get(device)
@@ -214,9 +218,14 @@ def amax_rc(x, rows, cols, ld, off=0, want_rows=True, want_cols=True):
     the product then stays on the exact split."""
     if (cols & 3) or (ld & 3) or ((x.data_ptr() + 4 * off) & 15) or rows < 1 or cols < 1:
         return None, None
-    rm = torch.empty(rows, device=x.device, dtype=torch.float32) if want_rows else None
-    cm, pooled = _zeroed_cols(x.device, cols) if want_cols else (None, False)
-    check(hip.lib().ekaid_amax_rc(x.data_ptr() + 4 * off, rows, cols, ld, ptr(rm), ptr(cm), int(pooled), stream()), 'amax_rc')
+    if not want_rows:
+        rm, rpooled = None, True
+    elif cols > _AMAX_SLICE:               # several column slices meet in a row's maximum: an atomic target like the column maxima
+        rm, rpooled = _zeroed_cols(x.device, rows)
+    else:
+        rm, rpooled = torch.empty(rows, device=x.device, dtype=torch.float32), True
+    cm, cpooled = _zeroed_cols(x.device, cols) if want_cols else (None, True)
+    check(hip.lib().ekaid_amax_rc(x.data_ptr() + 4 * off, rows, cols, ld, ptr(rm), ptr(cm), int(rpooled and cpooled), stream()), 'amax_rc')
     return rm, cm
 
 
@@ -250,8 +259,9 @@ def weight_bounds_prepare(weights):
         n = len(chunk)
         dev = chunk[0].device
         tot_r, tot_c = sum(w.shape[0] for w in chunk), sum((w.shape[1] + 3) & ~3 for w in chunk)
-        buf = torch.empty(tot_r, device=dev, dtype=torch.float32)
+        buf, rpooled = _zeroed_cols(dev, tot_r)
         cbuf, pooled = _zeroed_cols(dev, tot_c)
+        pooled = pooled and rpooled
         rms, cms, o = [], [], 0
         for w in chunk:
             rms.append(buf[o:o + w.shape[0]])

@@ -166,13 +166,15 @@ int ekaid_gemm_slabs2(const ekaid_gemm_t* g0, float* slabs0, size_t slab_bytes0,
  * (A stored [M][K]) or its column maxima when transA = 1 (stored [K][M]); b_amax = the row maxima of B when transB = 1 (stored [N][K])
  * or its column maxima when transB = 0 (stored [K][N]); bounds taken over a larger block of the same rows / columns stay valid.
  * Exact and order-independent (integer max of the magnitude's bit pattern); an all-zero row gives 0, a NaN element NaN.  One launch
- * (+ one memset node per column output) for up to 32 matrices (x, rows, cols, ld, rowmax, colmax: HOST arrays).  colmax_zeroed = 1: the
- * caller hands in column outputs that already hold zeros (slices of a pool cleared once per step: a bounds pass is then ONE graph node
- * instead of two -- at 32 pairs per GPU the step is a chain of ~500 small nodes and every one counts).  cols, ld multiples of 4 and
- * 16-byte aligned x, else EKAID_ERR_UNSUPPORTED (the caller then leaves the product on the exact split).  No reference counterpart. */
+ * for up to 32 matrices (x, rows, cols, ld, rowmax, colmax: HOST arrays).  The outputs are atomic-max targets -- every column output, and
+ * the row output of a matrix wider than 256 columns (narrower ones are stored) -- so they must start at zero: outputs_zeroed = 0 clears
+ * them here (one memset node each), outputs_zeroed = 1 says the caller hands in memory that already holds zeros (slices of a pool cleared
+ * once per step: a bounds pass is then ONE graph node -- at 32 pairs per GPU the step is a chain of ~500 small nodes and every one
+ * counts).  cols, ld multiples of 4 and 16-byte aligned x, else EKAID_ERR_UNSUPPORTED (the caller then leaves the product on the exact
+ * split).  No reference counterpart. */
 int ekaid_amax_rc_multi(const float* const* x, const long long* rows, const int* cols, const int* ld, float* const* rowmax,
-                        float* const* colmax, int count, int colmax_zeroed, void* stream);
-int ekaid_amax_rc(const float* x, long long rows, int cols, int ld, float* rowmax, float* colmax, int colmax_zeroed, void* stream);
+                        float* const* colmax, int count, int outputs_zeroed, void* stream);
+int ekaid_amax_rc(const float* x, long long rows, int cols, int ld, float* rowmax, float* colmax, int outputs_zeroed, void* stream);
 int ekaid_set_gemm_mode(int mode);
 int ekaid_get_gemm_mode(void);
 

@@ -237,7 +237,8 @@ def test_amax_rc_row_and_column_maxima():
     import ctypes
     from ekaid_amd import hip, ops
     g = torch.Generator().manual_seed(21)
-    for rows, cols, ld in [(1, 4, 4), (5, 64, 64), (37, 300, 300), (129, 1024, 1024), (600, 2048, 2052), (4100, 36, 40), (33, 4096, 4096), (8200, 256, 256)]:
+    for rows, cols, ld in [(1, 4, 4), (5, 64, 64), (37, 300, 300), (129, 1024, 1024), (600, 2048, 2052), (4100, 36, 40), (33, 4096, 4096), (8200, 256, 256),
+                           (18500, 1028, 1032), (70000, 8, 8), (2304, 1024, 1024), (65, 260, 260)]:
         buf = (torch.randn(rows, ld, generator=g) * torch.exp(2 * torch.randn(rows, 1, generator=g))).to(DEV)
         if rows > 3:
             buf[2] = 0
@@ -259,9 +260,20 @@ def test_amax_rc_row_and_column_maxima():
     assert L.ekaid_amax_rc(x.data_ptr(), 8, 30, 30, out.data_ptr(), None, 0, hip.stream()) == hip.ERR_UNSUPPORTED
     # the pool of column outputs: cleared once, slices handed out once each; an exhausted pool falls back to a memset per pass
     ops.bounds_pool_reset(torch.device(DEV, torch.cuda.current_device()))
-    xs = [torch.randn(64, 4096, generator=g).to(DEV) for _ in range(70)]                    # 70 x 4096 columns > the pool's 2^18 floats
-    outs = [ops.amax_rc(t, 64, 4096, 4096) for t in xs]
+    xs = [torch.randn(64, 4096, generator=g).to(DEV) for _ in range(70)]                    # 70 x (4096 columns + 64 rows) > 2^18 floats
+    full, ops._BOUNDS_POOL_FLOATS = ops._BOUNDS_POOL_FLOATS, 1 << 18
+    try:
+        outs = [ops.amax_rc(t, 64, 4096, 4096) for t in xs]
+    finally:
+        ops._BOUNDS_POOL_FLOATS = full
     for t, (rm, cm) in zip(xs, outs):
+        assert torch.equal(rm, t.abs().amax(1)) and torch.equal(cm, t.abs().amax(0))
+    # raw entry point, outputs NOT zeroed by the caller (garbage in them): the library clears what it accumulates into
+    L = hip.lib()
+    for rows, cols in ((300, 1024), (300, 128)):
+        t = torch.randn(rows, cols, generator=g).to(DEV)
+        rm, cm = torch.full((rows,), 9e9, device=DEV), torch.full((cols,), 9e9, device=DEV)
+        assert L.ekaid_amax_rc(t.data_ptr(), rows, cols, cols, rm.data_ptr(), cm.data_ptr(), 0, hip.stream()) == 0
         assert torch.equal(rm, t.abs().amax(1)) and torch.equal(cm, t.abs().amax(0))
     ops.bounds_pool_reset(torch.device(DEV, torch.cuda.current_device()))
     rm, cm = ops.amax_rc(xs[3], 64, 4096, 4096)
