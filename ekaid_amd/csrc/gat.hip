@@ -23,6 +23,8 @@
 
 namespace ekaid {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 #define NEG_MASK (-9e15f)
 #define GEO_EPS 1e-6f
 
@@ -226,6 +228,240 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             *reinterpret_cast<f32x4*>(op) = v;
         }
     }
+}
+
+// ---------------- backward of the aggregation and of the edge softmax, one workgroup per slice (round 6):
+//   dP[nh][m]  = sum_c d(outT)[nh][c] S[m][c]          (K = A)
+//   dS[m][c]   = sum_nh P[nh][m] d(outT)[nh][c]        (K = N H)
+//   daff = mask * P (dP - <P, dP>),  d(label bias) = sum over heads,  d(geometry) = daff / geo
+// As batched products the first two were R problems of (N H) x M x A and M x A x (N H) with M = 36 rows or columns on 64-wide tiles
+// (120 + 140 us at 512 slices), each reading d(outT) -- 302 MB of the backward's 0.77 GB -- on its own, followed by the softmax
+// kernel.  Here d(outT) is read ONCE, in chunks of CW feature columns staged through LDS (CW * 4-byte row segments: 256 bytes at
+// CW = 64 -- with 128-byte segments 16 KB apart the kernel ran at 1.9 TB/s); both products run on v_mfma_f32_16x16x4_f32 (exact
+// f32: a k-ordered fmaf chain per accumulator):
+//   * dP accumulates over the chunks in registers: its (N H / 16) x (M / 16) tiles are dealt round-robin to the four waves;
+//   * dS of a chunk is complete within the chunk: the waves split its K = N H range (the P fragments of a wave's k-steps do not
+//     depend on the chunk: loaded once, kept in registers), their partial tiles meet in LDS (in the buffer the chunk was staged
+//     in) and leave as CW * 4-byte row segments;
+//   * the next chunk's loads are in flight while the current one is multiplied.
+// After the last chunk dP goes to LDS and the softmax backward runs on it, a wave per query node (its H rows share the adjacency
+// row and the label-bias sum), exactly as masked_softmax_bwd_kernel.  MT = neighbour tiles (16 columns each), TPW = dP tiles per wave.
+template <int MT, int TPW, int CW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gat_bwd_core_kernel(const float* __restrict__ doutT, const float* __restrict__ S,
+                                                           const float* __restrict__ P, const float* __restrict__ dPext,
+                                                           const float* __restrict__ cond, const float* __restrict__ geo,
+                                                           int N, int M, int A, int H, int dir,
+                                                           float* __restrict__ dS, float* __restrict__ daff,
+                                                           float* __restrict__ dlbias, float* __restrict__ dgeo, int csoff) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LD = CW + 2;                 // row stride of the staged chunk: 16 rows x 2 k-columns of an A-type fragment hit 32 banks
+    constexpr int PLD = 16 * MT + 1;           // row stride of dP in LDS (odd: a thread per row walks it without bank conflicts)
+    constexpr int RLD = CW + 1;
+    constexpr int RTMAX = 4 * TPW / MT;        // row tiles the accumulators cover
+    constexpr int V4 = CW / 4;                 // 16-byte vectors per staged row
+    constexpr int DU = (RTMAX * 16 * V4 + 255) / 256;            // 16-byte loads per thread and chunk: d(outT) ...
+    constexpr int SU = (MT * 16 * V4 + 255) / 256;               // ... and the values
+    constexpr int KPW = (RTMAX * 4 + 3) / 4;   // k-steps (4 rows each) of the dS product per wave
+    const int NH = N * H, NHp = (NH + 15) & ~15, RT = NHp >> 4;
+    float* Dc = smem;                          // [NHp][LD]     d(outT) chunk (rows >= N H zero)
+    float* Sc = Dc + NHp * LD;                 // [16 MT][LD]   value chunk (rows >= M zero)
+    float* red = Dc;                           // [4][16 MT][RLD]  partial dS tiles of the four waves (after the chunk's products)
+    float* dPs = Dc;                           // [NHp][PLD]    dP (after the last chunk)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const long long r = blockIdx.x;
+    const float* Dr = doutT + r * NH * (long long)A;
+    const float* Sr = S + r * N * (long long)A;
+    const float* Pr = P + r * NH * (long long)M;
+
+    f32x4 dreg[DU], sreg[SU];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+            const int idx = tid + 256 * u, row = idx / V4, c4 = idx % V4;
+            dreg[u] = row < NH ? *reinterpret_cast<const f32x4*>(Dr + (long long)row * A + c0 + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int idx = tid + 256 * u, row = idx / V4, c4 = idx % V4;
+            sreg[u] = row < M ? *reinterpret_cast<const f32x4*>(Sr + (long long)row * A + c0 + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+            const int idx = tid + 256 * u, row = idx / V4, c4 = idx % V4;
+            if (row < NHp) {
+                float* d = Dc + row * LD + 4 * c4;                       // (row stride 8 mod 16 bytes: 8-byte aligned stores)
+                *reinterpret_cast<f32x2*>(d) = f32x2{dreg[u][0], dreg[u][1]};
+                *reinterpret_cast<f32x2*>(d + 2) = f32x2{dreg[u][2], dreg[u][3]};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int idx = tid + 256 * u, row = idx / V4, c4 = idx % V4;
+            if (row < 16 * MT) {
+                float* d = Sc + row * LD + 4 * c4;
+                *reinterpret_cast<f32x2*>(d) = f32x2{sreg[u][0], sreg[u][1]};
+                *reinterpret_cast<f32x2*>(d + 2) = f32x2{sreg[u][2], sreg[u][3]};
+            }
+        }
+    };
+    // chunk order: slice r starts at chunk (5 r) mod nch and wraps.  The rows of d(outT) are 16 KB apart and the slices a multiple of that:
+    // walked in the same order by every workgroup, the chunk loads of the whole grid fall on a few memory channels at any one time
+    // (measured: 2.3 TB/s for the bare load loop); staggered they spread over all of them.  (The order a slice adds its chunks into dP
+    // depends on r only: deterministic.)
+    const int nch = A / CW;
+    const int cstart = (int)((r * 5) % nch);
+    fetch(cstart * CW);
+    // P and the adjacency of the slice: contiguous copies in LDS for the whole kernel (the dS fragments below and the softmax backward
+    // at the end read them), requested here so that they arrive under the first chunk
+    float* cs = smem + csoff;                  // [N][N]        adjacency, as stored
+    float* Pl = cs + N * N;                    // [NH][M + 1]   probabilities
+    const int PM = M + 1;
+    // flat index -> (row, column): n / d = umulhi(n, 2^32 / d + 1) for the small n, d here (an integer division is ~40 instructions)
+    const unsigned mgM = M > 1 ? 0xFFFFFFFFu / (unsigned)M + 1u : 0u, mgH = H > 1 ? 0xFFFFFFFFu / (unsigned)H + 1u : 0u,
+                   mgN = N > 1 ? 0xFFFFFFFFu / (unsigned)N + 1u : 0u;
+    auto divM = [&](int i) { return M > 1 ? (int)__umulhi((unsigned)i, mgM) : i; };
+    auto divH = [&](int i) { return H > 1 ? (int)__umulhi((unsigned)i, mgH) : i; };
+    auto divN = [&](int i) { return N > 1 ? (int)__umulhi((unsigned)i, mgN) : i; };
+    {
+        constexpr int UB = 8;                  // loads in flight per thread (a loop of load -> store pays one round trip per element)
+        for (int i0 = tid; i0 < NH * M; i0 += 256 * UB) {
+            float v[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) v[u] = i0 + 256 * u < NH * M ? Pr[i0 + 256 * u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int i = i0 + 256 * u, row = divM(i);
+                if (i < NH * M) Pl[row * PM + (i - row * M)] = v[u];
+            }
+        }
+        for (int i0 = tid; i0 < N * N; i0 += 256 * UB) {
+            float v[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) v[u] = i0 + 256 * u < N * N ? cond[r * N * N + i0 + 256 * u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+                if (i0 + 256 * u < N * N) cs[i0 + 256 * u] = v[u];
+        }
+    }
+    __syncthreads();
+    // the P^T fragments of this wave's k-steps (k-step ks = wave + 4 i covers rows 4 ks .. 4 ks + 3 of P): A[i = m][k = row];
+    // they do not depend on the chunk: registers
+    float pa[KPW][MT];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        const int krow = 4 * (wave + 4 * i) + l4;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = 16 * mt + l15;
+            pa[i][mt] = (krow < NH && m < M) ? Pl[krow * PM + m] : 0.f;
+        }
+    }
+    // this wave's dP tiles: t = wave + 4 j -> (row tile t / MT, neighbour tile t % MT); fragment base addresses in the staged chunk
+    f32x4 accP[TPW];
+    int aoff[TPW], boff[TPW];
+    const int ntiles = RT * MT;
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int t = min(wave + 4 * j, ntiles - 1);
+        aoff[j] = (16 * (t / MT) + l15) * LD + l4;
+        boff[j] = (16 * (t % MT) + l15) * LD + l4;
+        accP[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int ci = 0; ci < nch; ++ci) {
+        const int c = ci + cstart < nch ? ci + cstart : ci + cstart - nch;
+        stage();
+        __syncthreads();
+        if (ci + 1 < nch) fetch((c + 1 < nch ? c + 1 : 0) * CW);
+        // ---- dP += d(outT)_c . S_c^T
+        // (no branch inside: a wave with fewer than TPW tiles repeats its last one into an accumulator nobody stores -- with a
+        // test per tile every product sat in a block of its own behind the full latency of its two LDS reads)
+#pragma unroll 2
+        for (int ks = 0; ks < CW / 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < TPW; ++j)
+                accP[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(Dc[aoff[j] + 4 * ks], Sc[boff[j] + 4 * ks], accP[j], 0, 0, 0);
+        // ---- dS_c = P^T . d(outT)_c over this wave's quarter of the (node, head) rows
+        f32x4 accS[MT][CW / 16];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int c2 = 0; c2 < CW / 16; ++c2) accS[mt][c2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+            const int krow = min(4 * (wave + 4 * i) + l4, NHp - 1);       // (a k-step past the last row: its P fragment is zero)
+            float b[CW / 16];
+#pragma unroll
+            for (int c2 = 0; c2 < CW / 16; ++c2) b[c2] = Dc[krow * LD + 16 * c2 + l15];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int c2 = 0; c2 < CW / 16; ++c2) accS[mt][c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[i][mt], b[c2], accS[mt][c2], 0, 0, 0);
+        }
+        __syncthreads();                                            // every wave is done with the staged chunk
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int c2 = 0; c2 < CW / 16; ++c2)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) red[(wave * 16 * MT + 16 * mt + 4 * l4 + v) * RLD + 16 * c2 + l15] = accS[mt][c2][v];
+        __syncthreads();
+        for (int i = tid; i < M * CW; i += 256) {
+            const int m = i / CW, cc = i - m * CW;
+            const float* q0 = red + m * RLD + cc;
+            const float sum = (q0[0] + q0[16 * MT * RLD]) + (q0[2 * 16 * MT * RLD] + q0[3 * 16 * MT * RLD]);
+            dS[(r * N + m) * (long long)A + c * CW + cc] = sum;
+        }
+        __syncthreads();                                            // the partials are read: the buffer takes the next chunk
+    }
+    // ---- dP to LDS, then the softmax backward
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+        if (wave + 4 * j < ntiles) {
+            const int t = wave + 4 * j, rt = t / MT, ct = t % MT;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) dPs[(16 * rt + 4 * l4 + v) * PLD + 16 * ct + l15] = accP[j][v];
+        }
+    __syncthreads();
+    // ---- softmax backward on the slice's N H rows.  (First form: a wave per query node, one row per pass with shuffle reductions and
+    // 4-byte strided accesses -- 46 us of the kernel with 8 waves per CU to hide them.)  Now: P and the adjacency come in as contiguous
+    // copies, a THREAD owns a row (dot product and dx in registers / LDS, no cross-lane step), and every output leaves in flat index
+    // order from LDS.
+    if (tid < NH) {
+        float* dpr = dPs + tid * PLD;
+        const float* pr = Pl + tid * PM;
+        if (dPext) for (int m = 0; m < M; ++m) dpr[m] += dPext[(r * NH + tid) * M + m];
+        float dot = 0.f;
+#pragma unroll 4
+        for (int m = 0; m < M; ++m) dot = fmaf(pr[m], dpr[m], dot);
+#pragma unroll 4
+        for (int m = 0; m < M; ++m) dpr[m] = pr[m] * (dpr[m] - dot);          // dx, unmasked (the label-bias gradient sums it as it is)
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = tid; i < NH * M; i += 256) {                                // daff[r][n][h][m]
+        const int row = divM(i), m = i - row * M, n = divH(row);
+        const float c = cs[dir ? m * N + n : n * N + m];
+        daff[r * NH * M + i] = c > 0.f ? dPs[row * PLD + m] : 0.f;
+    }
+    if (dgeo)
+#pragma unroll 4
+        for (int i = tid; i < N * M * H; i += 256) {                         // dgeo[r][n][m][h]
+            const int nm = divH(i), hd = i - nm * H, n = divM(nm), m = nm - n * M;
+            const float c = cs[dir ? m * N + n : n * N + m];
+            const float gv = geo[r * N * M * H + i];
+            dgeo[r * N * M * H + i] = (c > 0.f && gv > GEO_EPS) ? dPs[(n * H + hd) * PLD + m] / gv : 0.f;
+        }
+    if (dlbias)
+        for (int i = tid; i < N * M; i += 256) {                             // dlbias[r][n][m] (dir 0) / [r][m][n] (dir 1): flat order of the output
+            const int a = dir ? divN(i) : divM(i), b = i - a * (dir ? N : M);
+            const int n = dir ? b : a, m = dir ? a : b;
+            float sum = 0.f;
+            for (int hd = 0; hd < H; ++hd) sum += dPs[(n * H + hd) * PLD + m];
+            dlbias[r * N * N + (dir ? m * N + n : n * N + m)] = sum;
+        }
 }
 
 // ---------------- stand-alone edge softmax (used with the GEMM-composed affinities, and by every backward)
@@ -452,6 +688,50 @@ extern "C" int ekaid_gat_dqk(const float* daff, const float* q, const float* k, 
     if (N <= 36) return launch_dqk<36>(daff, q, k, R, N, M, A, H, scale, dq, dk, ST);
     if (N <= 40) return launch_dqk<40>(daff, q, k, R, N, M, A, H, scale, dq, dk, ST);
     set_error("gat_dqk: more than 40 nodes (N=%d): compose from batched products", N);
+    return EKAID_ERR_UNSUPPORTED;
+}
+
+template <int MT, int TPW, int CW>
+static int launch_bwd_core(const float* doutT, const float* S, const float* P, const float* dPext, const float* cond, const float* geo, int R,
+                           int N, int M, int A, int H, int dir, float* dS, float* daff, float* dlbias, float* dgeo, hipStream_t st) {
+    auto kern = gat_bwd_core_kernel<MT, TPW, CW>;
+    const int NHp = (N * H + 15) & ~15;
+    size_t area = (size_t)NHp * (CW + 2) + (size_t)16 * MT * (CW + 2);                 // the staged chunk ...
+    if ((size_t)4 * 16 * MT * (CW + 1) > area) area = (size_t)4 * 16 * MT * (CW + 1);  // ... the four waves' partial dS tiles ...
+    if ((size_t)NHp * (16 * MT + 1) > area) area = (size_t)NHp * (16 * MT + 1);        // ... dP after the last chunk: one buffer
+    const size_t lds = sizeof(float) * (area + (size_t)N * N + (size_t)N * H * (M + 1));      // + the slice's adjacency and probabilities
+    if (lds > 64 * 1024) {
+        if (lds > 160 * 1024) { set_error("gat_bwd_core: LDS need %zu too large", lds); return EKAID_ERR_UNSUPPORTED; }
+        if (func_attr_once((const void*)kern)) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                (void)hipGetLastError();
+                set_error("gat_bwd_core: cannot raise dynamic LDS limit to %zu bytes", lds);
+                return EKAID_ERR_UNSUPPORTED;
+            }
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(R), dim3(256), lds, st, doutT, S, P, dPext, cond, geo, N, M, A, H, dir, dS, daff, dlbias, dgeo, (int)area);
+    count_launch(EKAID_COUNT_GAT_BWD_CORE);
+    return check_launch("gat_bwd_core");
+}
+
+extern "C" int ekaid_gat_bwd_core(const float* doutT, const float* S, const float* P, const float* dP_ext, const float* cond, const float* geo,
+                                  int R, int N, int M, int A, int H, int dir, float* dS, float* daff, float* dlbias, float* dgeo,
+                                  void* stream) {
+    if (R <= 0) return EKAID_OK;
+    if (!doutT || !S || !P || !cond || !dS || !daff) { set_error("gat_bwd_core: null pointer"); return EKAID_ERR_ARG; }
+    if (N < 1 || N > 64 || M < 1 || M > N || H < 1 || (A & 31) || (geo == nullptr) != (dgeo == nullptr)) {
+        set_error("gat_bwd_core: unsupported shape N=%d M=%d A=%d H=%d", N, M, A, H);
+        return EKAID_ERR_UNSUPPORTED;
+    }
+    const int RT = (N * H + 15) >> 4;
+    if (M <= 48 && RT <= 9) {
+        if (!(A & 63)) return launch_bwd_core<3, 7, 64>(doutT, S, P, dP_ext, cond, geo, R, N, M, A, H, dir, dS, daff, dlbias, dgeo, ST);
+        return launch_bwd_core<3, 7, 32>(doutT, S, P, dP_ext, cond, geo, R, N, M, A, H, dir, dS, daff, dlbias, dgeo, ST);
+    }
+    // (a <4, 13, 32> instantiation for 52 nodes x 4 heads was measured and removed: 255 registers with spills, one workgroup per CU,
+    // 916 vs 631 us for the backward of 512 slices next to the composition)
+    set_error("gat_bwd_core: %d (node, head) rows x %d neighbours outside the register tile (compose from batched products)", N * H, M);
     return EKAID_ERR_UNSUPPORTED;
 }
 

@@ -157,6 +157,7 @@ SIGNATURES = {
     'ekaid_expand_rows_bwd': [P, P, L, I, I, I, P, F, U64, P],
     'ekaid_gat_fused_fwd': [P, P, P, P, P, P, I, I, I, I, I, I, P, P, P],
     'ekaid_gat_dqk': [P, P, P, I, I, I, I, I, F, P, P, P],
+    'ekaid_gat_bwd_core': [P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P],
     'ekaid_masked_softmax_fwd': [P, P, P, P, I, I, I, I, I, P, P],
     'ekaid_masked_softmax_bwd': [P, P, P, P, I, I, I, I, I, P, P, P, P],
     'ekaid_geom_embed': [P, P, I, I, I, I, P, P],
@@ -291,7 +292,7 @@ def seq_status_take():
 
 # indices of ekaid_launch_count (include/ekaid_hip.h)
 COUNT = dict(spk_fwd_persistent=0, spk_bwd_persistent=1, greedy_persistent=2, gru_fwd_persistent=3, gru_bwd_persistent=4,
-             spk_fwd_stepwise=5, spk_bwd_stepwise=6, greedy_stepwise=7, gemm_f32=8, gemm_split3=9, gemm_split2=10)
+             spk_fwd_stepwise=5, spk_bwd_stepwise=6, greedy_stepwise=7, gemm_f32=8, gemm_split3=9, gemm_split2=10, gat_bwd_core=11)
 
 
 def launch_counts():

@@ -1954,6 +1954,10 @@ def geom_embed(bb_dev, M, feat_dim, dim_mat, p=0.0):
 
 
 _GAT_DQK = os.environ.get('EKAID_GAT_DQK', '1') != '0'      # A/B knob: 0 = dq / dk as two batched products
+_GAT_BWD_CORE = os.environ.get('EKAID_GAT_BWD_CORE', '1') != '0'      # A/B knob: 0 = dP / dS as two batched products + the softmax-backward kernel
+# one workgroup per slice: from this many slices on the one-launch form wins (kernel time of the backward, 36 nodes x 4 heads x 1024:
+# 512 slices 435 -> 338 us, 256: 223 -> 207, 128: 145 -> 176, 64: 112 -> 167; profiles/r06_gat_bwd_core_ab.txt)
+_GAT_BWD_CORE_MIN_SLICES = int(os.environ.get('EKAID_GAT_BWD_CORE_MIN_SLICES', 256))
 
 
 class GatAttentionFn(Function):
@@ -2010,20 +2014,27 @@ class GatAttentionFn(Function):
             doutT = torch.zeros(R, N, H * A, device=dev, dtype=torch.float32)
         doutT = _c(doutT)
         doutT = _c(doutT)
-        # dP = doutT . S[:M]^T   (R, N*H, M)
-        dP = torch.empty(R, N, H, M, device=dev, dtype=torch.float32)
-        gemm(doutT, S, dP, N * H, M, A, A, A, M, 0, 1, batch=(R, 1), strides=(N * H * A, 0, N * A, 0, N * H * M, 0))
-        if dP_ext is not None:
-            dP = AxpbyFn.apply(dP, _c(dP_ext), 1.0, 1.0)
-        # dS[:M] = P^T . doutT
         dS = torch.zeros(R, N, A, device=dev, dtype=torch.float32) if M < N else \
             torch.empty(R, N, A, device=dev, dtype=torch.float32)
-        gemm(P, doutT, dS, M, A, N * H, M, A, A, 1, 0, batch=(R, 1), strides=(N * H * M, 0, N * H * A, 0, N * A, 0))
         daff = torch.empty(R, N, H, M, device=dev, dtype=torch.float32)
-        dlbias = torch.zeros(R, N, N, device=dev, dtype=torch.float32)
+        dlbias = torch.zeros(R, N, N, device=dev, dtype=torch.float32) if M < N else torch.empty(R, N, N, device=dev, dtype=torch.float32)
         dgeo = torch.empty_like(geo) if ctx.has_geo else None
-        check(L.ekaid_masked_softmax_bwd(ptr(P), ptr(dP), ptr(cond), ptr(geo), R, N, M, H, direction, ptr(daff),
-                                         ptr(dlbias), ptr(dgeo), stream()), 'masked_softmax_bwd')
+        # d(aggregation) + d(edge softmax) in ONE launch that reads doutT once (csrc/gat.hip: gat_bwd_core_kernel); outside its envelope
+        # the same from two batched products around the softmax-backward kernel
+        rc = L.ekaid_gat_bwd_core(ptr(doutT), ptr(S), ptr(P), ptr(_c(dP_ext)) if dP_ext is not None else None, ptr(cond), ptr(geo) if ctx.has_geo else None,
+                                  R, N, M, A, H, direction, ptr(dS), ptr(daff), ptr(dlbias), ptr(dgeo), stream()) if (_GAT_BWD_CORE and R >= _GAT_BWD_CORE_MIN_SLICES) else hip.ERR_UNSUPPORTED
+        if rc == hip.ERR_UNSUPPORTED:
+            # dP = doutT . S[:M]^T   (R, N*H, M)
+            dP = torch.empty(R, N, H, M, device=dev, dtype=torch.float32)
+            gemm(doutT, S, dP, N * H, M, A, A, A, M, 0, 1, batch=(R, 1), strides=(N * H * A, 0, N * A, 0, N * H * M, 0))
+            if dP_ext is not None:
+                dP = AxpbyFn.apply(dP, _c(dP_ext), 1.0, 1.0)
+            # dS[:M] = P^T . doutT
+            gemm(P, doutT, dS, M, A, N * H, M, A, A, 1, 0, batch=(R, 1), strides=(N * H * M, 0, N * H * A, 0, N * A, 0))
+            check(L.ekaid_masked_softmax_bwd(ptr(P), ptr(dP), ptr(cond), ptr(geo), R, N, M, H, direction, ptr(daff),
+                                             ptr(dlbias), ptr(dgeo), stream()), 'masked_softmax_bwd')
+        else:
+            check(rc, 'gat_bwd_core')
         # dq[r,:,h] = sc * daff[r,:,h,:] . k[r,:,h]      dk[r,:,h] = sc * daff[r,:,h,:]^T . q[r,:,h]: one kernel (both are 36-deep
         # contractions: poor batched products), two batched products outside its envelope
         dq = torch.empty(R, N, A, device=dev, dtype=torch.float32)

@@ -260,6 +260,15 @@ int ekaid_gat_fused_fwd(const float* q, const float* k, const float* S, const fl
  * ref: autograd of graph_att_layer.py:79-108 */
 int ekaid_gat_dqk(const float* daff, const float* q, const float* k, int R, int N, int M, int A, int H, float scale, float* dq,
                   float* dk, void* stream);
+/* Backward of the aggregation and of the edge softmax in one launch, one workgroup per slice (graph_att_layer.py:146-172, autograd):
+ *   dP[r][n][h][m] = <doutT[r][n][h][:], S[r][m][:]> (+ dP_ext, the gradient arriving on the returned softmax, or NULL)
+ *   dS[r][m][:]    = sum_{n,h} P[r][n][h][m] doutT[r][n][h][:]            (rows m < M; the caller zeroes rows M .. N-1 when M < N)
+ *   daff, dlbias, dgeo as ekaid_masked_softmax_bwd computes them from P and dP.
+ * doutT (R, N, H, A) is read once; exact f32 products (v_mfma_f32_16x16x4_f32).  geo and dgeo both NULL or both given.
+ * ERR_UNSUPPORTED outside M <= N, M <= 48, N H <= 144 rows, A % 32 == 0: the caller composes the same from two batched
+ * ekaid_gemm_f32 calls + ekaid_masked_softmax_bwd then (also the faster form below ~256 slices: one workgroup per slice). */
+int ekaid_gat_bwd_core(const float* doutT, const float* S, const float* P, const float* dP_ext, const float* cond, const float* geo,
+                       int R, int N, int M, int A, int H, int dir, float* dS, float* daff, float* dlbias, float* dgeo, void* stream);
 int ekaid_masked_softmax_fwd(const float* aff, const float* cond, const float* lbias, const float* geo, int R,
                              int N, int M, int H, int dir, float* P, void* stream);
 int ekaid_masked_softmax_bwd(const float* P, const float* dP, const float* cond, const float* geo, int R, int N,
@@ -659,7 +668,8 @@ int ekaid_seq_fault_flag(float* flag, void* stream);
 #define EKAID_COUNT_GEMM_F32 8              /* products launched on the f32 matrix pipe (gemm mode 0, or a shape routed there) */
 #define EKAID_COUNT_GEMM_SPLIT3 9           /* products launched as the exact 3-way bf16 split (6 matrix products per product) */
 #define EKAID_COUNT_GEMM_SPLIT2 10          /* products launched as a 2-term split (3 matrix products per product) */
-#define EKAID_COUNT_N 11
+#define EKAID_COUNT_GAT_BWD_CORE 11        /* ekaid_gat_bwd_core launches (the graph-attention backward in its one-launch form) */
+#define EKAID_COUNT_N 12
 long long ekaid_launch_count(int which);
 
 #ifdef __cplusplus

@@ -253,11 +253,18 @@ def test_fused_adam_two_steps_match_reference():
         assert np.abs(tensor_summary(cur[k])[2:] - ref[2:]).max() <= 4.1e-4, k
 
 
-def test_full_width_matches_reference_golden():
-    """F4: the 87 M-parameter model at config-2 shapes (N=36, D=2048, Lq=20, T=16), B=2."""
+@pytest.mark.parametrize('gat_core', [False, True])
+def test_full_width_matches_reference_golden(gat_core, monkeypatch):
+    """F4: the 87 M-parameter model at config-2 shapes (N=36, D=2048, Lq=20, T=16), B=2.  ``gat_core``: the graph-attention backward in
+    its one-launch form (ekaid_gat_bwd_core: what the 128- and 256-pair steps run; the routing asks for >= 256 slices, lifted here --
+    the library's launch counter says it ran, once per encoder) or composed from batched products (what 4 slices get by default)."""
+    from ekaid_amd import hip, ops
     g = load_golden('f4_full')
     cfg = bench_cfg()
     cd, sp = build_models(cfg, 147, 148, DEV)
+    if gat_core:
+        monkeypatch.setattr(ops, '_GAT_BWD_CORE_MIN_SLICES', 0)
+    c0 = hip.launch_counts()['gat_bwd_core']
     loss, sp_loss, outs, logp, _ = hip_step(cfg, cd, sp, make_batch(B=2, **FULL), 'mode2', 'all')
     close(loss, g['loss'], 1e-4, 'loss')
     e = close(logp[:, :16], g['logp'], LOGIT_TOL, 'logp')
@@ -290,6 +297,7 @@ def test_full_width_matches_reference_golden():
         if hip_err > max(1e-3, 3 * ref_err):
             bad.append((k, hip_err, ref_err))
     assert not bad, 'gradients farther from the float64 truth than the reference float32 path: %s' % bad[:8]
+    assert hip.launch_counts()['gat_bwd_core'] - c0 == (3 if gat_core else 0)
 
 
 def test_config2_batch64_forward_against_cpu_oracle():

@@ -833,6 +833,43 @@ def test_gat_attention_fused_and_composed(N, M, A, H, direction, with_geo):
             check(a, r.float(), 5e-5, '%s %s' % (n, impl))
 
 
+@pytest.mark.parametrize('N,M,A,H,core', [(36, 36, 1024, 4, True), (52, 52, 1024, 4, False), (36, 20, 256, 4, True), (6, 6, 64, 16, True), (9, 7, 32, 2, True),
+                                          (36, 36, 96, 4, True), (48, 48, 192, 3, True), (64, 64, 128, 4, False), (36, 36, 48, 2, False), (20, 20, 64, 16, False)])
+@pytest.mark.parametrize('direction', [0, 1])
+def test_gat_backward_in_one_launch_equals_the_composed_backward(N, M, A, H, core, direction):
+    """ekaid_gat_bwd_core (d aggregation + d edge softmax, doutT read once, f32 matrix pipe) against the composition it replaces (two
+    batched products on the exact split around ekaid_masked_softmax_bwd), with a gradient arriving on the returned softmax as well and
+    with / without the geometry term; outside the kernel's envelope (more than 144 (node, head) rows, width not a multiple of 32) the
+    composition runs -- asserted from the library's launch counter.  (The production routing also asks for >= 256 slices: lifted here.)"""
+    from ekaid_amd import hip, ops
+    R = 5
+    sc = 1.0 / math.sqrt(A / H) ** 0.5
+    cond = (torch.rand(R, N, N, generator=torch.Generator().manual_seed(5)) > 0.4).float().to(DEV)
+    w = rnd(R, N, H * A, seed=71).to(DEV)
+    wP = rnd(R, N, H, M, seed=72).to(DEV)
+    for with_geo in (False, True):
+        res = {}
+        for use_core in (True, False):
+            ins = [rnd(R, N, A, seed=57, scale=sc), rnd(R, M, A, seed=58, scale=sc), rnd(R, N, A, seed=59), rnd(R, N, N, seed=60, scale=0.3)]
+            if with_geo:
+                ins.append(torch.relu(rnd(R, N, M, H, seed=61)))
+            ins = [t.to(DEV).requires_grad_(True) for t in ins]
+            old = (ops._GAT_BWD_CORE, ops._GAT_BWD_CORE_MIN_SLICES)
+            ops._GAT_BWD_CORE, ops._GAT_BWD_CORE_MIN_SLICES = use_core, 0
+            try:
+                c0 = hip.launch_counts()['gat_bwd_core']
+                out, P = ops.gat_attention(ins[0], ins[1], ins[2], cond, ins[3], ins[4] if with_geo else None, H, direction)
+                gs = torch.autograd.grad([out, P], ins, [w, wP])
+                torch.cuda.synchronize()
+                ran = hip.launch_counts()['gat_bwd_core'] - c0
+            finally:
+                ops._GAT_BWD_CORE, ops._GAT_BWD_CORE_MIN_SLICES = old
+            assert ran == (1 if (use_core and core) else 0), (ran, use_core, core)
+            res[use_core] = gs
+        for name, a, b in zip(('dq', 'dk', 'dS', 'dlbias', 'dgeo'), res[True], res[False]):
+            check(a, b.cpu(), 1e-5, '%s (geo %s)' % (name, with_geo))
+
+
 @pytest.mark.parametrize('R', [1, 5, 200, 400])
 @pytest.mark.parametrize('N,M,A,H', [(9, 7, 64, 2), (36, 36, 128, 4), (3, 3, 32, 1)])
 def test_gat_fused_forward_query_node_split(R, N, M, A, H):
