@@ -147,8 +147,8 @@ def pmc_traffic():
 def gat_roofline(R, N, A=1024, H=4):
     """The graph-attention core (north_star's named kernel: neighbour gather + edge softmax + weighted aggregation) as the step runs it,
     against the HBM roof (reported separately from the matrix-pipe line).  R graph slices of N regions, timed alone with
-    HIP events on the launch stream: forward = the batched affinity product + gat_fused_fwd_kernel, backward = the batched products +
-    masked_softmax_bwd + gat_dqk.  Algorithmic bytes per slice: forward reads q, k, S (3 N A) and writes the aggregated values (N H A) and
+    HIP events on the launch stream: forward = the batched affinity product + gat_fused_fwd_kernel, backward = gat_bwd_core_kernel (from 256
+    slices on; below: two batched products + masked_softmax_bwd) + gat_dqk.  Algorithmic bytes per slice: forward reads q, k, S (3 N A) and writes the aggregated values (N H A) and
     the probabilities (N H M); backward reads d(values) (N H A), q, k, S and the probabilities and writes dq, dk, dS.  `traffic`: the
     committed rocprofv3 PMC summary of the same kernels (tools/pmc_gat_all.sh: FETCH_SIZE doubled as the gfx950 guide prescribes)."""
     from ekaid_amd import ops
@@ -187,8 +187,13 @@ def gat_roofline(R, N, A=1024, H=4):
             traffic['source'] = os.path.relpath(cands[-1], ROOT)
         except (KeyError, ValueError):
             traffic = None
-    return {'bound': 'hbm', 'kernel': 'graph-attention core: batched affinity product + ekaid::gat_fused_fwd_kernel (forward); batched products + '
-                                      'masked_softmax_bwd_kernel + gat_dqk_kernel (backward)',
+    from ekaid_amd import hip
+    c0 = hip.launch_counts()['gat_bwd_core']
+    run()
+    one_launch = hip.launch_counts()['gat_bwd_core'] > c0
+    return {'bound': 'hbm', 'kernel': 'graph-attention core: batched affinity product + ekaid::gat_fused_fwd_kernel (forward); ' +
+                                      ('ekaid::gat_bwd_core_kernel (d aggregation + d edge softmax in one launch, d(outT) read once)' if one_launch else
+                                       'batched products + masked_softmax_bwd_kernel') + ' + gat_dqk_kernel (backward)',
             'shape': {'slices': R, 'regions': N, 'width': A, 'heads': H},
             'forward': {'us': round(fwd, 1), 'algorithmic_bytes': b_fwd, 'achieved': round(b_fwd / fwd / 1e3, 1), 'peak': 8000.0, 'unit': 'GB/s',
                         'frac': round(b_fwd / fwd / 1e3 / 8000.0, 4)},

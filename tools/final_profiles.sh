@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round-end measurement campaign (run on the GPU box from the repo root); everything lands under gpurun_out/r06_*; the summaries that are
 # cited in DESIGN.md are copied to profiles/ by hand afterwards.   usage: tools/final_profiles.sh [quick]
+# (Run it in pieces under gpurun: one rocprofv3 --pmc pass that aborts can sit in its signal handler until the outer limit -- every pass runs under
+# `timeout -k 10`, and the campaign as a whole cost 40 GPU-minutes the one time a pass did that without -k.)
 o=gpurun_out
 tools/stats_step.sh $o/r06_bench_b256 --steps 20 --no-ladder
 tools/stats_step.sh $o/r06_bench_b32 --steps 20 --batch 32 --hip-graph on

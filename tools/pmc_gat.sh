@@ -12,7 +12,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
            "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 150 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/g$i -o p -- python3 tools/gat_bench.py --kernel ekaid_amd/lib/libekaid_hip.so "$@" > $out/g$i.log 2>&1
+  timeout -k 10 150 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/g$i -o p -- python3 tools/gat_bench.py --kernel ekaid_amd/lib/libekaid_hip.so "$@" > $out/g$i.log 2>&1
 done
 python3 - "$out" "$@" <<'PY'
 import csv, glob, json, os, sys

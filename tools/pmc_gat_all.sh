@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes over the graph-attention core as the step runs it (tools/gat_bench.py: forward through ops.gat_attention, backward through
-# autograd: batched products + masked_softmax_bwd + gat_dqk): the counters of the LAST launch of each of its own kernels.
+# autograd: ekaid_gat_bwd_core from 256 slices on, else batched products + masked_softmax_bwd; then gat_dqk): the counters of the LAST launch of each of its own kernels.
 # usage: tools/pmc_gat_all.sh <outdir> R N M A H      -> <outdir>/summary.json      (separate --pmc passes, kernel trace only)
 out=$1; shift
 REPO="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
@@ -12,7 +12,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/g$i -o p -- python3 tools/gat_bench.py "$@" > $out/g$i.log 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/g$i -o p -- python3 tools/gat_bench.py "$@" > $out/g$i.log 2>&1
 done
 python3 - "$out" "$@" <<'PY'
 import csv, glob, json, os, sys
@@ -20,7 +20,8 @@ out = sys.argv[1]
 R, N, M, A, H = [int(x) for x in sys.argv[2:7]]
 KERNELS = {'gat_fused_fwd': R * (3 * N * A * 4 + N * H * A * 4 + N * H * M * 4),             # q, k, S in; outT, P out
            'gat_dqk': R * (2 * N * H * M * 4 + 2 * N * A * 4 + 2 * N * A * 4),              # daff (+P) in, q, k in; dq, dk out
-           'masked_softmax_bwd': R * (3 * N * H * M * 4)}                                    # P, dP in; daff out (+ small label / geometry sums)
+           'masked_softmax_bwd': R * (3 * N * H * M * 4),                                   # P, dP in; daff out (+ small label / geometry sums)
+           'gat_bwd_core': R * (N * H * A * 4 + 2 * N * A * 4 + 2 * N * H * M * 4 + 2 * N * N * 4)}   # d(outT), S, P, adjacency in; dS, daff, label-bias gradient out
 res = {k: {} for k in KERNELS}
 for g in sorted(glob.glob(os.path.join(out, 'g*'))):
     if not os.path.isdir(g):

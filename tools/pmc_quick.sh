@@ -7,7 +7,7 @@ mkdir -p $out
 i=0
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout 150 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/g$i -o p -- python3 tools/pmc_gemm.py "$@" > $out/g$i.log 2>&1
+  timeout -k 10 150 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/g$i -o p -- python3 tools/pmc_gemm.py "$@" > $out/g$i.log 2>&1
 done
 python3 - "$out" <<'PY'
 import csv, glob, os, sys

@@ -5,7 +5,7 @@ out=$1; shift
 REPO="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd /tmp && export TMPDIR=/tmp && cd "$REPO"
 d=$(mktemp -d /tmp/trace.XXXX)
-timeout 900 rocprofv3 --kernel-trace --output-format csv -d $d -o t -- python3 bench.py --warmup 3 --no-cpu-baseline --no-extra "$@" > ${out}.log 2>&1
+timeout -k 10 900 rocprofv3 --kernel-trace --output-format csv -d $d -o t -- python3 bench.py --warmup 3 --no-cpu-baseline --no-extra "$@" > ${out}.log 2>&1
 f=$(find $d -name "*kernel_trace.csv" | head -1)
 [ -n "$f" ] && cp $f ${out}_kernel_trace.csv
 rm -rf $d
