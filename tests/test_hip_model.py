@@ -254,16 +254,24 @@ def test_fused_adam_two_steps_match_reference():
 
 
 @pytest.mark.parametrize('gat_core', [False, True])
-def test_full_width_matches_reference_golden(gat_core, monkeypatch):
+def test_full_width_matches_reference_golden(gat_core):
     """F4: the 87 M-parameter model at config-2 shapes (N=36, D=2048, Lq=20, T=16), B=2.  ``gat_core``: the graph-attention backward in
     its one-launch form (ekaid_gat_bwd_core: what the 128- and 256-pair steps run; the routing asks for >= 256 slices, lifted here --
     the library's launch counter says it ran, once per encoder) or composed from batched products (what 4 slices get by default)."""
-    from ekaid_amd import hip, ops
+    from ekaid_amd import ops
+    old = ops._GAT_BWD_CORE_MIN_SLICES
+    ops._GAT_BWD_CORE_MIN_SLICES = 0 if gat_core else old
+    try:
+        _full_width_case(gat_core)
+    finally:
+        ops._GAT_BWD_CORE_MIN_SLICES = old
+
+
+def _full_width_case(gat_core):
+    from ekaid_amd import hip
     g = load_golden('f4_full')
     cfg = bench_cfg()
     cd, sp = build_models(cfg, 147, 148, DEV)
-    if gat_core:
-        monkeypatch.setattr(ops, '_GAT_BWD_CORE_MIN_SLICES', 0)
     c0 = hip.launch_counts()['gat_bwd_core']
     loss, sp_loss, outs, logp, _ = hip_step(cfg, cd, sp, make_batch(B=2, **FULL), 'mode2', 'all')
     close(loss, g['loss'], 1e-4, 'loss')
@@ -788,7 +796,7 @@ def test_f16x2_arithmetic_meets_the_parity_bars_of_the_exact_split():
         ops.set_gemm_mode(ops.GEMM_F16X2)
         ops.F16X2_MIN_WORK = 0                    # (B = 2: 144 rows -- below the work threshold of the performance routing; every eligible product here)
         c0 = hip.launch_counts()
-        test_full_width_matches_reference_golden()
+        test_full_width_matches_reference_golden(True)
         c1 = hip.launch_counts()
         assert c1['gemm_split2'] - c0['gemm_split2'] >= 60, 'the full-width step ran %d products on the two-term split' % (c1['gemm_split2'] - c0['gemm_split2'])
         cfg = bench_cfg()
