@@ -237,8 +237,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // As batched products the first two were R problems of (N H) x M x A and M x A x (N H) with M = 36 rows or columns on 64-wide tiles
 // (120 + 140 us at 512 slices), each reading d(outT) -- 302 MB of the backward's 0.77 GB -- on its own, followed by the softmax
 // kernel.  Here d(outT) is read ONCE, in chunks of CW feature columns staged through LDS (CW * 4-byte row segments: 256 bytes at
-// CW = 64 -- with 128-byte segments 16 KB apart the kernel ran at 1.9 TB/s); both products run on v_mfma_f32_16x16x4_f32 (exact
-// f32: a k-ordered fmaf chain per accumulator):
+// CW = 64; 128-byte segments measured the same: the bare load loop moves 4.2 TB/s either way, half as many barriers at 64); both
+// products run on v_mfma_f32_16x16x4_f32 (exact f32: a k-ordered fmaf chain per accumulator):
 //   * dP accumulates over the chunks in registers: its (N H / 16) x (M / 16) tiles are dealt round-robin to the four waves;
 //   * dS of a chunk is complete within the chunk: the waves split its K = N H range (the P fragments of a wave's k-steps do not
 //     depend on the chunk: loaded once, kept in registers), their partial tiles meet in LDS (in the buffer the chunk was staged
@@ -308,9 +308,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
     // chunk order: slice r starts at chunk (5 r) mod nch and wraps.  The rows of d(outT) are 16 KB apart and the slices a multiple of that:
-    // walked in the same order by every workgroup, the chunk loads of the whole grid fall on a few memory channels at any one time
-    // (measured: 2.3 TB/s for the bare load loop); staggered they spread over all of them.  (The order a slice adds its chunks into dP
-    // depends on r only: deterministic.)
+    // walked in the same order by every workgroup, the chunk loads of the whole grid start on the same few memory channels; staggered
+    // they spread (measured on the bare load loop of 512 slices: 164 -> 150 us -- the address hash already does most of it).  The
+    // order a slice adds its chunks into dP depends on r only: deterministic.
     const int nch = A / CW;
     const int cstart = (int)((r * 5) % nch);
     fetch(cstart * CW);
