@@ -23,6 +23,10 @@ from .hip import ACT_NONE, ACT_RELU, ACT_SIGMOID, check, ptr, stream
 from .ops import gemm
 
 PERSISTENT_BWD_MIN_STEPS = int(os.environ.get('EKAID_SEQ_BWD_MIN_STEPS', '32'))
+# ... or any number of steps at small batches, where the step-wise chain's ~10 launches per decode step are issue latency, not work:
+# same-box A/B on the replayed rungs (profiles/r06_ab_seq_bwd_min.txt, r06_ab_seq_bwd_batch.txt; ms x GHz): 32 pairs -0.7 ... -2.5 %,
+# 64 pairs level (-1.4 ... +0.4 %), 128 level, 256 +2.8 % -> up to 32 pairs
+PERSISTENT_BWD_MAX_BATCH_SHORT = int(os.environ.get('EKAID_SEQ_BWD_MAX_BATCH_SHORT', '32'))
 
 PARAM_NAMES = ('embed.0.weight', 'core.embed.0.weight', 'core.embed.0.bias',
                'core.module_att_lstm.weight_ih', 'core.module_att_lstm.weight_hh',
@@ -306,8 +310,8 @@ class SpeakerSeqFn(Function):
             sqb.DCAT, sqb.DZFC, sqb.DWP, sqb.DPP, sqb.DZ2 = ptr(DCAT), ptr(DZFC), ptr(DWP), ptr(DPP), ptr(DZ2)
             sqb.d_bef, sqb.d_diff, sqb.d_aft = ptr(d_bef), ptr(d_diff), ptr(d_aft)
             # (same-box A/B, profiles/r04_ab_seq_mode.txt: the persistent backward pays 4 weight transposes + 4 small products in front and 4
-            # time-batched products behind; it wins from ~32 decode steps on -- the real-data answers -- and is level below)
-            need_p = L.ekaid_speaker_seq_bwd_persistent_workspace_bytes(ctypes.byref(sqb.f)) if (L.ekaid_get_seq_mode() == 1 and T >= PERSISTENT_BWD_MIN_STEPS) else 0
+            # time-batched products behind; it wins from ~32 decode steps on -- the real-data answers -- and, round 6, at <= 32 pairs for any length)
+            need_p = L.ekaid_speaker_seq_bwd_persistent_workspace_bytes(ctypes.byref(sqb.f)) if (L.ekaid_get_seq_mode() == 1 and (T >= PERSISTENT_BWD_MIN_STEPS or B <= PERSISTENT_BWD_MAX_BATCH_SHORT)) else 0
             if need_p:
                 # ONE persistent launch for the whole BPTT loop (csrc/persist_bwd.hip).  Its contract leaves two time-batched
                 # pieces to the caller: DPP (read only by the pos2 weight gradient below) and the gate-MLP part of d feat_m

@@ -109,7 +109,7 @@ def test_decoder_through_the_model_agrees_between_the_sequence_modes(train, monk
     from ekaid_amd.config import bench_cfg
     hip.load()
     L = hip.lib()
-    monkeypatch.setattr(speaker_seq, 'PERSISTENT_BWD_MIN_STEPS', 4)      # (the default keeps short sequences on the step-wise backward)
+    monkeypatch.setattr(speaker_seq, 'PERSISTENT_BWD_MIN_STEPS', 4)      # (24 pairs run it by default since round 6; pinned here for any routing)
     cfg = bench_cfg(D=256, seq_length=12)
     cd, sp = build_models(cfg, 147, 148, 'cuda', train=train)
     g = torch.Generator().manual_seed(11)
